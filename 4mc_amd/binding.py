@@ -1,0 +1,109 @@
+"""ctypes view of the C ABI declared in include/fourmc_gpu.h and include/fourmc.h."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+BLOCKSIZE = 4 << 20                   # native/4mc.c:116
+MAGIC_4MC = 0x344D4300                # native/4mc.c:111
+MAGIC_4MZ = 0x344D5A00                # native/4mc.c:112
+CODEC_LZ4_FAST, CODEC_LZ4_MC, CODEC_LZ4_HC, CODEC_ZSTD = 0, 1, 2, 3
+BLK_BADSUM = -1000000001
+BLK_CORRUPT = -1000000002
+
+# struct fourmc_block (32 bytes)
+BLOCK_DTYPE = np.dtype([("src_off", "<u8"), ("dst_off", "<u8"), ("src_len", "<u4"),
+                        ("dst_cap", "<u4"), ("result", "<i4"), ("xxh32", "<u4")])
+assert BLOCK_DTYPE.itemsize == 32
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libhadoop-4mc.so")
+
+
+def cli_path():
+    return os.path.join(_HERE, "bin", "4mc")
+
+
+_lib = None
+
+# every symbol include/fourmc_gpu.h and include/fourmc.h declare
+_GPU_API = {
+    "fourmc_gpu_device_count": (C.c_int, []),
+    "fourmc_gpu_init": (C.c_int, [C.c_int]),
+    "fourmc_gpu_last_error": (C.c_char_p, []),
+    "fourmc_gpu_arch": (C.c_char_p, []),
+    "fourmc_gpu_lz4_decompress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "fourmc_gpu_lz4_compress_fast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "fourmc_gpu_xxh32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "fourmc_gpu_4mc_encode_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
+    "fourmc_gpu_4mc_decode_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
+    "fourmc_LZ4_compressBound": (C.c_int, [C.c_int]),
+    "fourmc_LZ4_compress_default": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "fourmc_LZ4_decompress_safe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "fourmc_XXH32": (C.c_uint32, [C.c_void_p, C.c_size_t, C.c_uint32]),
+    "fourmc_host_4mc_encode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
+    "fourmc_host_4mc_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_int]),
+}
+_FILE_API = {
+    "fourMCcompressFilename": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_int]),
+    "fourMcDecompressFileName": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_char_p]),
+    "fourMZcompressFilename": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_int]),
+    "fourMZDecompressFileName": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_char_p]),
+    "fourmc_frame_header": (None, [C.c_void_p, C.c_uint32]),
+    "fourmc_frame_check_header": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "fourmc_frame_block_header": (None, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "fourmc_frame_parse_block_header": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fourmc_frame_footer": (C.c_size_t, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
+    "fourmc_frame_parse_footer": (C.c_int64, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
+    "fourmc_index_find_next": (C.c_int64, [C.c_void_p, C.c_uint32, C.c_uint64]),
+    "fourmc_index_find_block": (C.c_int64, [C.c_void_p, C.c_uint32, C.c_uint64]),
+    "fourmc_index_align_start": (C.c_uint64, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
+    "fourmc_index_align_end": (C.c_uint64, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
+}
+
+
+def exported_symbols():
+    """Names the headers declare (C-ABI + file API); the JNI names are listed in tests."""
+    return list(_GPU_API) + list(_FILE_API)
+
+
+def lib():
+    """Load libhadoop-4mc.so (built in-tree by __graft_entry__.build()).  Fails loudly."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise EngineError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(the HIP extension is mandatory; there is no fallback path)")
+        L = C.CDLL(path)
+        for name, (res, args) in {**_GPU_API, **_FILE_API}.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise EngineError(f"{what} failed ({rc}): {lib().fourmc_gpu_last_error().decode()}")
+
+
+def gpu_init(device=-1):
+    check(lib().fourmc_gpu_init(device), "fourmc_gpu_init")
+    return lib().fourmc_gpu_arch().decode()
+
+
+def make_blocks(src_off, dst_off, src_len, dst_cap, xxh32=None):
+    """Host-side descriptor array (numpy structured, one row per block)."""
+    n = len(src_len)
+    b = np.zeros(n, dtype=BLOCK_DTYPE)
+    b["src_off"], b["dst_off"], b["src_len"], b["dst_cap"] = src_off, dst_off, src_len, dst_cap
+    if xxh32 is not None:
+        b["xxh32"] = xxh32
+    return b

@@ -1,0 +1,217 @@
+// 4mc_amd/csrc/engine.hip — host side of the C ABI in include/fourmc_gpu.h: device selection,
+// batched launches, and the host-buffer staging used by the CLI / JNI entry points.
+//
+// There is NO CPU codec behind these calls: without a usable gfx950 device every entry point
+// fails with FOURMC_ENODEV (the product must fail loudly rather than fall back).
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "fourmc_gpu.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+std::mutex g_mu;                 // guards device selection and the host-staging arena
+int  g_device = -1;
+char g_arch[128] = "";
+
+int fail_hip(hipError_t e, const char* what)
+{
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    return FOURMC_EHIP;
+}
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail_hip(e_, #x); } while (0)
+
+int ensure_device()
+{
+    if (g_device >= 0) return FOURMC_OK;
+    return fourmc_gpu_init(-1);
+}
+
+// Host-staging arena: device buffers reused across host-buffer calls (grown on demand).
+struct Arena {
+    void* d_src = nullptr; size_t src_cap = 0;
+    void* d_dst = nullptr; size_t dst_cap = 0;
+    fourmc_block* d_blk = nullptr; size_t blk_cap = 0;
+    hipStream_t stream = nullptr;
+} g_arena;
+
+int arena_reserve(size_t src_bytes, size_t dst_bytes, size_t nblk)
+{
+    if (!g_arena.stream) HIP_TRY(hipStreamCreateWithFlags(&g_arena.stream, hipStreamNonBlocking));
+    auto grow = [](void** p, size_t* cap, size_t need) -> hipError_t {
+        if (need <= *cap) return hipSuccess;
+        if (*p) { hipError_t e = hipFree(*p); if (e != hipSuccess) return e; *p = nullptr; *cap = 0; }
+        size_t want = need + need / 4 + 4096;
+        hipError_t e = hipMalloc(p, want);
+        if (e == hipSuccess) *cap = want;
+        return e;
+    };
+    HIP_TRY(grow(&g_arena.d_src, &g_arena.src_cap, src_bytes + 64));
+    HIP_TRY(grow(&g_arena.d_dst, &g_arena.dst_cap, dst_bytes + 64));
+    HIP_TRY(grow(reinterpret_cast<void**>(&g_arena.d_blk), &g_arena.blk_cap, nblk * sizeof(fourmc_block)));
+    return FOURMC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* fourmc_gpu_last_error(void) { return g_err; }
+const char* fourmc_gpu_arch(void) { return g_arch; }
+
+int fourmc_gpu_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { fail_hip(e, "hipGetDeviceCount"); return FOURMC_ENODEV; }
+    return n;
+}
+
+int fourmc_gpu_init(int device)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = fourmc_gpu_device_count();
+    if (n <= 0) {
+        if (n == 0) snprintf(g_err, sizeof g_err, "no HIP device visible (4mc GPU engine has no CPU fallback)");
+        return FOURMC_ENODEV;
+    }
+    if (device < 0) {
+        // honour an already-selected device (one process per GPU: LOCAL_RANK / hipSetDevice upstream)
+        const char* env = getenv("FOURMC_DEVICE");
+        if (env) device = atoi(env);
+        else if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= n) { snprintf(g_err, sizeof g_err, "device %d out of range (%d visible)", device, n); return FOURMC_EINVAL; }
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    snprintf(g_arch, sizeof g_arch, "%s", prop.gcnArchName);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        snprintf(g_err, sizeof g_err, "device %d is %s; this build carries gfx950 code only", device, prop.gcnArchName);
+        return FOURMC_ENODEV;
+    }
+    g_device = device;
+    return FOURMC_OK;
+}
+
+// ------------------------------------------------------------------------ device-resident API
+int fourmc_gpu_lz4_decompress(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, void* stream)
+{
+    if (int r = ensure_device()) return r;
+    HIP_TRY(fourmc_launch_lz4_decode(d_src, d_dst, d_blocks, n, 0, static_cast<hipStream_t>(stream)));
+    return FOURMC_OK;
+}
+
+int fourmc_gpu_lz4_compress_fast(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, void* stream)
+{
+    if (int r = ensure_device()) return r;
+    HIP_TRY(fourmc_launch_lz4_encode_fast(d_src, d_dst, d_blocks, n, 0, static_cast<hipStream_t>(stream)));
+    return FOURMC_OK;
+}
+
+int fourmc_gpu_xxh32(const void* d_src, fourmc_block* d_blocks, uint32_t n, uint32_t seed, void* stream)
+{
+    if (int r = ensure_device()) return r;
+    HIP_TRY(fourmc_launch_xxh32(d_src, d_blocks, n, seed, FOURMC_HASH_SRC, static_cast<hipStream_t>(stream)));
+    return FOURMC_OK;
+}
+
+int fourmc_gpu_4mc_encode_blocks(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
+                                 int codec, int level, void* stream)
+{
+    (void)level;
+    if (int r = ensure_device()) return r;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (codec != FOURMC_CODEC_LZ4_FAST) {
+        snprintf(g_err, sizeof g_err, "codec %d not implemented on the device yet", codec);
+        return FOURMC_EUNSUP;
+    }
+    HIP_TRY(fourmc_launch_lz4_encode_fast(d_src, d_dst, d_blocks, n, 1, s));
+    HIP_TRY(fourmc_launch_xxh32(d_dst, d_blocks, n, 0, FOURMC_HASH_DST_RESULT, s));
+    return FOURMC_OK;
+}
+
+int fourmc_gpu_4mc_decode_blocks(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
+                                 int codec, void* stream)
+{
+    if (int r = ensure_device()) return r;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (codec != FOURMC_CODEC_LZ4_FAST && codec != FOURMC_CODEC_LZ4_MC && codec != FOURMC_CODEC_LZ4_HC) {
+        snprintf(g_err, sizeof g_err, "codec %d not implemented on the device yet", codec);
+        return FOURMC_EUNSUP;
+    }
+    HIP_TRY(fourmc_launch_xxh32(d_src, d_blocks, n, 0, FOURMC_VERIFY_SRC, s));
+    HIP_TRY(fourmc_launch_lz4_decode(d_src, d_dst, d_blocks, n, 1, s));
+    return FOURMC_OK;
+}
+
+// ------------------------------------------------------------------------ host-buffer API
+int fourmc_LZ4_compressBound(int n) { return (unsigned)n > 0x7E000000u ? 0 : n + n / 255 + 16; }
+
+static int host_roundtrip(const void* src, size_t src_bytes, void* dst, size_t dst_bytes,
+                          fourmc_block* blocks, uint32_t n, int op, int codec, int level)
+{
+    if (int r = ensure_device()) return r;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (int r = arena_reserve(src_bytes, dst_bytes, n)) return r;
+    hipStream_t s = g_arena.stream;
+    HIP_TRY(hipMemcpyAsync(g_arena.d_src, src, src_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(g_arena.d_blk, blocks, n * sizeof(fourmc_block), hipMemcpyHostToDevice, s));
+    int r;
+    switch (op) {
+        case 0: r = fourmc_gpu_4mc_encode_blocks(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, codec, level, s); break;
+        case 1: r = fourmc_gpu_4mc_decode_blocks(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, codec, s); break;
+        case 2: r = fourmc_gpu_lz4_compress_fast(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
+        case 3: r = fourmc_gpu_lz4_decompress(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
+        default: r = fourmc_gpu_xxh32(g_arena.d_src, g_arena.d_blk, n, (uint32_t)level, s); break;
+    }
+    if (r) return r;
+    HIP_TRY(hipMemcpyAsync(blocks, g_arena.d_blk, n * sizeof(fourmc_block), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (op != 4) {
+        // copy back only what each block produced
+        for (uint32_t b = 0; b < n; b++) {
+            if (blocks[b].result > 0)
+                HIP_TRY(hipMemcpyAsync(static_cast<char*>(dst) + blocks[b].dst_off,
+                                       static_cast<char*>(g_arena.d_dst) + blocks[b].dst_off,
+                                       (size_t)blocks[b].result, hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return FOURMC_OK;
+}
+
+int fourmc_host_4mc_encode(const void* src, size_t src_bytes, void* dst, size_t dst_bytes,
+                           fourmc_block* blocks, uint32_t n, int codec, int level)
+{ return host_roundtrip(src, src_bytes, dst, dst_bytes, blocks, n, 0, codec, level); }
+
+int fourmc_host_4mc_decode(const void* src, size_t src_bytes, void* dst, size_t dst_bytes,
+                           fourmc_block* blocks, uint32_t n, int codec)
+{ return host_roundtrip(src, src_bytes, dst, dst_bytes, blocks, n, 1, codec, 0); }
+
+int fourmc_LZ4_compress_default(const char* src, char* dst, int srcSize, int dstCapacity)
+{
+    if (srcSize < 0 || dstCapacity < 0) return 0;
+    fourmc_block b; memset(&b, 0, sizeof b);
+    b.src_len = (uint32_t)srcSize; b.dst_cap = (uint32_t)dstCapacity;
+    size_t dst_bytes = (size_t)dstCapacity;
+    int r = host_roundtrip(src, (size_t)srcSize, dst, dst_bytes, &b, 1, 2, FOURMC_CODEC_LZ4_FAST, 0);
+    if (r) { fprintf(stderr, "4mc-gpu: %s\n", g_err); return 0; }
+    return b.result;
+}
+
+int fourmc_LZ4_decompress_safe(const char* src, char* dst, int compressedSize, int dstCapacity)
+{
+    if (compressedSize < 0 || dstCapacity < 0) return -1;
+    fourmc_block b; memset(&b, 0, sizeof b);
+    b.src_len = (uint32_t)compressedSize; b.dst_cap = (uint32_t)dstCapacity;
+    int r = host_roundtrip(src, (size_t)compressedSize, dst, (size_t)dstCapacity, &b, 1, 3, FOURMC_CODEC_LZ4_FAST, 0);
+    if (r) { fprintf(stderr, "4mc-gpu: %s\n", g_err); return -1; }
+    return b.result;
+}
+
+} // extern "C"

@@ -1,0 +1,30 @@
+// 4mc_amd/csrc/kernels.h — launchers of the gfx950 kernels (internal to the engine).
+#ifndef FOURMC_KERNELS_H
+#define FOURMC_KERNELS_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fourmc_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+// what a hash launch covers for each block descriptor
+enum {
+    FOURMC_HASH_SRC        = 0,   // XXH32(src + src_off, src_len)          -> blocks[b].xxh32
+    FOURMC_HASH_DST_RESULT = 1,   // XXH32(dst + dst_off, max(result,0))    -> blocks[b].xxh32
+    FOURMC_VERIFY_SRC      = 2    // compare XXH32(src..) with blocks[b].xxh32; mismatch -> result = BADSUM,
+                                  // match -> result = 0
+};
+
+hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, fourmc_block* d_blocks,
+                                    uint32_t n, int container_mode, hipStream_t stream);
+hipError_t fourmc_launch_lz4_encode_fast(const void* d_src, void* d_dst, fourmc_block* d_blocks,
+                                         uint32_t n, int container_mode, hipStream_t stream);
+hipError_t fourmc_launch_xxh32(const void* d_base, fourmc_block* d_blocks, uint32_t n,
+                               uint32_t seed, int mode, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

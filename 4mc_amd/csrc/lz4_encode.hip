@@ -1,0 +1,267 @@
+// 4mc_amd/csrc/lz4_encode.hip — K2: batched LZ4 "fast" block encode on gfx950, BYTE-IDENTICAL to
+// LZ4_compress_default of the reference's 64-bit little-endian build.
+//
+// Replaces native/4mc.c:301 (capacity n-1, stored fallback) and native/jniCompressor.c:91
+// (capacity LZ4_compressBound) -> native/lz4/lz4.c:1435 -> :1416 -> :1346-1367 -> :910-1302.
+//
+// The reference parse is a serial greedy walk whose bytes depend on the exact order of hash
+// table reads and overwrites (lz4.c:1059,1207,1247), on the probe stride schedule
+// (`step = searchMatchNb++ >> 6`, :1017-1027) and on backward extension (:1080).  It is
+// reproduced exactly, but 64 probes at a time:
+//   * one wavefront owns one block; its hash table (4096 x u32, or 8192 x u16 for blocks
+//     < 65547 B, lz4.c:1353) lives in LDS and is zeroed per block like LZ4_initStream (:1348);
+//   * lane l speculatively executes probe k0+l of the current search (its position follows from
+//     the closed form of the stride schedule), reads its candidate from the LDS table and tests
+//     the 4-byte match; a ballot finds the FIRST lane (serial order) that hits, or that runs
+//     into the end-of-block limit; only lanes before it commit their table writes;
+//   * two probes of one batch that fall into the same table slot would see each other's write in
+//     the serial order, so the batch is cut at the first lane that shares a (folded) slot with an
+//     earlier lane - detected with an LDS atomic-min scoreboard; the cut lane simply becomes
+//     lane 0 of the next batch.  False sharing of the scoreboard only shortens a batch;
+//   * match extension (backwards and forwards) and literal / length emission are wave-wide
+//     compares + ballots and wave-wide byte copies.
+// Per block HBM traffic: n bytes read (+ candidate re-reads that hit L2/MALL), csize written.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fourmc_gpu.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int      kHashLog   = 12;          // lz4.h:654
+constexpr int      kSmallLim  = 65536 + 11;  // lz4.c:689 LZ4_64Klimit
+constexpr uint32_t kMaxDist   = 65535;       // lz4.h:633
+constexpr int      kMfLimit   = 12, kLastLit = 5, kMinLen = 13;
+constexpr int      kScore     = 1024;        // entries of the same-slot scoreboard
+
+struct __attribute__((packed, aligned(1))) U8B  { uint64_t v; };
+struct __attribute__((packed, aligned(1))) U4B  { uint32_t v; };
+struct __attribute__((packed, aligned(1))) U16B { uint64_t a, b; };
+__device__ __forceinline__ uint64_t ld8(const uint8_t* p) { return reinterpret_cast<const U8B*>(p)->v; }
+__device__ __forceinline__ uint32_t ld4(const uint8_t* p) { return reinterpret_cast<const U4B*>(p)->v; }
+
+template <bool U32TAB> __device__ __forceinline__ uint32_t hash_at(const uint8_t* p)
+{
+    if (U32TAB) return uint32_t(((ld8(p) << 24) * 889523592379ULL) >> (64 - kHashLog));   // lz4.c:764-769
+    return (ld4(p) * 2654435761u) >> (32 - (kHashLog + 1));                                 // lz4.c:758-759
+}
+
+// offset of probe K from the first probe of a search: steps are 1 for the first 65 probes, then
+// grow by one every 64 probes (lz4.c:1014-1023)
+__device__ __forceinline__ uint32_t probe_offset(uint32_t K)
+{
+    if (K == 0) return 0;
+    const uint32_t T = K - 1, m = T >> 6, r = T & 63;
+    return 1 + T + 32 * m * (m - 1) + m * r;
+}
+
+// wave-wide byte copy, non-overlapping
+__device__ __forceinline__ void copy_bytes(uint8_t* dst, const uint8_t* src, uint32_t n, int lane)
+{
+    if (n <= 64) { if (uint32_t(lane) < n) dst[lane] = src[lane]; return; }
+    const uint32_t head = min(n, uint32_t((16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15));
+    if (uint32_t(lane) < head) dst[lane] = src[lane];
+    uint32_t k = head;
+    for (; k + 1024 <= n; k += 1024) {
+        const U16B v = *reinterpret_cast<const U16B*>(src + k + 16 * lane);
+        *reinterpret_cast<uint4*>(dst + k + 16 * lane) =
+            make_uint4(uint32_t(v.a), uint32_t(v.a >> 32), uint32_t(v.b), uint32_t(v.b >> 32));
+    }
+    for (; k < n; k += 64) { const uint32_t i = k + lane; if (i < n) dst[i] = src[i]; }
+}
+
+// emits the length continuation bytes for value `rest` (>= 0): rest/255 bytes of 255, then rest%255
+__device__ __forceinline__ uint32_t emit_len(uint8_t* op, uint32_t rest, int lane)
+{
+    const uint32_t n255 = rest / 255;
+    for (uint32_t k = 0; k < n255; k += 64) if (k + lane < n255) op[k + lane] = 255;
+    if (lane == 0) op[n255] = uint8_t(rest - n255 * 255);
+    return n255 + 1;
+}
+
+template <bool U32TAB>
+__device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, const int cap,
+                                uint32_t* tab32, uint32_t* score, const int lane)
+{
+    uint16_t* tab16 = reinterpret_cast<uint16_t*>(tab32);
+    const bool limited = cap < n + n / 255 + 16;                       // lz4.c:1352
+    uint32_t op = 0, anchor = 0;
+
+    for (int i = lane; i < (1 << kHashLog); i += 64) tab32[i] = 0;     // LZ4_initStream
+    for (int i = lane; i < kScore; i += 64) score[i] = 0xFFFFFFFFu;
+
+    auto tab_get = [&](uint32_t h) -> uint32_t { return U32TAB ? tab32[h] : uint32_t(tab16[h]); };
+    auto tab_put = [&](uint32_t h, uint32_t v) { if (U32TAB) tab32[h] = v; else tab16[h] = uint16_t(v); };
+
+    if (n >= kMinLen) {
+        const uint32_t lim = uint32_t(n) - kMfLimit + 1;               // mflimitPlusOne
+        const uint32_t matchlimit = uint32_t(n) - kLastLit;
+        if (lane == 0) tab_put(hash_at<U32TAB>(src), 0);
+        uint32_t sp = 1;                                               // first probe of the search
+        for (;;) {
+            // ------------------------------------------------------------ search (lz4.c:1014-1076)
+            uint32_t ip, cand;
+            for (uint32_t k0 = 0;; ) {
+                const uint32_t pos  = sp + probe_offset(k0 + lane);
+                const uint32_t next = sp + probe_offset(k0 + lane + 1);
+                const bool in_range = next <= lim;                     // else: this probe ends the block
+                const uint32_t rp = in_range ? pos : 0;                // keep speculative reads in bounds
+                const uint32_t h = hash_at<U32TAB>(src + rp);
+                const uint32_t c = tab_get(h);
+                // scoreboard: does an earlier lane of this batch touch the same (folded) slot?
+                uint32_t* sc = &score[h & (kScore - 1)];
+                atomicMin(sc, uint32_t(lane));
+                const bool shared = (*sc != uint32_t(lane));
+                *sc = 0xFFFFFFFFu;
+                const bool hit = in_range && (!U32TAB || c + kMaxDist >= pos) && ld4(src + c) == ld4(src + rp);
+                const unsigned long long m_cut  = __ballot(shared);
+                const unsigned long long m_term = __ballot(!in_range);
+                const unsigned long long m_hit  = __ballot(hit);
+                const int cut = m_cut ? __builtin_ctzll(m_cut) : 64;
+                // first lane (serial order) that ends this batch
+                const unsigned long long ev = (m_term | m_hit) & ((cut == 64) ? ~0ull : ((1ull << cut) - 1));
+                const int e = ev ? __builtin_ctzll(ev) : cut;
+                const bool e_is_hit = ev && ((m_hit >> e) & 1) && !((m_term >> e) & 1);
+                // commit table writes of the probes that really happen
+                if (lane < e || (lane == e && e_is_hit)) tab_put(h, pos);
+                if (ev) {
+                    if (!e_is_hit) goto last_literals;
+                    ip   = __builtin_amdgcn_readlane(pos, e);
+                    cand = __builtin_amdgcn_readlane(c, e);
+                    break;
+                }
+                k0 += e;
+            }
+            // ------------------------------------------------------------ catch up (lz4.c:1080)
+            for (;;) {
+                const uint32_t j = uint32_t(lane) + 1;
+                const bool ok = (ip >= anchor + j) && (cand >= j) && src[ip - j] == src[cand - j];
+                const unsigned long long bad = ~__ballot(ok);
+                const int back = bad ? __builtin_ctzll(bad) : 64;
+                ip -= back; cand -= back;
+                if (back < 64) break;
+            }
+            // ------------------------------------------------------------ literals (lz4.c:1083-1107)
+            uint32_t token_pos, tok;          // the token byte is written once both nibbles are known
+            {
+                const uint32_t lit = ip - anchor;
+                token_pos = op++;
+                if (limited && op + lit + (2 + 1 + kLastLit) + lit / 255 > uint32_t(cap)) return 0;
+                if (lit >= 15) { tok = 0xF0; op += emit_len(dst + op, lit - 15, lane); }
+                else tok = lit << 4;
+                copy_bytes(dst + op, src + anchor, lit, lane);
+                op += lit;
+            }
+            for (;;) {   // _next_match (lz4.c:1109-1200)
+                const uint32_t off = ip - cand;
+                if (lane == 0) { dst[op] = uint8_t(off); dst[op + 1] = uint8_t(off >> 8); }
+                op += 2;
+                // forward extension: bytes equal from ip+4 / cand+4, bounded by matchlimit
+                uint32_t mcode = 0;
+                {
+                    uint32_t a = ip + 4, b = cand + 4;
+                    for (;;) {
+                        if (a + 1024 <= matchlimit && mcode >= 64) {
+                            // 16 bytes per lane
+                            const U16B x = *reinterpret_cast<const U16B*>(src + a + 16 * lane);
+                            const U16B y = *reinterpret_cast<const U16B*>(src + b + 16 * lane);
+                            const uint64_t d0 = x.a ^ y.a, d1 = x.b ^ y.b;
+                            const uint32_t eq = d0 ? uint32_t(__builtin_ctzll(d0) >> 3)
+                                                   : (d1 ? 8u + uint32_t(__builtin_ctzll(d1) >> 3) : 16u);
+                            const unsigned long long bad = __ballot(eq < 16);
+                            if (bad) {
+                                const int l = __builtin_ctzll(bad);
+                                mcode += 16 * l + __builtin_amdgcn_readlane(eq, l);
+                                break;
+                            }
+                            mcode += 1024; a += 1024; b += 1024;
+                        } else {
+                            const uint32_t i = a + lane;
+                            const bool same = (i < matchlimit) && src[i] == src[b + lane];
+                            const unsigned long long bad = ~__ballot(same);
+                            if (bad) { mcode += __builtin_ctzll(bad); break; }
+                            mcode += 64; a += 64; b += 64;
+                        }
+                    }
+                }
+                ip += mcode + 4;
+                if (limited && op + (1 + kLastLit) + (mcode + 240) / 255 > uint32_t(cap)) return 0;
+                uint32_t tok_add;
+                if (mcode >= 15) { tok_add = 15; op += emit_len(dst + op, mcode - 15, lane); }
+                else tok_add = mcode;
+                if (lane == 0) dst[token_pos] = uint8_t(tok + tok_add);
+                anchor = ip;
+                if (ip >= lim) goto last_literals;
+                // refill ip-2, then test ip immediately (lz4.c:1207-1259)
+                if (lane == 0) tab_put(hash_at<U32TAB>(src + ip - 2), ip - 2);
+                const uint32_t h = hash_at<U32TAB>(src + ip);
+                cand = uint32_t(__builtin_amdgcn_readfirstlane(int(tab_get(h))));
+                if (lane == 0) tab_put(h, ip);
+                const bool again = (!U32TAB || cand + kMaxDist >= ip) && ld4(src + cand) == ld4(src + ip);
+                if (!__builtin_amdgcn_readfirstlane(int(again))) break;
+                token_pos = op++; tok = 0;
+            }
+            sp = ip + 1;
+        }
+    }
+last_literals:
+    {
+        const uint32_t run = uint32_t(n) - anchor;                      // lz4.c:1266-1293
+        if (limited && op + run + 1 + (run + 255 - 15) / 255 > uint32_t(cap)) return 0;
+        if (run >= 15) {
+            if (lane == 0) dst[op] = 0xF0;
+            op++;
+            op += emit_len(dst + op, run - 15, lane);
+        } else {
+            if (lane == 0) dst[op] = uint8_t(run << 4);
+            op++;
+        }
+        copy_bytes(dst + op, src + anchor, run, lane);
+        op += run;
+    }
+    return int(op);
+}
+
+// container_mode = 0: result = LZ4_compress_default(src, dst, src_len, dst_cap).
+// container_mode = 1: one iteration of fourMCcompressFilename's loop (native/4mc.c:301-329):
+//   capacity src_len-1; a result <= 0 stores the block raw (payload = input, result = src_len).
+__global__ __launch_bounds__(64)
+void lz4_encode_fast_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
+                            fourmc_block* blocks, uint32_t nblocks, int container_mode)
+{
+    __shared__ uint32_t tab[1 << kHashLog];
+    __shared__ uint32_t score[kScore];
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    const fourmc_block blk = blocks[b];
+    const uint8_t* src = src_base + blk.src_off;
+    uint8_t* dst = dst_base + blk.dst_off;
+    const int n = int(blk.src_len);
+    const int cap = container_mode ? n - 1 : int(blk.dst_cap);
+    const int lane = threadIdx.x;
+    int r;
+    if (uint32_t(n) > 0x7E000000u) r = 0;                               // lz4.c:1324
+    else if (n == 0) {                                                  // lz4.c:1325-1335
+        const bool limited = cap < 16;
+        if (limited && cap <= 0) r = 0; else { if (lane == 0) dst[0] = 0; r = 1; }
+    }
+    else if (n < kSmallLim) r = lz4_encode_block<false>(src, dst, n, cap, tab, score, lane);
+    else                    r = lz4_encode_block<true>(src, dst, n, cap, tab, score, lane);
+    if (container_mode && r <= 0) {
+        copy_bytes(dst, src, uint32_t(n), lane);
+        r = n;
+    }
+    if (lane == 0) blocks[b].result = r;
+}
+
+} // namespace
+
+extern "C" hipError_t fourmc_launch_lz4_encode_fast(const void* d_src, void* d_dst, fourmc_block* d_blocks,
+                                                    uint32_t n, int container_mode, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(lz4_encode_fast_kernel, dim3(n), dim3(64), 0, stream,
+                       static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n,
+                       container_mode);
+    return hipGetLastError();
+}

@@ -1,0 +1,67 @@
+/*
+ * include/fourmc.h — file-level API and container framing of the MI355X 4mc build.
+ *
+ * The four file functions keep the exact signatures and behaviour of the reference library API
+ * (native/4mc.h:36-41): messages on stderr gated by displayLevel, errors leave through exit()
+ * with the reference's codes (1 generic / 2 input / 3 output / 4 content, native/4mc.c:135-161),
+ * return value 0.  Internally they batch independent blocks into single HIP launches through
+ * include/fourmc_gpu.h.
+ *
+ * The fourmc_frame_* / fourmc_index_* functions are the byte-exact framing (header, block
+ * header, end mark, footer index) factored out so that it can be tested without a GPU and
+ * reused by bindings; they restate native/4mc.c:264-274,:309-312,:336-362 (writer),
+ * :575-585,:670-688 (reader) and the footer consumer
+ * java/hadoop-4mc/src/main/java/com/fing/compression/fourmc/FourMcBlockIndex.java:92-173.
+ */
+#ifndef FOURMC_H
+#define FOURMC_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- reference library API (native/4mc.h:36-41) ------------------------------------------ */
+int fourMCcompressFilename  (int displayLevel, int overwrite, char* input_filename, char* output_filename, int compressionlevel);
+int fourMcDecompressFileName(int displayLevel, int overwrite, char* input_filename, char* output_filename);
+int fourMZcompressFilename  (int displayLevel, int overwrite, char* input_filename, char* output_filename, int compressionlevel);
+int fourMZDecompressFileName(int displayLevel, int overwrite, char* input_filename, char* output_filename);
+
+/* stdin / stdout / null markers (native/4mc.h:45-52) */
+#define FOURMC_NULL_OUTPUT "null"
+#define FOURMC_STDINMARK   "stdin"
+#define FOURMC_STDOUTMARK  "stdout"
+#define FOURMC_NULMARK     "/dev/null"
+
+/* ---- framing (all fields big-endian u32; 4mc-format-spec, 4mz-format-spec) ---------------- */
+#define FOURMC_HEADERSIZE 12u
+#define FOURMC_FOOTERSIZE(nblocks) (20u + 4u * (nblocks))          /* native/4mc.c:117        */
+
+unsigned fourmc_XXH32(const void* input, size_t len, unsigned seed); /* host scalar, for framing
+                                                                       bytes and JNI xxhash32   */
+void     fourmc_frame_header(uint8_t out[12], uint32_t magic);      /* native/4mc.c:264-268    */
+/* 0 ok; 1 wrong magic; 2 wrong version; 3 wrong checksum (native/4mc.c:575-585,:870-873) */
+int      fourmc_frame_check_header(const uint8_t in[12], uint32_t magic);
+void     fourmc_frame_block_header(uint8_t out[12], uint32_t usize, uint32_t csize, uint32_t xxh32);
+void     fourmc_frame_parse_block_header(const uint8_t in[12], uint32_t* usize, uint32_t* csize, uint32_t* xxh32);
+/* Footer from ABSOLUTE file offsets of each block header (first = 12); writes
+ * FOURMC_FOOTERSIZE(n) bytes; native/4mc.c:344-358. */
+size_t   fourmc_frame_footer(uint8_t* out, uint32_t magic, const uint64_t* block_offsets, uint32_t nblocks);
+/* Parses/validates a footer image; fills absolute offsets (may be NULL).  Returns the number of
+ * blocks, or -1 bad size, -2 bad checksum, -3 bad version, -4 bad magic/size echo. */
+int64_t  fourmc_frame_parse_footer(const uint8_t* foot, size_t len, uint32_t magic, uint64_t* block_offsets);
+
+/* ---- footer-index queries (FourMcBlockIndex.java:92-173) ---------------------------------- */
+/* index of the first block whose offset is >= pos, or -1            (findNextPosition :104)    */
+int64_t  fourmc_index_find_next(const uint64_t* offsets, uint32_t n, uint64_t pos);
+/* index of the block containing pos, or -1                          (findBelongingBlockIndex)  */
+int64_t  fourmc_index_find_block(const uint64_t* offsets, uint32_t n, uint64_t pos);
+/* split alignment: start/end rounded forward to block starts        (alignSlice* :142-173)     */
+uint64_t fourmc_index_align_start(const uint64_t* offsets, uint32_t n, uint64_t start, uint64_t end);
+uint64_t fourmc_index_align_end(const uint64_t* offsets, uint32_t n, uint64_t end, uint64_t file_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,107 @@
+/*
+ * include/fourmc_gpu.h — C ABI of the MI355X block engine behind 4mc's codec call sites.
+ *
+ * This is the drop-in boundary for the hot path of fingltd/4mc (SURVEY.md §8(a),(b)): every place
+ * where the reference calls ONE codec function on ONE <=4 MiB block
+ *     native/4mc.c:301,311,323  (compress loop),  :637,645,661 (decode loop), 4mz twins :467,:810
+ *     native/jniCompressor.c:91,124,157   native/jniDecompressor.c:88
+ *     native/jniZstdCompressor.c:93,126,159   native/jniZstdDecompressor.c:90
+ * is served here, with independent blocks batched into single HIP launches on gfx950.
+ *
+ * Plain pointers and sizes only; no C++ or torch types.  `stream` is a hipStream_t passed as
+ * void* (NULL = the null stream).  All `d_` pointers are device (HBM) pointers.
+ * Every function returns FOURMC_OK or a negative FOURMC_E* code; nothing here ever falls back to
+ * a CPU codec: without a usable gfx950 device the calls fail with FOURMC_ENODEV.
+ */
+#ifndef FOURMC_GPU_H
+#define FOURMC_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FOURMC_BLOCKSIZE   (4u * 1024u * 1024u)   /* native/4mc.c:116                          */
+#define FOURMC_MAGIC_4MC   0x344D4300u            /* native/4mc.c:111                          */
+#define FOURMC_MAGIC_4MZ   0x344D5A00u            /* native/4mc.c:112                          */
+
+enum {
+    FOURMC_OK       =  0,
+    FOURMC_ENODEV   = -1,   /* no HIP device / wrong architecture                              */
+    FOURMC_EHIP     = -2,   /* a HIP runtime call failed (fourmc_gpu_last_error() has the text) */
+    FOURMC_EINVAL   = -3,
+    FOURMC_ENOMEM   = -4,
+    FOURMC_EUNSUP   = -5    /* codec/level not implemented on the device yet                   */
+};
+
+/* Codec selectors: the (function, level) pairs 4mc can reach (native/4mc.c:243-253,:411-419). */
+enum {
+    FOURMC_CODEC_LZ4_FAST = 0,   /* LZ4_compress_default            4mc -1  (Lz4Compressor)    */
+    FOURMC_CODEC_LZ4_MC   = 1,   /* LZ4_compressMC                  4mc -2                     */
+    FOURMC_CODEC_LZ4_HC   = 2,   /* LZ4_compress_HC(level 4 / 8)    4mc -3 / -4                */
+    FOURMC_CODEC_ZSTD     = 3    /* ZSTD_compress(level 1/3/6/12)   4mz -1..-4                 */
+};
+
+/* One independent block.  Offsets are relative to the base pointers given to the batch call, so
+ * one descriptor array describes a whole file image resident in HBM.  32 bytes, no padding. */
+typedef struct fourmc_block {
+    uint64_t src_off;   /* in : byte offset of the block's input                                */
+    uint64_t dst_off;   /* in : byte offset of the block's output                               */
+    uint32_t src_len;   /* in : input bytes                                                     */
+    uint32_t dst_cap;   /* in : output capacity in bytes                                        */
+    int32_t  result;    /* out: codec return value (reference convention, see each call)        */
+    uint32_t xxh32;     /* out (encode/hash) or in (4mc decode: expected checksum)              */
+} fourmc_block;
+
+/* ---- device management ------------------------------------------------------------------- */
+int         fourmc_gpu_device_count(void);           /* >=0, or FOURMC_ENODEV                    */
+int         fourmc_gpu_init(int device);             /* select device, check gfx950              */
+const char* fourmc_gpu_last_error(void);
+const char* fourmc_gpu_arch(void);                   /* "gfx950:..." of the selected device      */
+
+/* ---- raw block codecs, device resident (one launch for `n` blocks) ------------------------ */
+/* result = LZ4_decompress_safe(src, dst, src_len, dst_cap)        native/lz4/lz4.c:2345        */
+int fourmc_gpu_lz4_decompress(const void* d_src, void* d_dst, fourmc_block* d_blocks,
+                              uint32_t n, void* stream);
+/* result = LZ4_compress_default(src, dst, src_len, dst_cap)       native/lz4/lz4.c:1435
+ * (0 = does not fit dst_cap).  Payload bytes identical to the reference 64-bit LE build.      */
+int fourmc_gpu_lz4_compress_fast(const void* d_src, void* d_dst, fourmc_block* d_blocks,
+                                 uint32_t n, void* stream);
+/* xxh32 = XXH32(src + src_off, src_len, seed)                     native/lz4/xxhash.c:392      */
+int fourmc_gpu_xxh32(const void* d_src, fourmc_block* d_blocks, uint32_t n, uint32_t seed,
+                     void* stream);
+
+/* ---- container-level block ops (what one iteration of the 4mc.c loops does) --------------- */
+/* Encode: codec with capacity src_len-1 (native/4mc.c:301); result<=0 => the block is stored
+ * raw (:318-329): payload = input, result = src_len.  xxh32 = XXH32(stored payload) (:311,:323).
+ * dst_cap must be >= src_len.  `codec`/`level` as FOURMC_CODEC_*.                               */
+int fourmc_gpu_4mc_encode_blocks(const void* d_src, void* d_dst, fourmc_block* d_blocks,
+                                 uint32_t n, int codec, int level, void* stream);
+/* Decode: verify XXH32(payload)==xxh32 (native/4mc.c:637,645); src_len==dst_cap => stored copy
+ * (:635-642) else codec decode (:661).  result = decoded bytes, or
+ * FOURMC_BLK_BADSUM / FOURMC_BLK_CORRUPT (the two exit-4 conditions of the reference CLI).      */
+#define FOURMC_BLK_BADSUM   (-1000000001)
+#define FOURMC_BLK_CORRUPT  (-1000000002)
+int fourmc_gpu_4mc_decode_blocks(const void* d_src, void* d_dst, fourmc_block* d_blocks,
+                                 uint32_t n, int codec, void* stream);
+
+/* ---- host-buffer conveniences with the reference's per-block signatures ------------------- */
+/* These stage one block through HBM (H2D, one launch, D2H).  They exist so the JNI entry points
+ * keep their exact one-call-one-block contract (SURVEY.md §8(b) "Batching constraint").        */
+int      fourmc_LZ4_compressBound(int inputSize);                       /* lz4.h:212            */
+int      fourmc_LZ4_compress_default(const char* src, char* dst, int srcSize, int dstCapacity);
+int      fourmc_LZ4_decompress_safe(const char* src, char* dst, int compressedSize, int dstCapacity);
+unsigned fourmc_XXH32(const void* input, size_t len, unsigned seed);    /* GPU for len >= 1 MiB */
+
+/* Host batch: `n` blocks described by host-side descriptors over host buffers; the engine does
+ * one H2D of the inputs, one launch, one D2H of outputs + descriptors.  Used by the file API.  */
+int fourmc_host_4mc_encode(const void* src, size_t src_bytes, void* dst, size_t dst_bytes,
+                           fourmc_block* blocks, uint32_t n, int codec, int level);
+int fourmc_host_4mc_decode(const void* src, size_t src_bytes, void* dst, size_t dst_bytes,
+                           fourmc_block* blocks, uint32_t n, int codec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
