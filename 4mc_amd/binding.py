@@ -43,6 +43,7 @@ _GPU_API = {
     "fourmc_gpu_xxh32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "fourmc_gpu_4mc_encode_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
     "fourmc_gpu_4mc_decode_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
+    "fourmc_gpu_4mc_pack_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "fourmc_LZ4_compressBound": (C.c_int, [C.c_int]),
     "fourmc_LZ4_compress_default": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "fourmc_LZ4_decompress_safe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),

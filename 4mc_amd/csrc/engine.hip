@@ -149,6 +149,14 @@ int fourmc_gpu_4mc_decode_blocks(const void* d_src, void* d_dst, fourmc_block* d
     return FOURMC_OK;
 }
 
+int fourmc_gpu_4mc_pack_image(const void* d_staging, void* d_image, const fourmc_block* d_blocks,
+                              const uint64_t* d_image_off, uint32_t n, void* stream)
+{
+    if (int r = ensure_device()) return r;
+    HIP_TRY(fourmc_launch_pack_image(d_staging, d_image, d_blocks, d_image_off, n, static_cast<hipStream_t>(stream)));
+    return FOURMC_OK;
+}
+
 // ------------------------------------------------------------------------ host-buffer API
 int fourmc_LZ4_compressBound(int n) { return (unsigned)n > 0x7E000000u ? 0 : n + n / 255 + 16; }
 

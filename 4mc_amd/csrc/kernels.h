@@ -21,6 +21,8 @@ hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, fourmc_block
                                     uint32_t n, int container_mode, hipStream_t stream);
 hipError_t fourmc_launch_lz4_encode_fast(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                                          uint32_t n, int container_mode, hipStream_t stream);
+hipError_t fourmc_launch_pack_image(const void* d_staging, void* d_image, const fourmc_block* d_blocks,
+                                    const uint64_t* d_image_off, uint32_t n, hipStream_t stream);
 hipError_t fourmc_launch_xxh32(const void* d_base, fourmc_block* d_blocks, uint32_t n,
                                uint32_t seed, int mode, hipStream_t stream);
 

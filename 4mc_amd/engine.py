@@ -64,3 +64,9 @@ def decode_blocks(d_src, d_dst, batch, codec=CODEC_LZ4_FAST, stream=None):
     """One iteration of the reference's decode loop per block (native/4mc.c:603-668)."""
     check(lib().fourmc_gpu_4mc_decode_blocks(_ptr(d_src), _ptr(d_dst), batch.ptr, batch.n, codec,
                                              _stream_ptr(stream)), "fourmc_gpu_4mc_decode_blocks")
+
+
+def pack_image(d_staging, d_image, batch, d_image_off, stream=None):
+    """Block headers + payloads -> contiguous file image (native/4mc.c:309-315); d_image_off: int64/uint64 tensor."""
+    check(lib().fourmc_gpu_4mc_pack_image(_ptr(d_staging), _ptr(d_image), batch.ptr, _ptr(d_image_off), batch.n,
+                                          _stream_ptr(stream)), "fourmc_gpu_4mc_pack_image")

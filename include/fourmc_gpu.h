@@ -86,13 +86,21 @@ int fourmc_gpu_4mc_encode_blocks(const void* d_src, void* d_dst, fourmc_block* d
 int fourmc_gpu_4mc_decode_blocks(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                                  uint32_t n, int codec, void* stream);
 
+/* Pack: after fourmc_gpu_4mc_encode_blocks, copy each block's 12-byte big-endian header
+ * (usize = src_len, csize = result, xxh32; native/4mc.c:309-312) and its payload from the staging
+ * slot (d_staging + dst_off) to d_image + d_image_off[b].  d_image_off[b] is the absolute file
+ * offset of block b's header = 12 + sum_{j<b}(12 + csize_j) (native/4mc.c:293), i.e. exactly the
+ * footer-index entries; the caller (host or RCCL-gathered prefix sum) supplies them.            */
+int fourmc_gpu_4mc_pack_image(const void* d_staging, void* d_image, const fourmc_block* d_blocks,
+                              const uint64_t* d_image_off, uint32_t n, void* stream);
+
 /* ---- host-buffer conveniences with the reference's per-block signatures ------------------- */
 /* These stage one block through HBM (H2D, one launch, D2H).  They exist so the JNI entry points
  * keep their exact one-call-one-block contract (SURVEY.md §8(b) "Batching constraint").        */
 int      fourmc_LZ4_compressBound(int inputSize);                       /* lz4.h:212            */
 int      fourmc_LZ4_compress_default(const char* src, char* dst, int srcSize, int dstCapacity);
 int      fourmc_LZ4_decompress_safe(const char* src, char* dst, int compressedSize, int dstCapacity);
-unsigned fourmc_XXH32(const void* input, size_t len, unsigned seed);    /* GPU for len >= 1 MiB */
+unsigned fourmc_XXH32(const void* input, size_t len, unsigned seed);    /* host scalar: framing bytes, JNI xxhash32 */
 
 /* Host batch: `n` blocks described by host-side descriptors over host buffers; the engine does
  * one H2D of the inputs, one launch, one D2H of outputs + descriptors.  Used by the file API.  */
