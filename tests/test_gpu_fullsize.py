@@ -1,0 +1,57 @@
+"""GPU, BASELINE.json configs[1] size (2048 x 4 MiB = 8 GiB HBM resident): size-independent
+properties — replicas encode identically, every payload equals the oracle's for its base block,
+decode(encode(x)) == x over the whole corpus, one corrupted byte flags exactly one block."""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from helpers import B
+
+pytestmark = pytest.mark.gpu
+
+
+def test_8gib_roundtrip_and_replica_consistency(gpu):
+    base_n, nb = 48, 2048
+    base = helpers.corpus(base_n * B)
+    d_src = torch.from_numpy(base).cuda().repeat(-(-nb // base_n))[: nb * B].contiguous()
+    offs = np.arange(nb, dtype=np.uint64) * B
+    lens = np.full(nb, B, dtype=np.uint32)
+    enc = gpu.DeviceBatch(gpu.make_blocks(offs, offs, lens, lens))
+    d_stage = torch.empty(nb * B, dtype=torch.uint8, device="cuda")
+    gpu.encode_blocks(d_src, d_stage, enc)
+    e = enc.download()
+    # replicas of one base block give identical (csize, xxh32): idempotence across the batch
+    for b in range(nb):
+        assert (e["result"][b], e["xxh32"][b]) == (e["result"][b % base_n], e["xxh32"][b % base_n]), b
+    # the 48 distinct blocks equal the oracle's bytes (checked through size + checksum + a full compare of 6)
+    stage = d_stage[: base_n * B].cpu().numpy()
+    for b in range(base_n):
+        r, comp = helpers.orc_compress(base[b * B:(b + 1) * B], B - 1)
+        want = comp if r > 0 else base[b * B:(b + 1) * B]
+        assert e["result"][b] == len(want) and e["xxh32"][b] == helpers.orc_xxh32(want), b
+        if b % 8 == 0:
+            assert np.array_equal(stage[b * B: b * B + len(want)], want), b
+    # pack into one image, decode in place, compare all 8 GiB
+    csz = torch.from_numpy(e["result"].astype(np.int64)).cuda()
+    img_off = (torch.cumsum(csz + 12, 0) - (csz + 12) + 12).contiguous()
+    d_img = torch.zeros(int((csz + 12).sum().item()) + 4096, dtype=torch.uint8, device="cuda")
+    gpu.pack_image(d_stage, d_img, enc, img_off)
+    assert list(gpu.container.block_offsets(e["result"])) == img_off.cpu().tolist()
+    dblocks = gpu.make_blocks(img_off.cpu().numpy().astype(np.uint64) + 12, offs, e["result"].astype(np.uint32), lens, e["xxh32"])
+    dec = gpu.DeviceBatch(dblocks)
+    d_out = torch.empty(nb * B + 64, dtype=torch.uint8, device="cuda")
+    gpu.decode_blocks(d_img, d_out, dec)
+    assert bool((torch.from_numpy(dec.download()["result"].astype(np.int64)) == B).all())
+    assert torch.equal(d_out[: nb * B], d_src)
+    # block headers inside the image are the reference's big-endian triples
+    hdr = d_img[int(img_off[5]): int(img_off[5]) + 12].cpu().numpy()
+    assert [int.from_bytes(bytes(hdr[i:i + 4]), "big") for i in (0, 4, 8)] == [B, int(e["result"][5]), int(e["xxh32"][5])]
+    # one flipped byte -> exactly one BADSUM
+    victim = 1234
+    pos = int(img_off[victim]) + 12 + 77
+    d_img[pos] ^= 0x40
+    dec = gpu.DeviceBatch(dblocks)
+    gpu.decode_blocks(d_img, d_out, dec)
+    r = dec.download()["result"]
+    assert r[victim] == gpu.BLK_BADSUM and int((r != B).sum()) == 1

@@ -1,0 +1,99 @@
+"""CPU: pins the oracle (oracle/*.c) against the golden vectors generated from the reference
+itself (tests/golden/make_golden.py) and, when oracle/_ref is built, against the reference's own
+compiled sources on seeded + fuzzed inputs.  No GPU, no product code."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from helpers import B
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_xxh32_known_answers():
+    for k in json.load(open(os.path.join(G, "xxh32_kat.json"))):
+        d = np.frombuffer(bytes.fromhex(k["hex"]), dtype=np.uint8)
+        assert helpers.orc_xxh32(d, k["seed"]) == k["xxh32"]
+
+
+def test_small_container_files_match_reference_cli():
+    files = json.load(open(os.path.join(G, "small_files.json")))
+    for name, f in files.items():
+        data = np.frombuffer(bytes.fromhex(f["input_hex"]), dtype=np.uint8)
+        img = helpers.orc_container(data)
+        assert img.tobytes().hex() == f["4mc_fast_hex"], name
+        n, out, used = helpers.orc_container_decode(img, len(data))
+        assert n == len(data) and used == len(img) and np.array_equal(out, data), name
+    # vectors quoted in SURVEY.md §8(c)
+    assert files["empty"]["4mc_fast_hex"].endswith("849b8d65")
+    assert "0000003b000000100f7fec0a6f68656c6c6f2006001d5068656c6c6f" in files["hello10"]["4mc_fast_hex"]
+
+
+def test_corpus_manifest_lz4_fast():
+    m = json.load(open(os.path.join(G, "corpus_manifest.json")))
+    data = helpers.corpus(m["corpus"]["bytes"], m["corpus"]["first_block"], m["corpus"]["seed"])
+    assert hashlib.sha256(data.tobytes()).hexdigest() == m["corpus"]["sha256"], "corpus generator drifted"
+    lvl = m["levels"]["4mc-1"]
+    img = helpers.orc_container(data)
+    assert len(img) == lvl["file_bytes"] and hashlib.sha256(img.tobytes()).hexdigest() == lvl["sha256"]
+    for b, (u, c, s) in enumerate(lvl["blocks"]):
+        blk = data[b * B: b * B + u]
+        r, comp = helpers.orc_compress(blk, u - 1)
+        payload = comp if r > 0 else blk
+        assert (len(payload), helpers.orc_xxh32(payload)) == (c, s), b
+    assert img.tobytes().hex().endswith(lvl["footer_hex"])
+
+
+def test_decoder_roundtrip_edges():
+    for name, d in helpers.edge_inputs().items():
+        r, comp = helpers.orc_compress(d)
+        assert r > 0
+        n, out = helpers.orc_decompress(comp, len(d))
+        assert n == len(d) and np.array_equal(out, d), name
+
+
+@pytest.mark.skipif(helpers.ref() is None, reason="oracle/_ref not built (needs /root/reference)")
+def test_port_equals_reference_sources():
+    ref = helpers.ref()
+    rng = np.random.default_rng(3)
+    inputs = dict(helpers.edge_inputs())
+    for ln in (1, 2, 11, 12, 13, 14, 64, 65, 4095, 65535, 65546, 65547, 65548):
+        inputs[f"rnd{ln}"] = (rng.integers(0, 4, ln) * 17).astype(np.uint8)
+    for name, d in inputs.items():
+        bound = helpers.oracle().orc_lz4_compress_bound(len(d))
+        for cap in (bound, max(len(d) - 1, 0), max(len(d) // 2, 0)):
+            out = np.zeros(bound + 64, np.uint8)
+            r_ref = ref.LZ4_compress_default(d.ctypes.data, out.ctypes.data, len(d), cap)
+            r, comp = helpers.orc_compress(d, cap)
+            assert r == r_ref, (name, cap)
+            assert np.array_equal(comp, out[:max(r_ref, 0)]), (name, cap)
+        assert helpers.orc_xxh32(d, 5) == ref.XXH32(d.ctypes.data, len(d), 5)
+    # fuzzed streams: same accept/reject and the same negative codes
+    n_checked = 0
+    for name in ("text_60k", "period37", "lit_then_run", "hello10", "far_repeat"):
+        d = inputs[name][:120000]
+        _, comp = helpers.orc_compress(d)
+        for t in range(300):
+            m = comp.copy()
+            k = t % 4
+            if k == 0: m[rng.integers(0, len(m))] ^= 1 << rng.integers(0, 8)
+            elif k == 1: m = m[: rng.integers(1, len(m))]
+            elif k == 2:
+                i = rng.integers(0, len(m)); m[i:i + 3] = rng.integers(0, 256, len(m[i:i + 3]), dtype=np.uint8)
+            else: m = np.concatenate([m, rng.integers(0, 256, rng.integers(1, 9), dtype=np.uint8)])
+            cap = len(d) + (0 if t % 2 else 100)
+            r, out = helpers.orc_decompress(m, cap)
+            if r == -(2 ** 31):
+                continue                      # offset 0: undefined behaviour in the reference
+            o2 = np.zeros(cap + 64, np.uint8)
+            r_ref = ref.LZ4_decompress_safe(m.ctypes.data, o2.ctypes.data, len(m), cap)
+            assert r == r_ref, (name, t, r, r_ref)
+            if r >= 0:
+                assert np.array_equal(out, o2[:r])
+            n_checked += 1
+    assert n_checked > 1000
