@@ -17,6 +17,7 @@
 //     period so that every step is a full-width copy instead of a byte-serial chain.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "fourmc_gpu.h"
 #include "kernels.h"
 
@@ -281,13 +282,183 @@ void lz4_decode_exact_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
     if (threadIdx.x == 0) blocks[b].result = r;
 }
 
+
+// ================================================================================================
+// Fast path ("batch" decoder).  Same block format, same results on every stream it accepts; any
+// irregularity (rule violation, offset beyond the produced output, odd end-of-block shape) makes it
+// return kRetry and the exact kernel above redoes the block, so error codes stay the reference's.
+//
+// Instead of one sequence per step it takes a 64-byte window of the compressed stream and
+//   1. treats EVERY byte as a candidate token in parallel (lane j: literal count, next-token slot),
+//   2. walks the chain of real tokens with v_readlane only (no memory in the serial part),
+//   3. prefix-sums the output sizes of all sequences found (typically 6-12),
+//   4. produces the batch's output 64 bytes per step in OUTPUT order: each lane finds the sequence
+//      that owns its byte (LDS owner map + max-scan), literals are pulled from the window register
+//      with a lane permute, match bytes whose source precedes the step are loaded from the
+//      block's own output, sources inside the step are resolved by pointer jumping over lanes.
+// Long literal runs / long matches (length nibble 15) and the block tail take the one-sequence
+// path, which is already 64 bytes wide per step.
+constexpr int kRetry = -1000000003;      // internal: "let the exact kernel decide"
+constexpr int kOwnBytes = 768;           // >= max bytes one window can produce (21 x 32 = 672)
+
+__device__ __forceinline__ uint32_t scan_add(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d); if (lane >= d) v += t; }
+    return v;
+}
+__device__ __forceinline__ uint32_t scan_max(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d); if (lane >= d) v = max(v, t); }
+    return v;
+}
+
+__device__ int lz4_decode_block_fast(const uint8_t* src, int csize, uint8_t* dst, int cap,
+                                     uint8_t* lds, uint8_t* own, int lane)
+{
+    if (cap < 64 || csize < 1) return kRetry;
+    Stream s; s.init(src, csize, lds, lane);
+    const int iend = csize, oend = cap;
+    int ip = 0, op = 0;
+
+    for (;;) {
+        // ---------------------------------------------------------------- batch of simple sequences
+        if (ip + 64 + 16 <= iend && op + kOwnBytes + 16 <= oend) {
+            s.reload(ip);
+            const uint32_t b = s.la;
+            const uint32_t L = b >> 4, Mn = b & 15;
+            const uint32_t nxt = uint32_t(lane) + 3 + L;
+            const unsigned long long okmask = __ballot(L != 15 && Mn != 15 && nxt <= 64);
+            unsigned long long tokmask = 0;
+            uint32_t pos = 0;
+            while (pos < 64 && ((okmask >> pos) & 1)) {
+                tokmask |= 1ull << pos;
+                pos = uint32_t(__builtin_amdgcn_readlane(int(nxt), int(pos)));
+            }
+            if (tokmask) {
+                const bool is_tok = (tokmask >> lane) & 1;
+                const uint32_t sz = is_tok ? L + Mn + 4 : 0;
+                const uint32_t incl = scan_add(sz, lane);
+                const uint32_t ostart = incl - sz;
+                const uint32_t T = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+                const uint32_t lo = __shfl(b, (lane + 1 + int(L)) & 63), hi = __shfl(b, (lane + 2 + int(L)) & 63);
+                const uint32_t off = lo | (hi << 8);
+                const bool bad = is_tok && (off == 0 || off > uint32_t(op) + ostart + L);
+                if (__ballot(bad)) return kRetry;
+                const uint32_t pack = ostart | (L << 12) | (off << 16);
+                // owner map: own[o] = token lane + 1 at the first output byte of each sequence
+                for (uint32_t k = 4u * lane; k < T; k += 256) *reinterpret_cast<uint32_t*>(own + k) = 0;
+                if (is_tok) own[ostart] = uint8_t(lane + 1);
+                uint32_t carry = 0;
+                for (uint32_t c0 = 0; c0 < T; c0 += 64) {
+                    const uint32_t o = c0 + lane;
+                    const bool live = o < T;
+                    uint32_t m = live ? uint32_t(own[o]) : 0u;
+                    m = max(scan_max(m, lane), carry);
+                    carry = uint32_t(__builtin_amdgcn_readlane(int(m), 63));
+                    const int tl = int(m) - 1;                                  // owning token lane
+                    const uint32_t P = __shfl(pack, tl & 63);
+                    const uint32_t rel = o - (P & 0xFFF);
+                    const uint32_t Lt = (P >> 12) & 15, offt = P >> 16;
+                    const bool is_lit = rel < Lt;
+                    uint32_t v = __shfl(b, (tl + 1 + int(rel)) & 63);          // literal byte from the window
+                    const int sp = op + int(o) - int(offt);                     // absolute source of a match byte
+                    const int cs = op + int(c0);
+                    const bool from_mem = live && !is_lit && sp < cs;
+                    if (from_mem) v = dst[sp];
+                    bool done = !live || is_lit || from_mem;
+                    int dep = sp - cs;                                          // lane that produces my byte
+                    while (__ballot(!done)) {                                   // pointer jumping, <= 6 rounds
+                        const int d = dep & 63;
+                        const uint32_t v2 = __shfl(v, d);
+                        const int dn = __shfl(int(done), d);
+                        const int dd = __shfl(dep, d);
+                        if (!done) { if (dn) { v = v2; done = true; } else dep = dd; }
+                    }
+                    if (live) dst[op + o] = uint8_t(v);
+                }
+                op += int(T);
+                ip += int(pos);
+                continue;
+            }
+        }
+        // ---------------------------------------------------------------- one general sequence (strict rules)
+        if (ip >= iend) return kRetry;
+        if (ip < s.la_pos || ip + 24 > s.la_pos + 64) s.reload(ip);
+        const uint32_t token = s.get(ip); ip++;
+        int lit = int(token >> 4), mlen = int(token & 15);
+        if (lit == 15) { if (!more_len(s, ip, iend - 15, true, lit)) return kRetry; }
+        if (op + lit > oend - 12 || ip + lit > iend - 8) {
+            if (ip + lit != iend || op + lit > oend) return kRetry;
+            copy_literals(s, src, dst, ip, op, lit);
+            return op + lit;
+        }
+        copy_literals(s, src, dst, ip, op, lit);
+        ip += lit; op += lit;
+        const int off = int(s.get(ip)) | (int(s.get(ip + 1)) << 8);
+        ip += 2;
+        if (mlen == 15) { if (!more_len(s, ip, iend - 4, false, mlen)) return kRetry; }
+        mlen += 4;
+        if (off == 0 || off > op || op + mlen > oend - 5) return kRetry;
+        copy_match(dst, op, off, mlen, lane);
+        op += mlen;
+    }
+}
+
+// retry_only = 0: fast path for every block (container rules as in the exact kernel);
+__global__ __launch_bounds__(64)
+void lz4_decode_fast_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
+                            fourmc_block* blocks, uint32_t nblocks, int container_mode)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
+    __shared__ __attribute__((aligned(16))) uint8_t own[kOwnBytes];
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    const fourmc_block blk = blocks[b];
+    const uint8_t* src = src_base + blk.src_off;
+    uint8_t* dst = dst_base + blk.dst_off;
+    int r;
+    if (container_mode) {
+        if (blk.result == FOURMC_BLK_BADSUM) return;
+        if (blk.src_len == blk.dst_cap) { wave_copy(dst, src, int(blk.src_len), threadIdx.x); r = int(blk.src_len); }
+        else r = lz4_decode_block_fast(src, int(blk.src_len), dst, int(blk.dst_cap), ring, own, threadIdx.x);
+    } else {
+        r = lz4_decode_block_fast(src, int(blk.src_len), dst, int(blk.dst_cap), ring, own, threadIdx.x);
+    }
+    if (threadIdx.x == 0) blocks[b].result = r;
+}
+
+// second pass: blocks the fast path handed back (result == kRetry) are decoded by the exact walker
+__global__ __launch_bounds__(64)
+void lz4_decode_retry_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
+                             fourmc_block* blocks, uint32_t nblocks, int container_mode)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    const fourmc_block blk = blocks[b];
+    if (blk.result != kRetry) return;
+    int r = lz4_decode_block(src_base + blk.src_off, int(blk.src_len), dst_base + blk.dst_off, int(blk.dst_cap),
+                             ring, threadIdx.x);
+    if (container_mode && r < 0) r = FOURMC_BLK_CORRUPT;
+    if (threadIdx.x == 0) blocks[b].result = r;
+}
+
 } // namespace
 
 extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                                                uint32_t n, int container_mode, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(lz4_decode_exact_kernel, dim3(n), dim3(64), 0, stream,
-                       static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n, container_mode);
+    const uint8_t* s8 = static_cast<const uint8_t*>(d_src);
+    uint8_t* d8 = static_cast<uint8_t*>(d_dst);
+    static const bool exact_only = getenv("FOURMC_DECODE_EXACT") != nullptr;     // debugging / A-B switch
+    if (exact_only) {
+        hipLaunchKernelGGL(lz4_decode_exact_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(lz4_decode_fast_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
+    hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
     return hipGetLastError();
 }
