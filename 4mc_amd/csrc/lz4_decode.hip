@@ -57,9 +57,10 @@ struct Stream {
         pend = fetch(fill_hi);
     }
     __device__ __forceinline__ void init(const uint8_t* src, int csize, uint8_t* lds, int ln) {
-        const uintptr_t a = reinterpret_cast<uintptr_t>(src);
-        abase = reinterpret_cast<const uint8_t*>(a & ~uintptr_t(15));
-        delta = int(a & 15);
+        // pointer arithmetic (not an integer round trip) keeps the address space known: global_load,
+        // not flat_load - a pending FLAT access would force every later s_waitcnt to vmcnt(0)
+        delta = int(reinterpret_cast<uintptr_t>(src) & 15);
+        abase = src - delta;
         qend = delta + csize;
         ring = lds; lane = ln;
         fill_hi = 0;
@@ -110,7 +111,7 @@ __device__ __forceinline__ bool more_len(Stream& s, int& ip, int lim, bool check
 
 // dst[0..n) = src[0..n), non-overlapping, any alignment: byte head up to a 16 B boundary of dst,
 // then 16 B per lane (unaligned loads are legal on gfx950, stores are aligned), byte tail.
-__device__ __noinline__ void wave_copy(uint8_t* dst, const uint8_t* src, int n, int lane)
+__device__ __forceinline__ void wave_copy(uint8_t* dst, const uint8_t* src, int n, int lane)
 {
     const int head = min(n, int((16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15));
     if (lane < head) dst[lane] = src[lane];
@@ -180,7 +181,7 @@ __device__ __forceinline__ void copy_match(uint8_t* dst, int op, int off, int n,
 }
 
 // One wave decodes one block.  Mirrors the control flow restated in oracle/lz4_port.c.
-__device__ int lz4_decode_block(const uint8_t* src, int csize, uint8_t* dst, int cap,
+__device__ __forceinline__ int lz4_decode_block(const uint8_t* src, int csize, uint8_t* dst, int cap,
                                 uint8_t* lds, int lane)
 {
     if (cap < 0) return -1;
@@ -299,37 +300,62 @@ void lz4_decode_exact_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
 // Long literal runs / long matches (length nibble 15) and the block tail take the one-sequence
 // path, which is already 64 bytes wide per step.
 constexpr int kRetry = -1000000003;      // internal: "let the exact kernel decide"
-constexpr int kOwnBytes = 768;           // >= max bytes one window can produce (21 x 32 = 672)
+constexpr int kOwnBytes = 4096;          // cap on the bytes one batch may produce (owner map size)
 
-__device__ __forceinline__ uint32_t scan_add(uint32_t v, int lane)
+// Wave64 inclusive scans on the VALU cross-lane network (DPP row shifts + row broadcasts, no LDS):
+// 4 row_shr steps scan each row of 16 lanes, row_bcast15 / row_bcast31 carry the row totals.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v)
+{ return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, ROWMASK, 0xf, false)); }
+
+__device__ __forceinline__ uint32_t scan_add(uint32_t v, int)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d); if (lane >= d) v += t; }
+    v += dpp0<0x111, 0xf>(v); v += dpp0<0x112, 0xf>(v); v += dpp0<0x114, 0xf>(v); v += dpp0<0x118, 0xf>(v);
+    v += dpp0<0x142, 0xa>(v);            // row_bcast15 -> rows 1,3
+    v += dpp0<0x143, 0xc>(v);            // row_bcast31 -> rows 2,3
     return v;
 }
-__device__ __forceinline__ uint32_t scan_max(uint32_t v, int lane)
+__device__ __forceinline__ uint32_t scan_max(uint32_t v, int)      // values are >= 0, identity 0
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d); if (lane >= d) v = max(v, t); }
+    v = max(v, dpp0<0x111, 0xf>(v)); v = max(v, dpp0<0x112, 0xf>(v)); v = max(v, dpp0<0x114, 0xf>(v)); v = max(v, dpp0<0x118, 0xf>(v));
+    v = max(v, dpp0<0x142, 0xa>(v));
+    v = max(v, dpp0<0x143, 0xc>(v));
     return v;
 }
 
-__device__ int lz4_decode_block_fast(const uint8_t* src, int csize, uint8_t* dst, int cap,
+__device__ __forceinline__ int lz4_decode_block_fast(const uint8_t* src, int csize, uint8_t* dst, int cap,
                                      uint8_t* lds, uint8_t* own, int lane)
 {
     if (cap < 64 || csize < 1) return kRetry;
     Stream s; s.init(src, csize, lds, lane);
     const int iend = csize, oend = cap;
     int ip = 0, op = 0;
+    // One 64-byte step of output is kept PENDING in registers: it is stored only after the next
+    // step's loads have been issued, so a step waits for its own loads (vmcnt leaves the younger
+    // store outstanding) and never for a store acknowledgement.  Sources that fall into the
+    // pending step are forwarded from its registers.
+    uint32_t pv = 0; int p_base = 0, p_n = 0;
 
     for (;;) {
-        // ---------------------------------------------------------------- batch of simple sequences
-        if (ip + 64 + 16 <= iend && op + kOwnBytes + 16 <= oend) {
+        // ---------------------------------------------------------------- batch of sequences inside one window
+        if (ip + 64 + 16 <= iend && op + kOwnBytes + 64 + 16 <= oend) {
+            // w: 4 consecutive stream bytes per lane (lane j = bytes ip+j .. ip+j+3)
             s.reload(ip);
-            const uint32_t b = s.la;
-            const uint32_t L = b >> 4, Mn = b & 15;
-            const uint32_t nxt = uint32_t(lane) + 3 + L;
-            const unsigned long long okmask = __ballot(L != 15 && Mn != 15 && nxt <= 64);
+            const int q0 = ip + s.delta + lane;
+            const uint32_t w = s.la | (uint32_t(s.ring[(q0 + 1) & (kRing - 1)]) << 8) |
+                               (uint32_t(s.ring[(q0 + 2) & (kRing - 1)]) << 16) | (uint32_t(s.ring[(q0 + 3) & (kRing - 1)]) << 24);
+            const uint32_t b = w & 0xff, b1 = (w >> 8) & 0xff;
+            const uint32_t L0 = b >> 4, M0 = b & 15;
+            // literal count: nibble, or 15 + ONE continuation byte (longer runs take the general path)
+            const uint32_t L = (L0 == 15) ? 15 + b1 : L0;
+            const uint32_t lhdr = (L0 == 15) ? 2 : 1;                   // token (+ continuation byte)
+            const uint32_t offpos = uint32_t(lane) + lhdr + L;         // window slot of the offset's low byte
+            const uint32_t wo = __shfl(w, offpos & 63);                 // offset lo, hi, first match continuation byte
+            const uint32_t e1 = (wo >> 16) & 0xff;
+            const uint32_t ml = (M0 == 15) ? 19 + e1 : M0 + 4;
+            const uint32_t nxt = offpos + 2 + (M0 == 15 ? 1 : 0);
+            const bool ok = (L0 != 15 || b1 != 255) && (M0 != 15 || e1 != 255) && nxt <= 64;
+            const unsigned long long okmask = __ballot(ok);
             unsigned long long tokmask = 0;
             uint32_t pos = 0;
             while (pos < 64 && ((okmask >> pos) & 1)) {
@@ -337,20 +363,28 @@ __device__ int lz4_decode_block_fast(const uint8_t* src, int csize, uint8_t* dst
                 pos = uint32_t(__builtin_amdgcn_readlane(int(nxt), int(pos)));
             }
             if (tokmask) {
-                const bool is_tok = (tokmask >> lane) & 1;
-                const uint32_t sz = is_tok ? L + Mn + 4 : 0;
-                const uint32_t incl = scan_add(sz, lane);
+                bool is_tok = (tokmask >> lane) & 1;
+                uint32_t sz = is_tok ? L + ml : 0;
+                uint32_t incl = scan_add(sz, lane);
+                uint32_t T = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+                if (T > uint32_t(kOwnBytes)) {                           // cap the batch (first sequence always fits)
+                    tokmask = __ballot(is_tok && incl <= uint32_t(kOwnBytes));
+                    const int last = 63 - __builtin_clzll(tokmask);
+                    pos = uint32_t(__builtin_amdgcn_readlane(int(nxt), last));
+                    T = uint32_t(__builtin_amdgcn_readlane(int(incl), last));
+                    is_tok = (tokmask >> lane) & 1;
+                    sz = is_tok ? sz : 0;
+                }
                 const uint32_t ostart = incl - sz;
-                const uint32_t T = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
-                const uint32_t lo = __shfl(b, (lane + 1 + int(L)) & 63), hi = __shfl(b, (lane + 2 + int(L)) & 63);
-                const uint32_t off = lo | (hi << 8);
+                const uint32_t off = wo & 0xffff;
                 const bool bad = is_tok && (off == 0 || off > uint32_t(op) + ostart + L);
                 if (__ballot(bad)) return kRetry;
-                const uint32_t pack = ostart | (L << 12) | (off << 16);
+                const uint32_t pack = ostart | (L << 13) | ((lhdr - 1) << 19);
                 // owner map: own[o] = token lane + 1 at the first output byte of each sequence
                 for (uint32_t k = 4u * lane; k < T; k += 256) *reinterpret_cast<uint32_t*>(own + k) = 0;
                 if (is_tok) own[ostart] = uint8_t(lane + 1);
                 uint32_t carry = 0;
+                if (p_n == 0) p_base = op;
                 for (uint32_t c0 = 0; c0 < T; c0 += 64) {
                     const uint32_t o = c0 + lane;
                     const bool live = o < T;
@@ -359,15 +393,26 @@ __device__ int lz4_decode_block_fast(const uint8_t* src, int csize, uint8_t* dst
                     carry = uint32_t(__builtin_amdgcn_readlane(int(m), 63));
                     const int tl = int(m) - 1;                                  // owning token lane
                     const uint32_t P = __shfl(pack, tl & 63);
-                    const uint32_t rel = o - (P & 0xFFF);
-                    const uint32_t Lt = (P >> 12) & 15, offt = P >> 16;
+                    const uint32_t offt = __shfl(off, tl & 63);
+                    const uint32_t rel = o - (P & 0x1FFF);
+                    const uint32_t Lt = (P >> 13) & 63, hdr = 1 + ((P >> 19) & 1);
                     const bool is_lit = rel < Lt;
-                    uint32_t v = __shfl(b, (tl + 1 + int(rel)) & 63);          // literal byte from the window
+                    uint32_t v = __shfl(b, (tl + int(hdr) + int(rel)) & 63);    // literal byte from the window
                     const int sp = op + int(o) - int(offt);                     // absolute source of a match byte
-                    const int cs = op + int(c0);
-                    const bool from_mem = live && !is_lit && sp < cs;
-                    if (from_mem) v = dst[sp];
-                    bool done = !live || is_lit || from_mem;
+                    const int cs = op + int(c0);                                // == p_base + p_n while a step is pending
+                    const bool is_match = live && !is_lit;
+                    const bool from_mem = is_match && sp < cs - p_n;
+                    const bool in_pend = is_match && sp >= cs - p_n && sp < cs;
+                    const uint32_t ld = dst[from_mem ? sp : 0];                 // issue this step's loads (branch-free) ...
+                    // ... then store the previous step.  All 64 lanes store (no branch, so the load above
+                    // and this store sit in one basic block and the wait below becomes vmcnt(1)): lanes
+                    // >= p_n hit [cs, cs+64-p_n), bytes this very step re-writes later and that nothing
+                    // reads from memory before then (they are served from the pending registers).
+                    dst[p_base + lane] = uint8_t(pv);
+                    const uint32_t fw = __shfl(pv, (sp - p_base) & 63);
+                    if (in_pend) v = fw;
+                    if (from_mem) v = ld;
+                    bool done = !is_match || from_mem || in_pend;
                     int dep = sp - cs;                                          // lane that produces my byte
                     while (__ballot(!done)) {                                   // pointer jumping, <= 6 rounds
                         const int d = dep & 63;
@@ -376,7 +421,7 @@ __device__ int lz4_decode_block_fast(const uint8_t* src, int csize, uint8_t* dst
                         const int dd = __shfl(dep, d);
                         if (!done) { if (dn) { v = v2; done = true; } else dep = dd; }
                     }
-                    if (live) dst[op + o] = uint8_t(v);
+                    pv = v; p_base = cs; p_n = min(64, int(T - c0));
                 }
                 op += int(T);
                 ip += int(pos);
@@ -384,6 +429,8 @@ __device__ int lz4_decode_block_fast(const uint8_t* src, int csize, uint8_t* dst
             }
         }
         // ---------------------------------------------------------------- one general sequence (strict rules)
+        if (lane < p_n) dst[p_base + lane] = uint8_t(pv);
+        p_n = 0; p_base = 0;
         if (ip >= iend) return kRetry;
         if (ip < s.la_pos || ip + 24 > s.la_pos + 64) s.reload(ip);
         const uint32_t token = s.get(ip); ip++;

@@ -25,9 +25,8 @@ __device__ __forceinline__ uint32_t rotl(uint32_t x, int r) { return (x << r) | 
 
 __device__ uint32_t xxh32_block(const uint8_t* p, uint32_t len, uint32_t seed, uint8_t* ring, int lane)
 {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const uint8_t* abase = reinterpret_cast<const uint8_t*>(a & ~uintptr_t(15));
-    const uint32_t delta = uint32_t(a & 15);
+    const uint32_t delta = uint32_t(reinterpret_cast<uintptr_t>(p) & 15);
+    const uint8_t* abase = p - delta;          // pointer arithmetic keeps the global address space (no flat_load)
     const uint32_t qend = delta + len;                 // end in aligned coordinates
     const uint32_t nstripes = len >> 4;
     const uint32_t sh = delta & 3;
