@@ -39,6 +39,24 @@ struct Arena {
     hipStream_t stream = nullptr;
 } g_arena;
 
+// scratch for regenerated zstd literals: one 128 KiB slot per block of the largest batch seen
+void*  g_zscratch = nullptr;
+size_t g_zscratch_cap = 0;
+std::mutex g_zmu;
+
+int zstd_scratch(uint32_t n, void** out)
+{
+    std::lock_guard<std::mutex> lk(g_zmu);
+    const size_t need = fourmc_zstd_scratch_bytes(n);
+    if (need > g_zscratch_cap) {
+        if (g_zscratch) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g_zscratch)); g_zscratch = nullptr; g_zscratch_cap = 0; }
+        HIP_TRY(hipMalloc(&g_zscratch, need));
+        g_zscratch_cap = need;
+    }
+    *out = g_zscratch;
+    return FOURMC_OK;
+}
+
 int arena_reserve(size_t src_bytes, size_t dst_bytes, size_t nblk)
 {
     if (!g_arena.stream) HIP_TRY(hipStreamCreateWithFlags(&g_arena.stream, hipStreamNonBlocking));
@@ -113,6 +131,15 @@ int fourmc_gpu_lz4_compress_fast(const void* d_src, void* d_dst, fourmc_block* d
     return FOURMC_OK;
 }
 
+int fourmc_gpu_zstd_decompress(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, void* stream)
+{
+    if (int r = ensure_device()) return r;
+    void* scratch = nullptr;
+    if (int r = zstd_scratch(n, &scratch)) return r;
+    HIP_TRY(fourmc_launch_zstd_decode(d_src, d_dst, d_blocks, n, scratch, 0, static_cast<hipStream_t>(stream)));
+    return FOURMC_OK;
+}
+
 int fourmc_gpu_xxh32(const void* d_src, fourmc_block* d_blocks, uint32_t n, uint32_t seed, void* stream)
 {
     if (int r = ensure_device()) return r;
@@ -140,6 +167,13 @@ int fourmc_gpu_4mc_decode_blocks(const void* d_src, void* d_dst, fourmc_block* d
 {
     if (int r = ensure_device()) return r;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (codec == FOURMC_CODEC_ZSTD) {              // .4mz: every level decodes with the same kernel
+        void* scratch = nullptr;
+        if (int r = zstd_scratch(n, &scratch)) return r;
+        HIP_TRY(fourmc_launch_xxh32(d_src, d_blocks, n, 0, FOURMC_VERIFY_SRC, s));
+        HIP_TRY(fourmc_launch_zstd_decode(d_src, d_dst, d_blocks, n, scratch, 1, s));
+        return FOURMC_OK;
+    }
     if (codec != FOURMC_CODEC_LZ4_FAST && codec != FOURMC_CODEC_LZ4_MC && codec != FOURMC_CODEC_LZ4_HC) {
         snprintf(g_err, sizeof g_err, "codec %d not implemented on the device yet", codec);
         return FOURMC_EUNSUP;
@@ -175,6 +209,7 @@ static int host_roundtrip(const void* src, size_t src_bytes, void* dst, size_t d
         case 1: r = fourmc_gpu_4mc_decode_blocks(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, codec, s); break;
         case 2: r = fourmc_gpu_lz4_compress_fast(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
         case 3: r = fourmc_gpu_lz4_decompress(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
+        case 5: r = fourmc_gpu_zstd_decompress(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
         default: r = fourmc_gpu_xxh32(g_arena.d_src, g_arena.d_blk, n, (uint32_t)level, s); break;
     }
     if (r) return r;
@@ -220,6 +255,17 @@ int fourmc_LZ4_decompress_safe(const char* src, char* dst, int compressedSize, i
     int r = host_roundtrip(src, (size_t)compressedSize, dst, (size_t)dstCapacity, &b, 1, 3, FOURMC_CODEC_LZ4_FAST, 0);
     if (r) { fprintf(stderr, "4mc-gpu: %s\n", g_err); return -1; }
     return b.result;
+}
+
+size_t fourmc_ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, size_t compressedSize)
+{
+    const size_t kCorrupt = (size_t)-20;           /* ZSTD_error_corruption_detected: ZSTD_isError() is true */
+    if (compressedSize > 0x7FFFFFFFu || dstCapacity > 0x7FFFFFFFu) return (size_t)-72;   /* srcSize_wrong */
+    fourmc_block b; memset(&b, 0, sizeof b);
+    b.src_len = (uint32_t)compressedSize; b.dst_cap = (uint32_t)dstCapacity;
+    int r = host_roundtrip(src, compressedSize, dst, dstCapacity, &b, 1, 5, FOURMC_CODEC_ZSTD, 0);
+    if (r) { fprintf(stderr, "4mc-gpu: %s\n", g_err); return (size_t)-1; }
+    return b.result < 0 ? kCorrupt : (size_t)b.result;
 }
 
 } // extern "C"

@@ -99,14 +99,20 @@ JNIEXPORT jint JNICALL
 Java_com_fing_compression_fourmc_ZstdDecompressor_decompressBytesDirect(JNIEnv* env, jobject self)
 {
     jobject cbuf = (*env)->GetObjectField(env, self, zd_cbuf);
+    unsigned clen = (unsigned)(*env)->GetIntField(env, self, zd_clen);
     jobject ubuf = (*env)->GetObjectField(env, self, zd_ubuf);
+    unsigned cap = (unsigned)(*env)->GetIntField(env, self, zd_bufsize);
     char* dst = (char*)(*env)->GetDirectBufferAddress(env, ubuf);
     const char* src = (const char*)(*env)->GetDirectBufferAddress(env, cbuf);
-    int r = -1;                       /* zstd block decode is not on the device yet */
-    char msg[256];
+    int r;
     if (!dst || !src) return 0;
-    snprintf(msg, sizeof msg, "LZ4_decompress_safe returned: %d", r);   /* text as in jniZstdDecompressor.c:96 */
-    fourmc_jni_throw_internal(env, msg);
+    r = (int)fourmc_ZSTD_decompress(dst, cap, src, clen);     /* int truncation as in jniZstdDecompressor.c:73,90 */
+    if (r >= 0) (*env)->SetIntField(env, self, zd_clen, 0);
+    else {
+        char msg[256];
+        snprintf(msg, sizeof msg, "LZ4_decompress_safe returned: %d", r);   /* text as in jniZstdDecompressor.c:96 */
+        fourmc_jni_throw_internal(env, msg);
+    }
     return r;
 }
 

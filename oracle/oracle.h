@@ -52,6 +52,11 @@ int64_t orc_container_decompress(const uint8_t* src, size_t n, uint8_t* dst, siz
                                  uint32_t magic, orc_block_codec_fn decompress, void* ctx,
                                  size_t* consumed);
 
+/* ZSTD_decompress for 4mz payloads (zstd_port.cpp) - native/zstd/decompress/zstd_decompress.c:1112.
+ * Returns decoded bytes or < 0 where the reference reports an error. */
+int64_t orc_zstd_decompress(const uint8_t* src, size_t csize, uint8_t* dst, size_t cap);
+int     orc_codec_zstd_decode(void* ctx, const uint8_t* src, int n, uint8_t* dst, int cap);
+
 /* codec adaptors with the orc_block_codec_fn shape (ctx unused) */
 int orc_codec_lz4_fast(void* ctx, const uint8_t* src, int n, uint8_t* dst, int cap);
 int orc_codec_lz4_decode(void* ctx, const uint8_t* src, int n, uint8_t* dst, int cap);

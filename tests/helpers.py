@@ -24,7 +24,8 @@ def pkg():
 
 
 def _build_if_missing(path, cmd, cwd):
-    if not os.path.exists(path):
+    srcs = [os.path.join(cwd, f) for f in os.listdir(cwd) if f.endswith((".c", ".cpp", ".h"))]
+    if not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):
         subprocess.run(cmd, cwd=cwd, check=True, stdout=subprocess.DEVNULL)
     return path
 
@@ -64,6 +65,7 @@ def oracle():
         L.orc_container_compress.restype = C.c_int64
         L.orc_container_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_container_decompress.restype = C.c_int64
+        L.orc_zstd_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]; L.orc_zstd_decompress.restype = C.c_int64
         _cache["oracle"] = L
     return _cache["oracle"]
 
@@ -105,6 +107,13 @@ def orc_decompress(comp, cap):
     comp = np.ascontiguousarray(comp, dtype=np.uint8)
     dst = np.zeros(max(cap, 1), dtype=np.uint8)
     r = oracle().orc_lz4_decompress_safe(comp.ctypes.data, dst.ctypes.data, len(comp), cap)
+    return r, dst[:max(r, 0)].copy()
+
+
+def orc_zstd_decompress(frame, cap):
+    frame = np.ascontiguousarray(np.frombuffer(bytes(frame), dtype=np.uint8))
+    dst = np.zeros(max(cap, 1) + 64, dtype=np.uint8)
+    r = oracle().orc_zstd_decompress(frame.ctypes.data, len(frame), dst.ctypes.data, cap)
     return r, dst[:max(r, 0)].copy()
 
 

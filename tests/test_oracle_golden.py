@@ -97,3 +97,76 @@ def test_port_equals_reference_sources():
                 assert np.array_equal(out, o2[:r])
             n_checked += 1
     assert n_checked > 1000
+
+
+# ------------------------------------------------------------------------------------------ zstd decode port
+def test_zstd_port_golden_frames_and_4mz_files():
+    z = json.load(open(os.path.join(G, "zstd_frames.json")))
+    for name, e in z.items():
+        for lvl, hx in e["frames"].items():
+            for slack in (0, 123):
+                r, out = helpers.orc_zstd_decompress(bytes.fromhex(hx), e["input_bytes"] + slack)
+                assert r == e["input_bytes"], (name, lvl, r)
+                assert hashlib.sha256(out.tobytes()).hexdigest() == e["input_sha256"], (name, lvl)
+            # one byte short of the content size -> dstSize_tooSmall in the reference
+            if e["input_bytes"] > 0:
+                assert helpers.orc_zstd_decompress(bytes.fromhex(hx), e["input_bytes"] - 1)[0] < 0
+    files = json.load(open(os.path.join(G, "small_files.json")))
+    p = helpers.pkg()
+    for name, f in files.items():
+        img = np.frombuffer(bytes.fromhex(f["4mz_fast_hex"]), np.uint8)
+        blocks, _ = p.split_container(img, p.MAGIC_4MZ)
+        got = b""
+        for b in blocks:
+            pay = img[int(b["src_off"]): int(b["src_off"]) + int(b["src_len"])]
+            assert helpers.orc_xxh32(pay) == int(b["xxh32"])
+            if b["src_len"] == b["dst_cap"]:
+                got += pay.tobytes()
+            else:
+                r, out = helpers.orc_zstd_decompress(pay.tobytes(), int(b["dst_cap"]))
+                assert r == int(b["dst_cap"])
+                got += out.tobytes()
+        assert got == bytes.fromhex(f["input_hex"]), name
+
+
+@pytest.mark.skipif(helpers.ref() is None, reason="oracle/_ref not built (needs /root/reference)")
+def test_zstd_port_equals_reference_sources():
+    ref = helpers.ref()
+    rng = np.random.default_rng(23)
+    data = helpers.corpus(12 * B)
+    for lvl, blocks in ((1, range(12)), (3, (0, 4, 7)), (6, (1, 4, 10)), (12, (3,))):
+        for b in blocks:
+            src = data[b * B:(b + 1) * B]
+            out = np.zeros(B + 65536, np.uint8)
+            r = ref.ZSTD_compress(out.ctypes.data, len(out), src.ctypes.data, B, lvl)
+            assert not ref.ZSTD_isError(r)
+            d, dec = helpers.orc_zstd_decompress(out[:r].tobytes(), B)
+            assert d == B and np.array_equal(dec, src), (lvl, b)
+    # mutated frames: same accept/reject as ZSTD_decompress, identical bytes when accepted
+    z = json.load(open(os.path.join(G, "zstd_frames.json")))
+    n = lenient = 0
+    for name in ("text_30k", "lit_then_run_30k", "two_symbols_30k", "period37_20k"):
+        for lvl in ("1", "3", "6", "12"):
+            base = np.frombuffer(bytes.fromhex(z[name]["frames"][lvl]), np.uint8)
+            cap = z[name]["input_bytes"]
+            for t in range(120):
+                m = base.copy()
+                k = t % 4
+                if k == 0: m[rng.integers(0, len(m))] ^= 1 << rng.integers(0, 8)
+                elif k == 1: m = m[: rng.integers(1, len(m))]
+                elif k == 2:
+                    i = rng.integers(4, len(m)); m[i:i + 2] = rng.integers(0, 256, len(m[i:i + 2]), dtype=np.uint8)
+                else: m = np.concatenate([m, rng.integers(0, 256, rng.integers(1, 6), dtype=np.uint8)])
+                m = np.ascontiguousarray(m)
+                dst = np.zeros(cap + 64, np.uint8)
+                rr = ref.ZSTD_decompress(dst.ctypes.data, cap, m.ctypes.data, len(m))
+                r, out = helpers.orc_zstd_decompress(m.tobytes(), cap)
+                if ref.ZSTD_isError(rr):
+                    assert r < 0, (name, lvl, t, r)              # never accept what the reference rejects
+                elif r >= 0:
+                    assert r == rr and np.array_equal(out, dst[:rr]), (name, lvl, t, r, rr)   # same bytes when both accept
+                else:
+                    lenient += 1    # corrupt Huffman stream the reference's double-symbol (X2) decoder lets
+                                    # through with unspecified literals (huf_decompress.c:1199-1216); X1 rules reject
+                n += 1
+    assert n > 1500 and lenient < 0.05 * n, (n, lenient)
