@@ -44,10 +44,15 @@ void*  g_zscratch = nullptr;
 size_t g_zscratch_cap = 0;
 std::mutex g_zmu;
 
-int zstd_scratch(uint32_t n, void** out)
+int zstd_scratch_bytes(size_t need, void** out);
+int zstd_scratch(uint32_t n, void** out) { return zstd_scratch_bytes(fourmc_zstd_scratch_bytes(n), out); }
+
+// one growable device workspace shared by the kernels that need per-block scratch
+// (zstd literals: 128 KiB / block, LZ4 HC tables: 256 KiB / block); calls are stream-ordered
+// on the caller's stream, so one buffer serves consecutive launches.
+int zstd_scratch_bytes(size_t need, void** out)
 {
     std::lock_guard<std::mutex> lk(g_zmu);
-    const size_t need = fourmc_zstd_scratch_bytes(n);
     if (need > g_zscratch_cap) {
         if (g_zscratch) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g_zscratch)); g_zscratch = nullptr; g_zscratch_cap = 0; }
         HIP_TRY(hipMalloc(&g_zscratch, need));
@@ -131,6 +136,16 @@ int fourmc_gpu_lz4_compress_fast(const void* d_src, void* d_dst, fourmc_block* d
     return FOURMC_OK;
 }
 
+int fourmc_gpu_lz4_compress_hc(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, int level, void* stream)
+{
+    if (int r = ensure_device()) return r;
+    if (level < 1 || level > 8) { snprintf(g_err, sizeof g_err, "LZ4 HC level %d not on the device (hash-chain levels 1..8 are)", level); return FOURMC_EUNSUP; }
+    void* work = nullptr;
+    if (int r = zstd_scratch_bytes(fourmc_lz4hc_work_bytes(n), &work)) return r;
+    HIP_TRY(fourmc_launch_lz4hc_encode(d_src, d_dst, d_blocks, n, work, level, 0, static_cast<hipStream_t>(stream)));
+    return FOURMC_OK;
+}
+
 int fourmc_gpu_zstd_decompress(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, void* stream)
 {
     if (int r = ensure_device()) return r;
@@ -150,9 +165,16 @@ int fourmc_gpu_xxh32(const void* d_src, fourmc_block* d_blocks, uint32_t n, uint
 int fourmc_gpu_4mc_encode_blocks(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                  int codec, int level, void* stream)
 {
-    (void)level;
     if (int r = ensure_device()) return r;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (codec == FOURMC_CODEC_LZ4_HC) {
+        if (level < 1 || level > 8) { snprintf(g_err, sizeof g_err, "LZ4 HC level %d not on the device", level); return FOURMC_EUNSUP; }
+        void* work = nullptr;
+        if (int r = zstd_scratch_bytes(fourmc_lz4hc_work_bytes(n), &work)) return r;
+        HIP_TRY(fourmc_launch_lz4hc_encode(d_src, d_dst, d_blocks, n, work, level, 1, s));
+        HIP_TRY(fourmc_launch_xxh32(d_dst, d_blocks, n, 0, FOURMC_HASH_DST_RESULT, s));
+        return FOURMC_OK;
+    }
     if (codec != FOURMC_CODEC_LZ4_FAST) {
         snprintf(g_err, sizeof g_err, "codec %d not implemented on the device yet", codec);
         return FOURMC_EUNSUP;
@@ -210,6 +232,7 @@ static int host_roundtrip(const void* src, size_t src_bytes, void* dst, size_t d
         case 2: r = fourmc_gpu_lz4_compress_fast(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
         case 3: r = fourmc_gpu_lz4_decompress(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
         case 5: r = fourmc_gpu_zstd_decompress(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
+        case 6: r = fourmc_gpu_lz4_compress_hc(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, level, s); break;
         default: r = fourmc_gpu_xxh32(g_arena.d_src, g_arena.d_blk, n, (uint32_t)level, s); break;
     }
     if (r) return r;
@@ -243,6 +266,16 @@ int fourmc_LZ4_compress_default(const char* src, char* dst, int srcSize, int dst
     b.src_len = (uint32_t)srcSize; b.dst_cap = (uint32_t)dstCapacity;
     size_t dst_bytes = (size_t)dstCapacity;
     int r = host_roundtrip(src, (size_t)srcSize, dst, dst_bytes, &b, 1, 2, FOURMC_CODEC_LZ4_FAST, 0);
+    if (r) { fprintf(stderr, "4mc-gpu: %s\n", g_err); return 0; }
+    return b.result;
+}
+
+int fourmc_LZ4_compress_HC(const char* src, char* dst, int srcSize, int dstCapacity, int compressionLevel)
+{
+    if (srcSize < 0 || dstCapacity < 0) return 0;
+    fourmc_block b; memset(&b, 0, sizeof b);
+    b.src_len = (uint32_t)srcSize; b.dst_cap = (uint32_t)dstCapacity;
+    int r = host_roundtrip(src, (size_t)srcSize, dst, (size_t)dstCapacity, &b, 1, 6, FOURMC_CODEC_LZ4_HC, compressionLevel);
     if (r) { fprintf(stderr, "4mc-gpu: %s\n", g_err); return 0; }
     return b.result;
 }

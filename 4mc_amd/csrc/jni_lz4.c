@@ -44,6 +44,9 @@ typedef int (*block_fn)(const char* src, char* dst, int n, int level);
 static int enc_fast(const char* src, char* dst, int n, int level)
 { (void)level; return fourmc_LZ4_compress_default(src, dst, n, fourmc_LZ4_compressBound(n)); }   /* LZ4_compress, lz4.c:2661 */
 
+static int enc_hc(const char* src, char* dst, int n, int level)
+{ return fourmc_LZ4_compress_HC(src, dst, n, fourmc_LZ4_compressBound(n), level); }   /* LZ4_compressHC2, lz4hc.c:1205 */
+
 static int enc_unavailable(const char* src, char* dst, int n, int level)
 { (void)src; (void)dst; (void)n; (void)level; return 0; }   /* codec not on the device yet: fails loudly below */
 
@@ -76,7 +79,7 @@ Java_com_fing_compression_fourmc_Lz4Compressor_compressBytesDirectMC(JNIEnv* env
 
 JNIEXPORT jint JNICALL
 Java_com_fing_compression_fourmc_Lz4Compressor_compressBytesDirectHC(JNIEnv* env, jobject self, jint level)
-{ return compress_common(env, self, enc_unavailable, level, "LZ4_compressHC2"); }
+{ return compress_common(env, self, enc_hc, level, "LZ4_compressHC2"); }
 
 JNIEXPORT jint JNICALL
 Java_com_fing_compression_fourmc_Lz4Compressor_compressBound(JNIEnv* env, jclass cls, jint n)

@@ -23,6 +23,9 @@ hipError_t fourmc_launch_lz4_encode_fast(const void* d_src, void* d_dst, fourmc_
                                          uint32_t n, int container_mode, hipStream_t stream);
 hipError_t fourmc_launch_pack_image(const void* d_staging, void* d_image, const fourmc_block* d_blocks,
                                     const uint64_t* d_image_off, uint32_t n, hipStream_t stream);
+size_t     fourmc_lz4hc_work_bytes(uint32_t n);
+hipError_t fourmc_launch_lz4hc_encode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
+                                      void* d_work, int level, int container_mode, hipStream_t stream);
 size_t     fourmc_zstd_scratch_bytes(uint32_t n);
 hipError_t fourmc_launch_zstd_decode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                      void* d_scratch, int container_mode, hipStream_t stream);

@@ -1,0 +1,335 @@
+// 4mc_amd/csrc/lz4hc_encode.hip — K3: batched LZ4 HC (hash-chain) block encode on gfx950,
+// BYTE-IDENTICAL to LZ4_compress_HC of the reference at the levels 4mc reaches
+// (4mc High = level 4, 4mc Ultra = level 8).
+//
+// Replaces native/4mc.c:301 with LZ4_compress_HC (:249-252) and native/jniCompressor.c:157
+// (LZ4_compressHC2) -> native/lz4/lz4hc.c:958-973 -> :800-861 -> LZ4HC_compress_hashChain :553-788,
+// search LZ4HC_InsertAndGetWiderMatch :239-447 (patternAnalysis off for <= 128 attempts :565,
+// chainSwap off :461,:603,:648), tables LZ4HC_Insert :120-141.
+//
+// One wavefront owns one block.  The 256 KiB of match-finder state (32768 x u32 hash heads +
+// 65536 x u16 chain deltas) exceeds LDS, so it lives in a per-block HBM workspace slot (L2/MALL
+// resident while the block is in flight).  What is parallel:
+//   * inserting positions: 64 positions per step; lanes that fall into one hash bucket are
+//     serialised in position order with an LDS atomic-min scoreboard (rounds), everything else is
+//     one gather + two scatters;
+//   * evaluating a chain: the chain is walked once (serial pointer chase through the chain table),
+//     then up to 64 candidates are measured at once, one per lane - pattern check, forward length
+//     (8 bytes per step; candidates still equal after 32 bytes are finished by the whole
+//     wavefront, 1 KiB per step) and backward length.  The reference's running
+//     "if (ml > longest)" over candidates in chain order equals max-length with earliest-wins
+//     ties, which is what the wave reduction computes (its 2-byte pre-filter at `longest` can
+//     never reject a winner, so it does not change results);
+//   * the lazy three-match arbitration (lz4hc.c:592-732) is scalar code, mirrored statement by
+//     statement; sequence emission is wave-wide copies.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fourmc_gpu.h"
+#include "kernels.h"
+#include "devenc.h"
+
+namespace {
+
+constexpr int      kHashLog = 15;
+constexpr uint32_t kIdx0 = 65536;            // table index of position 0 (LZ4HC_init_internal)
+constexpr uint32_t kMaxDist = 65535;
+constexpr int      kMinMatch = 4, kMfLimit = 12, kLastLit = 5, kOptimalML = 18;
+constexpr int      kScore = 1024;
+constexpr size_t   kWorkBytes = (size_t(4) << kHashLog) + 2 * 65536;     // per block: heads + chain
+
+__device__ __forceinline__ uint32_t hc_hash(uint32_t v) { return (v * 2654435761u) >> (32 - kHashLog); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+struct HC {
+    const uint8_t* src;
+    uint32_t* heads;       // [32768]
+    uint16_t* chain;       // [65536]
+    uint32_t* score;       // LDS [kScore], all 0xFFFFFFFF between uses
+    uint32_t  ntu;         // next position to insert
+    int       lane;
+};
+
+// LZ4HC_Insert (lz4hc.c:120-141): positions [ntu, upto) enter the tables in order.
+__device__ __forceinline__ void hc_insert(HC& c, uint32_t upto)
+{
+    while (c.ntu < upto) {
+        const uint32_t pos = c.ntu + c.lane;
+        bool pending = pos < upto;
+        const uint32_t h = pending ? hc_hash(ld4(c.src + pos)) : 0u;
+        const uint32_t idx = pos + kIdx0;
+        uint32_t* sc = &c.score[h & (kScore - 1)];
+        while (__ballot(pending)) {
+            if (pending) atomicMin(sc, uint32_t(c.lane));
+            const bool win = pending && (*sc == uint32_t(c.lane));     // lowest pending lane of its bucket
+            if (win) {
+                uint32_t delta = idx - c.heads[h];
+                if (delta > kMaxDist) delta = kMaxDist;
+                c.chain[idx & 0xFFFF] = uint16_t(delta);
+                c.heads[h] = idx;
+                *sc = 0xFFFFFFFFu;
+                pending = false;
+            }
+        }
+        c.ntu = min(upto, c.ntu + 64u);
+    }
+}
+
+// number of equal bytes at a / b (a > b), a stops at lim; the whole wavefront works on one pair
+__device__ __forceinline__ uint32_t wave_count_fwd(const uint8_t* s, uint32_t a, uint32_t b, uint32_t lim, int lane)
+{
+    uint32_t n = 0;
+    for (;;) {
+        if (a + 1024 <= lim) {
+            const U16B x = *reinterpret_cast<const U16B*>(s + a + 16 * lane);
+            const U16B y = *reinterpret_cast<const U16B*>(s + b + 16 * lane);
+            const uint64_t d0 = x.a ^ y.a, d1 = x.b ^ y.b;
+            const uint32_t eq = d0 ? uint32_t(__builtin_ctzll(d0) >> 3) : (d1 ? 8u + uint32_t(__builtin_ctzll(d1) >> 3) : 16u);
+            const unsigned long long bad = __ballot(eq < 16);
+            if (bad) { const int l = __builtin_ctzll(bad); return n + 16 * l + __builtin_amdgcn_readlane(eq, l); }
+            n += 1024; a += 1024; b += 1024;
+        } else {
+            const uint32_t i = a + lane;
+            const bool same = (i < lim) && s[i] == s[b + lane];
+            const unsigned long long bad = ~__ballot(same);
+            if (bad) return n + __builtin_ctzll(bad);
+            n += 64; a += 64; b += 64;
+        }
+    }
+}
+
+// number of equal bytes going backwards from a / b (exclusive), at most `maxn`
+__device__ __forceinline__ uint32_t wave_count_back(const uint8_t* s, uint32_t a, uint32_t b, uint32_t maxn, int lane)
+{
+    uint32_t n = 0;
+    for (;;) {
+        const uint32_t j = n + lane + 1;
+        const bool same = (j <= maxn) && s[a - j] == s[b - j];
+        const unsigned long long bad = ~__ballot(same);
+        if (bad) return n + __builtin_ctzll(bad);
+        n += 64;
+    }
+}
+
+// LZ4HC_InsertAndGetWiderMatch (lz4hc.c:239-447), no dictionary, no pattern analysis, no chain swap.
+__device__ __forceinline__ int hc_wider(HC& c, uint32_t ip, uint32_t low, uint32_t high, int longest,
+                                        uint32_t& mpos, uint32_t& spos, int attempts)
+{
+    const uint8_t* s = c.src;
+    const int lane = c.lane;
+    hc_insert(c, ip);
+    const uint32_t ip_idx = ip + kIdx0;
+    const uint32_t lowest = (kIdx0 + 65536 > ip_idx) ? kIdx0 : ip_idx - kMaxDist;
+    const uint32_t lookback = ip - low;
+    const uint32_t pattern = ld4(s + ip);
+    uint32_t mi = uint32_t(uni(int(c.heads[hc_hash(pattern)])));
+    while (mi >= lowest && attempts > 0) {
+        // ---- collect up to 64 candidates of the chain (serial pointer chase)
+        uint32_t cand = 0; int nc = 0;
+        while (mi >= lowest && attempts > 0 && nc < 64) {
+            if (lane == nc) cand = mi;
+            nc++; attempts--;
+            mi -= uint32_t(uni(int(c.chain[mi & 0xFFFF])));
+        }
+        // ---- measure them, one per lane
+        const uint32_t m = cand - kIdx0;
+        bool live = lane < nc && ld4(s + (lane < nc ? m : 0u)) == pattern;
+        uint32_t fl = 0; bool more_f = false;
+        if (live) {                                           // forward: up to 32 bytes here
+            uint32_t a = ip + kMinMatch, b = m + kMinMatch;
+            more_f = true;
+            for (int it = 0; it < 4; it++) {
+                if (a + 8 > high) { while (a < high && s[a] == s[b]) { a++; b++; fl++; } more_f = false; break; }
+                const uint64_t x = ld8(s + a) ^ ld8(s + b);
+                if (x) { fl += uint32_t(__builtin_ctzll(x) >> 3); more_f = false; break; }
+                a += 8; b += 8; fl += 8;
+            }
+        }
+        uint32_t bk = 0; bool more_b = false;
+        if (live && lookback) {                               // backward: up to 32 bytes here
+            const uint32_t maxb = min(lookback, m);
+            more_b = true;
+            for (int it = 0; it < 4; it++) {
+                if (bk + 8 > maxb) { while (bk < maxb && s[ip - bk - 1] == s[m - bk - 1]) bk++; more_b = false; break; }
+                const uint64_t x = ld8(s + ip - bk - 8) ^ ld8(s + m - bk - 8);
+                if (x) { bk += uint32_t(__builtin_clzll(x) >> 3); more_b = false; break; }
+                bk += 8;
+            }
+        }
+        // ---- candidates still equal after 32 bytes: finish each with the whole wavefront
+        for (unsigned long long todo = __ballot(more_f); todo; todo &= todo - 1) {
+            const int l = __builtin_ctzll(todo);
+            const uint32_t mm = uint32_t(__builtin_amdgcn_readlane(int(m), l));
+            const uint32_t extra = wave_count_fwd(s, ip + kMinMatch + 32, mm + kMinMatch + 32, high, lane);
+            if (lane == l) fl += extra;
+        }
+        for (unsigned long long todo = __ballot(more_b); todo; todo &= todo - 1) {
+            const int l = __builtin_ctzll(todo);
+            const uint32_t mm = uint32_t(__builtin_amdgcn_readlane(int(m), l));
+            const uint32_t maxb = min(lookback, mm);
+            const uint32_t extra = wave_count_back(s, ip - 32, mm - 32, maxb - 32, lane);
+            if (lane == l) bk += extra;
+        }
+        // ---- running "ml > longest" in chain order == max length, earliest candidate wins ties
+        const uint32_t ml = live ? kMinMatch + fl + bk : 0u;
+        uint32_t key = (live && int(ml) > longest) ? ((ml << 6) | uint32_t(63 - lane)) : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) key = max(key, uint32_t(__shfl_xor(int(key), d)));
+        key = uint32_t(uni(int(key)));
+        if (key) {
+            const int l = 63 - int(key & 63);
+            longest = int(key >> 6);
+            const uint32_t bm = uint32_t(__builtin_amdgcn_readlane(int(m), l)), bb = uint32_t(__builtin_amdgcn_readlane(int(bk), l));
+            mpos = bm - bb; spos = ip - bb;
+        }
+    }
+    return longest;
+}
+
+// LZ4HC_encodeSequence (lz4hc.c:467-548): returns true when `limited` and the output would overflow
+__device__ __forceinline__ bool hc_emit(const uint8_t* src, uint8_t* dst, uint32_t& ip, uint32_t& op, uint32_t& anchor,
+                                        int ml, uint32_t match, bool limited, uint32_t cap, int lane)
+{
+    const uint32_t lit = ip - anchor;
+    const uint32_t token_pos = op++;
+    if (limited && op + lit / 255 + lit + (2 + 1 + kLastLit) > cap) return true;
+    uint32_t tok;
+    if (lit >= 15) { tok = 0xF0; op += emit_len(dst + op, lit - 15, lane); }
+    else tok = lit << 4;
+    copy_bytes(dst + op, src + anchor, lit, lane);
+    op += lit;
+    const uint32_t off = ip - match;
+    if (lane == 0) { dst[op] = uint8_t(off); dst[op + 1] = uint8_t(off >> 8); }
+    op += 2;
+    const uint32_t mcode = uint32_t(ml) - kMinMatch;
+    if (limited && op + mcode / 255 + (1 + kLastLit) > cap) return true;
+    if (mcode >= 15) { tok += 15; op += emit_len(dst + op, mcode - 15, lane); }
+    else tok += mcode;
+    if (lane == 0) dst[token_pos] = uint8_t(tok);
+    ip += uint32_t(ml);
+    anchor = ip;
+    return false;
+}
+
+__device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int cap, int attempts,
+                                  uint8_t* work, uint32_t* score, int lane)
+{
+    if (uint32_t(n) > 0x7E000000u) return 0;
+    HC c; c.src = src; c.lane = lane; c.ntu = 0; c.score = score;
+    c.heads = reinterpret_cast<uint32_t*>(work);
+    c.chain = reinterpret_cast<uint16_t*>(work + (size_t(4) << kHashLog));
+    {   // LZ4HC_clearTables: heads = 0, chain = 0xFFFF
+        uint4* w = reinterpret_cast<uint4*>(work);
+        const uint32_t nh = uint32_t((size_t(4) << kHashLog) / 16), nt = uint32_t(kWorkBytes / 16);
+        for (uint32_t i = lane; i < nt; i += 64) w[i] = i < nh ? make_uint4(0, 0, 0, 0) : make_uint4(~0u, ~0u, ~0u, ~0u);
+        for (int i = lane; i < kScore; i += 64) score[i] = 0xFFFFFFFFu;
+    }
+    const bool limited = cap < n + n / 255 + 16;
+    const uint32_t ucap = uint32_t(cap);
+    uint32_t ip = 0, anchor = 0, op = 0;
+
+    if (n >= kMfLimit + 1) {
+        const uint32_t mflimit = uint32_t(n) - kMfLimit, matchlimit = uint32_t(n) - kLastLit;
+        int ml, ml2, ml3, ml0;
+        uint32_t ref = 0, start2 = 0, ref2 = 0, start3 = 0, ref3 = 0, start0, ref0, dummy = 0;
+        while (ip <= mflimit) {
+            ml = hc_wider(c, ip, ip, matchlimit, kMinMatch - 1, ref, dummy, attempts);
+            if (ml < kMinMatch) { ip++; continue; }
+            start0 = ip; ref0 = ref; ml0 = ml;
+        search2:
+            if (ip + ml <= mflimit) ml2 = hc_wider(c, ip + ml - 2, ip, matchlimit, ml, ref2, start2, attempts);
+            else ml2 = ml;
+            if (ml2 == ml) {
+                if (hc_emit(src, dst, ip, op, anchor, ml, ref, limited, ucap, lane)) return 0;
+                continue;
+            }
+            if (start0 < ip && start2 < ip + ml0) { ip = start0; ref = ref0; ml = ml0; }
+            if (start2 - ip < 3) { ml = ml2; ip = start2; ref = ref2; goto search2; }
+        search3:
+            if (start2 - ip < kOptimalML) {
+                int new_ml = ml;
+                if (new_ml > kOptimalML) new_ml = kOptimalML;
+                if (ip + new_ml > start2 + ml2 - kMinMatch) new_ml = int(start2 - ip) + ml2 - kMinMatch;
+                const int correction = new_ml - int(start2 - ip);
+                if (correction > 0) { start2 += correction; ref2 += correction; ml2 -= correction; }
+            }
+            if (start2 + ml2 <= mflimit) ml3 = hc_wider(c, start2 + ml2 - 3, start2, matchlimit, ml2, ref3, start3, attempts);
+            else ml3 = ml2;
+            if (ml3 == ml2) {
+                if (start2 < ip + ml) ml = int(start2 - ip);
+                if (hc_emit(src, dst, ip, op, anchor, ml, ref, limited, ucap, lane)) return 0;
+                ip = start2;
+                if (hc_emit(src, dst, ip, op, anchor, ml2, ref2, limited, ucap, lane)) return 0;
+                continue;
+            }
+            if (start3 < ip + ml + 3) {
+                if (start3 >= ip + ml) {
+                    if (start2 < ip + ml) {
+                        const int correction = int(ip + ml - start2);
+                        start2 += correction; ref2 += correction; ml2 -= correction;
+                        if (ml2 < kMinMatch) { start2 = start3; ref2 = ref3; ml2 = ml3; }
+                    }
+                    if (hc_emit(src, dst, ip, op, anchor, ml, ref, limited, ucap, lane)) return 0;
+                    ip = start3; ref = ref3; ml = ml3;
+                    start0 = start2; ref0 = ref2; ml0 = ml2;
+                    goto search2;
+                }
+                start2 = start3; ref2 = ref3; ml2 = ml3;
+                goto search3;
+            }
+            if (start2 < ip + ml) {
+                if (start2 - ip < kOptimalML) {
+                    if (ml > kOptimalML) ml = kOptimalML;
+                    if (ip + ml > start2 + ml2 - kMinMatch) ml = int(start2 - ip) + ml2 - kMinMatch;
+                    const int correction = ml - int(start2 - ip);
+                    if (correction > 0) { start2 += correction; ref2 += correction; ml2 -= correction; }
+                } else ml = int(start2 - ip);
+            }
+            if (hc_emit(src, dst, ip, op, anchor, ml, ref, limited, ucap, lane)) return 0;
+            ip = start2; ref = ref2; ml = ml2;
+            start2 = start3; ref2 = ref3; ml2 = ml3;
+            goto search3;
+        }
+    }
+    {   // last literals (lz4hc.c:735-762)
+        const uint32_t run = uint32_t(n) - anchor, add = (run + 255 - 15) / 255;
+        if (limited && op + 1 + add + run > ucap) return 0;
+        if (run >= 15) { if (lane == 0) dst[op] = 0xF0; op++; op += emit_len(dst + op, run - 15, lane); }
+        else { if (lane == 0) dst[op] = uint8_t(run << 4); op++; }
+        copy_bytes(dst + op, src + anchor, run, lane);
+        op += run;
+    }
+    return int(op);
+}
+
+__global__ __launch_bounds__(64)
+void lz4hc_encode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks,
+                         uint32_t nblocks, uint8_t* work_base, int attempts, int container_mode)
+{
+    __shared__ uint32_t score[kScore];
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    const fourmc_block blk = blocks[b];
+    const uint8_t* src = src_base + blk.src_off;
+    uint8_t* dst = dst_base + blk.dst_off;
+    const int n = int(blk.src_len);
+    const int cap = container_mode ? n - 1 : int(blk.dst_cap);
+    int r = lz4hc_encode_block(src, dst, n, cap, attempts, work_base + size_t(b) * kWorkBytes, score, threadIdx.x);
+    if (container_mode && r <= 0) { copy_bytes(dst, src, uint32_t(n), threadIdx.x); r = n; }
+    if (threadIdx.x == 0) blocks[b].result = r;
+}
+
+} // namespace
+
+extern "C" size_t fourmc_lz4hc_work_bytes(uint32_t n) { return size_t(n) * kWorkBytes; }
+
+extern "C" hipError_t fourmc_launch_lz4hc_encode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
+                                                 void* d_work, int level, int container_mode, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    static const int searches[9] = {2, 2, 2, 4, 8, 16, 32, 64, 128};       // lz4hc.c:817-827, levels 0..8
+    if (level < 1 || level > 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lz4hc_encode_kernel, dim3(n), dim3(64), 0, stream,
+                       static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n,
+                       static_cast<uint8_t*>(d_work), searches[level], container_mode);
+    return hipGetLastError();
+}

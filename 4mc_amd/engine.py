@@ -43,6 +43,12 @@ def lz4_decompress(d_src, d_dst, batch, stream=None):
           "fourmc_gpu_lz4_decompress")
 
 
+def lz4_compress_hc(d_src, d_dst, batch, level, stream=None):
+    """result[b] = LZ4_compress_HC(src+src_off, dst+dst_off, src_len, dst_cap, level)."""
+    check(lib().fourmc_gpu_lz4_compress_hc(_ptr(d_src), _ptr(d_dst), batch.ptr, batch.n, level, _stream_ptr(stream)),
+          "fourmc_gpu_lz4_compress_hc")
+
+
 def zstd_decompress(d_src, d_dst, batch, stream=None):
     """result[b] = ZSTD_decompress(dst+dst_off, dst_cap, src+src_off, src_len) (negative on error)."""
     check(lib().fourmc_gpu_zstd_decompress(_ptr(d_src), _ptr(d_dst), batch.ptr, batch.n, _stream_ptr(stream)),

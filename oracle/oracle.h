@@ -34,6 +34,10 @@ int orc_lz4_compress_bound(int n);
  * Returns bytes written, or 0 when the output does not fit `cap` (limitedOutput). */
 int orc_lz4_compress_fast(const uint8_t* src, uint8_t* dst, int n, int cap);
 
+/* LZ4_compress_HC, hash-chain levels 1..8 (4mc uses 4 and 8) - native/lz4/lz4hc.c:958-973 -> :553-788.
+ * Returns bytes written, 0 when it does not fit `cap`, -2 for levels this port does not cover. */
+int orc_lz4hc_compress(const uint8_t* src, uint8_t* dst, int n, int cap, int level);
+
 /* LZ4_decompress_safe — native/lz4/lz4.c:2345-2350 -> :1936-2339 (noDict, full block).
  * Returns decoded size (>=0) or a negative error. */
 int orc_lz4_decompress_safe(const uint8_t* src, uint8_t* dst, int csize, int cap);
@@ -60,6 +64,8 @@ int     orc_codec_zstd_decode(void* ctx, const uint8_t* src, int n, uint8_t* dst
 /* codec adaptors with the orc_block_codec_fn shape (ctx unused) */
 int orc_codec_lz4_fast(void* ctx, const uint8_t* src, int n, uint8_t* dst, int cap);
 int orc_codec_lz4_decode(void* ctx, const uint8_t* src, int n, uint8_t* dst, int cap);
+int orc_codec_lz4hc4(void* ctx, const uint8_t* src, int n, uint8_t* dst, int cap);
+int orc_codec_lz4hc8(void* ctx, const uint8_t* src, int n, uint8_t* dst, int cap);
 
 #ifdef __cplusplus
 }

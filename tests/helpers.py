@@ -173,3 +173,14 @@ def edge_inputs():
         "far_repeat": np.concatenate([text[:70000], rng.integers(0, 256, 70000, dtype=np.uint8), text[:70000]]),
     }
     return out
+
+
+def orc_compress_hc(src, level, cap=None):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    L = oracle()
+    L.orc_lz4hc_compress.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]; L.orc_lz4hc_compress.restype = C.c_int
+    bound = L.orc_lz4_compress_bound(len(src))
+    cap = bound if cap is None else cap
+    dst = np.empty(max(cap, 1) + 8, dtype=np.uint8)
+    r = L.orc_lz4hc_compress(src.ctypes.data, dst.ctypes.data, len(src), cap, level)
+    return r, dst[:max(r, 0)].copy()

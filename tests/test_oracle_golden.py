@@ -170,3 +170,34 @@ def test_zstd_port_equals_reference_sources():
                                     # through with unspecified literals (huf_decompress.c:1199-1216); X1 rules reject
                 n += 1
     assert n > 1500 and lenient < 0.05 * n, (n, lenient)
+
+
+# ------------------------------------------------------------------------------------------ LZ4 HC port
+def test_lz4hc_port_golden_manifest():
+    """`4mc -3` (LZ4 HC level 4) per-block sizes/checksums written by the reference CLI."""
+    m = json.load(open(os.path.join(G, "corpus_manifest.json")))
+    data = helpers.corpus(m["corpus"]["bytes"])
+    for b, (u, c, x) in enumerate(m["levels"]["4mc-3"]["blocks"]):
+        if b % 3 and b != 12:
+            continue                                   # HC is slow on one host core: sample + the ragged tail
+        blk = data[b * B: b * B + u]
+        r, comp = helpers.orc_compress_hc(blk, 4, u - 1)
+        payload = comp if r > 0 else blk
+        assert (len(payload), helpers.orc_xxh32(payload)) == (c, x), b
+    u, c, x = m["levels"]["4mc-4"]["blocks"][3]        # `4mc -4` = HC level 8
+    r, comp = helpers.orc_compress_hc(data[3 * B: 3 * B + u], 8, u - 1)
+    assert (len(comp), helpers.orc_xxh32(comp)) == (c, x)
+
+
+@pytest.mark.skipif(helpers.ref() is None, reason="oracle/_ref not built (needs /root/reference)")
+def test_lz4hc_port_equals_reference_sources():
+    ref = helpers.ref()
+    for name, d in helpers.edge_inputs().items():
+        d = np.ascontiguousarray(d)
+        bound = helpers.oracle().orc_lz4_compress_bound(len(d))
+        for lvl in (4, 8):
+            for cap in (bound, max(len(d) - 1, 0), len(d) // 3):
+                out = np.zeros(bound + 64, np.uint8)
+                rr = ref.LZ4_compress_HC(d.ctypes.data, out.ctypes.data, len(d), cap, lvl)
+                r, comp = helpers.orc_compress_hc(d, lvl, cap)
+                assert r == rr and np.array_equal(comp, out[:max(rr, 0)]), (name, lvl, cap, r, rr)
