@@ -41,6 +41,7 @@ _GPU_API = {
     "fourmc_gpu_lz4_decompress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "fourmc_gpu_lz4_compress_fast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "fourmc_gpu_lz4_compress_hc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
+    "fourmc_gpu_lz4_compress_mc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "fourmc_gpu_zstd_decompress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "fourmc_gpu_xxh32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "fourmc_gpu_4mc_encode_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
@@ -48,6 +49,8 @@ _GPU_API = {
     "fourmc_gpu_4mc_pack_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "fourmc_LZ4_compressBound": (C.c_int, [C.c_int]),
     "fourmc_LZ4_compress_default": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "fourmc_LZ4_compressMC": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "fourmc_LZ4_compressMC_limitedOutput": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "fourmc_LZ4_compress_HC": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "fourmc_LZ4_decompress_safe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "fourmc_ZSTD_decompress": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),

@@ -146,6 +146,15 @@ int fourmc_gpu_lz4_compress_hc(const void* d_src, void* d_dst, fourmc_block* d_b
     return FOURMC_OK;
 }
 
+int fourmc_gpu_lz4_compress_mc(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, void* stream)
+{
+    if (int r = ensure_device()) return r;
+    void* work = nullptr;
+    if (int r = zstd_scratch_bytes(fourmc_lz4hc_work_bytes(n), &work)) return r;     // same 256 KiB/block layout as HC
+    HIP_TRY(fourmc_launch_lz4mc_encode(d_src, d_dst, d_blocks, n, work, 0, static_cast<hipStream_t>(stream)));
+    return FOURMC_OK;
+}
+
 int fourmc_gpu_zstd_decompress(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, void* stream)
 {
     if (int r = ensure_device()) return r;
@@ -172,6 +181,13 @@ int fourmc_gpu_4mc_encode_blocks(const void* d_src, void* d_dst, fourmc_block* d
         void* work = nullptr;
         if (int r = zstd_scratch_bytes(fourmc_lz4hc_work_bytes(n), &work)) return r;
         HIP_TRY(fourmc_launch_lz4hc_encode(d_src, d_dst, d_blocks, n, work, level, 1, s));
+        HIP_TRY(fourmc_launch_xxh32(d_dst, d_blocks, n, 0, FOURMC_HASH_DST_RESULT, s));
+        return FOURMC_OK;
+    }
+    if (codec == FOURMC_CODEC_LZ4_MC) {
+        void* work = nullptr;
+        if (int r = zstd_scratch_bytes(fourmc_lz4hc_work_bytes(n), &work)) return r;
+        HIP_TRY(fourmc_launch_lz4mc_encode(d_src, d_dst, d_blocks, n, work, 1, s));
         HIP_TRY(fourmc_launch_xxh32(d_dst, d_blocks, n, 0, FOURMC_HASH_DST_RESULT, s));
         return FOURMC_OK;
     }
@@ -232,6 +248,7 @@ static int host_roundtrip(const void* src, size_t src_bytes, void* dst, size_t d
         case 2: r = fourmc_gpu_lz4_compress_fast(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
         case 3: r = fourmc_gpu_lz4_decompress(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
         case 5: r = fourmc_gpu_zstd_decompress(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
+        case 7: r = fourmc_gpu_lz4_compress_mc(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
         case 6: r = fourmc_gpu_lz4_compress_hc(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, level, s); break;
         default: r = fourmc_gpu_xxh32(g_arena.d_src, g_arena.d_blk, n, (uint32_t)level, s); break;
     }
@@ -269,6 +286,23 @@ int fourmc_LZ4_compress_default(const char* src, char* dst, int srcSize, int dst
     if (r) { fprintf(stderr, "4mc-gpu: %s\n", g_err); return 0; }
     return b.result;
 }
+
+static int host_mc(const char* src, char* dst, int srcSize, uint32_t cap_field, size_t dst_bytes)
+{
+    if (srcSize < 0) return 0;
+    fourmc_block b; memset(&b, 0, sizeof b);
+    b.src_len = (uint32_t)srcSize; b.dst_cap = cap_field;
+    int r = host_roundtrip(src, (size_t)srcSize, dst, dst_bytes, &b, 1, 7, FOURMC_CODEC_LZ4_MC, 0);
+    if (r) { fprintf(stderr, "4mc-gpu: %s\n", g_err); return 0; }
+    return b.result;
+}
+
+/* LZ4_compressMC writes without an output limit: dst must hold LZ4_compressBound(srcSize) (lz4mc.h) */
+int fourmc_LZ4_compressMC(const char* src, char* dst, int srcSize)
+{ return host_mc(src, dst, srcSize, 0xFFFFFFFFu, (size_t)fourmc_LZ4_compressBound(srcSize)); }
+
+int fourmc_LZ4_compressMC_limitedOutput(const char* src, char* dst, int srcSize, int maxOutputSize)
+{ return maxOutputSize < 0 ? 0 : host_mc(src, dst, srcSize, (uint32_t)maxOutputSize, (size_t)maxOutputSize); }
 
 int fourmc_LZ4_compress_HC(const char* src, char* dst, int srcSize, int dstCapacity, int compressionLevel)
 {

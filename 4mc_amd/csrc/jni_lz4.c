@@ -47,8 +47,8 @@ static int enc_fast(const char* src, char* dst, int n, int level)
 static int enc_hc(const char* src, char* dst, int n, int level)
 { return fourmc_LZ4_compress_HC(src, dst, n, fourmc_LZ4_compressBound(n), level); }   /* LZ4_compressHC2, lz4hc.c:1205 */
 
-static int enc_unavailable(const char* src, char* dst, int n, int level)
-{ (void)src; (void)dst; (void)n; (void)level; return 0; }   /* codec not on the device yet: fails loudly below */
+static int enc_mc(const char* src, char* dst, int n, int level)
+{ (void)level; return fourmc_LZ4_compressMC(src, dst, n); }
 
 static jint compress_common(JNIEnv* env, jobject self, block_fn fn, int level, const char* name)
 {
@@ -75,7 +75,7 @@ Java_com_fing_compression_fourmc_Lz4Compressor_compressBytesDirect(JNIEnv* env, 
 
 JNIEXPORT jint JNICALL
 Java_com_fing_compression_fourmc_Lz4Compressor_compressBytesDirectMC(JNIEnv* env, jobject self)
-{ return compress_common(env, self, enc_unavailable, 0, "LZ4_compressMC"); }
+{ return compress_common(env, self, enc_mc, 0, "LZ4_compressMC"); }
 
 JNIEXPORT jint JNICALL
 Java_com_fing_compression_fourmc_Lz4Compressor_compressBytesDirectHC(JNIEnv* env, jobject self, jint level)

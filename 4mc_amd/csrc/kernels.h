@@ -26,6 +26,8 @@ hipError_t fourmc_launch_pack_image(const void* d_staging, void* d_image, const 
 size_t     fourmc_lz4hc_work_bytes(uint32_t n);
 hipError_t fourmc_launch_lz4hc_encode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                       void* d_work, int level, int container_mode, hipStream_t stream);
+hipError_t fourmc_launch_lz4mc_encode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
+                                      void* d_work, int container_mode, hipStream_t stream);
 size_t     fourmc_zstd_scratch_bytes(uint32_t n);
 hipError_t fourmc_launch_zstd_decode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                      void* d_scratch, int container_mode, hipStream_t stream);

@@ -49,6 +49,12 @@ def lz4_compress_hc(d_src, d_dst, batch, level, stream=None):
           "fourmc_gpu_lz4_compress_hc")
 
 
+def lz4_compress_mc(d_src, d_dst, batch, stream=None):
+    """result[b] = LZ4_compressMC_limitedOutput(...) (dst_cap 0xFFFFFFFF: LZ4_compressMC, unlimited)."""
+    check(lib().fourmc_gpu_lz4_compress_mc(_ptr(d_src), _ptr(d_dst), batch.ptr, batch.n, _stream_ptr(stream)),
+          "fourmc_gpu_lz4_compress_mc")
+
+
 def zstd_decompress(d_src, d_dst, batch, stream=None):
     """result[b] = ZSTD_decompress(dst+dst_off, dst_cap, src+src_off, src_len) (negative on error)."""
     check(lib().fourmc_gpu_zstd_decompress(_ptr(d_src), _ptr(d_dst), batch.ptr, batch.n, _stream_ptr(stream)),

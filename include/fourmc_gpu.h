@@ -72,6 +72,10 @@ int fourmc_gpu_lz4_compress_fast(const void* d_src, void* d_dst, fourmc_block* d
  * Ultra = 8); byte-identical payloads                            native/lz4/lz4hc.c:958-973       */
 int fourmc_gpu_lz4_compress_hc(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                                uint32_t n, int level, void* stream);
+/* result = LZ4_compressMC_limitedOutput(src, dst, src_len, dst_cap), or LZ4_compressMC (no limit)
+ * when dst_cap == 0xFFFFFFFF; byte-identical payloads           native/lz4/lz4mc.c:582-606         */
+int fourmc_gpu_lz4_compress_mc(const void* d_src, void* d_dst, fourmc_block* d_blocks,
+                               uint32_t n, void* stream);
 /* result = ZSTD_decompress(dst, dst_cap, src, src_len) as int: decoded bytes, or < 0 where the
  * reference returns an error code (ZSTD_isError)            native/zstd/decompress/zstd_decompress.c:1112 */
 int fourmc_gpu_zstd_decompress(const void* d_src, void* d_dst, fourmc_block* d_blocks,
@@ -107,6 +111,8 @@ int fourmc_gpu_4mc_pack_image(const void* d_staging, void* d_image, const fourmc
  * keep their exact one-call-one-block contract (SURVEY.md §8(b) "Batching constraint").        */
 int      fourmc_LZ4_compressBound(int inputSize);                       /* lz4.h:212            */
 int      fourmc_LZ4_compress_default(const char* src, char* dst, int srcSize, int dstCapacity);
+int      fourmc_LZ4_compressMC(const char* src, char* dst, int srcSize);
+int      fourmc_LZ4_compressMC_limitedOutput(const char* src, char* dst, int srcSize, int maxOutputSize);
 int      fourmc_LZ4_compress_HC(const char* src, char* dst, int srcSize, int dstCapacity, int compressionLevel);
 int      fourmc_LZ4_decompress_safe(const char* src, char* dst, int compressedSize, int dstCapacity);
 size_t   fourmc_ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, size_t compressedSize);

@@ -184,3 +184,13 @@ def orc_compress_hc(src, level, cap=None):
     dst = np.empty(max(cap, 1) + 8, dtype=np.uint8)
     r = L.orc_lz4hc_compress(src.ctypes.data, dst.ctypes.data, len(src), cap, level)
     return r, dst[:max(r, 0)].copy()
+
+
+def orc_compress_mc(src, cap=-1):
+    """cap < 0: LZ4_compressMC (no limit); else LZ4_compressMC_limitedOutput."""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    L = oracle()
+    L.orc_lz4mc_compress.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]; L.orc_lz4mc_compress.restype = C.c_int
+    dst = np.empty(L.orc_lz4_compress_bound(len(src)) + 64, dtype=np.uint8)
+    r = L.orc_lz4mc_compress(src.ctypes.data, dst.ctypes.data, len(src), cap)
+    return r, dst[:max(r, 0)].copy()

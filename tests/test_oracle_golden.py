@@ -201,3 +201,30 @@ def test_lz4hc_port_equals_reference_sources():
                 rr = ref.LZ4_compress_HC(d.ctypes.data, out.ctypes.data, len(d), cap, lvl)
                 r, comp = helpers.orc_compress_hc(d, lvl, cap)
                 assert r == rr and np.array_equal(comp, out[:max(rr, 0)]), (name, lvl, cap, r, rr)
+
+
+# ------------------------------------------------------------------------------------------ 4mc Medium port
+def test_lz4mc_port_golden_manifest():
+    m = json.load(open(os.path.join(G, "corpus_manifest.json")))
+    data = helpers.corpus(m["corpus"]["bytes"])
+    for b, (u, c, x) in enumerate(m["levels"]["4mc-2"]["blocks"]):
+        blk = data[b * B: b * B + u]
+        r, comp = helpers.orc_compress_mc(blk, u - 1)
+        payload = comp if r > 0 else blk
+        assert (len(payload), helpers.orc_xxh32(payload)) == (c, x), b
+
+
+@pytest.mark.skipif(helpers.ref() is None, reason="oracle/_ref not built (needs /root/reference)")
+def test_lz4mc_port_equals_reference_sources():
+    import ctypes as C
+    ref = helpers.ref()
+    ref.LZ4_compressMC.argtypes = [C.c_void_p, C.c_void_p, C.c_int]; ref.LZ4_compressMC.restype = C.c_int
+    ref.LZ4_compressMC_limitedOutput.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]; ref.LZ4_compressMC_limitedOutput.restype = C.c_int
+    for name, d in helpers.edge_inputs().items():
+        d = np.ascontiguousarray(d)
+        for cap in (-1, max(len(d) - 1, 0), len(d) // 2):
+            out = np.zeros(len(d) + len(d) // 255 + 80, np.uint8)
+            rr = (ref.LZ4_compressMC(d.ctypes.data, out.ctypes.data, len(d)) if cap < 0
+                  else ref.LZ4_compressMC_limitedOutput(d.ctypes.data, out.ctypes.data, len(d), cap))
+            r, comp = helpers.orc_compress_mc(d, cap)
+            assert r == rr and np.array_equal(comp, out[:max(rr, 0)]), (name, cap, r, rr)
