@@ -50,6 +50,20 @@ __device__ __forceinline__ uint32_t probe_offset(uint32_t K)
     return 1 + T + 32 * m * (m - 1) + m * r;
 }
 
+__device__ __forceinline__ uint32_t U(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }   // pin to an SGPR
+
+// 16 bytes at p, any alignment, as four dwords (one global_load_dwordx4)
+struct Q16 { uint32_t d0, d1, d2, d3; };
+__device__ __forceinline__ Q16 ld16(const uint8_t* p) { const U16B t = *reinterpret_cast<const U16B*>(p); return Q16{uint32_t(t.a), uint32_t(t.a >> 32), uint32_t(t.b), uint32_t(t.b >> 32)}; }
+__device__ __forceinline__ uint64_t u64(uint32_t lo, uint32_t hi) { return (uint64_t(hi) << 32) | lo; }
+__device__ __forceinline__ uint32_t rl(uint32_t v, int l) { return uint32_t(__builtin_amdgcn_readlane(int(v), l)); }
+
+template <bool U32TAB> __device__ __forceinline__ uint32_t hash_of(uint64_t v)
+{
+    if (U32TAB) return uint32_t(((v << 24) * 889523592379ULL) >> (64 - kHashLog));
+    return (uint32_t(v) * 2654435761u) >> (32 - (kHashLog + 1));
+}
+
 template <bool U32TAB>
 __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, const int cap,
                                 uint32_t* tab32, uint32_t* score, const int lane)
@@ -65,32 +79,72 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
     auto tab_put = [&](uint32_t h, uint32_t v) { if (U32TAB) tab32[h] = v; else tab16[h] = uint16_t(v); };
 
     if (n >= kMinLen) {
-        const uint32_t lim = uint32_t(n) - kMfLimit + 1;               // mflimitPlusOne
-        const uint32_t matchlimit = uint32_t(n) - kLastLit;
+        const uint32_t un = uint32_t(n);
+        const uint32_t lim = un - kMfLimit + 1;                        // mflimitPlusOne
+        const uint32_t matchlimit = un - kLastLit;
         if (lane == 0) tab_put(hash_at<U32TAB>(src), 0);
         uint32_t sp = 1;                                               // first probe of the search
+        // Cursor window: lane l keeps the 16 bytes [wsp+l-4, wsp+l+12) of the input.  Loaded once per ~50
+        // bytes of progress, it feeds (through lane permutes / readlane, no memory round trip) the probe
+        // words of the following searches, the extension bytes around a hit, short literal runs and the
+        // ip-2 / ip refill after a match.
+        Q16 W = {0, 0, 0, 0}; uint32_t wsp = 0; bool wvalid = false;
         for (;;) {
             // ------------------------------------------------------------ search (lz4.c:1014-1076)
             uint32_t ip, cand;
+            uint64_t e_ipx = 0, e_cx = 0; uint32_t e_ipb = 0, e_cb = 0; bool e_regs = false;   // extension data of the hit
+            // Probe width: candidate checks are random 64 KiB-window gathers (one cache line each), the
+            // real cost of a batch.  In compressible data a match turns up within a few probes, so a
+            // search starts 16 lanes wide and doubles after every batch that found nothing.
+            uint32_t width = 16;
             for (uint32_t k0 = 0;; ) {
-                const uint32_t pos  = sp + probe_offset(k0 + lane);
-                const uint32_t next = sp + probe_offset(k0 + lane + 1);
+                const bool act = uint32_t(lane) < width;
+                uint32_t pos, next;
+                if (k0 == 0) { pos = sp + lane; next = pos + 1; }       // the first 65 probes of a search are 1 apart
+                else { pos = sp + probe_offset(k0 + lane); next = sp + probe_offset(k0 + lane + 1); }
                 const bool in_range = next <= lim;                     // else: this probe ends the block
-                const uint32_t rp = in_range ? pos : 0;                // keep speculative reads in bounds
-                const uint32_t h = hash_at<U32TAB>(src + rp);
-                const uint32_t c = tab_get(h);
-                // scoreboard: does an earlier lane of this batch touch the same (folded) slot?
-                uint32_t* sc = &score[h & (kScore - 1)];
-                atomicMin(sc, uint32_t(lane));
-                const bool shared = (*sc != uint32_t(lane));
-                *sc = 0xFFFFFFFFu;
-                const bool hit = in_range && (!U32TAB || c + kMaxDist >= pos) && ld4(src + c) == ld4(src + rp);
+                // One 16-byte load per lane covers everything needed on the cursor side: [pos-4, pos) for the
+                // backward extension, [pos, pos+8) for the hash, [pos+4, pos+12) for the forward extension
+                // (in_range lanes have pos+12 <= n; the first few positions of a block take the plain path).
+                const bool wide = sp >= 4;
+                const uint32_t rp = in_range ? pos : (wide ? 4u : 0u);   // keep speculative reads in bounds
+                uint64_t v8, ipx = 0; uint32_t ipb = 0;
+                if (wide && k0 == 0) {
+                    // probes of a search's first (stride-1) batch: from the cursor window when they are
+                    // inside it, else re-centre the window on this search
+                    if (!(wvalid && sp >= wsp && sp + width <= wsp + 64 && wsp + 64 + 12 <= un)) {
+                        W = ld16(src + rp - 4); wsp = sp; wvalid = (sp + 64 + 12 <= un);
+                    }
+                    Q16 q = W;
+                    if (wvalid && sp != wsp) {
+                        const int sl = (lane + int(sp - wsp)) & 63;
+                        q.d0 = __shfl(W.d0, sl); q.d1 = __shfl(W.d1, sl); q.d2 = __shfl(W.d2, sl); q.d3 = __shfl(W.d3, sl);
+                    }
+                    ipb = q.d0; v8 = u64(q.d1, q.d2); ipx = u64(q.d2, q.d3);
+                } else if (wide) {
+                    const Q16 q = ld16(src + rp - 4);
+                    ipb = q.d0; v8 = u64(q.d1, q.d2); ipx = u64(q.d2, q.d3);
+                } else v8 = ld8(src + rp);
+                const uint32_t h = hash_of<U32TAB>(v8);
+                uint32_t c = 0, cw = 0; uint64_t cx = 0; uint32_t cb = 0; bool shared = false, cregs = false;
+                if (act) {
+                    c = tab_get(h);
+                    // scoreboard: does an earlier lane of this batch touch the same (folded) slot?
+                    uint32_t* sc = &score[h & (kScore - 1)];
+                    atomicMin(sc, uint32_t(lane));
+                    shared = (*sc != uint32_t(lane));
+                    *sc = 0xFFFFFFFFu;
+                    // candidate side, same shape: [c-4, c+12) in one load (c + 12 <= n always holds)
+                    if (wide && c >= 4) { const Q16 q = ld16(src + c - 4); cb = q.d0; cw = q.d1; cx = u64(q.d2, q.d3); cregs = true; }
+                    else cw = ld4(src + c);
+                }
+                const bool hit = act && in_range && (!U32TAB || c + kMaxDist >= pos) && cw == uint32_t(v8);
                 const unsigned long long m_cut  = __ballot(shared);
-                const unsigned long long m_term = __ballot(!in_range);
+                const unsigned long long m_term = __ballot(act && !in_range);
                 const unsigned long long m_hit  = __ballot(hit);
-                const int cut = m_cut ? __builtin_ctzll(m_cut) : 64;
+                const int cut = m_cut ? __builtin_ctzll(m_cut) : int(width);
                 // first lane (serial order) that ends this batch
-                const unsigned long long ev = (m_term | m_hit) & ((cut == 64) ? ~0ull : ((1ull << cut) - 1));
+                const unsigned long long ev = (m_term | m_hit) & ((cut >= 64) ? ~0ull : ((1ull << cut) - 1));
                 const int e = ev ? __builtin_ctzll(ev) : cut;
                 const bool e_is_hit = ev && ((m_hit >> e) & 1) && !((m_term >> e) & 1);
                 // commit table writes of the probes that really happen
@@ -99,80 +153,146 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                     if (!e_is_hit) goto last_literals;
                     ip   = __builtin_amdgcn_readlane(pos, e);
                     cand = __builtin_amdgcn_readlane(c, e);
+                    if (rl(uint32_t(cregs), e)) {
+                        e_regs = true;
+                        e_ipx = u64(rl(uint32_t(ipx), e), rl(uint32_t(ipx >> 32), e));
+                        e_cx  = u64(rl(uint32_t(cx), e), rl(uint32_t(cx >> 32), e));
+                        e_ipb = rl(ipb, e); e_cb = rl(cb, e);
+                    }
+                    // literal run [anchor, ip) straight from the batch registers: possible when the search
+                    // began right behind the previous sequence and the hit is in its first, stride-1 batch
                     break;
                 }
-                k0 += e;
+                k0 = U(k0 + e);
+                if (e == int(width) && width < 64) width *= 2;
             }
             // ------------------------------------------------------------ catch up (lz4.c:1080)
-            for (;;) {
-                const uint32_t j = uint32_t(lane) + 1;
-                const bool ok = (ip >= anchor + j) && (cand >= j) && src[ip - j] == src[cand - j];
-                const unsigned long long bad = ~__ballot(ok);
-                const int back = bad ? __builtin_ctzll(bad) : 64;
-                ip -= back; cand -= back;
-                if (back < 64) break;
-            }
-            // ------------------------------------------------------------ literals (lz4.c:1083-1107)
-            uint32_t token_pos, tok;          // the token byte is written once both nibbles are known
             {
-                const uint32_t lit = ip - anchor;
-                token_pos = op++;
-                if (limited && op + lit + (2 + 1 + kLastLit) + lit / 255 > uint32_t(cap)) return 0;
-                if (lit >= 15) { tok = 0xF0; op += emit_len(dst + op, lit - 15, lane); }
-                else tok = lit << 4;
-                copy_bytes(dst + op, src + anchor, lit, lane);
-                op += lit;
-            }
-            for (;;) {   // _next_match (lz4.c:1109-1200)
-                const uint32_t off = ip - cand;
-                if (lane == 0) { dst[op] = uint8_t(off); dst[op + 1] = uint8_t(off >> 8); }
-                op += 2;
-                // forward extension: bytes equal from ip+4 / cand+4, bounded by matchlimit
-                uint32_t mcode = 0;
+                // forward bytes already known from the hit registers (relative to the ORIGINAL ip)
+                uint32_t fwd_known = 0; bool fwd_done = false;
+                if (e_regs) {
+                    const uint64_t x = e_ipx ^ e_cx;
+                    const uint32_t eq = x ? uint32_t(__builtin_ctzll(x) >> 3) : 8u;
+                    const uint32_t room = matchlimit - (ip + 4);       // ip < lim  =>  room >= 3
+                    fwd_known = min(eq, room);
+                    fwd_done = (eq < 8) || (room <= 8);
+                }
+                const uint32_t maxback = min(ip - anchor, cand);
+                uint32_t back = 0; bool more = maxback > 0;
+                if (e_regs && more && cand >= 4) {                     // first 4 bytes from registers
+                    const uint32_t x = e_ipb ^ e_cb;                   // byte 3 (MSB) is position -1
+                    const uint32_t eq = x ? uint32_t(__builtin_clz(x) >> 3) : 4u;
+                    back = min(eq, maxback);
+                    more = (eq == 4 && maxback > 4);
+                }
+                while (more) {
+                    const uint32_t j = back + uint32_t(lane) + 1;
+                    const bool ok = (j <= maxback) && src[ip - j] == src[cand - j];
+                    const unsigned long long bad = ~__ballot(ok);
+                    const int b = bad ? __builtin_ctzll(bad) : 64;
+                    back += b;
+                    if (b < 64) break;
+                }
+                back = U(back);
+                ip = U(ip - back); cand = U(cand - back);
+                // everything in [new ip, old ip + 4 + fwd_known) is equal: the forward count restarts from
+                // the new ip+4, so the `back` bytes just walked over are already part of it
+                if (e_regs) fwd_known += back;
+                // ---------------------------------------------------------- literals (lz4.c:1083-1107)
+                uint32_t token_pos, tok;      // the token byte is written once both nibbles are known
                 {
-                    uint32_t a = ip + 4, b = cand + 4;
-                    for (;;) {
-                        if (a + 1024 <= matchlimit && mcode >= 64) {
-                            // 16 bytes per lane
-                            const U16B x = *reinterpret_cast<const U16B*>(src + a + 16 * lane);
-                            const U16B y = *reinterpret_cast<const U16B*>(src + b + 16 * lane);
-                            const uint64_t d0 = x.a ^ y.a, d1 = x.b ^ y.b;
-                            const uint32_t eq = d0 ? uint32_t(__builtin_ctzll(d0) >> 3)
-                                                   : (d1 ? 8u + uint32_t(__builtin_ctzll(d1) >> 3) : 16u);
-                            const unsigned long long bad = __ballot(eq < 16);
-                            if (bad) {
-                                const int l = __builtin_ctzll(bad);
-                                mcode += 16 * l + __builtin_amdgcn_readlane(eq, l);
-                                break;
+                    const uint32_t lit = ip - anchor;
+                    token_pos = op++;
+                    if (limited && op + lit + (2 + 1 + kLastLit) + lit / 255 > uint32_t(cap)) return 0;
+                    if (lit >= 15) { tok = 0xF0; op += emit_len(dst + op, lit - 15, lane); }
+                    else tok = lit << 4;
+                    if (wvalid && anchor + 1 >= wsp && ip <= wsp + 64) {
+                        // the run lies inside the cursor window: lane l owns position wsp+l (byte 4 of its
+                        // 16), lane 0 also owns wsp-1 (byte 3)
+                        const uint32_t q = wsp + lane;
+                        if (q >= anchor && q < ip) dst[op + (q - anchor)] = uint8_t(W.d1);
+                        if (lane == 0 && anchor + 1 == wsp && lit) dst[op] = uint8_t(W.d0 >> 24);
+                    } else copy_bytes(dst + op, src + anchor, lit, lane);
+                    op += lit;
+                }
+                for (;;) {   // _next_match (lz4.c:1109-1200)
+                    const uint32_t off = ip - cand;
+                    if (lane == 0) { dst[op] = uint8_t(off); dst[op + 1] = uint8_t(off >> 8); }
+                    op += 2;
+                    // forward extension: bytes equal from ip+4 / cand+4, bounded by matchlimit
+                    uint32_t mcode = fwd_known;
+                    if (!fwd_done) {
+                        uint32_t a = ip + 4 + mcode, b = cand + 4 + mcode;
+                        for (;;) {
+                            if (a + 1024 <= matchlimit && mcode >= 64) {
+                                const U16B x = *reinterpret_cast<const U16B*>(src + a + 16 * lane);
+                                const U16B y = *reinterpret_cast<const U16B*>(src + b + 16 * lane);
+                                const uint64_t d0 = x.a ^ y.a, d1 = x.b ^ y.b;
+                                const uint32_t eq = d0 ? uint32_t(__builtin_ctzll(d0) >> 3)
+                                                       : (d1 ? 8u + uint32_t(__builtin_ctzll(d1) >> 3) : 16u);
+                                const unsigned long long bad = __ballot(eq < 16);
+                                if (bad) {
+                                    const int l = __builtin_ctzll(bad);
+                                    mcode += 16 * l + __builtin_amdgcn_readlane(eq, l);
+                                    break;
+                                }
+                                mcode += 1024; a += 1024; b += 1024;
+                            } else {
+                                const uint32_t i = a + lane;
+                                const bool same = (i < matchlimit) && src[i] == src[b + lane];
+                                const unsigned long long bad = ~__ballot(same);
+                                if (bad) { mcode += __builtin_ctzll(bad); break; }
+                                mcode += 64; a += 64; b += 64;
                             }
-                            mcode += 1024; a += 1024; b += 1024;
-                        } else {
-                            const uint32_t i = a + lane;
-                            const bool same = (i < matchlimit) && src[i] == src[b + lane];
-                            const unsigned long long bad = ~__ballot(same);
-                            if (bad) { mcode += __builtin_ctzll(bad); break; }
-                            mcode += 64; a += 64; b += 64;
                         }
                     }
+                    mcode = U(mcode);
+                    ip = U(ip + mcode + 4);
+                    if (limited && op + (1 + kLastLit) + (mcode + 240) / 255 > uint32_t(cap)) return 0;
+                    uint32_t tok_add;
+                    if (mcode >= 15) { tok_add = 15; op += emit_len(dst + op, mcode - 15, lane); }
+                    else tok_add = mcode;
+                    if (lane == 0) dst[token_pos] = uint8_t(tok + tok_add);
+                    anchor = ip; op = U(op);
+                    if (ip >= lim) goto last_literals;
+                    // refill ip-2, then test ip immediately (lz4.c:1207-1259)
+                    // [ip-2, ip+14) in one (wave-uniform) load: hash words of ip-2 and ip, forward bytes of ip
+                    uint64_t w2, w0, nx = 0; bool nregs = false;
+                    if (wvalid && ip >= wsp && ip < wsp + 64) {
+                        // lane ip-wsp holds [ip-4, ip+12): ip-2 is its byte 2, ip byte 4, ip+4 byte 8
+                        const int l = int(ip - wsp);
+                        const uint32_t a0 = rl(W.d0, l), a1 = rl(W.d1, l), a2 = rl(W.d2, l), a3 = rl(W.d3, l);
+                        w2 = u64(__builtin_amdgcn_alignbit(a1, a0, 16), __builtin_amdgcn_alignbit(a2, a1, 16));
+                        w0 = u64(a1, a2); nx = u64(a2, a3);
+                        nregs = true;
+                    } else if (ip + 14 <= un) {
+                        const Q16 q = ld16(src + ip - 2);
+                        w2 = u64(q.d0, q.d1);
+                        w0 = u64(__builtin_amdgcn_alignbit(q.d1, q.d0, 16), __builtin_amdgcn_alignbit(q.d2, q.d1, 16));
+                        nx = u64(__builtin_amdgcn_alignbit(q.d2, q.d1, 16), __builtin_amdgcn_alignbit(q.d3, q.d2, 16));
+                        nregs = true;
+                    } else { w2 = ld8(src + ip - 2); w0 = ld8(src + ip); }
+                    if (lane == 0) tab_put(hash_of<U32TAB>(w2), ip - 2);
+                    const uint32_t h = hash_of<U32TAB>(w0);
+                    cand = uint32_t(__builtin_amdgcn_readfirstlane(int(tab_get(h))));
+                    if (lane == 0) tab_put(h, ip);
+                    const uint32_t cw = ld4(src + cand);
+                    uint64_t cx = 0;
+                    if (nregs) cx = ld8(src + cand + 4);
+                    const bool again = (!U32TAB || cand + kMaxDist >= ip) && cw == uint32_t(w0);
+                    if (!__builtin_amdgcn_readfirstlane(int(again))) break;
+                    token_pos = op++; tok = 0;
+                    fwd_known = 0; fwd_done = false;
+                    if (nregs) {
+                        const uint64_t x = nx ^ cx;
+                        const uint32_t eq = x ? uint32_t(__builtin_ctzll(x) >> 3) : 8u;
+                        const uint32_t room = matchlimit - (ip + 4);
+                        fwd_known = min(eq, room);
+                        fwd_done = (eq < 8) || (room <= 8);
+                    }
                 }
-                ip += mcode + 4;
-                if (limited && op + (1 + kLastLit) + (mcode + 240) / 255 > uint32_t(cap)) return 0;
-                uint32_t tok_add;
-                if (mcode >= 15) { tok_add = 15; op += emit_len(dst + op, mcode - 15, lane); }
-                else tok_add = mcode;
-                if (lane == 0) dst[token_pos] = uint8_t(tok + tok_add);
-                anchor = ip;
-                if (ip >= lim) goto last_literals;
-                // refill ip-2, then test ip immediately (lz4.c:1207-1259)
-                if (lane == 0) tab_put(hash_at<U32TAB>(src + ip - 2), ip - 2);
-                const uint32_t h = hash_at<U32TAB>(src + ip);
-                cand = uint32_t(__builtin_amdgcn_readfirstlane(int(tab_get(h))));
-                if (lane == 0) tab_put(h, ip);
-                const bool again = (!U32TAB || cand + kMaxDist >= ip) && ld4(src + cand) == ld4(src + ip);
-                if (!__builtin_amdgcn_readfirstlane(int(again))) break;
-                token_pos = op++; tok = 0;
             }
-            sp = ip + 1;
+            sp = U(ip + 1); anchor = U(anchor); op = U(op);
         }
     }
 last_literals:
