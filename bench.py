@@ -239,10 +239,20 @@ def main():
     dom = "lz4_encode" if kts["lz4_encode"] >= kts["lz4_decode"] else "lz4_decode"
     alg = alg_enc if dom == "lz4_encode" else alg_dec
 
+    # HBM bytes per launch from the PMC passes (rocprofv3 FETCH_SIZE + WRITE_SIZE, separate runs of this
+    # same script at --blocks 512; summary and calibration note in profiles/), scaled to this launch
+    traffic = {}
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        for k in ("lz4_encode", "lz4_decode"):
+            traffic[k] = int((tj[k]["fetch_KiB"] + tj[k]["write_KiB"]) * 1024 * nb / tj["blocks"])
+    except Exception:
+        pass
+
     def roof(name, algb):
         a = algb / (kts[name] * 1e-3) / 1e9
         return {"kernel": name, "bound": "hbm", "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(a / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(a / HBM_PEAK_GBS, 5), "traffic": traffic.get(name),
                 "algorithmic_bytes_per_launch": algb, "avg_launch_ms": round(kts[name], 3)}
 
     if rank == 0:
