@@ -61,6 +61,14 @@ int64_t orc_container_decompress(const uint8_t* src, size_t n, uint8_t* dst, siz
 int64_t orc_zstd_decompress(const uint8_t* src, size_t csize, uint8_t* dst, size_t cap);
 int     orc_codec_zstd_decode(void* ctx, const uint8_t* src, int n, uint8_t* dst, int cap);
 
+/* ZSTD_compress(dst, cap, src, n, level) for the 4mz encode path (zstd_enc_port.c) -
+ * native/zstd/compress/zstd_compress.c:4806 as called by native/4mc.c:467.  Returns the frame size,
+ * a negative ZSTD error number (-70 = dstSize_tooSmall), or ORC_ZSTD_UNSUPPORTED for levels the
+ * port does not restate (only level 1 / strategy "fast" so far). */
+#define ORC_ZSTD_UNSUPPORTED (-1000)
+int64_t orc_zstd_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int level);
+int     orc_codec_zstd1(void* ctx, const uint8_t* src, int n, uint8_t* dst, int cap);
+
 /* codec adaptors with the orc_block_codec_fn shape (ctx unused) */
 int orc_codec_lz4_fast(void* ctx, const uint8_t* src, int n, uint8_t* dst, int cap);
 int orc_codec_lz4_decode(void* ctx, const uint8_t* src, int n, uint8_t* dst, int cap);

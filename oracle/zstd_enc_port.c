@@ -1,0 +1,919 @@
+/*
+ * oracle/zstd_enc_port.c — scalar restatement of ZSTD_compress() (zstd 1.5.3 as vendored under
+ * native/zstd) for the one-shot, no-dictionary, known-size call 4mz makes per block
+ * (native/4mc.c:467: ZSTD_compress(out+12, n-1, in, n, level)).  TEST INFRASTRUCTURE, NOT PRODUCT.
+ *
+ * Covered: strategy ZSTD_fast (4mz "fast" = zstd level 1; every size class of the level table).
+ * Other levels return ORC_ZSTD_UNSUPPORTED.
+ *
+ *   parameters   ZSTD_getCParams_internal        compress/zstd_compress.c:6465-6488, clevels.h:25-130,
+ *                ZSTD_adjustCParams_internal     compress/zstd_compress.c:1335-1399
+ *   frame        ZSTD_writeFrameHeader :4065-4116, ZSTD_compress_frameChunk :3983-4062,
+ *                ZSTD_writeEpilogue :4661-4698, block size :1883-1884
+ *   block        ZSTD_compressBlock_internal :3812-3877, ZSTD_buildSeqStore :2859-2940,
+ *                ZSTD_entropyCompressSeqStore(_internal) :2632-2775, ZSTD_buildSequencesStatistics :2489-2615
+ *   match finder ZSTD_compressBlock_fast_noDict_generic   compress/zstd_fast.c:95-365
+ *   literals     ZSTD_compressLiterals           compress/zstd_compress_literals.c:100-196
+ *   Huffman      HUF_compress_internal           compress/huf_compress.c:1250-1360 (+ sort :604, tree :665,
+ *                setMaxHeight :360, writeCTable :230, compressWeights :147, 1X/4X streams :1029-1194)
+ *   FSE          fse_compress.c: buildCTable :68-200, writeNCount :224-330, optimalTableLog :355-368,
+ *                normalizeCount :373-520, compress_usingCTable :560-620
+ *   sequences    zstd_compress_sequences.c: selectEncodingType :153-239, buildCTable :246-300,
+ *                encodeSequences :302-400;   codes: zstd_compress_internal.h:480-509
+ *
+ * Positions are offsets into the input; a hash-table index is position + 2 as in the reference
+ * (ZSTD_WINDOW_START_INDEX), so 0 means "empty".
+ * Parity: pinned — byte-identical to oracle/_ref (ZSTD_compress, level 1) on the corpus blocks, edge
+ * inputs and tails, with capacity n-1 and ZSTD_compressBound(n) (tests/test_oracle_golden.py), and
+ * to the per-block manifest of the reference CLI at `4mc -z -1` (tests/golden/corpus_manifest.json).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "oracle.h"
+
+#define ERR_GENERIC   (-1)
+#define ERR_TOOSMALL  (-70)               /* ZSTD_error_dstSize_tooSmall */
+#define BLOCK_MAX     (128 * 1024)
+
+typedef struct { uint32_t wlog, clog, hlog, slog, mml, tlen, strat; } zparams;
+
+static uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+static int hibit(uint32_t v) { return 31 - __builtin_clz(v); }
+
+/* ------------------------------------------------------------------------------------------------
+ * bit writer with the overflow rule of BIT_CStream_t / HUF_CStream_t: the stream "does not fit"
+ * when floor(total_bits / 8) >= cap - 8 (bitstream.h:153-163,:219-240, huf_compress.c:830-956).
+ */
+typedef struct { uint8_t* p; size_t cap, pos; uint64_t acc; unsigned nb; uint64_t total; } bitw;
+
+static int bw_init(bitw* w, uint8_t* p, size_t cap)
+{ w->p = p; w->cap = cap; w->pos = 0; w->acc = 0; w->nb = 0; w->total = 0; return cap > 8; }
+
+static void bw_put(bitw* w, uint64_t v, unsigned n)          /* n <= 32 */
+{
+    w->acc |= (v & ((1ull << n) - 1)) << w->nb;
+    w->nb += n; w->total += n;
+    while (w->nb >= 8) {
+        if (w->pos < w->cap) w->p[w->pos] = (uint8_t)w->acc;
+        w->pos++; w->acc >>= 8; w->nb -= 8;
+    }
+}
+
+static size_t bw_close(bitw* w)                              /* end mark + size, 0 = did not fit */
+{
+    bw_put(w, 1, 1);
+    if ((w->total >> 3) + 8 >= w->cap) return 0;
+    if (w->nb) { w->p[w->pos] = (uint8_t)w->acc; return w->pos + 1; }
+    return w->pos;
+}
+
+/* ------------------------------------------------------------------------------------------------ FSE */
+typedef struct {
+    uint16_t next[1 << 9];       /* state table (max table log 9 on this path) */
+    uint32_t dbits[64];          /* deltaNbBits   */
+    int32_t  dfind[64];          /* deltaFindState */
+    uint32_t log;
+} fse_ct;
+
+static unsigned hist(uint32_t* count, unsigned* max_sym, const uint8_t* s, size_t n)   /* hist.c:31-60 */
+{
+    unsigned m = *max_sym, largest = 0;
+    memset(count, 0, (m + 1) * sizeof *count);
+    if (!n) { *max_sym = 0; return 0; }
+    for (size_t i = 0; i < n; i++) count[s[i]]++;
+    while (!count[m]) m--;
+    *max_sym = m;
+    for (unsigned i = 0; i <= m; i++) if (count[i] > largest) largest = count[i];
+    return largest;
+}
+
+static uint32_t fse_min_log(size_t n, unsigned max_sym)
+{
+    const uint32_t a = (uint32_t)hibit((uint32_t)n) + 1, b = (uint32_t)hibit(max_sym) + 2;
+    return a < b ? a : b;
+}
+
+static uint32_t fse_optimal_log(uint32_t max_log, size_t n, unsigned max_sym, unsigned minus)
+{
+    const uint32_t src_bits = (uint32_t)hibit((uint32_t)(n - 1)) - minus, min_bits = fse_min_log(n, max_sym);
+    uint32_t log = max_log ? max_log : 11;
+    if (src_bits < log) log = src_bits;
+    if (min_bits > log) log = min_bits;
+    if (log < 5) log = 5;
+    if (log > 12) log = 12;
+    return log;
+}
+
+static int fse_normalize_m2(int16_t* norm, uint32_t log, const uint32_t* count, size_t total, unsigned max_sym, int16_t low)
+{
+    uint32_t distributed = 0, todo, s;
+    const uint32_t low_thr = (uint32_t)(total >> log);
+    uint32_t low_one = (uint32_t)((total * 3) >> (log + 1));
+    for (s = 0; s <= max_sym; s++) {
+        if (!count[s]) { norm[s] = 0; continue; }
+        if (count[s] <= low_thr) { norm[s] = low; distributed++; total -= count[s]; continue; }
+        if (count[s] <= low_one) { norm[s] = 1; distributed++; total -= count[s]; continue; }
+        norm[s] = -2;
+    }
+    todo = (1u << log) - distributed;
+    if (!todo) return 0;
+    if (total / todo > low_one) {
+        low_one = (uint32_t)((total * 3) / (todo * 2));
+        for (s = 0; s <= max_sym; s++)
+            if (norm[s] == -2 && count[s] <= low_one) { norm[s] = 1; distributed++; total -= count[s]; }
+        todo = (1u << log) - distributed;
+    }
+    if (distributed == max_sym + 1) {
+        uint32_t best = 0, bc = 0;
+        for (s = 0; s <= max_sym; s++) if (count[s] > bc) { best = s; bc = count[s]; }
+        norm[best] += (int16_t)todo;
+        return 0;
+    }
+    if (!total) {
+        for (s = 0; todo > 0; s = (s + 1) % (max_sym + 1)) if (norm[s] > 0) { todo--; norm[s]++; }
+        return 0;
+    }
+    {
+        const uint64_t vlog = 62 - log, mid = (1ull << (vlog - 1)) - 1;
+        const uint64_t rstep = (((1ull << vlog) * todo) + mid) / (uint32_t)total;
+        uint64_t acc = mid;
+        for (s = 0; s <= max_sym; s++) if (norm[s] == -2) {
+            const uint64_t end = acc + count[s] * rstep;
+            const uint32_t w = (uint32_t)(end >> vlog) - (uint32_t)(acc >> vlog);
+            if (w < 1) return ERR_GENERIC;
+            norm[s] = (int16_t)w; acc = end;
+        }
+    }
+    return 0;
+}
+
+static int fse_normalize(int16_t* norm, uint32_t log, const uint32_t* count, size_t total, unsigned max_sym, int use_low)
+{
+    static const uint32_t rtb[8] = {0, 473195, 504333, 520860, 550000, 700000, 750000, 830000};
+    const int16_t low = use_low ? -1 : 1;
+    const uint64_t scale = 62 - log, step = (1ull << 62) / (uint32_t)total, vstep = 1ull << (scale - 20);
+    const uint32_t low_thr = (uint32_t)(total >> log);
+    int remaining = 1 << log;
+    unsigned s, largest = 0;
+    int16_t largest_p = 0;
+    if (log < fse_min_log(total, max_sym)) return ERR_GENERIC;
+    for (s = 0; s <= max_sym; s++) {
+        if (count[s] == total) return 0;
+        if (!count[s]) { norm[s] = 0; continue; }
+        if (count[s] <= low_thr) { norm[s] = low; remaining--; continue; }
+        {
+            int16_t p = (int16_t)((count[s] * step) >> scale);
+            if (p < 8) p += (count[s] * step) - ((uint64_t)p << scale) > vstep * rtb[p];
+            if (p > largest_p) { largest_p = p; largest = s; }
+            norm[s] = p; remaining -= p;
+        }
+    }
+    if (-remaining >= (norm[largest] >> 1)) return fse_normalize_m2(norm, log, count, total, max_sym, low);
+    norm[largest] += (int16_t)remaining;
+    return 0;
+}
+
+/* returns bytes written or ERR_* */
+static int fse_write_ncount(uint8_t* out, size_t cap, const int16_t* norm, unsigned max_sym, uint32_t log)
+{
+    const size_t bound = max_sym ? (((max_sym + 1) * log + 4 + 2) / 8) + 1 + 2 : 512;
+    const int safe = cap >= bound;
+    const unsigned alphabet = max_sym + 1;
+    size_t o = 0;
+    int nbits = (int)log + 1, remaining = (1 << log) + 1, threshold = 1 << log, bc = 4, prev0 = 0;
+    uint32_t bs = log - 5;
+    unsigned sym = 0;
+#define NC_FLUSH() do { if (!safe && o + 2 > cap) return ERR_TOOSMALL; \
+        out[o] = (uint8_t)bs; out[o + 1] = (uint8_t)(bs >> 8); o += 2; bs >>= 16; } while (0)
+    while (sym < alphabet && remaining > 1) {
+        if (prev0) {
+            unsigned start = sym;
+            while (sym < alphabet && !norm[sym]) sym++;
+            if (sym == alphabet) break;
+            while (sym >= start + 24) { start += 24; bs += 0xFFFFu << bc; NC_FLUSH(); }
+            while (sym >= start + 3) { start += 3; bs += 3u << bc; bc += 2; }
+            bs += (sym - start) << bc; bc += 2;
+            if (bc > 16) { NC_FLUSH(); bc -= 16; }
+        }
+        {
+            int c = norm[sym++];
+            const int max = (2 * threshold - 1) - remaining;
+            remaining -= c < 0 ? -c : c;
+            c++;
+            if (c >= threshold) c += max;
+            bs += (uint32_t)c << bc;
+            bc += nbits; bc -= (c < max);
+            prev0 = (c == 1);
+            if (remaining < 1) return ERR_GENERIC;
+            while (remaining < threshold) { nbits--; threshold >>= 1; }
+        }
+        if (bc > 16) { NC_FLUSH(); bc -= 16; }
+    }
+    if (remaining != 1) return ERR_GENERIC;
+    if (!safe && o + 2 > cap) return ERR_TOOSMALL;
+    out[o] = (uint8_t)bs; out[o + 1] = (uint8_t)(bs >> 8);
+    o += (size_t)(bc + 7) / 8;
+#undef NC_FLUSH
+    return (int)o;
+}
+
+static void fse_build(fse_ct* ct, const int16_t* norm, unsigned max_sym, uint32_t log)
+{
+    const uint32_t size = 1u << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    uint16_t cumul[66];
+    uint8_t symbol_at[1 << 9];
+    uint32_t high = size - 1, pos = 0, total = 0;
+    ct->log = log;
+    cumul[0] = 0;
+    for (unsigned s = 0; s <= max_sym; s++) {
+        if (norm[s] == -1) { cumul[s + 1] = cumul[s] + 1; symbol_at[high--] = (uint8_t)s; }
+        else cumul[s + 1] = cumul[s] + (uint16_t)norm[s];
+    }
+    for (unsigned s = 0; s <= max_sym; s++)
+        for (int i = 0; i < norm[s]; i++) {
+            symbol_at[pos] = (uint8_t)s;
+            do pos = (pos + step) & mask; while (pos > high);
+        }
+    for (uint32_t u = 0; u < size; u++) ct->next[cumul[symbol_at[u]]++] = (uint16_t)(size + u);
+    for (unsigned s = 0; s <= max_sym; s++) {
+        const int n = norm[s];
+        if (n == 0) { ct->dbits[s] = ((log + 1) << 16) - size; ct->dfind[s] = 0; }
+        else if (n == -1 || n == 1) { ct->dbits[s] = (log << 16) - size; ct->dfind[s] = (int32_t)total - 1; total++; }
+        else {
+            const uint32_t max_out = log - (uint32_t)hibit((uint32_t)n - 1);
+            ct->dbits[s] = (max_out << 16) - ((uint32_t)n << max_out);
+            ct->dfind[s] = (int32_t)total - n;
+            total += (uint32_t)n;
+        }
+    }
+}
+
+static void fse_build_rle(fse_ct* ct, unsigned sym)
+{ ct->log = 0; ct->next[0] = ct->next[1] = 0; ct->dbits[sym] = 0; ct->dfind[sym] = 0; }
+
+static uint32_t fse_first_state(const fse_ct* ct, unsigned sym)              /* FSE_initCState2 */
+{
+    const uint32_t nb = (ct->dbits[sym] + (1u << 15)) >> 16;
+    const uint32_t v = (nb << 16) - ct->dbits[sym];
+    return ct->next[(int32_t)(v >> nb) + ct->dfind[sym]];
+}
+
+static uint32_t fse_encode(bitw* w, const fse_ct* ct, uint32_t state, unsigned sym)
+{
+    const uint32_t nb = (state + ct->dbits[sym]) >> 16;
+    bw_put(w, state, nb);
+    return ct->next[(int32_t)(state >> nb) + ct->dfind[sym]];
+}
+
+/* FSE_compress_usingCTable with two interleaved states (used for Huffman weights only) */
+static size_t fse_compress2(uint8_t* dst, size_t cap, const uint8_t* src, size_t n, const fse_ct* ct)
+{
+    bitw w;
+    size_t i = n;
+    uint32_t s1, s2;
+    if (n <= 2 || !bw_init(&w, dst, cap)) return 0;
+    if (n & 1) { s1 = fse_first_state(ct, src[--i]); s2 = fse_first_state(ct, src[--i]); s1 = fse_encode(&w, ct, s1, src[--i]); }
+    else       { s2 = fse_first_state(ct, src[--i]); s1 = fse_first_state(ct, src[--i]); }
+    while (i > 0) { s2 = fse_encode(&w, ct, s2, src[--i]); s1 = fse_encode(&w, ct, s1, src[--i]); }
+    bw_put(&w, s2, ct->log); bw_put(&w, s1, ct->log);
+    return bw_close(&w);
+}
+
+/* ------------------------------------------------------------------------------------------------ Huffman */
+typedef struct { uint8_t nbits[256]; uint16_t code[256]; uint32_t log; } huf_ct;
+typedef struct { uint32_t count; uint16_t parent; uint8_t byte, nbits; } hnode;
+
+static uint32_t huf_bucket(uint32_t c) { return c < 165 ? c : (uint32_t)hibit(c) + 158; }   /* huf_compress.c:497-517 */
+
+static void huf_isort(hnode* a, int n)
+{
+    for (int i = 1; i < n; i++) {
+        const hnode key = a[i];
+        int j = i - 1;
+        while (j >= 0 && a[j].count < key.count) { a[j + 1] = a[j]; j--; }
+        a[j + 1] = key;
+    }
+}
+
+static void huf_qsort(hnode* a, int lo, int hi)              /* descending; pivot = rightmost (:555-600) */
+{
+    if (hi - lo < 8) { huf_isort(a + lo, hi - lo + 1); return; }
+    while (lo < hi) {
+        const uint32_t pivot = a[hi].count;
+        int i = lo - 1, idx;
+        hnode t;
+        for (int j = lo; j < hi; j++) if (a[j].count > pivot) { i++; t = a[i]; a[i] = a[j]; a[j] = t; }
+        t = a[i + 1]; a[i + 1] = a[hi]; a[hi] = t;
+        idx = i + 1;
+        if (idx - lo < hi - idx) { huf_qsort(a, lo, idx - 1); lo = idx + 1; }
+        else                     { huf_qsort(a, idx + 1, hi); hi = idx - 1; }
+    }
+}
+
+static void huf_sort(hnode* node, const uint32_t* count, unsigned max_sym)
+{
+    struct { uint16_t base, curr; } rank[192];
+    memset(rank, 0, sizeof rank);
+    for (unsigned s = 0; s <= max_sym; s++) rank[huf_bucket(count[s])].base++;
+    for (int r = 191; r > 0; r--) { rank[r - 1].base += rank[r].base; rank[r - 1].curr = rank[r - 1].base; }
+    for (unsigned s = 0; s <= max_sym; s++) {
+        const uint32_t pos = rank[huf_bucket(count[s]) + 1].curr++;
+        node[pos].count = count[s]; node[pos].byte = (uint8_t)s;
+    }
+    for (int r = 165; r < 191; r++) {
+        const int len = rank[r].curr - rank[r].base;
+        if (len > 1) huf_qsort(node + rank[r].base, 0, len - 1);
+    }
+}
+
+static uint32_t huf_limit_height(hnode* node, uint32_t last, uint32_t target)   /* HUF_setMaxHeight :360-470 */
+{
+    const uint32_t largest = node[last].nbits;
+    int cost = 0, n = (int)last;
+    uint32_t rank_last[14];
+    if (largest <= target) return largest;
+    {
+        const int base = 1 << (largest - target);
+        while (node[n].nbits > target) { cost += base - (1 << (largest - node[n].nbits)); node[n].nbits = (uint8_t)target; n--; }
+        while (node[n].nbits == target) n--;
+        cost >>= (largest - target);
+    }
+    for (int i = 0; i < 14; i++) rank_last[i] = 0xF0F0F0F0u;
+    {
+        uint32_t cur = target;
+        for (int pos = n; pos >= 0; pos--) {
+            if (node[pos].nbits >= cur) continue;
+            cur = node[pos].nbits;
+            rank_last[target - cur] = (uint32_t)pos;
+        }
+    }
+    while (cost > 0) {
+        uint32_t dec = (uint32_t)hibit((uint32_t)cost) + 1;
+        for (; dec > 1; dec--) {
+            const uint32_t hp = rank_last[dec], lp = rank_last[dec - 1];
+            if (hp == 0xF0F0F0F0u) continue;
+            if (lp == 0xF0F0F0F0u) break;
+            if (node[hp].count <= 2 * node[lp].count) break;
+        }
+        while (dec <= 12 && rank_last[dec] == 0xF0F0F0F0u) dec++;
+        cost -= 1 << (dec - 1);
+        node[rank_last[dec]].nbits++;
+        if (rank_last[dec - 1] == 0xF0F0F0F0u) rank_last[dec - 1] = rank_last[dec];
+        if (rank_last[dec] == 0) rank_last[dec] = 0xF0F0F0F0u;
+        else {
+            rank_last[dec]--;
+            if (node[rank_last[dec]].nbits != target - dec) rank_last[dec] = 0xF0F0F0F0u;
+        }
+    }
+    while (cost < 0) {
+        if (rank_last[1] == 0xF0F0F0F0u) {
+            while (node[n].nbits == target) n--;
+            node[n + 1].nbits--;
+            rank_last[1] = (uint32_t)(n + 1);
+            cost++;
+            continue;
+        }
+        node[rank_last[1] + 1].nbits--;
+        rank_last[1]++;
+        cost++;
+    }
+    return target;
+}
+
+/* HUF_buildCTable_wksp: returns the table log */
+static uint32_t huf_build(huf_ct* ct, const uint32_t* count, unsigned max_sym, uint32_t max_bits)
+{
+    hnode store[513];
+    hnode* const node = store + 1;               /* node[-1] is the barrier entry */
+    int last, low_s, low_n, nb = 256, root;
+    memset(store, 0, sizeof store);
+    huf_sort(node, count, max_sym);
+    last = (int)max_sym;
+    while (!node[last].count) last--;
+    low_s = last; root = nb + low_s - 1; low_n = nb;
+    node[nb].count = node[low_s].count + node[low_s - 1].count;
+    node[low_s].parent = node[low_s - 1].parent = (uint16_t)nb;
+    nb++; low_s -= 2;
+    for (int n = nb; n <= root; n++) node[n].count = 1u << 30;
+    node[-1].count = 1u << 31;
+    while (nb <= root) {
+        const int n1 = node[low_s].count < node[low_n].count ? low_s-- : low_n++;
+        const int n2 = node[low_s].count < node[low_n].count ? low_s-- : low_n++;
+        node[nb].count = node[n1].count + node[n2].count;
+        node[n1].parent = node[n2].parent = (uint16_t)nb;
+        nb++;
+    }
+    node[root].nbits = 0;
+    for (int n = root - 1; n >= 256; n--) node[n].nbits = (uint8_t)(node[node[n].parent].nbits + 1);
+    for (int n = 0; n <= last; n++) node[n].nbits = (uint8_t)(node[node[n].parent].nbits + 1);
+    max_bits = huf_limit_height(node, (uint32_t)last, max_bits);
+    {   /* canonical codes: values ascend within a rank in symbol order (:714-735) */
+        uint16_t per_rank[13] = {0}, val[13] = {0}, min = 0;
+        for (int n = 0; n <= last; n++) per_rank[node[n].nbits]++;
+        for (int r = (int)max_bits; r > 0; r--) { val[r] = min; min = (uint16_t)((min + per_rank[r]) >> 1); }
+        memset(ct, 0, sizeof *ct);
+        for (unsigned n = 0; n <= max_sym; n++) ct->nbits[node[n].byte] = node[n].nbits;
+        for (unsigned s = 0; s <= max_sym; s++) ct->code[s] = ct->nbits[s] ? val[ct->nbits[s]]++ : 0;
+        ct->log = max_bits;
+    }
+    return max_bits;
+}
+
+/* HUF_writeCTable_wksp: bytes written or ERR_* */
+static int huf_write_table(uint8_t* dst, size_t cap, const huf_ct* ct, unsigned max_sym, uint32_t log)
+{
+    uint8_t weight[256];
+    for (unsigned s = 0; s < max_sym; s++) weight[s] = ct->nbits[s] ? (uint8_t)(log + 1 - ct->nbits[s]) : 0;
+    if (cap < 1) return ERR_TOOSMALL;
+    {   /* HUF_compressWeights (:147-186) */
+        uint8_t* const out = dst + 1;
+        const size_t ocap = cap - 1;
+        int h = 0;
+        if (max_sym > 1) {
+            uint32_t count[13];
+            int16_t norm[13];
+            unsigned wmax = 12;
+            const unsigned top = hist(count, &wmax, weight, max_sym);
+            if (top == max_sym) h = 1;
+            else if (top == 1) h = 0;
+            else {
+                fse_ct wt;
+                const uint32_t wlog = fse_optimal_log(6, max_sym, wmax, 2);
+                int nc, r = fse_normalize(norm, wlog, count, max_sym, wmax, 0);
+                size_t c;
+                if (r < 0) return r;
+                nc = fse_write_ncount(out, ocap, norm, wmax, wlog);
+                if (nc < 0) return nc;
+                fse_build(&wt, norm, wmax, wlog);
+                c = fse_compress2(out + nc, ocap - (size_t)nc, weight, max_sym, &wt);
+                h = c ? nc + (int)c : 0;
+            }
+        }
+        if (h > 1 && (unsigned)h < max_sym / 2) { dst[0] = (uint8_t)h; return h + 1; }
+    }
+    if (max_sym > 128) return ERR_GENERIC;
+    if (((max_sym + 1) / 2) + 1 > cap) return ERR_TOOSMALL;
+    dst[0] = (uint8_t)(128 + (max_sym - 1));
+    weight[max_sym] = 0;
+    for (unsigned s = 0; s < max_sym; s += 2) dst[s / 2 + 1] = (uint8_t)((weight[s] << 4) + weight[s + 1]);
+    return (int)((max_sym + 1) / 2) + 1;
+}
+
+static size_t huf_stream(uint8_t* dst, size_t cap, const uint8_t* src, size_t n, const huf_ct* ct)   /* 1X (:1029-1094) */
+{
+    bitw w;
+    if (cap < 8 || !bw_init(&w, dst, cap)) return 0;
+    for (size_t i = n; i-- > 0;) bw_put(&w, ct->code[src[i]], ct->nbits[src[i]]);
+    return bw_close(&w);
+}
+
+/* HUF_compressCTable_internal: `hdr` bytes of table description already sit in front of `dst` */
+static size_t huf_encode(uint8_t* dst, size_t cap, size_t hdr, const uint8_t* src, size_t n, int four, const huf_ct* ct)
+{
+    size_t c;
+    if (!four) c = huf_stream(dst, cap, src, n, ct);
+    else {
+        const size_t seg = (n + 3) / 4;
+        size_t o = 6;
+        if (cap < 6 + 1 + 1 + 1 + 8 || n < 12) return 0;
+        for (int k = 0; k < 4; k++) {
+            const size_t len = k < 3 ? seg : n - 3 * seg;
+            const size_t s = huf_stream(dst + o, cap - o, src + (size_t)k * seg, len, ct);
+            if (s == 0 || s > 65535) return 0;
+            if (k < 3) { dst[2 * k] = (uint8_t)s; dst[2 * k + 1] = (uint8_t)(s >> 8); }
+            o += s;
+        }
+        c = o;
+    }
+    if (!c) return 0;
+    if (hdr + c >= n - 1) return 0;
+    return hdr + c;
+}
+
+enum { REP_NONE = 0, REP_CHECK = 1, REP_VALID = 2 };
+
+/* HUF_compress_internal (1X/4X _repeat).  `table` holds the previous block's table on entry and the
+ * table in force on exit.  Returns compressed size, 0 (not compressible) or ERR_*. */
+static int64_t huf_compress(uint8_t* dst, size_t cap, const uint8_t* src, size_t n, int four,
+                            huf_ct* table, int* repeat, int prefer_repeat, int suspect)
+{
+    uint32_t count[256];
+    unsigned max_sym = 255;
+    huf_ct fresh;
+    uint32_t log;
+    int h;
+    if (!n || !cap) return 0;
+    if (prefer_repeat && *repeat == REP_VALID) return (int64_t)huf_encode(dst, cap, 0, src, n, four, table);
+    if (suspect && n >= 4096 * 10) {
+        unsigned m1 = 255, m2 = 255;
+        const unsigned a = hist(count, &m1, src, 4096), b = hist(count, &m2, src + n - 4096, 4096);
+        if (a + b <= ((2 * 4096) >> 7) + 4) return 0;
+    }
+    {
+        const unsigned largest = hist(count, &max_sym, src, n);
+        if (largest == n) { dst[0] = src[0]; return 1; }
+        if (largest <= (n >> 7) + 4) return 0;
+    }
+    if (*repeat == REP_CHECK) {
+        int bad = 0;
+        for (unsigned s = 0; s <= max_sym; s++) bad |= (count[s] != 0) & (table->nbits[s] == 0);
+        if (bad) *repeat = REP_NONE;
+    }
+    if (prefer_repeat && *repeat != REP_NONE) return (int64_t)huf_encode(dst, cap, 0, src, n, four, table);
+    log = fse_optimal_log(11, n, max_sym, 1);
+    log = huf_build(&fresh, count, max_sym, log);
+    h = huf_write_table(dst, cap, &fresh, max_sym, log);
+    if (h < 0) return h;
+    if (*repeat != REP_NONE) {
+        size_t old_bits = 0, new_bits = 0;
+        for (unsigned s = 0; s <= max_sym; s++) { old_bits += (size_t)table->nbits[s] * count[s]; new_bits += (size_t)fresh.nbits[s] * count[s]; }
+        if ((old_bits >> 3) <= (size_t)h + (new_bits >> 3) || (size_t)h + 12 >= n)
+            return (int64_t)huf_encode(dst, cap, 0, src, n, four, table);
+    }
+    if ((size_t)h + 12 >= n) return 0;
+    *repeat = REP_NONE;
+    *table = fresh;
+    return (int64_t)huf_encode(dst + h, cap - (size_t)h, (size_t)h, src, n, four, &fresh);
+}
+
+/* ------------------------------------------------------------------------------------------------ literals */
+typedef struct { huf_ct huf; int huf_repeat; uint32_t rep[3]; } zentropy;
+
+static int64_t raw_literals(uint8_t* dst, size_t cap, const uint8_t* src, size_t n, int rle)
+{
+    const unsigned fl = 1 + (n > 31) + (n > 4095);
+    const uint32_t type = rle ? 1u : 0u;
+    if (!rle && n + fl > cap) return ERR_TOOSMALL;
+    if (fl == 1) dst[0] = (uint8_t)(type + (n << 3));
+    else if (fl == 2) { const uint32_t v = type + (1u << 2) + ((uint32_t)n << 4); dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); }
+    else { const uint32_t v = type + (3u << 2) + ((uint32_t)n << 4); dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16); }
+    if (rle) { dst[fl] = src[0]; return fl + 1; }
+    memcpy(dst + fl, src, n);
+    return (int64_t)(n + fl);
+}
+
+static int64_t compress_literals(const zentropy* prev, zentropy* next, uint8_t* dst, size_t cap,
+                                 const uint8_t* src, size_t n, int suspect)
+{
+    const size_t min_gain = (n >> 6) + 2, lh = 3 + (n >= 1024) + (n >= 16384);
+    int single = n < 256, repeat = prev->huf_repeat, type = 2;
+    int64_t c;
+    next->huf = prev->huf; next->huf_repeat = prev->huf_repeat;
+    if (n <= (size_t)(prev->huf_repeat == REP_VALID ? 6 : 63)) return raw_literals(dst, cap, src, n, 0);
+    if (cap < lh + 1) return ERR_TOOSMALL;
+    if (repeat == REP_VALID && lh == 3) single = 1;
+    c = huf_compress(dst + lh, cap - lh, src, n, !single, &next->huf, &repeat, n <= 1024 /* strategy < lazy */, suspect);
+    if (repeat != REP_NONE) type = 3;
+    if (c <= 0 || (size_t)c >= n - min_gain) { next->huf = prev->huf; return raw_literals(dst, cap, src, n, 0); }
+    if (c == 1) { next->huf = prev->huf; return raw_literals(dst, cap, src, n, 1); }
+    if (type == 2) next->huf_repeat = REP_CHECK;
+    if (lh == 3) { const uint32_t v = (uint32_t)type + ((uint32_t)!single << 2) + ((uint32_t)n << 4) + ((uint32_t)c << 14); dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16); }
+    else if (lh == 4) { const uint32_t v = (uint32_t)type + (2u << 2) + ((uint32_t)n << 4) + ((uint32_t)c << 18); memcpy(dst, &v, 4); }
+    else { const uint32_t v = (uint32_t)type + (3u << 2) + ((uint32_t)n << 4) + ((uint32_t)c << 22); memcpy(dst, &v, 4); dst[4] = (uint8_t)(c >> 10); }
+    return (int64_t)lh + c;
+}
+
+/* ------------------------------------------------------------------------------------------------ sequences */
+typedef struct { uint32_t ll, ml /* match length - 3 */, off /* offBase */; } zseq;
+
+static const uint8_t  kLLBits[36] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16};
+static const uint8_t  kMLBits[53] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16};
+static const int16_t  kLLNorm[36] = {4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1};
+static const int16_t  kMLNorm[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1};
+static const int16_t  kOFNorm[29] = {1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1};
+
+static unsigned ll_code(uint32_t v)
+{
+    static const uint8_t t[64] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,16,17,17,18,18,19,19,20,20,20,20,21,21,21,21,
+        22,22,22,22,22,22,22,22,23,23,23,23,23,23,23,23,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24};
+    return v > 63 ? (unsigned)hibit(v) + 19 : t[v];
+}
+
+static unsigned ml_code(uint32_t v)
+{
+    if (v > 127) return (unsigned)hibit(v) + 36;
+    if (v < 32) return v;
+    if (v < 40) return 32 + ((v - 32) >> 1);
+    if (v < 48) return 36 + ((v - 40) >> 2);
+    if (v < 64) return 38 + ((v - 48) >> 3);
+    if (v < 96) return 40 + ((v - 64) >> 4);
+    return 42;
+}
+
+/* ZSTD_selectEncodingType, strategy < lazy, no dictionary (repeat mode is never "valid") */
+static int select_type(const uint32_t* count, unsigned max, size_t most, size_t nseq, uint32_t def_log, int def_ok)
+{
+    (void)count; (void)max;
+    if (most == nseq) return (def_ok && nseq <= 2) ? 0 : 1;
+    if (def_ok) {
+        const size_t dyn_min = (((size_t)1 << def_log) * (10 - 1 /* ZSTD_fast */)) >> 3;
+        if (nseq < dyn_min || most < (nseq >> (def_log - 1))) return 0;
+    }
+    return 2;
+}
+
+/* ZSTD_buildCTable: bytes of table description written, or ERR_* */
+static int build_seq_table(uint8_t* dst, size_t cap, fse_ct* ct, uint32_t fse_log, int type, uint32_t* count, unsigned max,
+                           const uint8_t* codes, size_t nseq, const int16_t* def_norm, uint32_t def_log, unsigned def_max)
+{
+    if (type == 1) { fse_build_rle(ct, max); if (!cap) return ERR_TOOSMALL; dst[0] = codes[0]; return 1; }
+    if (type == 0) { fse_build(ct, def_norm, def_max, def_log); return 0; }
+    {
+        int16_t norm[53];
+        size_t n1 = nseq;
+        const uint32_t log = fse_optimal_log(fse_log, nseq, max, 2);
+        int r;
+        if (count[codes[nseq - 1]] > 1) { count[codes[nseq - 1]]--; n1--; }
+        r = fse_normalize(norm, log, count, n1, max, n1 >= 2048);
+        if (r < 0) return r;
+        r = fse_write_ncount(dst, cap, norm, max, log);
+        if (r < 0) return r;
+        fse_build(ct, norm, max, log);
+        return r;
+    }
+}
+
+/* sequences section after the literals; returns bytes or 0 / ERR_* (ZSTD_entropyCompressSeqStore_internal tail) */
+static int64_t encode_sequences(uint8_t* dst, size_t cap, const zseq* seq, size_t nseq, uint8_t* llc, uint8_t* ofc, uint8_t* mlc)
+{
+    size_t o = 0, last_count = 0;
+    fse_ct ll, of, ml;
+    uint32_t count[64];
+    if (cap < 4) return ERR_TOOSMALL;
+    if (nseq < 128) dst[o++] = (uint8_t)nseq;
+    else if (nseq < 0x7F00) { dst[o++] = (uint8_t)((nseq >> 8) + 0x80); dst[o++] = (uint8_t)nseq; }
+    else { dst[o++] = 0xFF; dst[o++] = (uint8_t)(nseq - 0x7F00); dst[o++] = (uint8_t)((nseq - 0x7F00) >> 8); }
+    if (!nseq) return (int64_t)o;
+    for (size_t i = 0; i < nseq; i++) { llc[i] = (uint8_t)ll_code(seq[i].ll); ofc[i] = (uint8_t)hibit(seq[i].off); mlc[i] = (uint8_t)ml_code(seq[i].ml); }
+    {
+        uint8_t* const head = dst + o++;
+        int tll, tof, tml, r;
+        unsigned max;
+        size_t most;
+        max = 35; most = hist(count, &max, llc, nseq);
+        tll = select_type(count, max, most, nseq, 6, 1);
+        r = build_seq_table(dst + o, cap - o, &ll, 9, tll, count, max, llc, nseq, kLLNorm, 6, 35);
+        if (r < 0) return r;
+        if (tll == 2) last_count = (size_t)r;
+        o += (size_t)r;
+        max = 31; most = hist(count, &max, ofc, nseq);
+        tof = select_type(count, max, most, nseq, 5, max <= 28);
+        r = build_seq_table(dst + o, cap - o, &of, 8, tof, count, max, ofc, nseq, kOFNorm, 5, 28);
+        if (r < 0) return r;
+        if (tof == 2) last_count = (size_t)r;
+        o += (size_t)r;
+        max = 52; most = hist(count, &max, mlc, nseq);
+        tml = select_type(count, max, most, nseq, 6, 1);
+        r = build_seq_table(dst + o, cap - o, &ml, 9, tml, count, max, mlc, nseq, kMLNorm, 6, 52);
+        if (r < 0) return r;
+        if (tml == 2) last_count = (size_t)r;
+        o += (size_t)r;
+        *head = (uint8_t)((tll << 6) + (tof << 4) + (tml << 2));
+    }
+    {   /* ZSTD_encodeSequences_body: last sequence first */
+        bitw w;
+        size_t i = nseq - 1, bytes;
+        uint32_t sml, sof, sll;
+        if (!bw_init(&w, dst + o, cap - o)) return ERR_TOOSMALL;
+        sml = fse_first_state(&ml, mlc[i]); sof = fse_first_state(&of, ofc[i]); sll = fse_first_state(&ll, llc[i]);
+        bw_put(&w, seq[i].ll, kLLBits[llc[i]]);
+        bw_put(&w, seq[i].ml, kMLBits[mlc[i]]);
+        bw_put(&w, seq[i].off, ofc[i]);
+        while (i-- > 0) {
+            sof = fse_encode(&w, &of, sof, ofc[i]);
+            sml = fse_encode(&w, &ml, sml, mlc[i]);
+            sll = fse_encode(&w, &ll, sll, llc[i]);
+            bw_put(&w, seq[i].ll, kLLBits[llc[i]]);
+            bw_put(&w, seq[i].ml, kMLBits[mlc[i]]);
+            bw_put(&w, seq[i].off, ofc[i]);
+        }
+        bw_put(&w, sml, ml.log); bw_put(&w, sof, of.log); bw_put(&w, sll, ll.log);
+        bytes = bw_close(&w);
+        if (!bytes) return ERR_TOOSMALL;
+        o += bytes;
+        if (last_count && last_count + bytes < 4) return 0;      /* zstd <= 1.3.4 decoder workaround (:2737-2744) */
+    }
+    return (int64_t)o;
+}
+
+/* ------------------------------------------------------------------------------------------------ match finder */
+typedef struct {
+    uint32_t* table;
+    zparams   p;
+    zseq*     seq;  size_t nseq;
+    uint8_t*  lit;  size_t nlit;
+} zmatch;
+
+static uint32_t zhash(const uint8_t* p, uint32_t hlog, uint32_t mls)
+{
+    switch (mls) {
+    case 5:  return (uint32_t)(((rd64(p) << 24) * 889523592379ull) >> (64 - hlog));
+    case 6:  return (uint32_t)(((rd64(p) << 16) * 227718039650203ull) >> (64 - hlog));
+    case 7:  return (uint32_t)(((rd64(p) << 8) * 58295818150454627ull) >> (64 - hlog));
+    default: return (rd32(p) * 2654435761u) >> (32 - hlog);
+    }
+}
+
+static size_t count_eq(const uint8_t* s, size_t a, size_t b, size_t end)
+{
+    const size_t a0 = a;
+    while (a < end && s[a] == s[b]) { a++; b++; }
+    return a - a0;
+}
+
+static void store_seq(zmatch* m, const uint8_t* s, size_t anchor, size_t ll, uint32_t off_base, size_t ml)
+{
+    memcpy(m->lit + m->nlit, s + anchor, ll); m->nlit += ll;
+    m->seq[m->nseq].ll = (uint32_t)ll; m->seq[m->nseq].ml = (uint32_t)(ml - 3); m->seq[m->nseq].off = off_base;
+    m->nseq++;
+}
+
+/* ZSTD_compressBlock_fast_noDict_generic over s[start, end); returns the last-literals length */
+static size_t fast_block(zmatch* m, uint32_t rep[3], const uint8_t* s, size_t start, size_t end)
+{
+    uint32_t* const tab = m->table;
+    const uint32_t hlog = m->p.hlog, wsize = 1u << m->p.wlog;
+    const uint32_t mls = (m->p.mml >= 5 && m->p.mml <= 7) ? m->p.mml : 4;
+    const size_t step0 = m->p.tlen > 1 ? (size_t)m->p.tlen + 1 : 2;
+    const uint32_t end_idx = (uint32_t)end + 2;
+    const uint32_t prefix_idx = end_idx - 2 > wsize ? end_idx - wsize : 2;     /* dictLimit after enforceMaxDist */
+    const size_t prefix = prefix_idx - 2;
+    const int64_t ilimit = (int64_t)end - 8;       /* may be negative for a 7-byte input: compared as signed */
+    size_t anchor = start, ip0 = start, ip1, ip2, ip3, step, next_step, match0, mlen;
+    uint32_t rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0, cur0 = 0, idx, off_base;
+    uint32_t h0, h1;
+
+    ip0 += (ip0 == prefix);
+    {
+        const uint32_t cur = (uint32_t)ip0 + 2;
+        const uint32_t low = cur - prefix_idx > wsize ? cur - wsize : prefix_idx;
+        const uint32_t max_rep = cur - low;
+        if (rep2 > max_rep) { saved2 = rep2; rep2 = 0; }
+        if (rep1 > max_rep) { saved1 = rep1; rep1 = 0; }
+    }
+    for (;;) {                                     /* _start */
+        step = step0; next_step = ip0 + 128;
+        ip1 = ip0 + 1; ip2 = ip0 + step; ip3 = ip2 + 1;
+        if ((int64_t)ip3 >= ilimit) break;
+        h0 = zhash(s + ip0, hlog, mls); h1 = zhash(s + ip1, hlog, mls);
+        idx = tab[h0];
+        for (;;) {
+            const uint32_t rval = rd32(s + ip2 - rep1);
+            cur0 = (uint32_t)ip0 + 2;
+            tab[h0] = cur0;
+            if ((rd32(s + ip2) == rval) & (rep1 > 0)) {
+                ip0 = ip2; match0 = ip0 - rep1;
+                mlen = s[ip0 - 1] == s[match0 - 1];
+                ip0 -= mlen; match0 -= mlen;
+                off_base = 1; mlen += 4;
+                tab[h1] = (uint32_t)ip1 + 2;
+                goto match;
+            }
+            if (idx >= prefix_idx && rd32(s + idx - 2) == rd32(s + ip0)) { tab[h1] = (uint32_t)ip1 + 2; goto offset; }
+            idx = tab[h1]; h0 = h1; h1 = zhash(s + ip2, hlog, mls);
+            ip0 = ip1; ip1 = ip2; ip2 = ip3;
+            cur0 = (uint32_t)ip0 + 2;
+            tab[h0] = cur0;
+            if (idx >= prefix_idx && rd32(s + idx - 2) == rd32(s + ip0)) { if (step <= 4) tab[h1] = (uint32_t)ip1 + 2; goto offset; }
+            idx = tab[h1]; h0 = h1; h1 = zhash(s + ip2, hlog, mls);
+            ip0 = ip1; ip1 = ip2; ip2 = ip0 + step; ip3 = ip1 + step;
+            if (ip2 >= next_step) { step++; next_step += 128; }
+            if ((int64_t)ip3 >= ilimit) goto cleanup;
+        }
+    offset:
+        match0 = idx - 2;
+        rep2 = rep1; rep1 = (uint32_t)(ip0 - match0);
+        off_base = rep1 + 3;
+        mlen = 4;
+        while (ip0 > anchor && match0 > prefix && s[ip0 - 1] == s[match0 - 1]) { ip0--; match0--; mlen++; }
+    match:
+        mlen += count_eq(s, ip0 + mlen, match0 + mlen, end);
+        store_seq(m, s, anchor, ip0 - anchor, off_base, mlen);
+        ip0 += mlen; anchor = ip0;
+        if ((int64_t)ip0 <= ilimit) {
+            tab[zhash(s + cur0, hlog, mls)] = cur0 + 2;                  /* position cur0 - 2 + 2 */
+            tab[zhash(s + ip0 - 2, hlog, mls)] = (uint32_t)ip0;          /* index of ip0 - 2 */
+            if (rep2 > 0)
+                while ((int64_t)ip0 <= ilimit && rd32(s + ip0) == rd32(s + ip0 - rep2)) {
+                    const size_t rlen = count_eq(s, ip0 + 4, ip0 + 4 - rep2, end) + 4;
+                    const uint32_t t = rep2; rep2 = rep1; rep1 = t;
+                    tab[zhash(s + ip0, hlog, mls)] = (uint32_t)ip0 + 2;
+                    ip0 += rlen;
+                    store_seq(m, s, anchor, 0, 1, rlen);
+                    anchor = ip0;
+                }
+        }
+    }
+cleanup:
+    saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;
+    rep[0] = rep1 ? rep1 : saved1;
+    rep[1] = rep2 ? rep2 : saved2;
+    return end - anchor;
+}
+
+/* ------------------------------------------------------------------------------------------------ frame */
+static zparams level_params(int level, size_t n)
+{
+    static const zparams fast_rows[4] = {          /* clevels.h:29,:55,:81,:107 (level 1) */
+        {19, 13, 14, 1, 7, 0, 1}, {18, 13, 14, 1, 6, 0, 1}, {17, 12, 13, 1, 6, 0, 1}, {14, 14, 15, 1, 5, 0, 1}};
+    zparams p = fast_rows[(n <= 256 * 1024) + (n <= 128 * 1024) + (n <= 16 * 1024)];
+    const uint32_t src_log = n < 64 ? 6 : (uint32_t)hibit((uint32_t)(n - 1)) + 1;
+    (void)level;
+    if (p.wlog > src_log) p.wlog = src_log;
+    if (p.hlog > p.wlog + 1) p.hlog = p.wlog + 1;
+    if (p.clog > p.wlog) p.clog = p.wlog;
+    if (p.wlog < 10) p.wlog = 10;
+    return p;
+}
+
+static int is_rle(const uint8_t* s, size_t n)
+{ for (size_t i = 1; i < n; i++) if (s[i] != s[0]) return 0; return 1; }
+
+int64_t orc_zstd_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int level)
+{
+    zparams p;
+    zmatch m;
+    zentropy ent[2];
+    int cur = 0, first = 1;
+    size_t o = 0, pos = 0, block;
+    int64_t result;
+    uint8_t *llc, *ofc, *mlc;
+    if (level != 1) return ORC_ZSTD_UNSUPPORTED;
+    p = level_params(level, n);
+    if (cap < 18) return ERR_TOOSMALL;
+    {   /* frame header: magic, descriptor, [window], content size */
+        const uint32_t wsize = 1u << p.wlog;
+        const int single = wsize >= n;
+        const unsigned fcs = (n >= 256) + (n >= 65536 + 256) + (n >= 0xFFFFFFFFu);
+        dst[0] = 0x28; dst[1] = 0xB5; dst[2] = 0x2F; dst[3] = 0xFD;
+        o = 4;
+        dst[o++] = (uint8_t)((single << 5) + (fcs << 6));
+        if (!single) dst[o++] = (uint8_t)((p.wlog - 10) << 3);
+        if (fcs == 0) { if (single) dst[o++] = (uint8_t)n; }
+        else if (fcs == 1) { const uint32_t v = (uint32_t)n - 256; dst[o++] = (uint8_t)v; dst[o++] = (uint8_t)(v >> 8); }
+        else if (fcs == 2) { const uint32_t v = (uint32_t)n; memcpy(dst + o, &v, 4); o += 4; }
+        else { const uint64_t v = n; memcpy(dst + o, &v, 8); o += 8; }
+    }
+    if (!n) {
+        if (cap - o < 4) return ERR_TOOSMALL;
+        dst[o] = 1; dst[o + 1] = 0; dst[o + 2] = 0;
+        return (int64_t)o + 3;
+    }
+    block = (size_t)1 << p.wlog; if (block > n) block = n; if (block > BLOCK_MAX) block = BLOCK_MAX;
+    m.p = p;
+    m.table = (uint32_t*)calloc((size_t)1 << p.hlog, 4);
+    m.seq = (zseq*)malloc((BLOCK_MAX / 3 + 1) * sizeof(zseq));
+    m.lit = (uint8_t*)malloc(BLOCK_MAX + 64);
+    llc = (uint8_t*)malloc(3 * (BLOCK_MAX / 3 + 1)); ofc = llc + BLOCK_MAX / 3 + 1; mlc = ofc + BLOCK_MAX / 3 + 1;
+    memset(ent, 0, sizeof ent);
+    ent[0].rep[0] = 1; ent[0].rep[1] = 4; ent[0].rep[2] = 8;
+    result = 0;
+    while (pos < n) {
+        const size_t len = n - pos < block ? n - pos : block;
+        const int last = len >= n - pos;
+        const zentropy* prev = &ent[cur];
+        zentropy* next = &ent[cur ^ 1];
+        size_t bcap;
+        int64_t c = 0;
+        if (cap - o < 3 + 2 + 1) { result = ERR_TOOSMALL; break; }
+        bcap = cap - o - 3;
+        if (len >= 7) {
+            uint8_t* const out = dst + o + 3;
+            size_t tail;
+            int64_t lsz, ssz;
+            m.nseq = 0; m.nlit = 0;
+            memcpy(next->rep, prev->rep, sizeof next->rep);
+            tail = fast_block(&m, next->rep, src, pos, pos + len);
+            memcpy(m.lit + m.nlit, src + pos + len - tail, tail); m.nlit += tail;
+            lsz = compress_literals(prev, next, out, bcap, m.lit, m.nlit, m.nseq == 0 || m.nlit / m.nseq >= 20);
+            c = lsz;
+            if (lsz >= 0) {
+                ssz = encode_sequences(out + lsz, bcap - (size_t)lsz, m.seq, m.nseq, llc, ofc, mlc);
+                c = ssz <= 0 ? ssz : lsz + ssz;
+            }
+            if (c == ERR_TOOSMALL && len <= bcap) c = 0;
+            if (c < 0) { result = c; break; }
+            if (c > 0 && (size_t)c >= len - ((len >> 6) + 2)) c = 0;
+            if (!first && c < 25 && is_rle(src + pos, len)) { c = 1; out[0] = src[pos]; }
+            if (c > 1) cur ^= 1;
+        }
+        if (c == 0) {
+            const uint32_t h = (uint32_t)last + ((uint32_t)len << 3);
+            if (len + 3 > cap - o) { result = ERR_TOOSMALL; break; }
+            dst[o] = (uint8_t)h; dst[o + 1] = (uint8_t)(h >> 8); dst[o + 2] = (uint8_t)(h >> 16);
+            memcpy(dst + o + 3, src + pos, len);
+            o += 3 + len;
+        } else {
+            const uint32_t h = c == 1 ? (uint32_t)last + (1u << 1) + ((uint32_t)len << 3) : (uint32_t)last + (2u << 1) + ((uint32_t)c << 3);
+            dst[o] = (uint8_t)h; dst[o + 1] = (uint8_t)(h >> 8); dst[o + 2] = (uint8_t)(h >> 16);
+            o += 3 + (size_t)c;
+        }
+        pos += len; first = 0;
+    }
+    free(m.table); free(m.seq); free(m.lit); free(llc);
+    return result < 0 ? result : (int64_t)o;
+}
+
+int orc_codec_zstd1(void* ctx, const uint8_t* src, int n, uint8_t* dst, int cap)
+{ (void)ctx; const int64_t r = orc_zstd_compress(src, (size_t)n, dst, cap < 0 ? 0 : (size_t)cap, 1); return r < 0 ? 0 : (int)r; }

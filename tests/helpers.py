@@ -194,3 +194,19 @@ def orc_compress_mc(src, cap=-1):
     dst = np.empty(L.orc_lz4_compress_bound(len(src)) + 64, dtype=np.uint8)
     r = L.orc_lz4mc_compress(src.ctypes.data, dst.ctypes.data, len(src), cap)
     return r, dst[:max(r, 0)].copy()
+
+
+def zstd_bound(n):
+    """ZSTD_compressBound (zstd.h:206 ZSTD_COMPRESSBOUND)."""
+    return n + (n >> 8) + (((128 << 10) - n) >> 11 if n < (128 << 10) else 0)
+
+
+def orc_zstd_compress(src, level=1, cap=None):
+    """orc_zstd_compress -> (result, frame bytes); result < 0 is -(ZSTD error number)."""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    L = oracle()
+    L.orc_zstd_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]; L.orc_zstd_compress.restype = C.c_int64
+    cap = zstd_bound(len(src)) if cap is None else cap
+    dst = np.empty(max(cap, 1) + 64, dtype=np.uint8)
+    r = L.orc_zstd_compress(src.ctypes.data, len(src), dst.ctypes.data, cap, level)
+    return r, dst[:max(r, 0)].copy()

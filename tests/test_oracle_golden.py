@@ -228,3 +228,52 @@ def test_lz4mc_port_equals_reference_sources():
                   else ref.LZ4_compressMC_limitedOutput(d.ctypes.data, out.ctypes.data, len(d), cap))
             r, comp = helpers.orc_compress_mc(d, cap)
             assert r == rr and np.array_equal(comp, out[:max(rr, 0)]), (name, cap, r, rr)
+
+
+# ------------------------------------------------------------------------------------------ zstd level-1 encoder port
+def test_zstd_enc_port_golden_manifest():
+    """`4mc -z -1` (ZSTD_compress level 1, capacity n-1) per-block sizes/checksums written by the reference CLI."""
+    m = json.load(open(os.path.join(G, "corpus_manifest.json")))
+    data = helpers.corpus(m["corpus"]["bytes"])
+    for b, (u, c, x) in enumerate(m["levels"]["4mz-1"]["blocks"]):
+        blk = data[b * B: b * B + u]
+        r, comp = helpers.orc_zstd_compress(blk, 1, u - 1)
+        payload = comp if r > 0 else blk
+        assert (len(payload), helpers.orc_xxh32(payload)) == (c, x), b
+        if r > 0 and b % 4 == 0:                       # and the frames decode back with the decoder port
+            assert np.array_equal(helpers.orc_zstd_decompress(comp, u)[1], blk)
+
+
+@pytest.mark.skipif(helpers.ref() is None, reason="oracle/_ref not built (needs /root/reference)")
+def test_zstd_enc_port_equals_reference_sources():
+    import ctypes as C
+    ref = helpers.ref()
+    ref.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]; ref.ZSTD_compress.restype = C.c_size_t
+    ref.ZSTD_compressBound.argtypes = [C.c_size_t]; ref.ZSTD_compressBound.restype = C.c_size_t
+
+    def check(d, cap, tag):
+        d = np.ascontiguousarray(d)
+        out = np.zeros(max(cap, 1) + 64, np.uint8)
+        rr = ref.ZSTD_compress(out.ctypes.data, cap, d.ctypes.data, len(d), 1)
+        rr = rr if rr < (1 << 62) else rr - (1 << 64)           # size_t error code -> -(error number)
+        r, comp = helpers.orc_zstd_compress(d, 1, cap)
+        assert r == rr and np.array_equal(comp, out[:max(rr, 0)]), (tag, len(d), cap, r, rr)
+        return rr
+
+    for n in (0, 1, 6, 7, 18, 19, 63, 64, 300, 1024, 1025, 16384, 16385, 131072, 131073, 262144, 262145, 700001):
+        assert helpers.zstd_bound(n) == ref.ZSTD_compressBound(n)
+    rng = np.random.default_rng(11)
+    for name, d in helpers.edge_inputs().items():
+        for cap in {max(len(d) - 1, 0), helpers.zstd_bound(len(d)), len(d) // 3, 18}:
+            check(d, cap, name)
+    # size classes of the level table (16 KiB / 128 KiB / 256 KiB) and 128 KiB sub-block tails
+    src = helpers.corpus(3 * B, first_block=5)
+    for n in (16383, 16384, 16385, 131071, 131072, 131073, 131079, 262144, 262145, 262151, 524289, 1500001):
+        off = int(rng.integers(0, B))
+        check(src[off:off + n], n - 1, "size")
+    # capacity sweep around the real frame size: every overflow rule of the bit/byte writers
+    for n in (100, 1000, 20000, 140000):
+        d = src[7 * n: 8 * n]
+        c = check(d, helpers.zstd_bound(n), "bound")
+        for cap in range(max(0, c - 24), c + 10):
+            check(d, cap, "tight")
