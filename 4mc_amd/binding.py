@@ -43,6 +43,7 @@ _GPU_API = {
     "fourmc_gpu_lz4_compress_hc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
     "fourmc_gpu_lz4_compress_mc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "fourmc_gpu_zstd_decompress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "fourmc_gpu_zstd_compress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
     "fourmc_gpu_xxh32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "fourmc_gpu_4mc_encode_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
     "fourmc_gpu_4mc_decode_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
@@ -54,6 +55,8 @@ _GPU_API = {
     "fourmc_LZ4_compress_HC": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "fourmc_LZ4_decompress_safe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "fourmc_ZSTD_decompress": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "fourmc_ZSTD_compress": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]),
+    "fourmc_ZSTD_compressBound": (C.c_size_t, [C.c_size_t]),
     "fourmc_XXH32": (C.c_uint32, [C.c_void_p, C.c_size_t, C.c_uint32]),
     "fourmc_host_4mc_encode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
     "fourmc_host_4mc_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_int]),

@@ -164,6 +164,18 @@ int fourmc_gpu_zstd_decompress(const void* d_src, void* d_dst, fourmc_block* d_b
     return FOURMC_OK;
 }
 
+static int zstd_enc_serial() { const char* e = getenv("FOURMC_ZSTD_SERIAL"); return e && *e == '1'; }
+
+int fourmc_gpu_zstd_compress(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, int level, void* stream)
+{
+    if (int r = ensure_device()) return r;
+    if (level != 1) { snprintf(g_err, sizeof g_err, "ZSTD level %d not on the device (level 1 / strategy fast is)", level); return FOURMC_EUNSUP; }
+    void* work = nullptr;
+    if (int r = zstd_scratch_bytes(fourmc_zstd_enc_work_bytes(n), &work)) return r;
+    HIP_TRY(fourmc_launch_zstd_encode(d_src, d_dst, d_blocks, n, work, 0, zstd_enc_serial(), static_cast<hipStream_t>(stream)));
+    return FOURMC_OK;
+}
+
 int fourmc_gpu_xxh32(const void* d_src, fourmc_block* d_blocks, uint32_t n, uint32_t seed, void* stream)
 {
     if (int r = ensure_device()) return r;
@@ -188,6 +200,14 @@ int fourmc_gpu_4mc_encode_blocks(const void* d_src, void* d_dst, fourmc_block* d
         void* work = nullptr;
         if (int r = zstd_scratch_bytes(fourmc_lz4hc_work_bytes(n), &work)) return r;
         HIP_TRY(fourmc_launch_lz4mc_encode(d_src, d_dst, d_blocks, n, work, 1, s));
+        HIP_TRY(fourmc_launch_xxh32(d_dst, d_blocks, n, 0, FOURMC_HASH_DST_RESULT, s));
+        return FOURMC_OK;
+    }
+    if (codec == FOURMC_CODEC_ZSTD) {
+        if (level != 1) { snprintf(g_err, sizeof g_err, "ZSTD level %d not on the device (4mz fast = level 1 is)", level); return FOURMC_EUNSUP; }
+        void* work = nullptr;
+        if (int r = zstd_scratch_bytes(fourmc_zstd_enc_work_bytes(n), &work)) return r;
+        HIP_TRY(fourmc_launch_zstd_encode(d_src, d_dst, d_blocks, n, work, 1, zstd_enc_serial(), s));
         HIP_TRY(fourmc_launch_xxh32(d_dst, d_blocks, n, 0, FOURMC_HASH_DST_RESULT, s));
         return FOURMC_OK;
     }
@@ -248,6 +268,7 @@ static int host_roundtrip(const void* src, size_t src_bytes, void* dst, size_t d
         case 2: r = fourmc_gpu_lz4_compress_fast(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
         case 3: r = fourmc_gpu_lz4_decompress(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
         case 5: r = fourmc_gpu_zstd_decompress(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
+        case 8: r = fourmc_gpu_zstd_compress(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, level, s); break;
         case 7: r = fourmc_gpu_lz4_compress_mc(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
         case 6: r = fourmc_gpu_lz4_compress_hc(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, level, s); break;
         default: r = fourmc_gpu_xxh32(g_arena.d_src, g_arena.d_blk, n, (uint32_t)level, s); break;
@@ -333,6 +354,22 @@ size_t fourmc_ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, si
     int r = host_roundtrip(src, compressedSize, dst, dstCapacity, &b, 1, 5, FOURMC_CODEC_ZSTD, 0);
     if (r) { fprintf(stderr, "4mc-gpu: %s\n", g_err); return (size_t)-1; }
     return b.result < 0 ? kCorrupt : (size_t)b.result;
+}
+
+size_t fourmc_ZSTD_compressBound(size_t n)
+{ return n + (n >> 8) + (n < (128u << 10) ? ((128u << 10) - n) >> 11 : 0); }
+
+size_t fourmc_ZSTD_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel)
+{
+    if (srcSize > 0x7FFFFFFFu) return (size_t)-72;                           /* srcSize_wrong */
+    if (dstCapacity > 0x7FFFFFFFu) dstCapacity = 0x7FFFFFFFu;                /* Java passes 1 GiB (jniZstdCompressor.c:93) */
+    const size_t bound = fourmc_ZSTD_compressBound(srcSize);
+    const size_t cap = dstCapacity < bound ? dstCapacity : bound;            /* the frame never exceeds the bound */
+    fourmc_block b; memset(&b, 0, sizeof b);
+    b.src_len = (uint32_t)srcSize; b.dst_cap = (uint32_t)cap;
+    int r = host_roundtrip(src, srcSize, dst, cap, &b, 1, 8, FOURMC_CODEC_ZSTD, compressionLevel);
+    if (r) { fprintf(stderr, "4mc-gpu: %s\n", g_err); return (size_t)-1; }
+    return b.result < 0 ? (size_t)(ptrdiff_t)b.result : (size_t)b.result;  /* -(error number), ZSTD_isError() is true */
 }
 
 } // extern "C"

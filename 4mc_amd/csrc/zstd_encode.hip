@@ -1,0 +1,1172 @@
+// 4mc_amd/csrc/zstd_encode.hip — K6: batched ZSTD frame encode on gfx950, BYTE-IDENTICAL to the
+// reference's ZSTD_compress(dst, cap, src, n, 1) (zstd 1.5.3, strategy "fast"), the call 4mz makes per
+// 4 MiB block at its "fast" level (native/4mc.c:411-412,:467) and Java makes through
+// ZstdCompressor.compressBytesDirect (native/jniZstdCompressor.c:93).
+//
+//   parameters   ZSTD_getCParams_internal / ZSTD_adjustCParams_internal   compress/zstd_compress.c:6465-6488,:1335-1399
+//   frame        ZSTD_writeFrameHeader :4065, ZSTD_compress_frameChunk :3983, ZSTD_compressBlock_internal :3812
+//   match finder ZSTD_compressBlock_fast_noDict_generic                   compress/zstd_fast.c:95-365
+//   literals     ZSTD_compressLiterals + HUF_compress_internal            compress/zstd_compress_literals.c:100, huf_compress.c:1250
+//   sequences    ZSTD_buildSequencesStatistics / ZSTD_encodeSequences     compress/zstd_compress.c:2489, zstd_compress_sequences.c:302
+//   FSE          normalizeCount / writeNCount / buildCTable               compress/fse_compress.c:68-520
+//
+// One wavefront owns one 4mc block (one zstd frame of up to 32 blocks of 128 KiB).  Per 128 KiB
+// block it (1) runs the greedy match finder, (2) entropy-codes literals and sequences.
+//   * Match finder: the reference walks positions in pairs (ip0, ip0+1) with a repcode test at
+//     ip0+step; every tested position reads then overwrites its hash slot.  Lane j speculatively
+//     executes pair j of the current search (64 pairs per batch), a ballot picks the first event in
+//     serial order (repcode hit, hash hit, end of block); only lanes up to it commit their table
+//     writes.  Two pairs of one batch that touch the same slot are ordered by cutting the batch at
+//     the later lane (LDS atomic-min scoreboard), exactly as the LZ4 kernel does.  Extension and
+//     literal copies are wave-wide.  The hash table (<= 2^15 x u32) lives in the block's HBM
+//     workspace slot so that 8+ blocks stay resident per CU.
+//   * Entropy stage: histograms are wave-parallel (LDS atomics); Huffman bit packing is wave-parallel
+//     (8 symbols per lane, DPP prefix sum of code lengths, LDS atomic-or staging); table construction
+//     (Huffman tree, FSE normalisation/spread) and the three interleaved FSE state chains are serial
+//     by nature and run wave-uniform, fed 64 sequences at a time through readlane.
+// Per block HBM traffic: n bytes read (+ candidate re-reads, mostly L2/MALL hits), the sequence
+// store and literal buffer (<= 0.7 MiB, L2 resident), csize written.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fourmc_gpu.h"
+#include "kernels.h"
+#include "devenc.h"
+
+namespace {
+
+constexpr int      kErrGeneric = -1, kErrTooSmall = -70;     // ZSTD_error_GENERIC / _dstSize_tooSmall
+constexpr uint32_t kSub    = 128 * 1024;                     // ZSTD_BLOCKSIZE_MAX
+constexpr uint32_t kSeqCap = 32768 + 64;
+constexpr size_t   kTabBytes  = size_t(4) << 15;
+constexpr size_t   kSeqBytes  = size_t(kSeqCap) * 4;
+constexpr size_t   kCodeBytes = kSeqCap;
+constexpr size_t   kLitPad    = 64;
+constexpr size_t   kLitBytes  = kLitPad + kSub + 192;
+constexpr size_t   kWorkBytes = kTabBytes + 3 * kSeqBytes + 3 * kCodeBytes + kLitBytes;
+
+struct __attribute__((packed, aligned(1))) S4B { uint32_t v; };
+__device__ __forceinline__ void st4(uint8_t* p, uint32_t v) { reinterpret_cast<S4B*>(p)->v = v; }
+__device__ __forceinline__ uint32_t U(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
+__device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t l) { return uint32_t(__builtin_amdgcn_readlane(int(v), int(l))); }
+__device__ __forceinline__ int hibit(uint32_t v) { return 31 - __clz(v); }
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, uint32_t(__shfl_xor(int(v), d)));
+    return v;
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v)
+{ return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, ROWMASK, 0xf, false)); }
+__device__ __forceinline__ uint32_t scan_add(uint32_t v)          // wave64 inclusive prefix sum
+{
+    v += dpp0<0x111, 0xf>(v); v += dpp0<0x112, 0xf>(v); v += dpp0<0x114, 0xf>(v); v += dpp0<0x118, 0xf>(v);
+    v += dpp0<0x142, 0xa>(v);
+    v += dpp0<0x143, 0xc>(v);
+    return v;
+}
+
+struct FseCt { uint16_t next[512]; uint32_t dbits[64]; int32_t dfind[64]; uint32_t log; };
+
+struct ZLds {
+    uint32_t count[256];
+    uint32_t ncount[516];                 // Huffman nodes, index + 1 (entry 0 is the barrier node)
+    uint16_t nparent[516];
+    uint8_t  nbyte[516], nbits[516];
+    uint16_t rank_base[192], rank_curr[192];
+    uint32_t qstack[256];
+    uint32_t huf[2][256];                 // literal tables of the previous / next block: code | nbits << 16
+    uint32_t fresh[256];
+    FseCt    ct[3];                       // ll, of, ml   (ct[0] doubles as the Huffman-weight table)
+    int16_t  norm[64];
+    uint16_t cumul[72];
+    uint8_t  symbol_at[512];
+    uint8_t  weight[264];
+    uint32_t wcount[16];
+    uint32_t rank_last[16];
+    uint16_t per_rank[16], val[16];
+    uint32_t score[1024];
+    uint32_t stage[200];
+};
+
+// ------------------------------------------------------------------------------------------------ bit writer
+// serial writer (wave-uniform state, lane 0 stores); overflow rule of BIT_CStream_t (bitstream.h:153-240):
+// the stream does not fit when floor(total_bits / 8) + 8 >= cap.
+struct BitW {
+    uint8_t* p; uint32_t cap, pos, nb, total; uint64_t acc;
+    __device__ __forceinline__ bool init(uint8_t* p_, uint32_t cap_) { p = p_; cap = cap_; pos = 0; nb = 0; total = 0; acc = 0; return cap_ > 8; }
+    __device__ __forceinline__ void put(uint64_t v, uint32_t n, int lane)       // n <= 32
+    {
+        acc |= (v & ((1ull << n) - 1)) << nb; nb += n; total += n;
+        if (nb >= 32) { if (lane == 0 && pos + 4 <= cap) st4(p + pos, uint32_t(acc)); pos += 4; acc >>= 32; nb -= 32; }
+    }
+    __device__ __forceinline__ uint32_t close(int lane)
+    {
+        put(1, 1, lane);
+        for (uint32_t k = 0; 8 * k < nb; k++) if (lane == 0 && pos + k < cap) p[pos + k] = uint8_t(acc >> (8 * k));
+        return ((total >> 3) + 8 < cap) ? (total + 7) >> 3 : 0u;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ histograms
+__device__ __forceinline__ void hist_finish(ZLds& L, uint32_t& largest, uint32_t& max_sym, int lane)
+{
+    uint32_t lg = 0, hi = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint32_t c = L.count[4 * lane + k]; lg = max(lg, c); if (c) hi = uint32_t(4 * lane + k + 1); }
+    largest = wave_max(lg);
+    hi = wave_max(hi);
+    max_sym = hi ? hi - 1 : 0;
+}
+
+// byte histogram of s[0, n) (HBM) into L.count (hist.c:31-60)
+__device__ __forceinline__ void hist_bytes(ZLds& L, const uint8_t* s, uint32_t n, uint32_t& largest, uint32_t& max_sym, int lane)
+{
+    for (int i = lane; i < 256; i += 64) L.count[i] = 0;
+    uint32_t i = uint32_t(lane) * 16;
+    for (; i + 16 <= n; i += 1024) {
+        const U16B q = *reinterpret_cast<const U16B*>(s + i);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { atomicAdd(&L.count[(q.a >> (8 * k)) & 255], 1u); atomicAdd(&L.count[(q.b >> (8 * k)) & 255], 1u); }
+    }
+    if (i < n) for (uint32_t k = i; k < n; k++) atomicAdd(&L.count[s[k]], 1u);
+    hist_finish(L, largest, max_sym, lane);
+}
+
+// ------------------------------------------------------------------------------------------------ FSE (wave-uniform serial)
+__device__ __forceinline__ uint32_t fse_min_log(uint32_t n, uint32_t max_sym)
+{ return min(uint32_t(hibit(n)) + 1, uint32_t(hibit(max_sym)) + 2); }
+
+__device__ __forceinline__ uint32_t fse_optimal_log(uint32_t max_log, uint32_t n, uint32_t max_sym, uint32_t minus)
+{
+    const uint32_t src_bits = uint32_t(hibit(n - 1)) - minus;
+    uint32_t log = max_log;
+    if (src_bits < log) log = src_bits;
+    log = max(log, fse_min_log(n, max_sym));
+    return min(max(log, 5u), 12u);
+}
+
+// FSE_normalizeCount on L.count -> L.norm; 0 or kErrGeneric
+__device__ __forceinline__ int fse_normalize(ZLds& L, uint32_t log, uint32_t total0, uint32_t max_sym, bool use_low)
+{
+    const int16_t low = use_low ? int16_t(-1) : int16_t(1);
+    const uint64_t scale = 62 - log, step = (1ull << 62) / total0, vstep = 1ull << (scale - 20);
+    const uint32_t low_thr = total0 >> log;
+    int remaining = 1 << log;
+    uint32_t largest = 0; int largest_p = 0;
+    if (log < fse_min_log(total0, max_sym)) return kErrGeneric;
+    for (uint32_t s = 0; s <= max_sym; s++) {
+        const uint32_t c = L.count[s];
+        if (c == total0) return 0;
+        if (!c) { L.norm[s] = 0; continue; }
+        if (c <= low_thr) { L.norm[s] = low; remaining--; continue; }
+        int p = int(int16_t((c * step) >> scale));
+        if (p < 8) {
+            const uint32_t rtb = p == 0 ? 0u : p == 1 ? 473195u : p == 2 ? 504333u : p == 3 ? 520860u : p == 4 ? 550000u : p == 5 ? 700000u : p == 6 ? 750000u : 830000u;
+            p += ((c * step) - (uint64_t(p) << scale) > vstep * rtb) ? 1 : 0;
+        }
+        if (p > largest_p) { largest_p = p; largest = s; }
+        L.norm[s] = int16_t(p); remaining -= p;
+    }
+    if (-remaining < (int(L.norm[largest]) >> 1)) { L.norm[largest] = int16_t(L.norm[largest] + remaining); return 0; }
+    // FSE_normalizeM2 (fse_compress.c:373-455)
+    uint64_t total = total0;
+    uint32_t distributed = 0, todo;
+    uint32_t low_one = uint32_t((total * 3) >> (log + 1));
+    for (uint32_t s = 0; s <= max_sym; s++) {
+        const uint32_t c = L.count[s];
+        if (!c) { L.norm[s] = 0; continue; }
+        if (c <= low_thr) { L.norm[s] = low; distributed++; total -= c; continue; }
+        if (c <= low_one) { L.norm[s] = 1; distributed++; total -= c; continue; }
+        L.norm[s] = -2;
+    }
+    todo = (1u << log) - distributed;
+    if (!todo) return 0;
+    if (total / todo > low_one) {
+        low_one = uint32_t((total * 3) / (uint64_t(todo) * 2));
+        for (uint32_t s = 0; s <= max_sym; s++)
+            if (L.norm[s] == -2 && L.count[s] <= low_one) { L.norm[s] = 1; distributed++; total -= L.count[s]; }
+        todo = (1u << log) - distributed;
+    }
+    if (distributed == max_sym + 1) {
+        uint32_t best = 0, bc = 0;
+        for (uint32_t s = 0; s <= max_sym; s++) if (L.count[s] > bc) { best = s; bc = L.count[s]; }
+        L.norm[best] = int16_t(L.norm[best] + int(todo));
+        return 0;
+    }
+    if (!total) {
+        for (uint32_t s = 0; todo > 0; s = (s + 1) % (max_sym + 1)) if (L.norm[s] > 0) { todo--; L.norm[s] = int16_t(L.norm[s] + 1); }
+        return 0;
+    }
+    {
+        const uint64_t vlog = 62 - log, mid = (1ull << (vlog - 1)) - 1;
+        const uint64_t rstep = (((1ull << vlog) * todo) + mid) / uint32_t(total);
+        uint64_t acc = mid;
+        for (uint32_t s = 0; s <= max_sym; s++) if (L.norm[s] == -2) {
+            const uint64_t end = acc + L.count[s] * rstep;
+            const uint32_t w = uint32_t(end >> vlog) - uint32_t(acc >> vlog);
+            if (w < 1) return kErrGeneric;
+            L.norm[s] = int16_t(w); acc = end;
+        }
+    }
+    return 0;
+}
+
+// FSE_writeNCount of L.norm; bytes written or kErr*
+__device__ __forceinline__ int fse_write_ncount(ZLds& L, uint8_t* out, uint32_t cap, uint32_t max_sym, uint32_t log, int lane)
+{
+    const uint32_t bound = max_sym ? (((max_sym + 1) * log + 4 + 2) / 8) + 1 + 2 : 512u;
+    const bool safe = cap >= bound;
+    const uint32_t alphabet = max_sym + 1;
+    uint32_t o = 0, bs = log - 5, sym = 0;
+    int nbits = int(log) + 1, remaining = (1 << log) + 1, threshold = 1 << log, bc = 4;
+    bool prev0 = false;
+    auto flush16 = [&]() -> bool {
+        if (!safe && o + 2 > cap) return false;
+        if (lane == 0) { out[o] = uint8_t(bs); out[o + 1] = uint8_t(bs >> 8); }
+        o += 2; bs >>= 16; return true;
+    };
+    while (sym < alphabet && remaining > 1) {
+        if (prev0) {
+            uint32_t start = sym;
+            while (sym < alphabet && !L.norm[sym]) sym++;
+            if (sym == alphabet) break;
+            while (sym >= start + 24) { start += 24; bs += 0xFFFFu << bc; if (!flush16()) return kErrTooSmall; }
+            while (sym >= start + 3) { start += 3; bs += 3u << bc; bc += 2; }
+            bs += (sym - start) << bc; bc += 2;
+            if (bc > 16) { if (!flush16()) return kErrTooSmall; bc -= 16; }
+        }
+        {
+            int c = L.norm[sym++];
+            const int mx = (2 * threshold - 1) - remaining;
+            remaining -= c < 0 ? -c : c;
+            c++;
+            if (c >= threshold) c += mx;
+            bs += uint32_t(c) << bc;
+            bc += nbits; bc -= (c < mx) ? 1 : 0;
+            prev0 = (c == 1);
+            if (remaining < 1) return kErrGeneric;
+            while (remaining < threshold) { nbits--; threshold >>= 1; }
+        }
+        if (bc > 16) { if (!flush16()) return kErrTooSmall; bc -= 16; }
+    }
+    if (remaining != 1) return kErrGeneric;
+    if (!safe && o + 2 > cap) return kErrTooSmall;
+    if (lane == 0) { out[o] = uint8_t(bs); out[o + 1] = uint8_t(bs >> 8); }
+    o += uint32_t(bc + 7) / 8;
+    return int(o);
+}
+
+// FSE_buildCTable_wksp from norm[] (LDS `norm` or the default distributions passed through L.norm)
+__device__ __forceinline__ void fse_build(ZLds& L, FseCt& ct, uint32_t max_sym, uint32_t log)
+{
+    const uint32_t size = 1u << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    uint32_t high = size - 1, pos = 0, total = 0;
+    ct.log = log;
+    L.cumul[0] = 0;
+    for (uint32_t s = 0; s <= max_sym; s++) {
+        const int n = L.norm[s];
+        if (n == -1) { L.cumul[s + 1] = uint16_t(L.cumul[s] + 1); L.symbol_at[high--] = uint8_t(s); }
+        else L.cumul[s + 1] = uint16_t(L.cumul[s] + n);
+    }
+    for (uint32_t s = 0; s <= max_sym; s++) {
+        const int n = L.norm[s];
+        for (int i = 0; i < n; i++) {
+            L.symbol_at[pos] = uint8_t(s);
+            do pos = (pos + step) & mask; while (pos > high);
+        }
+    }
+    for (uint32_t u = 0; u < size; u++) {
+        const uint32_t s = L.symbol_at[u];
+        const uint32_t c = L.cumul[s];
+        ct.next[c] = uint16_t(size + u);
+        L.cumul[s] = uint16_t(c + 1);
+    }
+    for (uint32_t s = 0; s <= max_sym; s++) {
+        const int n = L.norm[s];
+        if (n == 0) { ct.dbits[s] = ((log + 1) << 16) - size; ct.dfind[s] = 0; }
+        else if (n == -1 || n == 1) { ct.dbits[s] = (log << 16) - size; ct.dfind[s] = int32_t(total) - 1; total++; }
+        else {
+            const uint32_t max_out = log - uint32_t(hibit(uint32_t(n) - 1));
+            ct.dbits[s] = (max_out << 16) - (uint32_t(n) << max_out);
+            ct.dfind[s] = int32_t(total) - n;
+            total += uint32_t(n);
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t fse_first_state(const FseCt& ct, uint32_t sym)
+{
+    const uint32_t d = ct.dbits[sym], nb = (d + (1u << 15)) >> 16, v = (nb << 16) - d;
+    return ct.next[int32_t(v >> nb) + ct.dfind[sym]];
+}
+
+// ------------------------------------------------------------------------------------------------ Huffman
+__device__ __forceinline__ uint32_t huf_bucket(uint32_t c) { return c < 165 ? c : uint32_t(hibit(c)) + 158; }
+
+__device__ __forceinline__ void node_swap(ZLds& L, int a, int b)     // a, b: node indices (+1 applied by caller)
+{
+    const uint32_t c = L.ncount[a]; const uint8_t y = L.nbyte[a];
+    L.ncount[a] = L.ncount[b]; L.nbyte[a] = L.nbyte[b];
+    L.ncount[b] = c; L.nbyte[b] = y;
+}
+
+// HUF_simpleQuickSort on nodes [base+lo, base+hi] (descending); deferred sub-ranges are disjoint, so
+// processing them from a stack gives the same array as the reference's recursion order.
+__device__ __forceinline__ void huf_qsort(ZLds& L, int base, int lo0, int hi0)
+{
+    int sp = 0;
+    L.qstack[sp++] = uint32_t(lo0) | (uint32_t(hi0) << 16);
+    while (sp > 0) {
+        const uint32_t f = L.qstack[--sp];
+        int lo = int(f & 0xFFFF), hi = int(f >> 16);
+        if (hi - lo < 8) {
+            for (int i = lo + 1; i <= hi; i++) {
+                const uint32_t kc = L.ncount[base + i]; const uint8_t kb = L.nbyte[base + i];
+                int j = i - 1;
+                while (j >= lo && L.ncount[base + j] < kc) { L.ncount[base + j + 1] = L.ncount[base + j]; L.nbyte[base + j + 1] = L.nbyte[base + j]; j--; }
+                L.ncount[base + j + 1] = kc; L.nbyte[base + j + 1] = kb;
+            }
+            continue;
+        }
+        while (lo < hi) {
+            const uint32_t pivot = L.ncount[base + hi];
+            int i = lo - 1;
+            for (int j = lo; j < hi; j++) if (L.ncount[base + j] > pivot) { i++; node_swap(L, base + i, base + j); }
+            node_swap(L, base + i + 1, base + hi);
+            const int idx = i + 1;
+            if (idx - lo < hi - idx) { if (idx - 1 > lo) L.qstack[sp++] = uint32_t(lo) | (uint32_t(idx - 1) << 16); lo = idx + 1; }
+            else                     { if (hi > idx + 1) L.qstack[sp++] = uint32_t(idx + 1) | (uint32_t(hi) << 16); hi = idx - 1; }
+        }
+    }
+}
+
+// HUF_buildCTable_wksp on L.count -> L.fresh (code | nbits << 16); returns the table log
+__device__ __forceinline__ uint32_t huf_build(ZLds& L, uint32_t max_sym, uint32_t max_bits, int lane)
+{
+    constexpr int N0 = 1;                                     // node k lives at array index k + N0
+    for (int i = lane; i < 516; i += 64) { L.ncount[i] = 0; L.nparent[i] = 0; L.nbyte[i] = 0; L.nbits[i] = 0; }
+    for (int i = lane; i < 192; i += 64) { L.rank_base[i] = 0; L.rank_curr[i] = 0; }
+    // HUF_sort (:604-640)
+    for (uint32_t s = 0; s <= max_sym; s++) { const uint32_t r = huf_bucket(L.count[s]); L.rank_base[r] = uint16_t(L.rank_base[r] + 1); }
+    for (int r = 191; r > 0; r--) { const uint16_t v = uint16_t(L.rank_base[r - 1] + L.rank_base[r]); L.rank_base[r - 1] = v; L.rank_curr[r - 1] = v; }
+    for (uint32_t s = 0; s <= max_sym; s++) {
+        const uint32_t c = L.count[s], r = huf_bucket(c) + 1;
+        const uint32_t pos = L.rank_curr[r];
+        L.rank_curr[r] = uint16_t(pos + 1);
+        L.ncount[N0 + pos] = c; L.nbyte[N0 + pos] = uint8_t(s);
+    }
+    for (int r = 165; r < 191; r++) {
+        const int len = int(L.rank_curr[r]) - int(L.rank_base[r]);
+        if (len > 1) huf_qsort(L, N0 + int(L.rank_base[r]), 0, len - 1);
+    }
+    // HUF_buildTree (:665-705)
+    int last = int(max_sym);
+    while (!L.ncount[N0 + last]) last--;
+    int low_s = last, nb = 256, low_n = 256;
+    const int root = nb + low_s - 1;
+    L.ncount[N0 + nb] = L.ncount[N0 + low_s] + L.ncount[N0 + low_s - 1];
+    L.nparent[N0 + low_s] = uint16_t(nb); L.nparent[N0 + low_s - 1] = uint16_t(nb);
+    nb++; low_s -= 2;
+    for (int n = nb; n <= root; n++) L.ncount[N0 + n] = 1u << 30;
+    L.ncount[0] = 1u << 31;
+    while (nb <= root) {
+        const int n1 = L.ncount[N0 + low_s] < L.ncount[N0 + low_n] ? low_s-- : low_n++;
+        const int n2 = L.ncount[N0 + low_s] < L.ncount[N0 + low_n] ? low_s-- : low_n++;
+        L.ncount[N0 + nb] = L.ncount[N0 + n1] + L.ncount[N0 + n2];
+        L.nparent[N0 + n1] = uint16_t(nb); L.nparent[N0 + n2] = uint16_t(nb);
+        nb++;
+    }
+    L.nbits[N0 + root] = 0;
+    for (int n = root - 1; n >= 256; n--) L.nbits[N0 + n] = uint8_t(L.nbits[N0 + L.nparent[N0 + n]] + 1);
+    for (int n = 0; n <= last; n++) L.nbits[N0 + n] = uint8_t(L.nbits[N0 + L.nparent[N0 + n]] + 1);
+    // HUF_setMaxHeight (:360-470)
+    {
+        const uint32_t largest = L.nbits[N0 + last], target = max_bits;
+        if (largest > target) {
+            int cost = 0, n = last;
+            const int base = 1 << (largest - target);
+            while (L.nbits[N0 + n] > target) { cost += base - (1 << (largest - L.nbits[N0 + n])); L.nbits[N0 + n] = uint8_t(target); n--; }
+            while (L.nbits[N0 + n] == target) n--;
+            cost >>= (largest - target);
+            for (int i = 0; i < 16; i++) L.rank_last[i] = 0xF0F0F0F0u;
+            {
+                uint32_t cur = target;
+                for (int pos = n; pos >= 0; pos--) {
+                    const uint32_t b = L.nbits[N0 + pos];
+                    if (b >= cur) continue;
+                    cur = b;
+                    L.rank_last[target - cur] = uint32_t(pos);
+                }
+            }
+            while (cost > 0) {
+                uint32_t dec = uint32_t(hibit(uint32_t(cost))) + 1;
+                for (; dec > 1; dec--) {
+                    const uint32_t hp = L.rank_last[dec], lp = L.rank_last[dec - 1];
+                    if (hp == 0xF0F0F0F0u) continue;
+                    if (lp == 0xF0F0F0F0u) break;
+                    if (L.ncount[N0 + hp] <= 2 * L.ncount[N0 + lp]) break;
+                }
+                while (dec <= 12 && L.rank_last[dec] == 0xF0F0F0F0u) dec++;
+                cost -= 1 << (dec - 1);
+                { const uint32_t q = L.rank_last[dec]; L.nbits[N0 + q] = uint8_t(L.nbits[N0 + q] + 1); }
+                if (L.rank_last[dec - 1] == 0xF0F0F0F0u) L.rank_last[dec - 1] = L.rank_last[dec];
+                if (L.rank_last[dec] == 0) L.rank_last[dec] = 0xF0F0F0F0u;
+                else {
+                    const uint32_t q = L.rank_last[dec] - 1;
+                    L.rank_last[dec] = (L.nbits[N0 + q] != target - dec) ? 0xF0F0F0F0u : q;
+                }
+            }
+            while (cost < 0) {
+                if (L.rank_last[1] == 0xF0F0F0F0u) {
+                    while (L.nbits[N0 + n] == target) n--;
+                    L.nbits[N0 + n + 1] = uint8_t(L.nbits[N0 + n + 1] - 1);
+                    L.rank_last[1] = uint32_t(n + 1);
+                    cost++;
+                    continue;
+                }
+                { const uint32_t q = L.rank_last[1] + 1; L.nbits[N0 + q] = uint8_t(L.nbits[N0 + q] - 1); L.rank_last[1] = q; }
+                cost++;
+            }
+            max_bits = target;
+        } else max_bits = largest;
+    }
+    // HUF_buildCTableFromTree (:714-735)
+    for (int i = 0; i < 16; i++) { L.per_rank[i] = 0; L.val[i] = 0; }
+    for (int n = 0; n <= last; n++) { const uint32_t b = L.nbits[N0 + n]; L.per_rank[b] = uint16_t(L.per_rank[b] + 1); }
+    {
+        uint32_t mn = 0;
+        for (int r = int(max_bits); r > 0; r--) { L.val[r] = uint16_t(mn); mn = (mn + L.per_rank[r]) >> 1; }
+    }
+    for (int i = lane; i < 256; i += 64) L.fresh[i] = 0;
+    for (uint32_t n = 0; n <= max_sym; n++) L.fresh[L.nbyte[N0 + n]] = uint32_t(L.nbits[N0 + n]) << 16;
+    for (uint32_t s = 0; s <= max_sym; s++) {
+        const uint32_t b = L.fresh[s] >> 16;
+        if (b) { const uint32_t v = L.val[b]; L.val[b] = uint16_t(v + 1); L.fresh[s] = (b << 16) | v; }
+    }
+    return max_bits;
+}
+
+// HUF_writeCTable_wksp of L.fresh; bytes or kErr*
+__device__ __forceinline__ int huf_write_table(ZLds& L, uint8_t* dst, uint32_t cap, uint32_t max_sym, uint32_t log, int lane)
+{
+    for (uint32_t s = lane; s < max_sym; s += 64) { const uint32_t b = L.fresh[s] >> 16; L.weight[s] = b ? uint8_t(log + 1 - b) : uint8_t(0); }
+    if (cap < 1) return kErrTooSmall;
+    int h = 0;
+    if (max_sym > 1) {                                        // HUF_compressWeights (:147-186)
+        uint8_t* const out = dst + 1;
+        const uint32_t ocap = cap - 1;
+        if (lane < 16) L.wcount[lane] = 0;
+        for (uint32_t s = lane; s < max_sym; s += 64) atomicAdd(&L.wcount[L.weight[s]], 1u);
+        uint32_t top = 0, wmax = 0;
+        for (uint32_t w = 0; w <= 12; w++) { const uint32_t c = L.wcount[w]; top = max(top, c); if (c) wmax = w; }
+        if (top == max_sym) h = 1;
+        else if (top == 1) h = 0;
+        else {
+            const uint32_t wlog = fse_optimal_log(6, max_sym, wmax, 2);
+            if (lane < 13) L.count[lane] = L.wcount[lane];            // the literal histogram is restored by the caller
+            int r = fse_normalize(L, wlog, max_sym, wmax, false);
+            if (r < 0) return r;
+            const int nc = fse_write_ncount(L, out, ocap, wmax, wlog, lane);
+            if (nc < 0) return nc;
+            FseCt& wt = L.ct[0];
+            fse_build(L, wt, wmax, wlog);
+            // FSE_compress_usingCTable, two interleaved states (:560-620)
+            uint32_t c = 0;
+            BitW w;
+            if (max_sym > 2 && w.init(out + nc, ocap - uint32_t(nc))) {
+                uint32_t i = max_sym, s1, s2;
+                auto enc = [&](uint32_t st, uint32_t sym) -> uint32_t {
+                    const uint32_t nb = (st + wt.dbits[sym]) >> 16;
+                    w.put(st, nb, lane);
+                    return wt.next[int32_t(st >> nb) + wt.dfind[sym]];
+                };
+                if (max_sym & 1) { s1 = fse_first_state(wt, L.weight[--i]); s2 = fse_first_state(wt, L.weight[--i]); s1 = enc(s1, L.weight[--i]); }
+                else             { s2 = fse_first_state(wt, L.weight[--i]); s1 = fse_first_state(wt, L.weight[--i]); }
+                while (i > 0) { s2 = enc(s2, L.weight[--i]); s1 = enc(s1, L.weight[--i]); }
+                w.put(s2, wt.log, lane); w.put(s1, wt.log, lane);
+                c = w.close(lane);
+            }
+            h = c ? nc + int(c) : 0;
+        }
+    }
+    if (h > 1 && uint32_t(h) < max_sym / 2) { if (lane == 0) dst[0] = uint8_t(h); return h + 1; }
+    if (max_sym > 128) return kErrGeneric;
+    if (((max_sym + 1) / 2) + 1 > cap) return kErrTooSmall;
+    if (lane == 0) { dst[0] = uint8_t(128 + (max_sym - 1)); L.weight[max_sym] = 0; }
+    for (uint32_t s = 2 * lane; s < max_sym; s += 128) dst[s / 2 + 1] = uint8_t((L.weight[s] << 4) + (s + 1 < max_sym ? L.weight[s + 1] : 0));
+    return int((max_sym + 1) / 2) + 1;
+}
+
+// one Huffman stream (HUF_compress1X_usingCTable_internal_body, :1029-1094): symbols lit[a, b), last first.
+// Wave-parallel: 8 symbols per lane and round, prefix sum of code lengths, LDS atomic-or staging.
+__device__ __forceinline__ uint32_t huf_stream(ZLds& L, const uint32_t* tab, uint8_t* dst, uint32_t cap,
+                                               const uint8_t* lit, uint32_t a, uint32_t b, int lane)
+{
+    if (cap <= 8) return 0;
+    uint32_t total = 0, pos = 0, carry = 0, carry_nb = 0;
+    for (uint32_t hi = b; hi > a; ) {
+        const int32_t top = int32_t(hi) - 1 - 8 * lane;
+        uint64_t v0 = 0, v1 = 0; uint32_t len = 0;
+        if (top >= int32_t(a)) {
+            const uint64_t w = ld8(lit + top - 7);                  // the literal buffer has a front pad
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (top - k >= int32_t(a)) {
+                    const uint32_t e = tab[(w >> (8 * (7 - k))) & 255];
+                    const uint64_t code = e & 0xFFFF; const uint32_t nbt = e >> 16;
+                    if (len < 64) { v0 |= code << len; if (len + nbt > 64) v1 |= code >> (64 - len); }
+                    else v1 |= code << (len - 64);
+                    len += nbt;
+                }
+            }
+        }
+        const uint32_t incl = scan_add(len);
+        const uint32_t round_bits = rl(incl, 63);
+        const uint32_t off = incl - len + carry_nb;
+        for (int i = lane; i < 200; i += 64) L.stage[i] = (i == 0) ? carry : 0u;
+        if (len) {
+            const uint32_t w0 = off >> 5, sh = off & 31;
+            const uint64_t lo = v0 << sh;
+            const uint64_t mid = (sh ? (v0 >> (64 - sh)) : 0ull) | (v1 << sh);
+            if (uint32_t(lo)) atomicOr(&L.stage[w0], uint32_t(lo));
+            if (uint32_t(lo >> 32)) atomicOr(&L.stage[w0 + 1], uint32_t(lo >> 32));
+            if (uint32_t(mid)) atomicOr(&L.stage[w0 + 2], uint32_t(mid));
+            if (uint32_t(mid >> 32)) atomicOr(&L.stage[w0 + 3], uint32_t(mid >> 32));
+        }
+        const uint32_t bits = carry_nb + round_bits, nbytes = bits >> 3;
+        for (uint32_t wi = lane; 4 * wi < nbytes; wi += 64) {
+            const uint32_t v = L.stage[wi];
+            if (4 * wi + 4 <= nbytes && pos + 4 * wi + 4 <= cap) st4(dst + pos + 4 * wi, v);
+            else for (uint32_t k = 0; k < 4; k++) if (4 * wi + k < nbytes && pos + 4 * wi + k < cap) dst[pos + 4 * wi + k] = uint8_t(v >> (8 * k));
+        }
+        carry_nb = bits & 7;
+        carry = (L.stage[nbytes >> 2] >> (8 * (nbytes & 3))) & ((1u << carry_nb) - 1);
+        pos += nbytes; total += round_bits;
+        hi = hi - a > 512 ? hi - 512 : a;
+    }
+    carry |= 1u << carry_nb; carry_nb++; total++;                 // HUF_endMark
+    if (lane == 0 && pos < cap) dst[pos] = uint8_t(carry);
+    return ((total >> 3) + 8 < cap) ? (total + 7) >> 3 : 0u;
+}
+
+// HUF_compressCTable_internal (:1208-1224); `hdr` table-description bytes already sit in front of dst
+__device__ __forceinline__ uint32_t huf_encode(ZLds& L, const uint32_t* tab, uint8_t* dst, uint32_t cap, uint32_t hdr,
+                                               const uint8_t* lit, uint32_t n, bool four, int lane)
+{
+    uint32_t c;
+    if (!four) c = huf_stream(L, tab, dst, cap, lit, 0, n, lane);
+    else {
+        const uint32_t seg = (n + 3) / 4;
+        uint32_t o = 6;
+        if (cap < 6 + 1 + 1 + 1 + 8 || n < 12) return 0;
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t a = k * seg, b = k < 3 ? a + seg : n;
+            const uint32_t s = huf_stream(L, tab, dst + o, cap - o, lit, a, b, lane);
+            if (s == 0 || s > 65535) return 0;
+            if (k < 3 && lane == 0) { dst[2 * k] = uint8_t(s); dst[2 * k + 1] = uint8_t(s >> 8); }
+            o += s;
+        }
+        c = o;
+    }
+    if (!c) return 0;
+    if (hdr + c >= n - 1) return 0;
+    return hdr + c;
+}
+
+enum { kRepNone = 0, kRepCheck = 1, kRepValid = 2 };
+
+// HUF_compress_internal (:1250-1360).  `table` = L.huf[next] holds the previous block's table on entry.
+__device__ __forceinline__ int huf_compress(ZLds& L, uint32_t* table, uint8_t* dst, uint32_t cap, const uint8_t* lit, uint32_t n,
+                                            bool four, int& repeat, bool prefer_repeat, bool suspect, int lane)
+{
+    uint32_t largest, max_sym;
+    if (!n || !cap) return 0;
+    if (prefer_repeat && repeat == kRepValid) return int(huf_encode(L, table, dst, cap, 0, lit, n, four, lane));
+    if (suspect && n >= 4096 * 10) {
+        uint32_t a, b, m;
+        hist_bytes(L, lit, 4096, a, m, lane);
+        hist_bytes(L, lit + n - 4096, 4096, b, m, lane);
+        if (a + b <= ((2 * 4096) >> 7) + 4) return 0;
+    }
+    hist_bytes(L, lit, n, largest, max_sym, lane);
+    if (largest == n) { if (lane == 0) dst[0] = lit[0]; return 1; }
+    if (largest <= (n >> 7) + 4) return 0;
+    if (repeat == kRepCheck) {
+        bool bad = false;
+        for (uint32_t s = lane; s <= max_sym; s += 64) bad |= (L.count[s] != 0) && ((table[s] >> 16) == 0);
+        if (__ballot(bad)) repeat = kRepNone;
+    }
+    if (prefer_repeat && repeat != kRepNone) return int(huf_encode(L, table, dst, cap, 0, lit, n, four, lane));
+    uint32_t log = fse_optimal_log(11, n, max_sym, 1);
+    log = huf_build(L, max_sym, log, lane);
+    // bit estimates before the weight coder borrows L.count
+    uint32_t old_bits = 0, new_bits = 0;
+    for (uint32_t s = lane; s <= max_sym; s += 64) { old_bits += (table[s] >> 16) * L.count[s]; new_bits += (L.fresh[s] >> 16) * L.count[s]; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { old_bits += uint32_t(__shfl_xor(int(old_bits), d)); new_bits += uint32_t(__shfl_xor(int(new_bits), d)); }
+    const int h = huf_write_table(L, dst, cap, max_sym, log, lane);
+    if (h < 0) return h;
+    if (repeat != kRepNone) {
+        if ((old_bits >> 3) <= uint32_t(h) + (new_bits >> 3) || uint32_t(h) + 12 >= n)
+            return int(huf_encode(L, table, dst, cap, 0, lit, n, four, lane));
+    }
+    if (uint32_t(h) + 12 >= n) return 0;
+    repeat = kRepNone;
+    for (int i = lane; i < 256; i += 64) table[i] = L.fresh[i];
+    return int(huf_encode(L, L.fresh, dst + h, cap - uint32_t(h), uint32_t(h), lit, n, four, lane));
+}
+
+// ZSTD_noCompressLiterals / ZSTD_compressRleLiteralsBlock
+__device__ __forceinline__ int raw_literals(uint8_t* dst, uint32_t cap, const uint8_t* lit, uint32_t n, bool rle, int lane)
+{
+    const uint32_t fl = 1 + (n > 31) + (n > 4095);
+    const uint32_t type = rle ? 1u : 0u;
+    if (!rle && n + fl > cap) return kErrTooSmall;
+    const uint32_t v = fl == 1 ? type + (n << 3) : fl == 2 ? type + (1u << 2) + (n << 4) : type + (3u << 2) + (n << 4);
+    if (uint32_t(lane) < fl) dst[lane] = uint8_t(v >> (8 * lane));
+    if (rle) { if (lane == 0) dst[fl] = lit[0]; return int(fl) + 1; }
+    copy_bytes(dst + fl, lit, n, lane);
+    return int(n + fl);
+}
+
+struct Entropy { int huf_repeat; uint32_t rep[3]; };       // per-block-state besides the LDS literal table
+
+// ZSTD_compressLiterals (strategy fast)
+__device__ __forceinline__ int compress_literals(ZLds& L, int prev, const Entropy& pe, Entropy& ne, uint8_t* dst, uint32_t cap,
+                                                 const uint8_t* lit, uint32_t n, bool suspect, int lane)
+{
+    const uint32_t min_gain = (n >> 6) + 2, lh = 3 + (n >= 1024) + (n >= 16384);
+    bool single = n < 256;
+    int repeat = pe.huf_repeat, type = 2;
+    uint32_t* const ptab = L.huf[prev];
+    uint32_t* const ntab = L.huf[prev ^ 1];
+    for (int i = lane; i < 256; i += 64) ntab[i] = ptab[i];
+    ne.huf_repeat = pe.huf_repeat;
+    if (n <= uint32_t(pe.huf_repeat == kRepValid ? 6 : 63)) return raw_literals(dst, cap, lit, n, false, lane);
+    if (cap < lh + 1) return kErrTooSmall;
+    if (repeat == kRepValid && lh == 3) single = true;
+    const int c = huf_compress(L, ntab, dst + lh, cap - lh, lit, n, !single, repeat, n <= 1024, suspect, lane);
+    if (repeat != kRepNone) type = 3;
+    if (c <= 0 || uint32_t(c) >= n - min_gain) { for (int i = lane; i < 256; i += 64) ntab[i] = ptab[i]; return raw_literals(dst, cap, lit, n, false, lane); }
+    if (c == 1) { for (int i = lane; i < 256; i += 64) ntab[i] = ptab[i]; return raw_literals(dst, cap, lit, n, true, lane); }
+    if (type == 2) ne.huf_repeat = kRepCheck;
+    uint64_t v;
+    if (lh == 3) v = uint32_t(type) + (uint32_t(!single) << 2) + (n << 4) + (uint32_t(c) << 14);
+    else if (lh == 4) v = uint32_t(type) + (2u << 2) + (n << 4) + (uint32_t(c) << 18);
+    else v = uint64_t(uint32_t(uint32_t(type) + (3u << 2) + (n << 4) + (uint32_t(c) << 22))) | (uint64_t(uint32_t(c) >> 10) << 32);
+    if (uint32_t(lane) < lh) dst[lane] = uint8_t(v >> (8 * lane));
+    return int(lh) + c;
+}
+
+// ------------------------------------------------------------------------------------------------ sequences
+__device__ __forceinline__ uint32_t ll_code(uint32_t v)
+{
+    if (v > 63) return uint32_t(hibit(v)) + 19;
+    if (v < 16) return v;
+    if (v < 24) return 16 + ((v - 16) >> 1);
+    if (v < 32) return 20 + ((v - 24) >> 2);
+    if (v < 48) return 22 + ((v - 32) >> 3);
+    return 24;
+}
+__device__ __forceinline__ uint32_t ml_code(uint32_t v)
+{
+    if (v > 127) return uint32_t(hibit(v)) + 36;
+    if (v < 32) return v;
+    if (v < 40) return 32 + ((v - 32) >> 1);
+    if (v < 48) return 36 + ((v - 40) >> 2);
+    if (v < 64) return 38 + ((v - 48) >> 3);
+    if (v < 96) return 40 + ((v - 64) >> 4);
+    return 42;
+}
+__device__ __forceinline__ uint32_t ll_bits(uint32_t c) { return c < 16 ? 0u : c < 26 ? uint32_t((0x6433221111ull >> (4 * (c - 16))) & 15) : c - 19; }
+__device__ __forceinline__ uint32_t ml_bits(uint32_t c) { return c < 32 ? 0u : c < 43 ? uint32_t((0x54433221111ull >> (4 * (c - 32))) & 15) : c - 36; }
+
+__device__ __forceinline__ int default_norm(int which, uint32_t s)       // LL_defaultNorm / OF_ / ML_ (zstd_internal.h)
+{
+    if (which == 0) return s == 0 ? 4 : (s == 1 || s == 25) ? 3 : (s >= 13 && s <= 15) ? 1 : (s >= 27 && s <= 31) ? 1 : s >= 32 ? -1 : 2;
+    if (which == 1) return (s >= 6 && s <= 8) ? 2 : s >= 24 ? -1 : 1;
+    return s == 0 ? 1 : s == 1 ? 4 : s == 2 ? 3 : (s >= 3 && s <= 8) ? 2 : s >= 46 ? -1 : 1;
+}
+
+// ZSTD_selectEncodingType for strategy fast without dictionary: 0 basic, 1 rle, 2 compressed
+__device__ __forceinline__ int select_type(uint32_t most, uint32_t nseq, uint32_t def_log, bool def_ok)
+{
+    if (most == nseq) return (def_ok && nseq <= 2) ? 0 : 1;
+    if (def_ok) {
+        const uint32_t dyn_min = ((1u << def_log) * 9u) >> 3;
+        if (nseq < dyn_min || most < (nseq >> (def_log - 1))) return 0;
+    }
+    return 2;
+}
+
+// ZSTD_buildCTable for table `which` (0 ll, 1 of, 2 ml): bytes of description or kErr*
+__device__ __forceinline__ int build_seq_table(ZLds& L, int which, uint8_t* dst, uint32_t cap, uint32_t fse_log, int type, uint32_t max,
+                                               const uint8_t* codes, uint32_t nseq, uint32_t def_log, uint32_t def_max, int lane)
+{
+    FseCt& ct = L.ct[which];
+    if (type == 1) {
+        if (lane == 0) { ct.log = 0; ct.next[0] = 0; ct.next[1] = 0; ct.dbits[max] = 0; ct.dfind[max] = 0; }
+        if (!cap) return kErrTooSmall;
+        if (lane == 0) dst[0] = codes[0];
+        return 1;
+    }
+    if (type == 0) {
+        if (uint32_t(lane) <= def_max) L.norm[lane] = int16_t(default_norm(which, uint32_t(lane)));
+        fse_build(L, ct, def_max, def_log);
+        return 0;
+    }
+    uint32_t n1 = nseq;
+    const uint32_t log = fse_optimal_log(fse_log, nseq, max, 2);
+    const uint32_t lastc = codes[nseq - 1];
+    if (L.count[lastc] > 1) { L.count[lastc] = L.count[lastc] - 1; n1--; }
+    int r = fse_normalize(L, log, n1, max, n1 >= 2048);
+    if (r < 0) return r;
+    r = fse_write_ncount(L, dst, cap, max, log, lane);
+    if (r < 0) return r;
+    fse_build(L, ct, max, log);
+    return r;
+}
+
+struct SeqStore { uint32_t *ll, *ml, *off; uint8_t *llc, *ofc, *mlc; uint8_t* lit; uint32_t nseq, nlit; };
+
+// sequences section (tail of ZSTD_entropyCompressSeqStore_internal); bytes, 0 or kErr*
+__device__ __forceinline__ int encode_sequences(ZLds& L, uint8_t* dst, uint32_t cap, const SeqStore& S, int lane)
+{
+    const uint32_t nseq = S.nseq;
+    uint32_t o = 0, last_count = 0;
+    if (cap < 4) return kErrTooSmall;
+    if (nseq < 128) { if (lane == 0) dst[0] = uint8_t(nseq); o = 1; }
+    else if (nseq < 0x7F00) { if (lane == 0) { dst[0] = uint8_t((nseq >> 8) + 0x80); dst[1] = uint8_t(nseq); } o = 2; }
+    else { if (lane == 0) { dst[0] = 0xFF; dst[1] = uint8_t(nseq - 0x7F00); dst[2] = uint8_t((nseq - 0x7F00) >> 8); } o = 3; }
+    if (!nseq) return int(o);
+    for (uint32_t i = lane; i < nseq; i += 64) {
+        S.llc[i] = uint8_t(ll_code(S.ll[i])); S.ofc[i] = uint8_t(hibit(S.off[i])); S.mlc[i] = uint8_t(ml_code(S.ml[i]));
+    }
+    {
+        uint8_t* const head = dst + o++;
+        uint32_t most, max;
+        hist_bytes(L, S.llc, nseq, most, max, lane);
+        const int tll = select_type(most, nseq, 6, true);
+        int r = build_seq_table(L, 0, dst + o, cap - o, 9, tll, max, S.llc, nseq, 6, 35, lane);
+        if (r < 0) return r;
+        if (tll == 2) last_count = uint32_t(r);
+        o += uint32_t(r);
+        hist_bytes(L, S.ofc, nseq, most, max, lane);
+        const int tof = select_type(most, nseq, 5, max <= 28);
+        r = build_seq_table(L, 1, dst + o, cap - o, 8, tof, max, S.ofc, nseq, 5, 28, lane);
+        if (r < 0) return r;
+        if (tof == 2) last_count = uint32_t(r);
+        o += uint32_t(r);
+        hist_bytes(L, S.mlc, nseq, most, max, lane);
+        const int tml = select_type(most, nseq, 6, true);
+        r = build_seq_table(L, 2, dst + o, cap - o, 9, tml, max, S.mlc, nseq, 6, 52, lane);
+        if (r < 0) return r;
+        if (tml == 2) last_count = uint32_t(r);
+        o += uint32_t(r);
+        if (lane == 0) *head = uint8_t((tll << 6) + (tof << 4) + (tml << 2));
+    }
+    {   // ZSTD_encodeSequences_body: last sequence first; 64 sequences per chunk, lane l holds sequence top - l
+        BitW w;
+        if (!w.init(dst + o, cap - o)) return kErrTooSmall;
+        const FseCt& cll = L.ct[0]; const FseCt& cof = L.ct[1]; const FseCt& cml = L.ct[2];
+        uint32_t sll = 0, sof = 0, sml = 0;
+        bool first = true;
+        for (int32_t top = int32_t(nseq) - 1; top >= 0; top -= 64) {
+            const int32_t i = top - lane;
+            uint32_t cl = 0, co = 0, cm = 0, x0 = 0, x1 = 0, n0 = 0, n1 = 0;
+            uint32_t dl = 0, dof = 0, dm = 0; int32_t fl = 0, fo = 0, fm = 0;
+            if (i >= 0) {
+                cl = S.llc[i]; co = S.ofc[i]; cm = S.mlc[i];
+                const uint32_t bl = ll_bits(cl), bm = ml_bits(cm);
+                const uint64_t ext = uint64_t(S.ll[i] & ((1u << bl) - 1)) | (uint64_t(S.ml[i] & ((1u << bm) - 1)) << bl);
+                x0 = uint32_t(ext); n0 = bl + bm;                      // <= 32 bits
+                x1 = S.off[i] & ((1u << co) - 1); n1 = co;              // <= 31 bits
+                dl = cll.dbits[cl]; fl = cll.dfind[cl]; dof = cof.dbits[co]; fo = cof.dfind[co]; dm = cml.dbits[cm]; fm = cml.dfind[cm];
+            }
+            const int cnt = top >= 63 ? 64 : top + 1;
+            for (int k = 0; k < cnt; k++) {
+                const uint32_t kl = rl(cl, k), ko = rl(co, k), km = rl(cm, k);
+                if (first) {
+                    sml = fse_first_state(cml, km); sof = fse_first_state(cof, ko); sll = fse_first_state(cll, kl);
+                    first = false;
+                } else {
+                    const uint32_t a = rl(dof, k), b = rl(dm, k), c = rl(dl, k);
+                    uint32_t nb = (sof + a) >> 16; w.put(sof, nb, lane); sof = cof.next[int32_t(sof >> nb) + int32_t(rl(uint32_t(fo), k))];
+                    nb = (sml + b) >> 16; w.put(sml, nb, lane); sml = cml.next[int32_t(sml >> nb) + int32_t(rl(uint32_t(fm), k))];
+                    nb = (sll + c) >> 16; w.put(sll, nb, lane); sll = cll.next[int32_t(sll >> nb) + int32_t(rl(uint32_t(fl), k))];
+                }
+                w.put(rl(x0, k), rl(n0, k), lane);
+                w.put(rl(x1, k), rl(n1, k), lane);
+            }
+        }
+        w.put(sml, cml.log, lane); w.put(sof, cof.log, lane); w.put(sll, cll.log, lane);
+        const uint32_t bytes = w.close(lane);
+        if (!bytes) return kErrTooSmall;
+        o += bytes;
+        if (last_count && last_count + bytes < 4) return 0;             // zstd <= 1.3.4 decoder workaround
+    }
+    return int(o);
+}
+
+// ------------------------------------------------------------------------------------------------ match finder
+struct Params { uint32_t wlog, hlog, mml, tlen; };
+
+__device__ __forceinline__ uint32_t zhash(uint64_t v, uint32_t hlog, uint32_t mls)
+{
+    if (mls == 7) return uint32_t(((v << 8) * 58295818150454627ull) >> (64 - hlog));
+    if (mls == 6) return uint32_t(((v << 16) * 227718039650203ull) >> (64 - hlog));
+    if (mls == 5) return uint32_t(((v << 24) * 889523592379ull) >> (64 - hlog));
+    return (uint32_t(v) * 2654435761u) >> (32 - hlog);
+}
+
+// bytes equal from s[a..] vs s[b..] (a > b), a stops at lim; wave-wide
+__device__ __forceinline__ uint32_t count_fwd(const uint8_t* s, uint32_t a, uint32_t b, uint32_t lim, int lane)
+{
+    uint32_t n = 0;
+    for (;;) {
+        if (a + 1024 <= lim) {
+            const U16B x = *reinterpret_cast<const U16B*>(s + a + 16 * lane);
+            const U16B y = *reinterpret_cast<const U16B*>(s + b + 16 * lane);
+            const uint64_t d0 = x.a ^ y.a, d1 = x.b ^ y.b;
+            const uint32_t eq = d0 ? uint32_t(__builtin_ctzll(d0) >> 3) : (d1 ? 8u + uint32_t(__builtin_ctzll(d1) >> 3) : 16u);
+            const unsigned long long bad = __ballot(eq < 16);
+            if (bad) { const int l = __builtin_ctzll(bad); return n + 16 * l + rl(eq, l); }
+            n += 1024; a += 1024; b += 1024;
+        } else {
+            const uint32_t i = a + lane;
+            const bool same = (i < lim) && s[i] == s[b + lane];
+            const unsigned long long bad = ~__ballot(same);
+            if (bad) return n + __builtin_ctzll(bad);
+            n += 64; a += 64; b += 64;
+        }
+    }
+}
+
+__device__ __forceinline__ void store_seq(SeqStore& S, const uint8_t* s, uint32_t anchor, uint32_t ll, uint32_t off_base, uint32_t ml, int lane)
+{
+    copy_bytes(S.lit + S.nlit, s + anchor, ll, lane);
+    S.nlit += ll;
+    if (lane == 0) { S.ll[S.nseq] = ll; S.ml[S.nseq] = ml - 3; S.off[S.nseq] = off_base; }
+    S.nseq++;
+}
+
+// after a match ending at ip0: table refills and the repcode-2 loop (zstd_fast.c:263-281)
+__device__ __forceinline__ void after_match(SeqStore& S, uint32_t* tab, const Params& P, const uint8_t* s, uint32_t& ip0, uint32_t& anchor,
+                                            uint32_t cur0_idx, uint32_t& rep1, uint32_t& rep2, uint32_t end, int64_t ilimit, int lane)
+{
+    if (int64_t(ip0) > ilimit) return;
+    {
+        const uint32_t h_a = zhash(ld8(s + cur0_idx), P.hlog, P.mml), h_b = zhash(ld8(s + ip0 - 2), P.hlog, P.mml);
+        if (lane == 0) { tab[h_a] = cur0_idx + 2; tab[h_b] = ip0; }
+    }
+    if (rep2 > 0)
+        while (int64_t(ip0) <= ilimit && ld4(s + ip0) == ld4(s + ip0 - rep2)) {
+            const uint32_t rlen = count_fwd(s, ip0 + 4, ip0 + 4 - rep2, end, lane) + 4;
+            const uint32_t t = rep2; rep2 = rep1; rep1 = t;
+            const uint32_t h = zhash(ld8(s + ip0), P.hlog, P.mml);
+            if (lane == 0) tab[h] = ip0 + 2;
+            ip0 += rlen;
+            store_seq(S, s, anchor, 0, 1, rlen, lane);
+            anchor = ip0;
+        }
+}
+
+// ZSTD_compressBlock_fast_noDict_generic over s[start, end), 64 position pairs per batch
+__device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* tab, const Params& P, uint32_t rep[3],
+                                               const uint8_t* s, uint32_t start, uint32_t end, uint32_t n_total, bool serial, int lane)
+{
+    const uint32_t hlog = P.hlog, wsize = 1u << P.wlog, mls = P.mml;
+    const uint32_t step0 = P.tlen > 1 ? P.tlen + 1 : 2;
+    const uint32_t prefix_idx = end > wsize ? end + 2 - wsize : 2;
+    const uint32_t prefix = prefix_idx - 2;
+    const int64_t ilimit = int64_t(end) - 8;
+    uint32_t anchor = start, ip0 = start;
+    uint32_t rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0;
+
+    ip0 += (ip0 == prefix) ? 1 : 0;
+    {
+        const uint32_t cur = ip0 + 2;
+        const uint32_t low = cur - prefix_idx > wsize ? cur - wsize : prefix_idx;
+        const uint32_t max_rep = cur - low;
+        if (rep2 > max_rep) { saved2 = rep2; rep2 = 0; }
+        if (rep1 > max_rep) { saved1 = rep1; rep1 = 0; }
+    }
+    for (;;) {                                                   // one search per iteration (_start)
+        uint32_t match0 = 0, mlen = 0, off_base = 0, cur0 = 0;
+        bool found = false;
+        if (int64_t(ip0) + step0 + 1 >= ilimit) break;
+        if (serial) {
+            // wave-uniform transcription of the reference loop (debug / cross-check path)
+            uint32_t step = step0, next_step = ip0 + 128, ip1 = ip0 + 1, ip2 = ip0 + step, ip3 = ip2 + 1;
+            uint32_t h0 = zhash(ld8(s + ip0), hlog, mls), h1 = zhash(ld8(s + ip1), hlog, mls);
+            uint32_t idx = tab[h0];
+            int kind = 0;                                        // 1 repcode, 2 hash hit
+            for (;;) {
+                const uint32_t rval = ld4(s + ip2 - rep1);
+                cur0 = ip0 + 2;
+                if (lane == 0) tab[h0] = cur0;
+                if ((ld4(s + ip2) == rval) & (rep1 > 0)) { if (lane == 0) tab[h1] = ip1 + 2; kind = 1; break; }
+                if (idx >= prefix_idx && ld4(s + idx - 2) == ld4(s + ip0)) { if (lane == 0) tab[h1] = ip1 + 2; kind = 2; break; }
+                idx = tab[h1]; h0 = h1; h1 = zhash(ld8(s + ip2), hlog, mls);
+                ip0 = ip1; ip1 = ip2; ip2 = ip3;
+                cur0 = ip0 + 2;
+                if (lane == 0) tab[h0] = cur0;
+                if (idx >= prefix_idx && ld4(s + idx - 2) == ld4(s + ip0)) { if (step <= 4 && lane == 0) tab[h1] = ip1 + 2; kind = 2; break; }
+                idx = tab[h1]; h0 = h1; h1 = zhash(ld8(s + ip2), hlog, mls);
+                ip0 = ip1; ip1 = ip2; ip2 = ip0 + step; ip3 = ip1 + step;
+                if (ip2 >= next_step) { step++; next_step += 128; }
+                if (int64_t(ip3) >= ilimit) break;
+            }
+            if (kind == 0) break;                                // _cleanup
+            if (kind == 1) {
+                ip0 = ip2; match0 = ip0 - rep1;
+                mlen = (s[ip0 - 1] == s[match0 - 1]) ? 1 : 0;
+                ip0 -= mlen; match0 -= mlen; off_base = 1; mlen += 4;
+            } else {
+                match0 = idx - 2;
+                rep2 = rep1; rep1 = ip0 - match0; off_base = rep1 + 3; mlen = 4;
+                while (ip0 > anchor && match0 > prefix && s[ip0 - 1] == s[match0 - 1]) { ip0--; match0--; mlen++; }
+            }
+            found = true;
+        } else {
+            // ---- batched search: lane j owns pair j = positions (b, b+1) and the repcode test at b+sj
+            uint32_t B = ip0, SJ = step0, V = step0, NS = ip0 + 128, width = 16;
+            int ev_kind = 0;                                     // 0 none yet, 1 rep, 2 hit at b, 3 hit at b+1, 4 end of block
+            uint32_t ev_b = 0, ev_s = 0, ev_v = 0, ev_idx = 0;
+            for (;;) {
+                // pair state of this lane and of its successor
+                uint32_t b = B, sj = SJ, v = V, ns = NS;
+                uint32_t nb_ = 0, nsj = 0, nv = 0, nns = 0;
+                for (uint32_t i = 0; i < width; i++) {
+                    nb_ = b + sj; nsj = v; nns = ns; nv = v;
+                    if (nb_ + v >= ns) { nv = v + 1; nns = ns + 128; }
+                    if (uint32_t(lane) > i) { b = nb_; sj = nsj; v = nv; ns = nns; }
+                }
+                // successor of (b, sj, v, ns) for this lane
+                nb_ = b + sj; nsj = v; nns = ns; nv = v;
+                if (nb_ + v >= ns) { nv = v + 1; nns = ns + 128; }
+                const bool act = uint32_t(lane) < width;
+                const bool term = int64_t(nb_) + 1 + int64_t(nsj) >= ilimit;            // this pair's iteration ends the block
+                // speculative lanes may lie beyond the block: keep their reads inside the input
+                const bool inb = int64_t(b) + 1 + int64_t(sj) < ilimit;
+                const uint32_t rb = inb ? b : start;
+                const uint64_t w0 = ld8(s + rb), w1 = ld8(s + rb + 1);
+                const uint32_t ip2 = inb ? b + sj : start + 4;
+                const uint32_t r_cur = ld4(s + ip2), r_rep = ld4(s + ip2 - (inb ? rep1 : 0));
+                const uint32_t h0 = zhash(w0, hlog, mls), h1 = zhash(w1, hlog, mls);
+                uint32_t i0 = 0, i1 = 0; bool shared = false;
+                if (act && inb) {
+                    i0 = tab[h0]; i1 = (h1 == h0) ? b + 2 : tab[h1];
+                    uint32_t* const sc0 = &L.score[h0 & 1023]; uint32_t* const sc1 = &L.score[h1 & 1023];
+                    atomicMin(sc0, uint32_t(lane)); atomicMin(sc1, uint32_t(lane));
+                    shared = (*sc0 != uint32_t(lane)) || (*sc1 != uint32_t(lane));
+                    *sc0 = 0xFFFFFFFFu; *sc1 = 0xFFFFFFFFu;
+                }
+                const bool ok0 = act && inb && i0 >= prefix_idx, ok1 = act && inb && i1 >= prefix_idx;
+                const uint32_t c0 = ld4(s + (ok0 ? i0 - 2 : 0)), c1 = ld4(s + (ok1 ? i1 - 2 : 0));
+                int kind = 0;
+                if (act && inb) {
+                    if ((r_cur == r_rep) & (rep1 > 0)) kind = 1;
+                    else if (ok0 && c0 == uint32_t(w0)) kind = 2;
+                    else if (ok1 && c1 == uint32_t(w1)) kind = 3;
+                    else if (term) kind = 4;
+                }
+                const unsigned long long cutm = __ballot(act && (shared || !inb)) & ~1ull;     // lane 0 never conflicts with an earlier lane
+                const int cut = cutm ? __builtin_ctzll(cutm) : int(width);
+                const unsigned long long evm = __ballot(kind != 0) & ((cut >= 64) ? ~0ull : ((1ull << cut) - 1));
+                if (evm) {
+                    const int J = __builtin_ctzll(evm);
+                    // commit table writes of lanes <= J (both positions; on every exit path the second is inserted too)
+                    if (lane <= J) { tab[h0] = b + 2; tab[h1] = b + 3; }
+                    ev_kind = int(rl(uint32_t(kind), J)); ev_b = rl(b, J); ev_s = rl(sj, J); ev_v = rl(v, J);
+                    ev_idx = ev_kind == 2 ? rl(i0, J) : rl(i1, J);
+                    break;
+                }
+                // nothing in [0, cut): commit them and continue from pair `cut`
+                if (lane < cut) { tab[h0] = b + 2; tab[h1] = b + 3; }
+                if (cut < int(width)) { B = rl(b, cut); SJ = rl(sj, cut); V = rl(v, cut); NS = rl(ns, cut); }
+                else { B = rl(nb_, width - 1); SJ = rl(nsj, width - 1); V = rl(nv, width - 1); NS = rl(nns, width - 1); }
+                width = min(64u, width * 2);
+            }
+            if (ev_kind == 4) break;                             // _cleanup
+            if (ev_kind == 1) {
+                cur0 = ev_b + 2;
+                ip0 = ev_b + ev_s; match0 = ip0 - rep1;
+                mlen = (s[ip0 - 1] == s[match0 - 1]) ? 1 : 0;
+                ip0 -= mlen; match0 -= mlen; off_base = 1; mlen += 4;
+            } else {
+                if (ev_kind == 3) {
+                    ip0 = ev_b + 1;
+                    if (ev_v <= 4) { const uint32_t q = ev_b + ev_s; const uint32_t h = zhash(ld8(s + q), hlog, mls); if (lane == 0) tab[h] = q + 2; }
+                } else ip0 = ev_b;
+                cur0 = ip0 + 2;
+                match0 = ev_idx - 2;
+                rep2 = rep1; rep1 = ip0 - match0; off_base = rep1 + 3; mlen = 4;
+                // backward extension, 64 bytes per step
+                for (;;) {
+                    const uint32_t room = min(ip0 - anchor, match0 - prefix);
+                    const bool same = uint32_t(lane) < room && s[ip0 - 1 - lane] == s[match0 - 1 - lane];
+                    const unsigned long long bad = ~__ballot(same);
+                    const uint32_t k = bad ? uint32_t(__builtin_ctzll(bad)) : 64u;
+                    ip0 -= k; match0 -= k; mlen += k;
+                    if (k < 64) break;
+                }
+            }
+            found = true;
+        }
+        if (!found) break;
+        mlen += count_fwd(s, ip0 + mlen, match0 + mlen, end, lane);
+        store_seq(S, s, anchor, ip0 - anchor, off_base, mlen, lane);
+        ip0 += mlen; anchor = ip0;
+        after_match(S, tab, P, s, ip0, anchor, cur0, rep1, rep2, end, ilimit, lane);
+    }
+    saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;
+    rep[0] = rep1 ? rep1 : saved1;
+    rep[1] = rep2 ? rep2 : saved2;
+    return end - anchor;
+}
+
+// ------------------------------------------------------------------------------------------------ frame
+__device__ __forceinline__ Params level_params(uint32_t n)
+{
+    Params p;
+    uint32_t wlog, hlog;
+    if (n <= 16 * 1024) { wlog = 14; hlog = 15; p.mml = 5; }
+    else if (n <= 128 * 1024) { wlog = 17; hlog = 13; p.mml = 6; }
+    else if (n <= 256 * 1024) { wlog = 18; hlog = 14; p.mml = 6; }
+    else { wlog = 19; hlog = 14; p.mml = 7; }
+    const uint32_t src_log = n < 64 ? 6u : uint32_t(hibit(n - 1)) + 1;
+    if (wlog > src_log) wlog = src_log;
+    if (hlog > wlog + 1) hlog = wlog + 1;
+    if (wlog < 10) wlog = 10;
+    p.wlog = wlog; p.hlog = hlog; p.tlen = 0;
+    return p;
+}
+
+__device__ __forceinline__ bool is_rle(const uint8_t* s, uint32_t n, int lane)
+{
+    const uint8_t v = s[0];
+    bool diff = false;
+    for (uint32_t i = lane; i < n; i += 64) diff |= s[i] != v;
+    return __ballot(diff) == 0;
+}
+
+// ZSTD_compress(dst, cap, src, n, 1); returns the frame size or a negative ZSTD error number
+__device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* work, bool serial, int lane)
+{
+    const Params P = level_params(n);
+    uint32_t* const tab = reinterpret_cast<uint32_t*>(work);
+    SeqStore S;
+    S.ll = reinterpret_cast<uint32_t*>(work + kTabBytes); S.ml = S.ll + kSeqCap; S.off = S.ml + kSeqCap;
+    S.llc = work + kTabBytes + 3 * kSeqBytes; S.ofc = S.llc + kCodeBytes; S.mlc = S.ofc + kCodeBytes;
+    S.lit = S.mlc + kCodeBytes + kLitPad;
+    uint32_t o = 0;
+    if (cap < 18) return kErrTooSmall;
+    {
+        const uint32_t wsize = 1u << P.wlog;
+        const bool single = wsize >= n;
+        const uint32_t fcs = (n >= 256) + (n >= 65536 + 256);
+        uint64_t lo = 0xFD2FB528ull | (uint64_t((uint32_t(single) << 5) + (fcs << 6)) << 32), hi = 0;
+        uint32_t k = 5;
+        if (!single) { lo |= uint64_t((P.wlog - 10) << 3) << 40; k = 6; }
+        const uint32_t fb = fcs == 0 ? (single ? 1u : 0u) : fcs == 1 ? 2u : 4u;
+        const uint64_t fv = fcs == 1 ? n - 256 : n;
+        lo |= fv << (8 * k); if (k == 6) hi = fv >> 16;
+        if (uint32_t(lane) < k + fb) dst[lane] = uint8_t(lane < 8 ? lo >> (8 * lane) : hi >> (8 * (lane - 8)));
+        o = k + fb;
+    }
+    if (!n) {
+        if (cap - o < 4) return kErrTooSmall;
+        if (lane == 0) { dst[o] = 1; dst[o + 1] = 0; dst[o + 2] = 0; }
+        return int(o) + 3;
+    }
+    {   // hash table = 0, same-slot scoreboard = empty, literal tables = none
+        uint4* t4 = reinterpret_cast<uint4*>(tab);
+        const uint32_t n16 = (4u << P.hlog) / 16;
+        for (uint32_t i = lane; i < n16; i += 64) t4[i] = make_uint4(0, 0, 0, 0);
+        for (int i = lane; i < 1024; i += 64) L.score[i] = 0xFFFFFFFFu;
+        for (int i = lane; i < 256; i += 64) { L.huf[0][i] = 0; L.huf[1][i] = 0; }
+    }
+    uint32_t block = 1u << P.wlog; if (block > n) block = n; if (block > kSub) block = kSub;
+    Entropy pe, ne;
+    pe.huf_repeat = kRepNone; pe.rep[0] = 1; pe.rep[1] = 4; pe.rep[2] = 8;
+    ne = pe;
+    int cur = 0;
+    bool first = true;
+    uint32_t pos = 0;
+    while (pos < n) {
+        const uint32_t len = min(n - pos, block);
+        const uint32_t last = (len >= n - pos) ? 1u : 0u;
+        int c = 0;
+        if (cap - o < 3 + 2 + 1) return kErrTooSmall;
+        const uint32_t bcap = cap - o - 3;
+        uint8_t* const out = dst + o + 3;
+        if (len >= 7) {
+            S.nseq = 0; S.nlit = 0;
+            ne.rep[0] = pe.rep[0]; ne.rep[1] = pe.rep[1]; ne.rep[2] = pe.rep[2];
+            const uint32_t tail = fast_block(L, S, tab, P, ne.rep, src, pos, pos + len, n, serial, lane);
+            copy_bytes(S.lit + S.nlit, src + pos + len - tail, tail, lane);
+            S.nlit += tail;
+            const bool suspect = S.nseq == 0 || S.nlit / S.nseq >= 20;
+            const int lsz = compress_literals(L, cur, pe, ne, out, bcap, S.lit, S.nlit, suspect, lane);
+            c = lsz;
+            if (lsz >= 0) {
+                const int ssz = encode_sequences(L, out + lsz, bcap - uint32_t(lsz), S, lane);
+                c = ssz <= 0 ? ssz : lsz + ssz;
+            }
+            if (c == kErrTooSmall && len <= bcap) c = 0;
+            if (c < 0) return c;
+            if (c > 0 && uint32_t(c) >= len - ((len >> 6) + 2)) c = 0;
+            if (!first && c < 25 && is_rle(src + pos, len, lane)) { c = 1; if (lane == 0) out[0] = src[pos]; }
+            if (c > 1) { cur ^= 1; pe = ne; }
+        }
+        if (c == 0) {
+            const uint32_t h = last + (len << 3);
+            if (len + 3 > cap - o) return kErrTooSmall;
+            if (lane < 3) dst[o + lane] = uint8_t(h >> (8 * lane));
+            copy_bytes(dst + o + 3, src + pos, len, lane);
+            o += 3 + len;
+        } else {
+            const uint32_t h = c == 1 ? last + (1u << 1) + (len << 3) : last + (2u << 1) + (uint32_t(c) << 3);
+            if (lane < 3) dst[o + lane] = uint8_t(h >> (8 * lane));
+            o += 3 + uint32_t(c);
+        }
+        pos += len; first = false;
+    }
+    return int(o);
+}
+
+// container_mode 0: ZSTD_compress(dst + dst_off, dst_cap, src + src_off, src_len, 1) -> size or -(error number)
+// container_mode 1: native/4mc.c:467-489 (capacity n-1; an error stores the block raw)
+__global__ __launch_bounds__(64)
+void zstd_encode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks, uint32_t nblocks,
+                        uint8_t* work_base, int container_mode, int serial)
+{
+    __shared__ ZLds L;
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    const int lane = threadIdx.x;
+    const fourmc_block blk = blocks[b];
+    const uint8_t* src = src_base + blk.src_off;
+    uint8_t* dst = dst_base + blk.dst_off;
+    const uint32_t n = blk.src_len;
+    const uint32_t cap = container_mode ? (n ? n - 1 : 0) : blk.dst_cap;
+    int r = zstd_encode_frame(L, src, n, dst, cap, work_base + size_t(b) * kWorkBytes, serial != 0, lane);
+    if (container_mode && r <= 0) { copy_bytes(dst, src, n, lane); r = int(n); }
+    if (lane == 0) blocks[b].result = r;
+}
+
+} // namespace
+
+extern "C" size_t fourmc_zstd_enc_work_bytes(uint32_t n) { return size_t(n) * kWorkBytes; }
+
+extern "C" hipError_t fourmc_launch_zstd_encode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
+                                                void* d_work, int container_mode, int serial, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(zstd_encode_kernel, dim3(n), dim3(64), 0, stream,
+                       static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n,
+                       static_cast<uint8_t*>(d_work), container_mode, serial);
+    return hipGetLastError();
+}

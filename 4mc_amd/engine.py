@@ -61,6 +61,12 @@ def zstd_decompress(d_src, d_dst, batch, stream=None):
           "fourmc_gpu_zstd_decompress")
 
 
+def zstd_compress(d_src, d_dst, batch, level=1, stream=None):
+    """result[b] = ZSTD_compress(dst+dst_off, dst_cap, src+src_off, src_len, level) (-(error number) on error)."""
+    check(lib().fourmc_gpu_zstd_compress(_ptr(d_src), _ptr(d_dst), batch.ptr, batch.n, level, _stream_ptr(stream)),
+          "fourmc_gpu_zstd_compress")
+
+
 def lz4_compress_fast(d_src, d_dst, batch, stream=None):
     """result[b] = LZ4_compress_default(src+src_off, dst+dst_off, src_len, dst_cap)."""
     check(lib().fourmc_gpu_lz4_compress_fast(_ptr(d_src), _ptr(d_dst), batch.ptr, batch.n, _stream_ptr(stream)),

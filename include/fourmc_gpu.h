@@ -76,6 +76,12 @@ int fourmc_gpu_lz4_compress_hc(const void* d_src, void* d_dst, fourmc_block* d_b
  * when dst_cap == 0xFFFFFFFF; byte-identical payloads           native/lz4/lz4mc.c:582-606         */
 int fourmc_gpu_lz4_compress_mc(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                                uint32_t n, void* stream);
+/* result = ZSTD_compress(dst + dst_off, dst_cap, src + src_off, src_len, level) as int: frame bytes, or
+ * -(ZSTD error number), e.g. -70 = dstSize_tooSmall        native/zstd/compress/zstd_compress.c:4806
+ * Level 1 (strategy "fast", 4mz -1) is on the device; other levels return FOURMC_EUNSUP. */
+int fourmc_gpu_zstd_compress(const void* d_src, void* d_dst, fourmc_block* d_blocks,
+                             uint32_t n, int level, void* stream);
+
 /* result = ZSTD_decompress(dst, dst_cap, src, src_len) as int: decoded bytes, or < 0 where the
  * reference returns an error code (ZSTD_isError)            native/zstd/decompress/zstd_decompress.c:1112 */
 int fourmc_gpu_zstd_decompress(const void* d_src, void* d_dst, fourmc_block* d_blocks,
@@ -116,6 +122,8 @@ int      fourmc_LZ4_compressMC_limitedOutput(const char* src, char* dst, int src
 int      fourmc_LZ4_compress_HC(const char* src, char* dst, int srcSize, int dstCapacity, int compressionLevel);
 int      fourmc_LZ4_decompress_safe(const char* src, char* dst, int compressedSize, int dstCapacity);
 size_t   fourmc_ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, size_t compressedSize);
+size_t   fourmc_ZSTD_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel);   /* zstd.h:156 */
+size_t   fourmc_ZSTD_compressBound(size_t srcSize);                                                             /* zstd.h:206 */
 unsigned fourmc_XXH32(const void* input, size_t len, unsigned seed);    /* host scalar: framing bytes, JNI xxhash32 */
 
 /* Host batch: `n` blocks described by host-side descriptors over host buffers; the engine does

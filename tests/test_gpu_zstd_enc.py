@@ -1,0 +1,107 @@
+"""GPU: ZSTD level-1 frame encode (4mz "fast") byte parity against the oracle port
+(oracle/zstd_enc_port.c, itself pinned to the reference's ZSTD_compress) and the reference CLI's
+`4mc -z -1` golden manifest; every frame also decodes back on the GPU."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from helpers import B
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _encode(gpu, srcs, caps):
+    offs, pos = [], 0
+    for s in srcs:
+        offs.append(pos); pos += len(s) + 5
+    buf = np.zeros(pos + 64, np.uint8)
+    for s, o in zip(srcs, offs):
+        buf[o:o + len(s)] = s
+    dsts, dpos = [], 0
+    for c in caps:
+        dsts.append(dpos); dpos += c + 40
+    batch = gpu.DeviceBatch(gpu.make_blocks(offs, dsts, [len(s) for s in srcs], caps))
+    d_out = torch.full((dpos + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+    gpu.zstd_compress(torch.from_numpy(buf).cuda(), d_out, batch, 1)
+    torch.cuda.synchronize()
+    res = batch.download()["result"]
+    out = d_out.cpu().numpy()
+    # a frame never writes past its capacity
+    for d, c in zip(dsts, caps):
+        assert (out[d + c: d + c + 40] == 0x5A).all()
+    return res, [out[d:d + max(int(r), 0)] for d, r in zip(dsts, res)]
+
+
+def _check(gpu, names, srcs, caps, tag):
+    res, outs = _encode(gpu, srcs, caps)
+    for k, s, cap, r, o in zip(names, srcs, caps, res, outs):
+        want_r, want = helpers.orc_zstd_compress(s, 1, cap)
+        assert int(r) == want_r, (tag, k, len(s), cap, int(r), want_r)
+        assert np.array_equal(o, want), (tag, k, len(s), cap)
+
+
+def test_zstd1_bytes_identical_edge_inputs(gpu):
+    inputs = helpers.edge_inputs()
+    names = list(inputs)
+    srcs = [inputs[k] for k in names]
+    _check(gpu, names, srcs, [helpers.zstd_bound(len(s)) for s in srcs], "bound")
+    _check(gpu, names, srcs, [max(len(s) - 1, 0) for s in srcs], "n-1")          # the capacity 4mz passes
+    _check(gpu, names, srcs, [len(s) // 3 for s in srcs], "n/3")                  # mostly dstSize_tooSmall
+
+
+def test_zstd1_size_classes_and_tails(gpu):
+    """Level-table size classes (16 KiB / 128 KiB / 256 KiB), 128 KiB sub-block boundaries and tails."""
+    rng = np.random.default_rng(5)
+    src = helpers.corpus(3 * B, first_block=5)
+    sizes = [7, 8, 18, 19, 20, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 16383, 16384, 16385, 65791, 65792,
+             131071, 131072, 131073, 131078, 131079, 131080, 262144, 262145, 262151, 393216 + 3, 524288, 524289, 1500001]
+    srcs = [src[int(o): int(o) + n].copy() for n, o in zip(sizes, rng.integers(0, B, len(sizes)))]
+    names = ["n=%d" % n for n in sizes]
+    _check(gpu, names, srcs, [max(n - 1, 0) for n in sizes], "n-1")
+    _check(gpu, names, srcs, [helpers.zstd_bound(n) for n in sizes], "bound")
+
+
+def test_zstd1_capacity_sweep(gpu):
+    """Capacities around the real frame size: every overflow rule of the bit and byte writers."""
+    src = helpers.corpus(B, first_block=2)
+    for n in (100, 1000, 20000, 140000):
+        d = src[7 * n: 8 * n]
+        c, _ = helpers.orc_zstd_compress(d, 1, helpers.zstd_bound(n))
+        caps = list(range(max(0, c - 24), c + 10))
+        _check(gpu, ["cap=%d" % x for x in caps], [d] * len(caps), caps, "tight n=%d" % n)
+
+
+def test_zstd1_corpus_blocks_golden_manifest_and_roundtrip(gpu):
+    m = json.load(open(os.path.join(G, "corpus_manifest.json")))
+    n = m["corpus"]["bytes"]
+    data = helpers.corpus(n)
+    assert hashlib.sha256(data.tobytes()).hexdigest() == m["corpus"]["sha256"]
+    nb = (n + B - 1) // B
+    lens = [min(B, n - b * B) for b in range(nb)]
+    blocks = gpu.make_blocks([b * B for b in range(nb)], [b * (B + 64) for b in range(nb)], lens, lens)
+    batch = gpu.DeviceBatch(blocks)
+    d_src = torch.from_numpy(data).cuda()
+    d_dst = torch.zeros(nb * (B + 64), dtype=torch.uint8, device="cuda")
+    gpu.encode_blocks(d_src, d_dst, batch, codec=gpu.CODEC_ZSTD, level=1)
+    torch.cuda.synchronize()
+    got = batch.download()
+    want = m["levels"]["4mz-1"]["blocks"]
+    for b, (u, c, x) in enumerate(want):
+        assert (int(got["src_len"][b]), int(got["result"][b]), int(got["xxh32"][b])) == (u, c, x), b
+    # decode the encoded payloads back on the GPU
+    csz = [int(r) for r in got["result"]]
+    dblocks = gpu.make_blocks([b * (B + 64) for b in range(nb)], [b * B for b in range(nb)], csz, lens)
+    dblocks["xxh32"] = got["xxh32"]
+    dbatch = gpu.DeviceBatch(dblocks)
+    d_back = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+    gpu.decode_blocks(d_dst, d_back, dbatch, codec=gpu.CODEC_ZSTD)
+    torch.cuda.synchronize()
+    res = dbatch.download()["result"]
+    assert [int(r) for r in res] == lens
+    assert torch.equal(d_back[:n], d_src)
