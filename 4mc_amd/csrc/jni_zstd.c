@@ -6,8 +6,9 @@
  * Block codec (native/jniZstdCompressor.c:60-201, native/jniZstdDecompressor.c:58-122): same field
  * names and error contract as the LZ4 pair; codec results follow zstd's size_t convention
  * (error <=> value > (size_t)-ZSTD_error_maxCode, native/zstd/common/error_private.h).
- * The zstd block kernels are not on the device yet (DESIGN.md "status"): until they are, these
- * entry points fail LOUDLY with java/lang/InternalError — there is no CPU fallback in this build.
+ * decompressBytesDirect (any level) and compressBytesDirect (zstd level 1) run on the device;
+ * compressBytesDirectMC / HC (zstd levels 3 / n) are not on the device yet and fail LOUDLY with
+ * java/lang/InternalError("ZSTD_compress returned: <error code>") — there is no CPU fallback.
  *
  * Streaming classes (native/jniZstd.c, native/jniZStreamCompressor.c, native/jniZStreamDecompressor.c)
  * are a serial, cross-chunk-window stream with no independent units — out of scope of the block
@@ -45,9 +46,11 @@ static jint zstd_compress_common(JNIEnv* env, jobject self, int level)
     jobject cbuf = (*env)->GetObjectField(env, self, zc_cbuf);
     const char* src = (const char*)(*env)->GetDirectBufferAddress(env, ubuf);
     char* dst = (char*)(*env)->GetDirectBufferAddress(env, cbuf);
-    size_t r = ZERR_GENERIC;          /* zstd level `level` block encode is not on the device yet */
-    (void)level;
+    unsigned ulen = (unsigned)(*env)->GetIntField(env, self, zc_ulen);
+    size_t r;
     if (!src || !dst) return 0;
+    /* level 1 runs on the device; other levels come back as an error code (no CPU fallback) and throw below */
+    r = fourmc_ZSTD_compress(dst, 1024u * 1024u * 1024u /* enforced in Java, jniZstdCompressor.c:93 */, src, ulen, level);
     if (!z_is_error(r)) (*env)->SetIntField(env, self, zc_ulen, 0);
     else {
         char msg[256];

@@ -105,3 +105,40 @@ def test_zstd1_corpus_blocks_golden_manifest_and_roundtrip(gpu):
     res = dbatch.download()["result"]
     assert [int(r) for r in res] == lens
     assert torch.equal(d_back[:n], d_src)
+
+
+def test_cli_4mz_fast_file_equals_reference(gpu, tmp_path):
+    """`4mc -z -1 file` writes the reference CLI's .4mz bytes; -z -2 (zstd level 3) fails loudly, no CPU fallback."""
+    import subprocess
+    m = json.load(open(os.path.join(G, "corpus_manifest.json")))
+    data = helpers.corpus(m["corpus"]["bytes"])
+    src = tmp_path / "c.bin"; src.write_bytes(data.tobytes())
+    out = tmp_path / "c.4mz"
+    r = subprocess.run([gpu.cli_path(), "-z", "-1", "-f", str(src), str(out)], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    img = out.read_bytes()
+    assert len(img) == m["levels"]["4mz-1"]["file_bytes"]
+    assert hashlib.sha256(img).hexdigest() == m["levels"]["4mz-1"]["sha256"], "file differs from the reference CLI's"
+    back = tmp_path / "back.bin"
+    assert subprocess.run([gpu.cli_path(), "-d", "-z", "-f", str(out), str(back)], capture_output=True).returncode == 0
+    assert back.read_bytes() == data.tobytes()
+    r = subprocess.run([gpu.cli_path(), "-z", "-2", "-f", str(src), str(tmp_path / "c2.4mz")], capture_output=True)
+    assert r.returncode != 0 and b"not on the device" in r.stderr
+
+
+def test_host_zstd_compress_entry_point(gpu):
+    """fourmc_ZSTD_compress / fourmc_ZSTD_compressBound: what jniZstdCompressor.c:93 binds (capacity 1 GiB)."""
+    import ctypes as C
+    L = gpu.lib()
+    d = helpers.corpus(300000, first_block=9)
+    for n in (0, 1, 19, 1000, 300000):
+        assert L.fourmc_ZSTD_compressBound(n) == helpers.zstd_bound(n)
+        out = np.zeros(helpers.zstd_bound(n) + 64, np.uint8)
+        r = L.fourmc_ZSTD_compress(out.ctypes.data, 1 << 30, d.ctypes.data, n, 1)
+        want_r, want = helpers.orc_zstd_compress(d[:n], 1)
+        assert r == want_r and np.array_equal(out[:r], want), n
+    out = np.zeros(64, np.uint8)
+    r = L.fourmc_ZSTD_compress(out.ctypes.data, 30, d.ctypes.data, 1000, 1)
+    assert r == (1 << 64) - 70                                     # (size_t)-ZSTD_error_dstSize_tooSmall
+    r = L.fourmc_ZSTD_compress(out.ctypes.data, 64, d.ctypes.data, 10, 3)
+    assert r > (1 << 64) - 120                                     # level 3: ZSTD_isError(), no CPU fallback

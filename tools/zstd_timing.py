@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Times the zstd level-1 encode kernel and the zstd decode kernel per S-mix block class (1 block per
+launch) and on the bench batch (FOURMC_BENCH_BLOCKS replicas of the 48-block S-mix)."""
+import importlib, sys, os
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers
+p = importlib.import_module("4mc_amd"); p.gpu_init(0)
+B = p.BLOCKSIZE
+names = ["text", "binary", "pcm6", "sdf", "binary", "db", "text", "code", "pcm11", "dict", "xml", "random"]
+def t(fn):
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    fn(); torch.cuda.synchronize(); s.record(); fn(); e.record(); torch.cuda.synchronize(); return s.elapsed_time(e)
+def run(src, nb, tag):
+    offs = np.arange(nb, dtype=np.uint64) * B; lens = np.full(nb, B, np.uint32)
+    enc = p.DeviceBatch(p.make_blocks(offs, offs, lens, lens))
+    stage = torch.empty(nb * B, dtype=torch.uint8, device="cuda")
+    te = t(lambda: p.encode_blocks(src, stage, enc, codec=p.CODEC_ZSTD, level=1))
+    r = enc.download()
+    dec = p.DeviceBatch(p.make_blocks(offs, offs, r["result"].astype(np.uint32), lens, r["xxh32"]))
+    out = torch.empty(nb * B + 64, dtype=torch.uint8, device="cuda")
+    td = t(lambda: p.decode_blocks(stage, out, dec, codec=p.CODEC_ZSTD))
+    ok = torch.equal(out[: nb * B], src[: nb * B])
+    cs = int(r["result"].astype(np.int64).sum())
+    print(f"{tag:12s} blocks {nb:5d} ratio {nb * B / cs:6.3f}  enc {te:9.2f} ms ({nb * B / te / 1e6:7.2f} GB/s)  dec {td:9.2f} ms ({nb * B / td / 1e6:7.2f} GB/s) roundtrip {'ok' if ok else 'BAD'}", flush=True)
+if "--classes" in sys.argv:
+    data = helpers.corpus(12 * B)
+    for b in range(12):
+        run(torch.from_numpy(data[b * B:(b + 1) * B].copy()).cuda(), 1, names[b])
+nb = int(os.environ.get("FOURMC_BENCH_BLOCKS", "2048"))
+base = helpers.corpus(48 * B)
+src = torch.from_numpy(base).cuda().repeat(-(-nb // 48))[: nb * B].contiguous()
+run(src, nb, "S-mix")
