@@ -65,23 +65,27 @@ __device__ __forceinline__ uint64_t load64_safe(const uint8_t* p, int avail)
 // reading below bit 0 yields zeros (the reference's "overflow" state), pos goes negative.
 struct BitsBack {
     const uint8_t* p; int len; int pos;
+    int wbase; uint64_t w;                  // cached window: w = stream bytes [wbase, wbase+8), wbase < 0: empty
     __device__ __forceinline__ bool init(const uint8_t* ptr, int n) {
-        p = ptr; len = n;
+        p = ptr; len = n; wbase = -1; w = 0;
         if (n < 1) return false;
         const uint32_t last = ptr[n - 1];
         if (last == 0) return false;
         pos = 8 * (n - 1) + hibit(last);
         return true;
     }
-    __device__ __forceinline__ uint32_t peek_at(int start, int n) const {       // bits [start, start+n), n <= 32
+    __device__ __forceinline__ void window(int byte) { wbase = byte; w = load64_safe(p + byte, len - byte); }
+    __device__ __forceinline__ uint32_t peek_at(int start, int n) {             // bits [start, start+n), n <= 32
         if (n == 0) return 0;
         const uint64_t mask = (1ull << n) - 1;
         if (start >= 0) {
-            const int byte = start >> 3;
-            return uint32_t((load64_safe(p + byte, len - byte) >> (start & 7)) & mask);
+            // one 8-byte load serves ~57 bits of backward reading: place the window so that it ends just above the request
+            if (wbase < 0 || start < 8 * wbase || start + n > 8 * wbase + 64) window(max(0, ((start + n + 7) >> 3) - 8));
+            return uint32_t((w >> (start - 8 * wbase)) & mask);
         }
         if (start + n <= 0) return 0;
-        return uint32_t((load64_safe(p, len) << (-start)) & mask);
+        if (wbase != 0) window(0);
+        return uint32_t((w << (-start)) & mask);
     }
     __device__ __forceinline__ uint32_t read(int n) { pos -= n; return peek_at(pos, n); }
 };
@@ -97,7 +101,7 @@ struct BitsFwd {
 };
 
 // FSE_readNCount (common/entropy_common.c:43-205).  Returns bytes consumed or -1.
-__device__ int read_ncount(const uint8_t* p, int len, int16_t* norm, int* max_sym, int* table_log, int max_log)
+__device__ __forceinline__ int read_ncount(const uint8_t* p, int len, int16_t* norm, int* max_sym, int* table_log, int max_log)
 {
     if (len < 1) return kErr;
     BitsFwd br{p, len, 0};
@@ -145,7 +149,7 @@ __device__ int read_ncount(const uint8_t* p, int len, int16_t* norm, int* max_sy
 }
 
 // FSE decode table (zstd_decompress_block.c:447-565 / fse_decompress.c:71-150): same spreading rule.
-__device__ void build_fse(uint32_t* tab, const int16_t* norm, int max_sym, int table_log, uint16_t* next)
+__device__ __forceinline__ void build_fse(uint32_t* tab, const int16_t* norm, int max_sym, int table_log, uint16_t* next)
 {
     const int size = 1 << table_log, mask = size - 1;
     int high = size - 1;
@@ -171,7 +175,7 @@ __device__ void build_fse(uint32_t* tab, const int16_t* norm, int max_sym, int t
 
 // Huffman tree description -> X1 decode table (entropy_common.c:235-340, huf_decompress.c:339-470).
 // Returns bytes consumed or -1; *log_out = table log.
-__device__ int read_huf_table(ZState* z, const uint8_t* p, int len, int* log_out)
+__device__ __forceinline__ int read_huf_table(ZState* z, const uint8_t* p, int len, int* log_out)
 {
     if (len < 1) return kErr;
     int isz = p[0], nsym;
@@ -254,7 +258,7 @@ __device__ __forceinline__ void copy_lits(uint8_t* dst, const Lits& l, uint32_t 
 }
 
 // One wavefront decodes `csize` bytes of zstd frames into dst[0..cap).  Returns bytes or < 0.
-__device__ int zstd_decode_frames(const uint8_t* src, int csize, uint8_t* dst, int cap, uint8_t* litbuf,
+__device__ __forceinline__ int zstd_decode_frames(const uint8_t* src, int csize, uint8_t* dst, int cap, uint8_t* litbuf,
                                   ZState* z, int lane)
 {
     int ip = 0, op = 0;
@@ -510,7 +514,7 @@ __device__ int zstd_decode_frames(const uint8_t* src, int csize, uint8_t* dst, i
 }
 
 // container_mode as in lz4_decode.hip (BADSUM skip, stored copy, negative -> CORRUPT)
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 void zstd_decode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks,
                         uint32_t nblocks, uint8_t* scratch, int container_mode)
 {

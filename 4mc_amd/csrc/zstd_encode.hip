@@ -938,10 +938,14 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
                 // pair state of this lane and of its successor
                 uint32_t b = B, sj = SJ, v = V, ns = NS;
                 uint32_t nb_ = 0, nsj = 0, nv = 0, nns = 0;
-                for (uint32_t i = 0; i < width; i++) {
-                    nb_ = b + sj; nsj = v; nns = ns; nv = v;
-                    if (nb_ + v >= ns) { nv = v + 1; nns = ns + 128; }
-                    if (uint32_t(lane) > i) { b = nb_; sj = nsj; v = nv; ns = nns; }
+                if (SJ == V && B + V * (width + 1) < NS) {
+                    b = B + V * uint32_t(lane);                  // no step change inside this batch
+                } else {
+                    for (uint32_t i = 0; i < width; i++) {
+                        nb_ = b + sj; nsj = v; nns = ns; nv = v;
+                        if (nb_ + v >= ns) { nv = v + 1; nns = ns + 128; }
+                        if (uint32_t(lane) > i) { b = nb_; sj = nsj; v = nv; ns = nns; }
+                    }
                 }
                 // successor of (b, sj, v, ns) for this lane
                 nb_ = b + sj; nsj = v; nns = ns; nv = v;
@@ -1139,7 +1143,7 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
 
 // container_mode 0: ZSTD_compress(dst + dst_off, dst_cap, src + src_off, src_len, 1) -> size or -(error number)
 // container_mode 1: native/4mc.c:467-489 (capacity n-1; an error stores the block raw)
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void zstd_encode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks, uint32_t nblocks,
                         uint8_t* work_base, int container_mode, int serial)
 {
