@@ -155,6 +155,17 @@ int fourmc_gpu_lz4_compress_mc(const void* d_src, void* d_dst, fourmc_block* d_b
     return FOURMC_OK;
 }
 
+/* profiling aid: copies `bytes` of the shared per-block workspace at `offset` to the host (phase cycle counters
+ * the zstd kernels leave behind their literal buffers) */
+int fourmc_gpu_debug_read_workspace(void* host, size_t offset, size_t bytes)
+{
+    if (int r = ensure_device()) return r;
+    if (!g_zscratch || offset + bytes > g_zscratch_cap) { snprintf(g_err, sizeof g_err, "workspace range out of bounds"); return FOURMC_EINVAL; }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host, static_cast<char*>(g_zscratch) + offset, bytes, hipMemcpyDeviceToHost));
+    return FOURMC_OK;
+}
+
 int fourmc_gpu_zstd_decompress(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, void* stream)
 {
     if (int r = ensure_device()) return r;

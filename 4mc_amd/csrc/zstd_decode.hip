@@ -27,6 +27,24 @@ namespace {
 
 constexpr int kBlockMax = 128 << 10;                  // ZSTD_BLOCKSIZE_MAX (zstd.h:132-133)
 constexpr int kErr = -1;
+constexpr int kOwnBytes = 1024;                       // cap on the bytes one sequence batch may produce
+
+// wave64 inclusive scans on the DPP network (see lz4_decode.hip)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v)
+{ return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, ROWMASK, 0xf, false)); }
+__device__ __forceinline__ uint32_t scan_add(uint32_t v)
+{
+    v += dpp0<0x111, 0xf>(v); v += dpp0<0x112, 0xf>(v); v += dpp0<0x114, 0xf>(v); v += dpp0<0x118, 0xf>(v);
+    v += dpp0<0x142, 0xa>(v); v += dpp0<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t scan_max(uint32_t v)
+{
+    v = max(v, dpp0<0x111, 0xf>(v)); v = max(v, dpp0<0x112, 0xf>(v)); v = max(v, dpp0<0x114, 0xf>(v)); v = max(v, dpp0<0x118, 0xf>(v));
+    v = max(v, dpp0<0x142, 0xa>(v)); v = max(v, dpp0<0x143, 0xc>(v));
+    return v;
+}
 
 // ---- code -> (baseline, extra bits) tables (zstd_decompress_internal.h:30-55, zstd_internal.h:121-145)
 __constant__ uint32_t kLLBase[36] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,0x80,0x100,0x200,0x400,0x800,0x1000,0x2000,0x4000,0x8000,0x10000};
@@ -45,11 +63,18 @@ struct ZState {
     uint32_t ll[512], ml[512], of[256];     // FSE decode entries: nextState<<16 | nbBits<<8 | symbol
     uint32_t wt[64];                        // FSE table of the Huffman weights (log <= 6)
     uint16_t huf[4096];                     // Huffman X1 entries: nbBits<<8 | symbol
-    int16_t  norm[256];
-    uint16_t next[256];
-    uint8_t  weights[256];
-    uint8_t  spread[520];
+    union {                                 // FSE build scratch / LDS ring of the sequence bitstream
+        struct { int16_t norm[256]; uint16_t next[256]; };
+        uint32_t ring[264];
+    };
     uint32_t rank[16];
+    uint32_t llv[512], mlv[512];            // per FSE state: baseline | extra bits << 20 of its symbol
+    uint32_t llb[36], mlb[56];              // code -> baseline / extra bits (copies of the constant tables)
+    uint8_t  llx[36], mlx[56];
+    union {                                 // table-build scratch and the copier's owner map are never live together
+        uint8_t own[1024];                  // owner map of the batch copier
+        struct { uint8_t weights[256]; uint8_t spread[520]; };
+    };
 };
 
 // 8 bytes at p (any alignment), never reading at or beyond p+avail
@@ -65,29 +90,74 @@ __device__ __forceinline__ uint64_t load64_safe(const uint8_t* p, int avail)
 // reading below bit 0 yields zeros (the reference's "overflow" state), pos goes negative.
 struct BitsBack {
     const uint8_t* p; int len; int pos;
-    int wbase; uint64_t w;                  // cached window: w = stream bytes [wbase, wbase+8), wbase < 0: empty
+    int wlo; uint64_t w;                    // cached window: w = stream bits [wlo, wlo + 64); wlo = INT_MAX: empty
     __device__ __forceinline__ bool init(const uint8_t* ptr, int n) {
-        p = ptr; len = n; wbase = -1; w = 0;
+        p = ptr; len = n; wlo = 0x7FFFFFFF; w = 0;
         if (n < 1) return false;
         const uint32_t last = ptr[n - 1];
         if (last == 0) return false;
         pos = 8 * (n - 1) + hibit(last);
         return true;
     }
-    __device__ __forceinline__ void window(int byte) { wbase = byte; w = load64_safe(p + byte, len - byte); }
-    __device__ __forceinline__ uint32_t peek_at(int start, int n) {             // bits [start, start+n), n <= 32
-        if (n == 0) return 0;
-        const uint64_t mask = (1ull << n) - 1;
-        if (start >= 0) {
-            // one 8-byte load serves ~57 bits of backward reading: place the window so that it ends just above the request
-            if (wbase < 0 || start < 8 * wbase || start + n > 8 * wbase + 64) window(max(0, ((start + n + 7) >> 3) - 8));
-            return uint32_t((w >> (start - 8 * wbase)) & mask);
+    // bits [start, start+n), n <= 31.  Reads walk downwards, so one 8-byte load placed just above the
+    // request serves the next ~57 bits; the common case is two compares, a shift and a mask.
+    __device__ __forceinline__ uint32_t peek_at(int start, int n) {
+        const uint32_t mask = (1u << n) - 1;
+        if (start < wlo || start + n > wlo + 64) {
+            if (start < 0) {
+                if (start + n <= 0) return 0;
+                if (wlo != 0) { wlo = 0; w = load64_safe(p, len); }
+                return uint32_t(w << (-start)) & mask;
+            }
+            const int byte = max(0, ((start + n + 7) >> 3) - 8);
+            wlo = 8 * byte; w = load64_safe(p + byte, len - byte);
         }
-        if (start + n <= 0) return 0;
-        if (wbase != 0) window(0);
-        return uint32_t((w << (-start)) & mask);
+        return uint32_t(w >> (start - wlo)) & mask;
     }
     __device__ __forceinline__ uint32_t read(int n) { pos -= n; return peek_at(pos, n); }
+};
+
+// The sequence bitstream is read by the whole wave (uniform position), so it is staged 1 KiB at a time in an
+// LDS ring: a window refill is an LDS read (~100 clk) instead of a dependent HBM/L2 load per ~2 sequences.
+struct SeqBits {
+    const uint8_t* p; int len; int pos; int wlo; uint64_t w; int rlo; uint32_t* ring; int lane;
+    __device__ __forceinline__ bool init(const uint8_t* ptr, int n, uint32_t* ring_, int lane_) {
+        p = ptr; len = n; wlo = 1 << 30; w = 0; rlo = 1 << 30; ring = ring_; lane = lane_;
+        if (n < 1) return false;
+        const uint32_t last = ptr[n - 1];
+        if (last == 0) return false;
+        pos = 8 * (n - 1) + hibit(last);
+        return true;
+    }
+    __device__ __forceinline__ void stage(int byte) {               // ring <- stream bytes [rlo, rlo + 1040), zeros beyond len
+        rlo = max(0, byte - 1016) & ~3;
+        const int at = rlo + 16 * lane;
+        uint8_t* const r8 = reinterpret_cast<uint8_t*>(ring);
+        if (at + 16 <= len) *reinterpret_cast<uint4*>(ring + 4 * lane) = ld16u(p + at);
+        else {
+#pragma unroll 1
+            for (int k = 0; k < 16; k++) r8[16 * lane + k] = (at + k < len) ? p[at + k] : uint8_t(0);
+        }
+        if (lane < 16) { const int a2 = rlo + 1024 + lane; r8[1024 + lane] = (a2 < len) ? p[a2] : uint8_t(0); }
+    }
+    // w <- stream bits [8*byte, 8*byte + 64)
+    __device__ __forceinline__ void window(int byte) {
+        if (byte < rlo || byte + 8 > rlo + 1040) stage(byte);
+        const int q = byte - rlo;
+        const uint32_t d0 = ring[q >> 2], d1 = ring[(q >> 2) + 1], d2 = ring[(q >> 2) + 2];
+        const uint32_t sh = uint32_t(q & 3);
+        const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        wlo = 8 * byte; w = (uint64_t(hi) << 32) | lo;
+    }
+    // after refill() the next 57 bits below pos are in the window (fewer only at the very start of the stream)
+    __device__ __forceinline__ void refill() { if (pos < wlo + 57 || pos > wlo + 64) window(max(0, ((pos + 7) >> 3) - 8)); }
+    // n <= 31 bits below pos; needs a refill() at most 57 bits ago.  Below bit 0 the stream reads as zeros.
+    __device__ __forceinline__ uint32_t read(int n) {
+        const uint32_t mask = (1u << n) - 1;
+        pos -= n;
+        if (pos < wlo) return (pos + n <= 0) ? 0u : uint32_t(w << (wlo - pos)) & mask;      // only when wlo == 0
+        return uint32_t(w >> (pos - wlo)) & mask;
+    }
 };
 
 // forward bit reader for FSE table descriptions
@@ -262,6 +332,10 @@ __device__ __forceinline__ int zstd_decode_frames(const uint8_t* src, int csize,
                                   ZState* z, int lane)
 {
     int ip = 0, op = 0;
+    uint64_t t_lit = 0, t_hdr = 0, t_seq = 0, t_exec = 0, t0 = __builtin_readcyclecounter(), t1;   // phase cycle counters (profiling aid)
+#define ZPH(acc) do { t1 = __builtin_readcyclecounter(); acc += t1 - t0; t0 = t1; } while (0)
+    if (lane < 36) { z->llb[lane] = kLLBase[lane]; z->llx[lane] = kLLBits[lane]; }
+    if (lane < 53) { z->mlb[lane] = kMLBase[lane]; z->mlx[lane] = kMLBits[lane]; }
     while (csize - ip >= 5) {                                         // ZSTD_startingInputLength
         if (csize - ip < 4) return kErr;
         const uint32_t magic = uint32_t(src[ip]) | (uint32_t(src[ip + 1]) << 8) | (uint32_t(src[ip + 2]) << 16) | (uint32_t(src[ip + 3]) << 24);
@@ -309,6 +383,7 @@ __device__ __forceinline__ int zstd_decode_frames(const uint8_t* src, int csize,
 
         // ---- per-frame entropy state (zstd_decompress.c: ZSTD_decompressBegin)
         uint32_t rep0 = 1, rep1 = 4, rep2 = 8;                        // zstd_internal.h:70
+        uint32_t pv = 0; int p_base = 0, p_n = 0;                     // pending 64-byte output step of the batch copier
         bool have_huf = false, have_fse = false;
         int huf_log = 0, ll_log = 0, of_log = 0, ml_log = 0;
 
@@ -336,6 +411,7 @@ __device__ __forceinline__ int zstd_decode_frames(const uint8_t* src, int csize,
                 const int bend = int(bsize);
                 int bpos = 0;
                 Lits lits; lits.pos = 0; lits.is_rle = false; lits.rle = 0; lits.p = litbuf; lits.size = 0;
+                ZPH(t_hdr);
                 {   // ---- literals section (zstd_decompress_block.c:120-330)
                     const uint32_t b0 = bp[0];
                     const int ltype = b0 & 3, fmt = (b0 >> 2) & 3;
@@ -406,6 +482,7 @@ __device__ __forceinline__ int zstd_decode_frames(const uint8_t* src, int csize,
                         }
                     }
                 }
+                ZPH(t_lit);
                 // ---- sequences header (zstd_decompress_block.c:656-735)
                 if (bend - bpos < 1) return kErr;
                 int nseq = bp[bpos++];
@@ -452,50 +529,140 @@ __device__ __forceinline__ int zstd_decode_frames(const uint8_t* src, int csize,
                         }
                     }
                     have_fse = true;
-                    // ---- sequence bitstream (zstd_decompress_block.c:1565-1650)
-                    BitsBack bs;
-                    if (!bs.init(bp + bpos, bend - bpos)) return kErr;
+                    for (int u = lane; u < (1 << ll_log); u += 64) { const uint32_t c = z->ll[u] & 0xff; z->llv[u] = c < 36 ? z->llb[c] | (uint32_t(z->llx[c]) << 20) : 0xFFFFFFFFu; }
+                    for (int u = lane; u < (1 << ml_log); u += 64) { const uint32_t c = z->ml[u] & 0xff; z->mlv[u] = c < 53 ? z->mlb[c] | (uint32_t(z->mlx[c]) << 20) : 0xFFFFFFFFu; }
+                    // ---- sequence bitstream (zstd_decompress_block.c:1565-1650): sequences are decoded serially
+                    // (three FSE states) into lanes, then executed up to 64 at a time by the batch copier below.
+                    ZPH(t_hdr);
+                    SeqBits bs;
+                    if (!bs.init(bp + bpos, bend - bpos, z->ring, lane)) return kErr;
+                    bs.refill();
                     uint32_t sl = bs.read(ll_log), so = bs.read(of_log), sm = bs.read(ml_log);
-                    for (int n = 0; n < nseq; n++) {
-                        const uint32_t el = z->ll[sl], eo = z->of[so], em = z->ml[sm];
-                        const uint32_t lcode = el & 0xff, ocode = eo & 0xff, mcode = em & 0xff;
-                        if (ocode > 31) return kErr;
-                        uint32_t offset;
-                        const uint32_t ll_base = kLLBase[lcode];
-                        if (ocode > 1) {
-                            offset = (1u << ocode) - 3 + bs.read(int(ocode));        // OF_base[code] = 2^code - 3
-                            rep2 = rep1; rep1 = rep0; rep0 = offset;
+                    int n = 0;
+                    bool have_c = false; uint32_t c_ll = 0, c_ml = 0, c_off = 0;
+                    for (;;) {
+                        uint32_t my_ll = 0, my_ml = 0, my_off = 0, T = 0, Lsum = 0;
+                        int cnt = 0;
+                        for (;;) {
+                            uint32_t llen, mlen, offset;
+                            if (have_c) { llen = c_ll; mlen = c_ml; offset = c_off; have_c = false; }
+                            else if (n < nseq) {
+                                bs.refill();
+                                const uint32_t el = z->ll[sl], eo = z->of[so], em = z->ml[sm];
+                                const uint32_t lv = z->llv[sl], mv = z->mlv[sm];
+                                const uint32_t ocode = eo & 0xff;
+                                if (ocode > 31) return kErr;
+                                const uint32_t ll_base = lv & 0xFFFFF;
+                                if (ocode > 1) {
+                                    offset = (1u << ocode) - 3 + bs.read(int(ocode));        // OF_base[code] = 2^code - 3
+                                    rep2 = rep1; rep1 = rep0; rep0 = offset;
+                                } else {
+                                    const uint32_t ll0 = (ll_base == 0);
+                                    if (ocode == 0) {
+                                        offset = ll0 ? rep1 : rep0;
+                                        rep1 = ll0 ? rep0 : rep1; rep0 = offset;
+                                    } else {
+                                        const uint32_t v = 1 + ll0 + bs.read(1);          // OF_base[1] = 1
+                                        uint32_t t = (v == 3) ? rep0 - 1 : (v == 1 ? rep1 : rep2);
+                                        t += !t;
+                                        if (v != 1) rep2 = rep1;
+                                        rep1 = rep0; rep0 = offset = t;
+                                    }
+                                }
+                                mlen = (mv & 0xFFFFF) + bs.read(int(mv >> 20));
+                                bs.refill();
+                                llen = ll_base + bs.read(int(lv >> 20));
+                                sl = (el >> 16) + bs.read(int((el >> 8) & 0xff));
+                                sm = (em >> 16) + bs.read(int((em >> 8) & 0xff));
+                                so = (eo >> 16) + bs.read(int((eo >> 8) & 0xff));
+                                n++;
+                            } else break;
+                            if (cnt == 64 || T + llen + mlen > uint32_t(kOwnBytes)) { have_c = true; c_ll = llen; c_ml = mlen; c_off = offset; break; }
+                            if (lane == cnt) { my_ll = llen; my_ml = mlen; my_off = offset; }
+                            cnt++; T += llen + mlen; Lsum += llen;
+                        }
+                        ZPH(t_seq);
+                        if (cnt > 0 && Lsum <= lits.size - lits.pos && uint32_t(op) + T + 64 <= uint32_t(cap)) {
+                            // ---- batch execute: every output byte finds its sequence through the owner map; literal
+                            // bytes come from the literal buffer, match bytes from memory / the pending step / this step
+                            const uint32_t sz = my_ll + my_ml;
+                            const uint32_t ostart = scan_add(sz) - sz, lstart = scan_add(my_ll) - my_ll;
+                            const bool bad = lane < cnt && my_off > uint32_t(op) + ostart + my_ll;
+                            if (__ballot(bad)) return kErr;
+                            for (uint32_t k = 4u * lane; k < T; k += 256) *reinterpret_cast<uint32_t*>(z->own + k) = 0;
+                            if (lane < cnt) z->own[ostart] = uint8_t(lane + 1);
+                            const uint8_t* const lbase = lits.is_rle ? dst : lits.p + lits.pos;
+                            uint32_t carry = 0;
+                            if (p_n == 0) p_base = op;
+                            for (uint32_t c0 = 0; c0 < T; c0 += 64) {
+                                const uint32_t o = c0 + lane;
+                                const bool live = o < T;
+                                uint32_t m = live ? uint32_t(z->own[o]) : 0u;
+                                m = max(scan_max(m), carry);
+                                carry = uint32_t(__builtin_amdgcn_readlane(int(m), 63));
+                                const int tl = (int(m) - 1) & 63;
+                                const uint32_t os = __shfl(ostart, tl), lt = __shfl(my_ll, tl), offt = __shfl(my_off, tl), ls = __shfl(lstart, tl);
+                                const uint32_t rel = o - os;
+                                const bool is_lit = live && rel < lt;
+                                const int sp = op + int(o) - int(offt);
+                                const int cs = op + int(c0);
+                                const bool is_match = live && !is_lit;
+                                const bool from_mem = is_match && sp < cs - p_n;
+                                const bool in_pend = is_match && sp >= cs - p_n && sp < cs;
+                                const uint8_t* const addr = (is_lit && !lits.is_rle) ? lbase + ls + rel : dst + (from_mem ? sp : 0);
+                                const uint32_t ld = *addr;
+                                dst[p_base + lane] = uint8_t(pv);                 // previous step, all 64 lanes (see lz4_decode.hip)
+                                const uint32_t fw = __shfl(pv, (sp - p_base) & 63);
+                                uint32_t v = ld;
+                                if (is_lit && lits.is_rle) v = lits.rle;
+                                if (in_pend) v = fw;
+                                bool done = !is_match || from_mem || in_pend;
+                                int dep = sp - cs;
+                                while (__ballot(!done)) {
+                                    const int d = dep & 63;
+                                    const uint32_t v2 = __shfl(v, d);
+                                    const int dn = __shfl(int(done), d);
+                                    const int dd = __shfl(dep, d);
+                                    if (!done) { if (dn) { v = v2; done = true; } else dep = dd; }
+                                }
+                                pv = v; p_base = cs; p_n = min(64, int(T - c0));
+                            }
+                            op += int(T); lits.pos += Lsum;
                         } else {
-                            const uint32_t ll0 = (ll_base == 0);
-                            if (ocode == 0) {
-                                offset = ll0 ? rep1 : rep0;
-                                rep1 = ll0 ? rep0 : rep1; rep0 = offset;
-                                if (ll0) { /* swapped */ }
-                            } else {
-                                const uint32_t v = 1 + ll0 + bs.read(1);          // OF_base[1] = 1
-                                uint32_t t = (v == 3) ? rep0 - 1 : (v == 1 ? rep1 : rep2);
-                                t += !t;
-                                if (v != 1) rep2 = rep1;
-                                rep1 = rep0; rep0 = offset = t;
+                            // ---- one sequence at a time (strict checks; long sequences, block ends)
+                            if (lane < p_n) dst[p_base + lane] = uint8_t(pv);
+                            p_n = 0;
+                            for (int k = 0; k < cnt; k++) {
+                                const uint32_t llen = uint32_t(__builtin_amdgcn_readlane(int(my_ll), k)), mlen = uint32_t(__builtin_amdgcn_readlane(int(my_ml), k));
+                                const uint32_t offset = uint32_t(__builtin_amdgcn_readlane(int(my_off), k));
+                                if (llen > lits.size - lits.pos) return kErr;
+                                if (llen + mlen > uint32_t(cap - op)) return kErr;
+                                copy_lits(dst + op, lits, llen, lane);
+                                lits.pos += llen; op += int(llen);
+                                if (offset > uint32_t(op)) return kErr;        // before the start of the output (no dictionary)
+                                copy_match(dst, op, int(offset), int(mlen), lane);
+                                op += int(mlen);
+                            }
+                            if (have_c && cnt == 0) {                          // a sequence larger than a whole batch
+                                have_c = false;
+                                if (c_ll > lits.size - lits.pos) return kErr;
+                                if (c_ll + c_ml > uint32_t(cap - op)) return kErr;
+                                copy_lits(dst + op, lits, c_ll, lane);
+                                lits.pos += c_ll; op += int(c_ll);
+                                if (c_off > uint32_t(op)) return kErr;
+                                copy_match(dst, op, int(c_off), int(c_ml), lane);
+                                op += int(c_ml);
                             }
                         }
-                        const uint32_t mlen = kMLBase[mcode] + bs.read(int(kMLBits[mcode]));
-                        const uint32_t llen = ll_base + bs.read(int(kLLBits[lcode]));
-                        sl = (el >> 16) + bs.read(int((el >> 8) & 0xff));
-                        sm = (em >> 16) + bs.read(int((em >> 8) & 0xff));
-                        so = (eo >> 16) + bs.read(int((eo >> 8) & 0xff));
-                        // ---- execute (zstd_decompress_block.c:956-1050)
-                        if (llen > lits.size - lits.pos) return kErr;
-                        if (llen + mlen > uint32_t(cap - op)) return kErr;
-                        copy_lits(dst + op, lits, llen, lane);
-                        lits.pos += llen; op += int(llen);
-                        if (offset > uint32_t(op)) return kErr;        // before the start of the output (no dictionary)
-                        copy_match(dst, op, int(offset), int(mlen), lane);
-                        op += int(mlen);
+                        ZPH(t_exec);
+                        if (!have_c && n >= nseq) break;
                     }
+                    if (lane < p_n) dst[p_base + lane] = uint8_t(pv);
+                    p_n = 0;
                     if (bs.pos > 0) return kErr;                       // bits left over: corruption
                     (void)frame_start;
                 }
+                ZPH(t_exec);
                 // ---- trailing literals
                 {
                     const uint32_t rest = lits.size - lits.pos;
@@ -510,6 +677,8 @@ __device__ __forceinline__ int zstd_decode_frames(const uint8_t* src, int csize,
         if (fcs != ~0ull && uint64_t(op - frame_start) != fcs) return kErr;
     }
     if (ip != csize) return kErr;
+    ZPH(t_exec);
+    if (lane == 0) { uint64_t* c = reinterpret_cast<uint64_t*>(litbuf + kBlockMax); c[0] = t_lit; c[1] = t_hdr; c[2] = t_seq; c[3] = t_exec; }
     return op;
 }
 

@@ -1093,6 +1093,8 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
         for (int i = lane; i < 256; i += 64) { L.huf[0][i] = 0; L.huf[1][i] = 0; }
     }
     uint32_t block = 1u << P.wlog; if (block > n) block = n; if (block > kSub) block = kSub;
+    uint64_t t_mf = 0, t_lit = 0, t_seq = 0, t_out = 0, t0 = __builtin_readcyclecounter(), t1;   // phase cycle counters (profiling aid)
+#define ZPH(acc) do { t1 = __builtin_readcyclecounter(); acc += t1 - t0; t0 = t1; } while (0)
     Entropy pe, ne;
     pe.huf_repeat = kRepNone; pe.rep[0] = 1; pe.rep[1] = 4; pe.rep[2] = 8;
     ne = pe;
@@ -1109,16 +1111,20 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
         if (len >= 7) {
             S.nseq = 0; S.nlit = 0;
             ne.rep[0] = pe.rep[0]; ne.rep[1] = pe.rep[1]; ne.rep[2] = pe.rep[2];
+            ZPH(t_out);
             const uint32_t tail = fast_block(L, S, tab, P, ne.rep, src, pos, pos + len, n, serial, lane);
             copy_bytes(S.lit + S.nlit, src + pos + len - tail, tail, lane);
             S.nlit += tail;
+            ZPH(t_mf);
             const bool suspect = S.nseq == 0 || S.nlit / S.nseq >= 20;
             const int lsz = compress_literals(L, cur, pe, ne, out, bcap, S.lit, S.nlit, suspect, lane);
             c = lsz;
+            ZPH(t_lit);
             if (lsz >= 0) {
                 const int ssz = encode_sequences(L, out + lsz, bcap - uint32_t(lsz), S, lane);
                 c = ssz <= 0 ? ssz : lsz + ssz;
             }
+            ZPH(t_seq);
             if (c == kErrTooSmall && len <= bcap) c = 0;
             if (c < 0) return c;
             if (c > 0 && uint32_t(c) >= len - ((len >> 6) + 2)) c = 0;
@@ -1138,6 +1144,8 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
         }
         pos += len; first = false;
     }
+    ZPH(t_out);
+    if (lane == 0) { uint64_t* c = reinterpret_cast<uint64_t*>(S.lit + kSub + 64); c[0] = t_mf; c[1] = t_lit; c[2] = t_seq; c[3] = t_out; }
     return int(o);
 }
 

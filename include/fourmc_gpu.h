@@ -76,6 +76,10 @@ int fourmc_gpu_lz4_compress_hc(const void* d_src, void* d_dst, fourmc_block* d_b
  * when dst_cap == 0xFFFFFFFF; byte-identical payloads           native/lz4/lz4mc.c:582-606         */
 int fourmc_gpu_lz4_compress_mc(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                                uint32_t n, void* stream);
+/* Profiling aid (not part of the reference boundary): copy a range of the engine's per-block device
+ * workspace to the host; the zstd kernels leave per-phase cycle counters there (tools/zstd_timing.py). */
+int fourmc_gpu_debug_read_workspace(void* host, size_t offset, size_t bytes);
+
 /* result = ZSTD_compress(dst + dst_off, dst_cap, src + src_off, src_len, level) as int: frame bytes, or
  * -(ZSTD error number), e.g. -70 = dstSize_tooSmall        native/zstd/compress/zstd_compress.c:4806
  * Level 1 (strategy "fast", 4mz -1) is on the device; other levels return FOURMC_EUNSUP. */

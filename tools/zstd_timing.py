@@ -12,6 +12,14 @@ names = ["text", "binary", "pcm6", "sdf", "binary", "db", "text", "code", "pcm11
 def t(fn):
     s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
     fn(); torch.cuda.synchronize(); s.record(); fn(); e.record(); torch.cuda.synchronize(); return s.elapsed_time(e)
+ENC_WORK, ENC_CTR = 754880, 131072 + 3 * 131328 + 3 * 32832 + 64 + 131072 + 64     # zstd_encode.hip: kWorkBytes, counters behind the literal buffer
+DEC_WORK, DEC_CTR = 131072 + 64, 131072                                                 # zstd_decode.hip
+def counters(work, off, names):
+    import ctypes as C
+    buf = (C.c_uint64 * 4)()
+    assert p.lib().fourmc_gpu_debug_read_workspace(buf, off, 32) == 0
+    tot = sum(buf) or 1
+    return " ".join(f"{n} {100 * v / tot:4.1f}%" for n, v in zip(names, buf))
 def run(src, nb, tag):
     offs = np.arange(nb, dtype=np.uint64) * B; lens = np.full(nb, B, np.uint32)
     enc = p.DeviceBatch(p.make_blocks(offs, offs, lens, lens))
@@ -20,10 +28,13 @@ def run(src, nb, tag):
     r = enc.download()
     dec = p.DeviceBatch(p.make_blocks(offs, offs, r["result"].astype(np.uint32), lens, r["xxh32"]))
     out = torch.empty(nb * B + 64, dtype=torch.uint8, device="cuda")
+    ec = counters(ENC_WORK, ENC_CTR, ("match", "literals", "sequences", "frame")) if nb == 1 else ""
     td = t(lambda: p.decode_blocks(stage, out, dec, codec=p.CODEC_ZSTD))
+    dc = counters(DEC_WORK, DEC_CTR, ("literals", "headers", "seq-decode", "execute")) if nb == 1 else ""
     ok = torch.equal(out[: nb * B], src[: nb * B])
     cs = int(r["result"].astype(np.int64).sum())
     print(f"{tag:12s} blocks {nb:5d} ratio {nb * B / cs:6.3f}  enc {te:9.2f} ms ({nb * B / te / 1e6:7.2f} GB/s)  dec {td:9.2f} ms ({nb * B / td / 1e6:7.2f} GB/s) roundtrip {'ok' if ok else 'BAD'}", flush=True)
+    if nb == 1: print(f"             enc phases: {ec}\n             dec phases: {dc}", flush=True)
 if "--classes" in sys.argv:
     data = helpers.corpus(12 * B)
     for b in range(12):
