@@ -1,0 +1,121 @@
+/*
+ * tests/jni_mock/mock_jni.c — drives the JNI entry points of libhadoop-4mc.so without a JVM, through
+ * a mock JNIEnv that implements exactly the function-table slots the library uses (include/jni_min.h;
+ * SURVEY.md §8(b)/(c) did the same against the reference's shipped .so).  TEST INFRASTRUCTURE.
+ *
+ * usage: mock_jni <libhadoop-4mc.so> <input file> <n bytes> <out dir>
+ * Writes <out dir>/<call>.bin for every codec call and prints one "name result thrown" line per call.
+ */
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "jni_min.h"
+
+/* a mock object = named int fields + two direct buffers */
+typedef struct { const char* name; int is_buf; jint ival; void* buf; } field_t;
+typedef struct { field_t f[8]; int nf; } obj_t;
+static char g_thrown[512];
+
+static jclass   m_FindClass(JNIEnv* e, const char* n) { (void)e; return (jclass)n; }
+static jint     m_ThrowNew(JNIEnv* e, jclass c, const char* msg) { (void)e; snprintf(g_thrown, sizeof g_thrown, "%s: %s", (const char*)c, msg); return 0; }
+static void     m_DeleteLocalRef(JNIEnv* e, jobject o) { (void)e; (void)o; }
+static jfieldID m_GetFieldID(JNIEnv* e, jclass c, const char* name, const char* sig) { (void)e; (void)c; (void)sig; return (jfieldID)strdup(name); }
+static field_t* find(jobject o, jfieldID id)
+{
+    obj_t* ob = (obj_t*)o;
+    for (int i = 0; i < ob->nf; i++) if (!strcmp(ob->f[i].name, (const char*)id)) return &ob->f[i];
+    fprintf(stderr, "mock: no field %s\n", (const char*)id); exit(2);
+}
+static jobject  m_GetObjectField(JNIEnv* e, jobject o, jfieldID id) { (void)e; return (jobject)find(o, id); }
+static jint     m_GetIntField(JNIEnv* e, jobject o, jfieldID id) { (void)e; return find(o, id)->ival; }
+static void     m_SetIntField(JNIEnv* e, jobject o, jfieldID id, jint v) { (void)e; find(o, id)->ival = v; }
+static void*    m_GetDirectBufferAddress(JNIEnv* e, jobject b) { (void)e; return ((field_t*)b)->buf; }
+static void*    m_GetCritical(JNIEnv* e, jarray a, jboolean* c) { (void)e; if (c) *c = 0; return a; }
+static void     m_ReleaseCritical(JNIEnv* e, jarray a, void* p, jint m) { (void)e; (void)a; (void)p; (void)m; }
+
+typedef void (*init_fn)(JNIEnv*, jclass);
+typedef jint (*call0_fn)(JNIEnv*, jobject);
+typedef jint (*call1_fn)(JNIEnv*, jobject, jint);
+typedef jint (*hash_fn)(JNIEnv*, jclass, jbyteArray, jint, jint, jint);
+typedef jint (*bound_fn)(JNIEnv*, jclass, jint);
+
+static void* sym(void* lib, const char* cls, const char* m)
+{
+    char name[256];
+    snprintf(name, sizeof name, "Java_com_fing_compression_fourmc_%s_%s", cls, m);
+    void* p = dlsym(lib, name);
+    if (!p) { fprintf(stderr, "mock: missing %s\n", name); exit(2); }
+    return p;
+}
+
+static void dump(const char* dir, const char* name, const void* p, long n)
+{
+    char path[1024];
+    snprintf(path, sizeof path, "%s/%s.bin", dir, name);
+    FILE* f = fopen(path, "wb");
+    if (n > 0) fwrite(p, 1, (size_t)n, f);
+    fclose(f);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 5) return 1;
+    void* lib = dlopen(argv[1], RTLD_NOW);
+    if (!lib) { fprintf(stderr, "mock: %s\n", dlerror()); return 2; }
+    const int n = atoi(argv[3]);
+    const char* dir = argv[4];
+    const int cap = 4 * 1024 * 1024, ccap = cap + cap / 255 + 16 + 65536;
+    char* raw = (char*)calloc(1, (size_t)cap + 64);
+    char* comp = (char*)calloc(1, (size_t)ccap);
+    char* back = (char*)calloc(1, (size_t)cap + 64);
+    FILE* fi = fopen(argv[2], "rb");
+    if (!fi || fread(raw, 1, (size_t)n, fi) != (size_t)n) { fprintf(stderr, "mock: cannot read input\n"); return 2; }
+    fclose(fi);
+
+    struct JNINativeInterface_ tab;
+    memset(&tab, 0, sizeof tab);
+    tab.FindClass = m_FindClass; tab.ThrowNew = m_ThrowNew; tab.DeleteLocalRef = m_DeleteLocalRef;
+    tab.GetFieldID = m_GetFieldID; tab.GetObjectField = m_GetObjectField; tab.GetIntField = m_GetIntField;
+    tab.SetIntField = m_SetIntField; tab.GetDirectBufferAddress = m_GetDirectBufferAddress;
+    tab.GetPrimitiveArrayCritical = m_GetCritical; tab.ReleasePrimitiveArrayCritical = m_ReleaseCritical;
+    JNIEnv env = &tab;
+
+    const char* codecs[2] = {"Lz4", "Zstd"};
+    for (int c = 0; c < 2; c++) {
+        char ccls[32], dcls[32], tag[64];
+        snprintf(ccls, sizeof ccls, "%sCompressor", codecs[c]);
+        snprintf(dcls, sizeof dcls, "%sDecompressor", codecs[c]);
+        ((init_fn)sym(lib, ccls, "initIDs"))(&env, (jclass)ccls);
+        ((init_fn)sym(lib, dcls, "initIDs"))(&env, (jclass)dcls);
+        printf("%s_compressBound %d -\n", codecs[c], ((bound_fn)sym(lib, ccls, "compressBound"))(&env, (jclass)ccls, n));
+        printf("%s_xxhash32 %d -\n", codecs[c], ((hash_fn)sym(lib, ccls, "xxhash32"))(&env, (jclass)ccls, (jbyteArray)raw, 3, n > 103 ? 100 : 0, 0));
+        const char* calls[3] = {"compressBytesDirect", "compressBytesDirectMC", "compressBytesDirectHC"};
+        for (int k = 0; k < 3; k++) {
+            obj_t co = {{{"finish", 0, 0, 0}, {"finished", 0, 0, 0}, {"uncompressedDirectBuf", 1, 0, raw}, {"uncompressedDirectBufLen", 0, n, 0},
+                         {"compressedDirectBuf", 1, 0, comp}, {"directBufferSize", 0, cap, 0}}, 6};
+            g_thrown[0] = 0;
+            memset(comp, 0, (size_t)ccap);
+            jint r = k < 2 ? ((call0_fn)sym(lib, ccls, calls[k]))(&env, &co) : ((call1_fn)sym(lib, ccls, calls[k]))(&env, &co, c == 0 ? 4 : 1);
+            snprintf(tag, sizeof tag, "%s_%s", codecs[c], calls[k]);
+            printf("%s %d %s | ulen_after=%d\n", tag, r, g_thrown[0] ? g_thrown : "-", co.f[3].ival);
+            if (r > 0 && r < ccap && !g_thrown[0]) {
+                dump(dir, tag, comp, r);
+                obj_t dob = {{{"finished", 0, 0, 0}, {"compressedDirectBuf", 1, 0, comp}, {"compressedDirectBufLen", 0, r, 0},
+                              {"uncompressedDirectBuf", 1, 0, back}, {"directBufferSize", 0, cap, 0}}, 5};
+                g_thrown[0] = 0;
+                memset(back, 0, (size_t)cap);
+                jint d = ((call0_fn)sym(lib, dcls, "decompressBytesDirect"))(&env, &dob);
+                printf("%s_roundtrip %d %s | same=%d clen_after=%d\n", tag, d, g_thrown[0] ? g_thrown : "-", d == n && !memcmp(back, raw, (size_t)n), dob.f[2].ival);
+            }
+        }
+        {   /* corrupt input: the decompressor throws InternalError and returns the codec's error */
+            obj_t dob = {{{"finished", 0, 0, 0}, {"compressedDirectBuf", 1, 0, raw}, {"compressedDirectBufLen", 0, n > 1000 ? 1000 : n, 0},
+                          {"uncompressedDirectBuf", 1, 0, back}, {"directBufferSize", 0, cap, 0}}, 5};
+            g_thrown[0] = 0;
+            jint d = ((call0_fn)sym(lib, dcls, "decompressBytesDirect"))(&env, &dob);
+            printf("%s_decompress_garbage %d %s\n", codecs[c], d, g_thrown[0] ? g_thrown : "-");
+        }
+    }
+    return 0;
+}
