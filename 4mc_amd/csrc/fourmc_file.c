@@ -16,6 +16,7 @@
  * treated as an existing file.
  */
 #define _FILE_OFFSET_BITS 64
+#define _POSIX_C_SOURCE 200809L
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -289,3 +290,91 @@ int fourMcDecompressFileName(int displayLevel, int overwrite, char* in, char* ou
 
 int fourMZDecompressFileName(int displayLevel, int overwrite, char* in, char* out)
 { return decompress_file(displayLevel, overwrite, in, out, FOURMC_MAGIC_4MZ, FOURMC_CODEC_ZSTD); }
+
+/* ------------------------------------------------------------------------------------------
+ * Random access through the footer block index — what a Hadoop split does with a .4mc / .4mz file
+ * (FourMcInputStream.readIndex, java/hadoop-4mc/.../FourMcInputStream.java:163-239, and
+ * FourMcBlockIndex.java:92-173): read the trailer, validate the footer, then decode any block
+ * range without touching the rest of the file.  Library calls, so errors are RETURNED (negative),
+ * never exit():  -1 I/O, -2 bad header/footer, -3 range, -4 corrupt block (checksum / decode),
+ * -5 dst too small, -6 engine (fourmc_gpu_last_error()).
+ */
+static int64_t read_index(FILE* f, uint32_t* magic_out, uint64_t** off_out, uint64_t* data_end)
+{
+    uint8_t hdr[12], tail[12];
+    uint32_t magic, fsz;
+    uint8_t* foot;
+    int64_t n;
+    long long fsize;
+    if (fread(hdr, 1, 12, f) != 12) return -1;
+    magic = ((uint32_t)hdr[0] << 24) | ((uint32_t)hdr[1] << 16) | ((uint32_t)hdr[2] << 8) | hdr[3];
+    if (magic != FOURMC_MAGIC_4MC && magic != FOURMC_MAGIC_4MZ) return -2;
+    if (fourmc_frame_check_header(hdr, magic) != 0) return -2;
+    if (fseeko(f, -12, SEEK_END) != 0) return -1;
+    fsize = (long long)ftello(f) + 12;
+    if (fread(tail, 1, 12, f) != 12) return -1;
+    fsz = ((uint32_t)tail[0] << 24) | ((uint32_t)tail[1] << 16) | ((uint32_t)tail[2] << 8) | tail[3];
+    if (fsz < 20 || (long long)fsz + 24 > fsize) return -2;
+    foot = (uint8_t*)malloc(fsz);
+    *off_out = (uint64_t*)malloc(((fsz - 20) / 4 + 1) * sizeof(uint64_t));
+    if (!foot || !*off_out) { free(foot); return -1; }
+    if (fseeko(f, -(long long)fsz, SEEK_END) != 0 || fread(foot, 1, fsz, f) != fsz) { free(foot); return -1; }
+    n = fourmc_frame_parse_footer(foot, fsz, magic, *off_out);
+    free(foot);
+    if (n < 0) return -2;
+    *magic_out = magic;
+    *data_end = (uint64_t)fsize - fsz - 12;              /* end of the last block = start of the 12 zero bytes */
+    return n;
+}
+
+int64_t fourmc_file_block_count(const char* path, int* is_zstd)
+{
+    FILE* f = fopen(path, "rb");
+    uint32_t magic = 0; uint64_t* off = NULL; uint64_t end = 0;
+    int64_t n;
+    if (!f) return -1;
+    n = read_index(f, &magic, &off, &end);
+    fclose(f); free(off);
+    if (n >= 0 && is_zstd) *is_zstd = (magic == FOURMC_MAGIC_4MZ);
+    return n;
+}
+
+int64_t fourmc_file_decode_blocks(const char* path, uint32_t first, uint32_t count, void* dst, size_t dst_cap)
+{
+    FILE* f = fopen(path, "rb");
+    uint32_t magic = 0, b; uint64_t* off = NULL; uint64_t end = 0, lo, hi, pos;
+    int64_t n, total = 0;
+    uint8_t* buf = NULL; fourmc_block* blk = NULL;
+    if (!f) return -1;
+    n = read_index(f, &magic, &off, &end);
+    if (n < 0) { fclose(f); free(off); return n; }
+    if ((uint64_t)first + count > (uint64_t)n) { fclose(f); free(off); return -3; }
+    if (count == 0) { fclose(f); free(off); return 0; }
+    lo = off[first]; hi = (first + count < (uint64_t)n) ? off[first + count] : end;
+    buf = (uint8_t*)malloc((size_t)(hi - lo) + 64);
+    blk = (fourmc_block*)calloc(count, sizeof *blk);
+    total = -1;
+    if (buf && blk && hi > lo && fseeko(f, (long long)lo, SEEK_SET) == 0 && fread(buf, 1, (size_t)(hi - lo), f) == (size_t)(hi - lo)) {
+        uint64_t out = 0;
+        total = 0;
+        for (b = 0, pos = 0; b < count; b++) {
+            uint32_t usize, csize, sum;
+            if (off[first + b] - lo != pos || pos + 12 > hi - lo) { total = -2; break; }   /* index and block headers disagree */
+            fourmc_frame_parse_block_header(buf + pos, &usize, &csize, &sum);
+            if (csize > BLOCKSIZE || usize > BLOCKSIZE || pos + 12 + csize > hi - lo) { total = -4; break; }
+            if (out + usize > dst_cap) { total = -5; break; }
+            blk[b].src_off = pos + 12; blk[b].dst_off = out; blk[b].src_len = csize; blk[b].dst_cap = usize; blk[b].xxh32 = sum;
+            pos += 12 + csize; out += usize;
+        }
+        if (total == 0) {
+            if (fourmc_host_4mc_decode(buf, (size_t)(hi - lo), dst, (size_t)out, blk, count,
+                                       magic == FOURMC_MAGIC_4MZ ? FOURMC_CODEC_ZSTD : FOURMC_CODEC_LZ4_FAST) != FOURMC_OK) total = -6;
+            else {
+                for (b = 0; b < count; b++) if (blk[b].result < 0 || (uint32_t)blk[b].result != blk[b].dst_cap) { total = -4; break; }
+                if (total == 0) total = (int64_t)out;
+            }
+        }
+    }
+    fclose(f); free(off); free(buf); free(blk);
+    return total;
+}

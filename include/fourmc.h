@@ -61,6 +61,13 @@ int64_t  fourmc_index_find_block(const uint64_t* offsets, uint32_t n, uint64_t p
 uint64_t fourmc_index_align_start(const uint64_t* offsets, uint32_t n, uint64_t start, uint64_t end);
 uint64_t fourmc_index_align_end(const uint64_t* offsets, uint32_t n, uint64_t end, uint64_t file_size);
 
+/* ---- random access through the footer index (what a Hadoop split does: FourMcInputStream.java:163-239) ----
+ * Library calls: errors are returned, never exit().  -1 I/O, -2 bad header/footer, -3 block range,
+ * -4 corrupt block, -5 dst too small, -6 engine error (fourmc_gpu_last_error()). */
+int64_t  fourmc_file_block_count(const char* path, int* is_zstd);           /* blocks in a .4mc/.4mz file   */
+/* decodes blocks [first, first+count) into dst; returns the decoded byte count */
+int64_t  fourmc_file_decode_blocks(const char* path, uint32_t first, uint32_t count, void* dst, size_t dst_cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -249,3 +249,30 @@ def test_cli_roundtrip_and_bytes(gpu, tmp_path):
     assert r.returncode == 0
     assert (tmp_path / "e.4mc").read_bytes().hex() == (
         "344d430000000001a4b73443" + "00" * 12 + "00000014" "00000001" "00000014" "344d4300" "849b8d65")
+
+
+def test_footer_index_random_access_decode(gpu, tmp_path):
+    """§8(f)1: decode an arbitrary block range of a .4mc / .4mz file through its footer index (a Hadoop split)."""
+    import ctypes as C
+    n = 9 * B + 12345
+    data = helpers.corpus(n, first_block=3)
+    src = tmp_path / "c.bin"; src.write_bytes(data.tobytes())
+    L = gpu.lib()
+    for flags, ext in (([], ".4mc"), (["-z"], ".4mz")):
+        out = tmp_path / ("c" + ext)
+        assert subprocess.run([gpu.cli_path(), *flags, "-1", "-f", str(src), str(out)], capture_output=True).returncode == 0
+        isz = C.c_int(-1)
+        assert L.fourmc_file_block_count(str(out).encode(), C.byref(isz)) == 10 and isz.value == (ext == ".4mz")
+        for first, count in ((0, 1), (3, 4), (9, 1), (0, 10), (7, 3)):
+            buf = np.zeros(count * B, np.uint8)
+            r = L.fourmc_file_decode_blocks(str(out).encode(), first, count, buf.ctypes.data, buf.size)
+            want = data[first * B: min(n, (first + count) * B)]
+            assert r == len(want) and np.array_equal(buf[:r], want), (ext, first, count, r)
+        buf = np.zeros(B, np.uint8)
+        assert L.fourmc_file_decode_blocks(str(out).encode(), 8, 3, buf.ctypes.data, buf.size) == -3      # range
+        assert L.fourmc_file_decode_blocks(str(out).encode(), 2, 2, buf.ctypes.data, buf.size) == -5      # capacity
+        raw = bytearray(out.read_bytes()); raw[12 + 12 + 1000] ^= 0x40                                   # corrupt block 0's payload
+        bad = tmp_path / ("bad" + ext); bad.write_bytes(bytes(raw))
+        assert L.fourmc_file_decode_blocks(str(bad).encode(), 0, 1, buf.ctypes.data, buf.size) == -4
+        assert L.fourmc_file_decode_blocks(str(bad).encode(), 1, 1, buf.ctypes.data, buf.size) == B       # other blocks unaffected
+    assert L.fourmc_file_block_count(str(src).encode(), None) == -2                                      # not a 4mc file
