@@ -3,8 +3,8 @@
  * native/zstd) for the one-shot, no-dictionary, known-size call 4mz makes per block
  * (native/4mc.c:467: ZSTD_compress(out+12, n-1, in, n, level)).  TEST INFRASTRUCTURE, NOT PRODUCT.
  *
- * Covered: strategy ZSTD_fast (4mz "fast" = zstd level 1; every size class of the level table).
- * Other levels return ORC_ZSTD_UNSUPPORTED.
+ * Covered: strategy ZSTD_fast (4mz "fast" = zstd level 1) and ZSTD_dfast (4mz "medium" = zstd level 3),
+ * every size class of the level table.  Other levels return ORC_ZSTD_UNSUPPORTED.
  *
  *   parameters   ZSTD_getCParams_internal        compress/zstd_compress.c:6465-6488, clevels.h:25-130,
  *                ZSTD_adjustCParams_internal     compress/zstd_compress.c:1335-1399
@@ -13,6 +13,7 @@
  *   block        ZSTD_compressBlock_internal :3812-3877, ZSTD_buildSeqStore :2859-2940,
  *                ZSTD_entropyCompressSeqStore(_internal) :2632-2775, ZSTD_buildSequencesStatistics :2489-2615
  *   match finder ZSTD_compressBlock_fast_noDict_generic   compress/zstd_fast.c:95-365
+ *                ZSTD_compressBlock_doubleFast_noDict_generic  compress/zstd_double_fast.c:98-330
  *   literals     ZSTD_compressLiterals           compress/zstd_compress_literals.c:100-196
  *   Huffman      HUF_compress_internal           compress/huf_compress.c:1250-1360 (+ sort :604, tree :665,
  *                setMaxHeight :360, writeCTable :230, compressWeights :147, 1X/4X streams :1029-1194)
@@ -602,12 +603,13 @@ static unsigned ml_code(uint32_t v)
 }
 
 /* ZSTD_selectEncodingType, strategy < lazy, no dictionary (repeat mode is never "valid") */
-static int select_type(const uint32_t* count, unsigned max, size_t most, size_t nseq, uint32_t def_log, int def_ok)
+static uint32_t g_unused;
+static int select_type(const uint32_t* count, unsigned max, size_t most, size_t nseq, uint32_t def_log, int def_ok, uint32_t strat)
 {
-    (void)count; (void)max;
+    (void)count; (void)max; (void)g_unused;
     if (most == nseq) return (def_ok && nseq <= 2) ? 0 : 1;
     if (def_ok) {
-        const size_t dyn_min = (((size_t)1 << def_log) * (10 - 1 /* ZSTD_fast */)) >> 3;
+        const size_t dyn_min = (((size_t)1 << def_log) * (10 - strat)) >> 3;      /* ZSTD_fast = 1, ZSTD_dfast = 2 */
         if (nseq < dyn_min || most < (nseq >> (def_log - 1))) return 0;
     }
     return 2;
@@ -635,7 +637,7 @@ static int build_seq_table(uint8_t* dst, size_t cap, fse_ct* ct, uint32_t fse_lo
 }
 
 /* sequences section after the literals; returns bytes or 0 / ERR_* (ZSTD_entropyCompressSeqStore_internal tail) */
-static int64_t encode_sequences(uint8_t* dst, size_t cap, const zseq* seq, size_t nseq, uint8_t* llc, uint8_t* ofc, uint8_t* mlc)
+static int64_t encode_sequences(uint8_t* dst, size_t cap, const zseq* seq, size_t nseq, uint8_t* llc, uint8_t* ofc, uint8_t* mlc, uint32_t strat)
 {
     size_t o = 0, last_count = 0;
     fse_ct ll, of, ml;
@@ -652,19 +654,19 @@ static int64_t encode_sequences(uint8_t* dst, size_t cap, const zseq* seq, size_
         unsigned max;
         size_t most;
         max = 35; most = hist(count, &max, llc, nseq);
-        tll = select_type(count, max, most, nseq, 6, 1);
+        tll = select_type(count, max, most, nseq, 6, 1, strat);
         r = build_seq_table(dst + o, cap - o, &ll, 9, tll, count, max, llc, nseq, kLLNorm, 6, 35);
         if (r < 0) return r;
         if (tll == 2) last_count = (size_t)r;
         o += (size_t)r;
         max = 31; most = hist(count, &max, ofc, nseq);
-        tof = select_type(count, max, most, nseq, 5, max <= 28);
+        tof = select_type(count, max, most, nseq, 5, max <= 28, strat);
         r = build_seq_table(dst + o, cap - o, &of, 8, tof, count, max, ofc, nseq, kOFNorm, 5, 28);
         if (r < 0) return r;
         if (tof == 2) last_count = (size_t)r;
         o += (size_t)r;
         max = 52; most = hist(count, &max, mlc, nseq);
-        tml = select_type(count, max, most, nseq, 6, 1);
+        tml = select_type(count, max, most, nseq, 6, 1, strat);
         r = build_seq_table(dst + o, cap - o, &ml, 9, tml, count, max, mlc, nseq, kMLNorm, 6, 52);
         if (r < 0) return r;
         if (tml == 2) last_count = (size_t)r;
@@ -699,7 +701,8 @@ static int64_t encode_sequences(uint8_t* dst, size_t cap, const zseq* seq, size_
 
 /* ------------------------------------------------------------------------------------------------ match finder */
 typedef struct {
-    uint32_t* table;
+    uint32_t* table;              /* fast: the hash table; dfast: the long (8-byte) hash table */
+    uint32_t* small;              /* dfast: the short hash table (the reference's chainTable) */
     zparams   p;
     zseq*     seq;  size_t nseq;
     uint8_t*  lit;  size_t nlit;
@@ -812,14 +815,105 @@ cleanup:
     return end - anchor;
 }
 
+
+/* ZSTD_compressBlock_doubleFast_noDict_generic (compress/zstd_double_fast.c:98-330) over s[start, end) */
+static size_t dfast_block(zmatch* m, uint32_t rep[3], const uint8_t* s, size_t start, size_t end)
+{
+    uint32_t* const tl = m->table; uint32_t* const ts = m->small;
+    const uint32_t hl_log = m->p.hlog, hs_log = m->p.clog, wsize = 1u << m->p.wlog;
+    const uint32_t mls = (m->p.mml >= 5 && m->p.mml <= 7) ? m->p.mml : 4;
+    const uint32_t end_idx = (uint32_t)end + 2;
+    const uint32_t prefix_idx = end_idx - 2 > wsize ? end_idx - wsize : 2;
+    const size_t prefix = prefix_idx - 2;
+    const int64_t ilimit = (int64_t)end - 8;
+    size_t anchor = start, ip = start, ip1, step, next_step, mlen, match;
+    uint32_t rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0, cur = 0, offset, idxl0, idxl1, hl0, hl1;
+#define HL(p_) ((uint32_t)((rd64(s + (p_)) * 0xCF1BBCDCB7A56463ull) >> (64 - hl_log)))
+    ip += (ip == prefix);
+    {
+        const uint32_t c = (uint32_t)ip + 2;
+        const uint32_t low = c - prefix_idx > wsize ? c - wsize : prefix_idx;
+        const uint32_t max_rep = c - low;
+        if (rep2 > max_rep) { saved2 = rep2; rep2 = 0; }
+        if (rep1 > max_rep) { saved1 = rep1; rep1 = 0; }
+    }
+    for (;;) {
+        step = 1; next_step = ip + 256; ip1 = ip + step;
+        if ((int64_t)ip1 > ilimit) goto cleanup;
+        hl0 = HL(ip); idxl0 = tl[hl0];
+        for (;;) {
+            const uint32_t hs0 = zhash(s + ip, hs_log, mls);
+            const uint32_t idxs0 = ts[hs0];
+            cur = (uint32_t)ip + 2;
+            tl[hl0] = ts[hs0] = cur;
+            if ((rep1 > 0) & (rd32(s + ip + 1 - rep1) == rd32(s + ip + 1))) {
+                mlen = count_eq(s, ip + 1 + 4, ip + 1 + 4 - rep1, end) + 4;
+                ip++;
+                store_seq(m, s, anchor, ip - anchor, 1, mlen);
+                goto stored;
+            }
+            hl1 = HL(ip1);
+            if (idxl0 > prefix_idx && rd64(s + idxl0 - 2) == rd64(s + ip)) {
+                match = idxl0 - 2;
+                mlen = count_eq(s, ip + 8, match + 8, end) + 8;
+                goto found;
+            }
+            idxl1 = tl[hl1];
+            if (idxs0 > prefix_idx && rd32(s + idxs0 - 2) == rd32(s + ip)) {
+                if (idxl1 > prefix_idx && rd64(s + idxl1 - 2) == rd64(s + ip1)) {      /* _search_next_long */
+                    ip = ip1; match = idxl1 - 2;
+                    mlen = count_eq(s, ip + 8, match + 8, end) + 8;
+                } else {
+                    match = idxs0 - 2;
+                    mlen = count_eq(s, ip + 4, match + 4, end) + 4;
+                }
+                goto found;
+            }
+            if (ip1 >= next_step) { step++; next_step += 256; }
+            ip = ip1; ip1 += step;
+            hl0 = hl1; idxl0 = idxl1;
+            if ((int64_t)ip1 > ilimit) goto cleanup;
+        }
+    found:
+        offset = (uint32_t)(ip - match);
+        while (ip > anchor && match > prefix && s[ip - 1] == s[match - 1]) { ip--; match--; mlen++; }
+        rep2 = rep1; rep1 = offset;
+        if (step < 4) tl[hl1] = (uint32_t)ip1 + 2;
+        store_seq(m, s, anchor, ip - anchor, offset + 3, mlen);
+    stored:
+        ip += mlen; anchor = ip;
+        if ((int64_t)ip <= ilimit) {
+            const uint32_t ins = cur + 2;                               /* index; its position is ins - 2 = cur */
+            tl[HL(cur)] = ins;
+            tl[HL(ip - 2)] = (uint32_t)ip;
+            ts[zhash(s + cur, hs_log, mls)] = ins;
+            ts[zhash(s + ip - 1, hs_log, mls)] = (uint32_t)ip + 1;
+            while ((int64_t)ip <= ilimit && ((rep2 > 0) & (rd32(s + ip) == rd32(s + ip - rep2)))) {
+                const size_t rlen = count_eq(s, ip + 4, ip + 4 - rep2, end) + 4;
+                const uint32_t t = rep2; rep2 = rep1; rep1 = t;
+                ts[zhash(s + ip, hs_log, mls)] = (uint32_t)ip + 2;
+                tl[HL(ip)] = (uint32_t)ip + 2;
+                store_seq(m, s, anchor, 0, 1, rlen);
+                ip += rlen; anchor = ip;
+            }
+        }
+    }
+cleanup:
+#undef HL
+    saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;
+    rep[0] = rep1 ? rep1 : saved1;
+    rep[1] = rep2 ? rep2 : saved2;
+    return end - anchor;
+}
+
 /* ------------------------------------------------------------------------------------------------ frame */
 static zparams level_params(int level, size_t n)
 {
-    static const zparams fast_rows[4] = {          /* clevels.h:29,:55,:81,:107 (level 1) */
-        {19, 13, 14, 1, 7, 0, 1}, {18, 13, 14, 1, 6, 0, 1}, {17, 12, 13, 1, 6, 0, 1}, {14, 14, 15, 1, 5, 0, 1}};
-    zparams p = fast_rows[(n <= 256 * 1024) + (n <= 128 * 1024) + (n <= 16 * 1024)];
+    static const zparams rows[2][4] = {            /* clevels.h, tables for > 256 KB, <= 256 KB, <= 128 KB, <= 16 KB */
+        {{19, 13, 14, 1, 7, 0, 1}, {18, 13, 14, 1, 6, 0, 1}, {17, 12, 13, 1, 6, 0, 1}, {14, 14, 15, 1, 5, 0, 1}},   /* level 1: fast  */
+        {{21, 16, 17, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {17, 15, 16, 2, 5, 0, 2}, {14, 14, 15, 2, 4, 0, 2}}};  /* level 3: dfast */
+    zparams p = rows[level == 3][(n <= 256 * 1024) + (n <= 128 * 1024) + (n <= 16 * 1024)];
     const uint32_t src_log = n < 64 ? 6 : (uint32_t)hibit((uint32_t)(n - 1)) + 1;
-    (void)level;
     if (p.wlog > src_log) p.wlog = src_log;
     if (p.hlog > p.wlog + 1) p.hlog = p.wlog + 1;
     if (p.clog > p.wlog) p.clog = p.wlog;
@@ -839,7 +933,7 @@ int64_t orc_zstd_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap
     size_t o = 0, pos = 0, block;
     int64_t result;
     uint8_t *llc, *ofc, *mlc;
-    if (level != 1) return ORC_ZSTD_UNSUPPORTED;
+    if (level != 1 && level != 3) return ORC_ZSTD_UNSUPPORTED;
     p = level_params(level, n);
     if (cap < 18) return ERR_TOOSMALL;
     {   /* frame header: magic, descriptor, [window], content size */
@@ -863,6 +957,7 @@ int64_t orc_zstd_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap
     block = (size_t)1 << p.wlog; if (block > n) block = n; if (block > BLOCK_MAX) block = BLOCK_MAX;
     m.p = p;
     m.table = (uint32_t*)calloc((size_t)1 << p.hlog, 4);
+    m.small = (uint32_t*)calloc((size_t)1 << p.clog, 4);
     m.seq = (zseq*)malloc((BLOCK_MAX / 3 + 1) * sizeof(zseq));
     m.lit = (uint8_t*)malloc(BLOCK_MAX + 64);
     llc = (uint8_t*)malloc(3 * (BLOCK_MAX / 3 + 1)); ofc = llc + BLOCK_MAX / 3 + 1; mlc = ofc + BLOCK_MAX / 3 + 1;
@@ -884,12 +979,12 @@ int64_t orc_zstd_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap
             int64_t lsz, ssz;
             m.nseq = 0; m.nlit = 0;
             memcpy(next->rep, prev->rep, sizeof next->rep);
-            tail = fast_block(&m, next->rep, src, pos, pos + len);
+            tail = p.strat == 2 ? dfast_block(&m, next->rep, src, pos, pos + len) : fast_block(&m, next->rep, src, pos, pos + len);
             memcpy(m.lit + m.nlit, src + pos + len - tail, tail); m.nlit += tail;
             lsz = compress_literals(prev, next, out, bcap, m.lit, m.nlit, m.nseq == 0 || m.nlit / m.nseq >= 20);
             c = lsz;
             if (lsz >= 0) {
-                ssz = encode_sequences(out + lsz, bcap - (size_t)lsz, m.seq, m.nseq, llc, ofc, mlc);
+                ssz = encode_sequences(out + lsz, bcap - (size_t)lsz, m.seq, m.nseq, llc, ofc, mlc, p.strat);
                 c = ssz <= 0 ? ssz : lsz + ssz;
             }
             if (c == ERR_TOOSMALL && len <= bcap) c = 0;
@@ -911,9 +1006,12 @@ int64_t orc_zstd_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap
         }
         pos += len; first = 0;
     }
-    free(m.table); free(m.seq); free(m.lit); free(llc);
+    free(m.table); free(m.small); free(m.seq); free(m.lit); free(llc);
     return result < 0 ? result : (int64_t)o;
 }
+
+int orc_codec_zstd3(void* ctx, const uint8_t* src, int n, uint8_t* dst, int cap)
+{ (void)ctx; const int64_t r = orc_zstd_compress(src, (size_t)n, dst, cap < 0 ? 0 : (size_t)cap, 3); return r < 0 ? 0 : (int)r; }
 
 int orc_codec_zstd1(void* ctx, const uint8_t* src, int n, uint8_t* dst, int cap)
 { (void)ctx; const int64_t r = orc_zstd_compress(src, (size_t)n, dst, cap < 0 ? 0 : (size_t)cap, 1); return r < 0 ? 0 : (int)r; }

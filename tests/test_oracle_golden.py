@@ -230,14 +230,15 @@ def test_lz4mc_port_equals_reference_sources():
             assert r == rr and np.array_equal(comp, out[:max(rr, 0)]), (name, cap, r, rr)
 
 
-# ------------------------------------------------------------------------------------------ zstd level-1 encoder port
-def test_zstd_enc_port_golden_manifest():
-    """`4mc -z -1` (ZSTD_compress level 1, capacity n-1) per-block sizes/checksums written by the reference CLI."""
+# ------------------------------------------------------------------------------------------ zstd encoder port (levels 1 and 3)
+@pytest.mark.parametrize("level,key", [(1, "4mz-1"), (3, "4mz-2")])
+def test_zstd_enc_port_golden_manifest(level, key):
+    """`4mc -z -1` / `-z -2` (ZSTD_compress level 1 / 3, capacity n-1) per-block sizes/checksums written by the reference CLI."""
     m = json.load(open(os.path.join(G, "corpus_manifest.json")))
     data = helpers.corpus(m["corpus"]["bytes"])
-    for b, (u, c, x) in enumerate(m["levels"]["4mz-1"]["blocks"]):
+    for b, (u, c, x) in enumerate(m["levels"][key]["blocks"]):
         blk = data[b * B: b * B + u]
-        r, comp = helpers.orc_zstd_compress(blk, 1, u - 1)
+        r, comp = helpers.orc_zstd_compress(blk, level, u - 1)
         payload = comp if r > 0 else blk
         assert (len(payload), helpers.orc_xxh32(payload)) == (c, x), b
         if r > 0 and b % 4 == 0:                       # and the frames decode back with the decoder port
@@ -245,7 +246,8 @@ def test_zstd_enc_port_golden_manifest():
 
 
 @pytest.mark.skipif(helpers.ref() is None, reason="oracle/_ref not built (needs /root/reference)")
-def test_zstd_enc_port_equals_reference_sources():
+@pytest.mark.parametrize("level", [1, 3])
+def test_zstd_enc_port_equals_reference_sources(level):
     import ctypes as C
     ref = helpers.ref()
     ref.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]; ref.ZSTD_compress.restype = C.c_size_t
@@ -254,9 +256,9 @@ def test_zstd_enc_port_equals_reference_sources():
     def check(d, cap, tag):
         d = np.ascontiguousarray(d)
         out = np.zeros(max(cap, 1) + 64, np.uint8)
-        rr = ref.ZSTD_compress(out.ctypes.data, cap, d.ctypes.data, len(d), 1)
+        rr = ref.ZSTD_compress(out.ctypes.data, cap, d.ctypes.data, len(d), level)
         rr = rr if rr < (1 << 62) else rr - (1 << 64)           # size_t error code -> -(error number)
-        r, comp = helpers.orc_zstd_compress(d, 1, cap)
+        r, comp = helpers.orc_zstd_compress(d, level, cap)
         assert r == rr and np.array_equal(comp, out[:max(rr, 0)]), (tag, len(d), cap, r, rr)
         return rr
 
@@ -268,7 +270,7 @@ def test_zstd_enc_port_equals_reference_sources():
             check(d, cap, name)
     # size classes of the level table (16 KiB / 128 KiB / 256 KiB) and 128 KiB sub-block tails
     src = helpers.corpus(3 * B, first_block=5)
-    for n in (16383, 16384, 16385, 131071, 131072, 131073, 131079, 262144, 262145, 262151, 524289, 1500001):
+    for n in (16383, 16384, 16385, 131071, 131072, 131073, 131079, 262144, 262145, 262151, 524289, 1500001, 2 * 1024 * 1024 + 77, 3 * 1024 * 1024):
         off = int(rng.integers(0, B))
         check(src[off:off + n], n - 1, "size")
     # capacity sweep around the real frame size: every overflow rule of the bit/byte writers
