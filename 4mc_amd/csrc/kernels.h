@@ -33,7 +33,7 @@ hipError_t fourmc_launch_zstd_decode(const void* d_src, void* d_dst, fourmc_bloc
                                      void* d_scratch, int container_mode, hipStream_t stream);
 size_t     fourmc_zstd_enc_work_bytes(uint32_t n);
 hipError_t fourmc_launch_zstd_encode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
-                                     void* d_work, int container_mode, int serial, hipStream_t stream);
+                                     void* d_work, int container_mode, int level, int serial, hipStream_t stream);
 hipError_t fourmc_launch_xxh32(const void* d_base, fourmc_block* d_blocks, uint32_t n,
                                uint32_t seed, int mode, hipStream_t stream);
 

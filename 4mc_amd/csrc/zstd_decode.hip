@@ -683,7 +683,7 @@ __device__ __forceinline__ int zstd_decode_frames(const uint8_t* src, int csize,
 }
 
 // container_mode as in lz4_decode.hip (BADSUM skip, stored copy, negative -> CORRUPT)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
 void zstd_decode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks,
                         uint32_t nblocks, uint8_t* scratch, int container_mode)
 {

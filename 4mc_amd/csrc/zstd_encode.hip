@@ -37,7 +37,8 @@ namespace {
 constexpr int      kErrGeneric = -1, kErrTooSmall = -70;     // ZSTD_error_GENERIC / _dstSize_tooSmall
 constexpr uint32_t kSub    = 128 * 1024;                     // ZSTD_BLOCKSIZE_MAX
 constexpr uint32_t kSeqCap = 32768 + 64;
-constexpr size_t   kTabBytes  = size_t(4) << 15;
+constexpr size_t   kLongBytes = size_t(4) << 17;                   // level 1: the hash table (<= 2^15 entries); level 3: long-hash table
+constexpr size_t   kTabBytes  = kLongBytes + (size_t(4) << 16);   // + level 3's short-hash table
 constexpr size_t   kSeqBytes  = size_t(kSeqCap) * 4;
 constexpr size_t   kCodeBytes = kSeqCap;
 constexpr size_t   kLitPad    = 64;
@@ -690,11 +691,11 @@ __device__ __forceinline__ int default_norm(int which, uint32_t s)       // LL_d
 }
 
 // ZSTD_selectEncodingType for strategy fast without dictionary: 0 basic, 1 rle, 2 compressed
-__device__ __forceinline__ int select_type(uint32_t most, uint32_t nseq, uint32_t def_log, bool def_ok)
+__device__ __forceinline__ int select_type(uint32_t most, uint32_t nseq, uint32_t def_log, bool def_ok, uint32_t strat)
 {
     if (most == nseq) return (def_ok && nseq <= 2) ? 0 : 1;
     if (def_ok) {
-        const uint32_t dyn_min = ((1u << def_log) * 9u) >> 3;
+        const uint32_t dyn_min = ((1u << def_log) * (10u - strat)) >> 3;      // ZSTD_fast = 1, ZSTD_dfast = 2
         if (nseq < dyn_min || most < (nseq >> (def_log - 1))) return 0;
     }
     return 2;
@@ -731,7 +732,7 @@ __device__ __forceinline__ int build_seq_table(ZLds& L, int which, uint8_t* dst,
 struct SeqStore { uint32_t *ll, *ml, *off; uint8_t *llc, *ofc, *mlc; uint8_t* lit; uint32_t nseq, nlit; };
 
 // sequences section (tail of ZSTD_entropyCompressSeqStore_internal); bytes, 0 or kErr*
-__device__ __forceinline__ int encode_sequences(ZLds& L, uint8_t* dst, uint32_t cap, const SeqStore& S, int lane)
+__device__ __forceinline__ int encode_sequences(ZLds& L, uint8_t* dst, uint32_t cap, const SeqStore& S, uint32_t strat, int lane)
 {
     const uint32_t nseq = S.nseq;
     uint32_t o = 0, last_count = 0;
@@ -747,19 +748,19 @@ __device__ __forceinline__ int encode_sequences(ZLds& L, uint8_t* dst, uint32_t 
         uint8_t* const head = dst + o++;
         uint32_t most, max;
         hist_bytes(L, S.llc, nseq, most, max, lane);
-        const int tll = select_type(most, nseq, 6, true);
+        const int tll = select_type(most, nseq, 6, true, strat);
         int r = build_seq_table(L, 0, dst + o, cap - o, 9, tll, max, S.llc, nseq, 6, 35, lane);
         if (r < 0) return r;
         if (tll == 2) last_count = uint32_t(r);
         o += uint32_t(r);
         hist_bytes(L, S.ofc, nseq, most, max, lane);
-        const int tof = select_type(most, nseq, 5, max <= 28);
+        const int tof = select_type(most, nseq, 5, max <= 28, strat);
         r = build_seq_table(L, 1, dst + o, cap - o, 8, tof, max, S.ofc, nseq, 5, 28, lane);
         if (r < 0) return r;
         if (tof == 2) last_count = uint32_t(r);
         o += uint32_t(r);
         hist_bytes(L, S.mlc, nseq, most, max, lane);
-        const int tml = select_type(most, nseq, 6, true);
+        const int tml = select_type(most, nseq, 6, true, strat);
         r = build_seq_table(L, 2, dst + o, cap - o, 9, tml, max, S.mlc, nseq, 6, 52, lane);
         if (r < 0) return r;
         if (tml == 2) last_count = uint32_t(r);
@@ -810,7 +811,7 @@ __device__ __forceinline__ int encode_sequences(ZLds& L, uint8_t* dst, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------ match finder
-struct Params { uint32_t wlog, hlog, mml, tlen; };
+struct Params { uint32_t wlog, hlog, clog, mml, tlen, strat; };
 
 __device__ __forceinline__ uint32_t zhash(uint64_t v, uint32_t hlog, uint32_t mls)
 {
@@ -1031,20 +1032,158 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
     return end - anchor;
 }
 
+
+// ZSTD_compressBlock_doubleFast_noDict_generic (compress/zstd_double_fast.c:98-330) over s[start, end): level 3.
+// Lane j speculates position j of the current search: long (8-byte) and short hash probes, the repcode test at
+// ip+1 and the "next long" probe at ip1; same first-event / commit / scoreboard-cut rules as fast_block.
+__device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* tl, uint32_t* ts, const Params& P, uint32_t rep[3],
+                                                const uint8_t* s, uint32_t start, uint32_t end, int lane)
+{
+    const uint32_t hl_log = P.hlog, hs_log = P.clog, wsize = 1u << P.wlog, mls = P.mml;
+    const uint32_t prefix_idx = end > wsize ? end + 2 - wsize : 2;
+    const uint32_t prefix = prefix_idx - 2;
+    const int64_t ilimit = int64_t(end) - 8;
+    uint32_t anchor = start, ip = start;
+    uint32_t rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0;
+    auto HL = [&](uint64_t v) -> uint32_t { return uint32_t((v * 0xCF1BBCDCB7A56463ull) >> (64 - hl_log)); };
+
+    ip += (ip == prefix) ? 1 : 0;
+    {
+        const uint32_t cur = ip + 2;
+        const uint32_t low = cur - prefix_idx > wsize ? cur - wsize : prefix_idx;
+        const uint32_t max_rep = cur - low;
+        if (rep2 > max_rep) { saved2 = rep2; rep2 = 0; }
+        if (rep1 > max_rep) { saved1 = rep1; rep1 = 0; }
+    }
+    for (;;) {                                                   // one search per iteration
+        if (int64_t(ip) + 1 > ilimit) break;
+        uint32_t IP = ip, SJ = 1, NS = ip + 256, width = 16;
+        int ev_kind = 0;                                         // 1 rep at ip+1, 2 long at ip, 3 long at ip1, 4 short at ip, 5 end of block
+        uint32_t ev_ip = 0, ev_s = 0, ev_idx = 0, ev_hl1 = 0;
+        for (;;) {
+            uint32_t p = IP, sj = SJ, ns = NS, np = 0, nsj = 0, nns = 0;
+            if (IP + SJ * width < NS) p = IP + SJ * uint32_t(lane);
+            else
+                for (uint32_t i = 0; i < width; i++) {
+                    np = p + sj; nsj = sj; nns = ns;
+                    if (np >= ns) { nsj = sj + 1; nns = ns + 256; }
+                    if (uint32_t(lane) > i) { p = np; sj = nsj; ns = nns; }
+                }
+            np = p + sj; nsj = sj; nns = ns;                     // successor position and its step
+            if (np >= ns) { nsj = sj + 1; nns = ns + 256; }
+            const bool act = uint32_t(lane) < width;
+            const bool inb = int64_t(np) <= ilimit;               // this position is reached only if its own ip1 fits
+            const bool term = int64_t(np) + int64_t(nsj) > ilimit;   // its iteration ends the block when nothing matches
+            const uint32_t rp = inb ? p : start, rp1 = inb ? np : start;
+            const uint64_t w0 = ld8(s + rp), w1 = ld8(s + rp1);
+            const uint32_t r_rep = ld4(s + rp + 1 - (inb ? rep1 : 0));
+            const uint32_t hl0 = HL(w0), hl1 = HL(w1), hs0 = zhash(w0, hs_log, mls);
+            const uint32_t cur = p + 2;
+            uint32_t il0 = 0, il1 = 0, is0 = 0; bool shared = false;
+            if (act && inb) {
+                il0 = tl[hl0]; is0 = ts[hs0]; il1 = (hl1 == hl0) ? cur : tl[hl1];
+                uint32_t* const a = &L.score[hl0 & 511]; uint32_t* const b = &L.score[512 + (hs0 & 511)];
+                atomicMin(a, uint32_t(lane)); atomicMin(b, uint32_t(lane));
+                shared = (*a != uint32_t(lane)) || (*b != uint32_t(lane)) || (L.score[hl1 & 511] < uint32_t(lane));
+                *a = 0xFFFFFFFFu; *b = 0xFFFFFFFFu;
+            }
+            const bool okl0 = act && inb && il0 > prefix_idx, oks0 = act && inb && is0 > prefix_idx, okl1 = act && inb && il1 > prefix_idx;
+            const uint64_t cl0 = ld8(s + (okl0 ? il0 - 2 : 0)), cl1 = ld8(s + (okl1 ? il1 - 2 : 0));
+            const uint32_t cs0 = ld4(s + (oks0 ? is0 - 2 : 0));
+            int kind = 0;
+            if (act && inb) {
+                if ((rep1 > 0) & (r_rep == uint32_t(w0 >> 8))) kind = 1;
+                else if (okl0 && cl0 == w0) kind = 2;
+                else if (oks0 && cs0 == uint32_t(w0)) kind = (okl1 && cl1 == w1) ? 3 : 4;
+                else if (term) kind = 5;
+            }
+            const unsigned long long cutm = __ballot(act && (shared || !inb)) & ~1ull;
+            const int cut = cutm ? __builtin_ctzll(cutm) : int(width);
+            const unsigned long long evm = __ballot(kind != 0) & ((cut >= 64) ? ~0ull : ((1ull << cut) - 1));
+            if (evm) {
+                const int J = __builtin_ctzll(evm);
+                if (lane <= J) { tl[hl0] = cur; ts[hs0] = cur; }
+                ev_kind = int(rl(uint32_t(kind), J)); ev_ip = rl(p, J); ev_s = rl(sj, J); ev_hl1 = rl(hl1, J);
+                ev_idx = ev_kind == 2 ? rl(il0, J) : (ev_kind == 3 ? rl(il1, J) : rl(is0, J));
+                break;
+            }
+            if (lane < cut) { tl[hl0] = cur; ts[hs0] = cur; }
+            if (cut < int(width)) { IP = rl(p, cut); SJ = rl(sj, cut); NS = rl(ns, cut); }
+            else { IP = rl(np, width - 1); SJ = rl(nsj, width - 1); NS = rl(nns, width - 1); }
+            width = min(64u, width * 2);
+        }
+        if (ev_kind == 5) break;                                 // _cleanup
+        const uint32_t cur0 = ev_ip + 2;                          // index of the probed position (`curr`)
+        uint32_t mlen, off_base;
+        if (ev_kind == 1) {
+            ip = ev_ip + 1;
+            mlen = count_fwd(s, ip + 4, ip + 4 - rep1, end, lane) + 4;
+            off_base = 1;
+        } else {
+            const uint32_t ip1 = ev_ip + ev_s;
+            uint32_t match = ev_idx - 2, base_len = ev_kind == 4 ? 4u : 8u;
+            ip = ev_kind == 3 ? ip1 : ev_ip;
+            mlen = count_fwd(s, ip + base_len, match + base_len, end, lane) + base_len;
+            const uint32_t offset = ip - match;
+            for (;;) {                                           // catch up, 64 bytes per step
+                const uint32_t room = min(ip - anchor, match - prefix);
+                const bool same = uint32_t(lane) < room && s[ip - 1 - lane] == s[match - 1 - lane];
+                const unsigned long long bad = ~__ballot(same);
+                const uint32_t k = bad ? uint32_t(__builtin_ctzll(bad)) : 64u;
+                ip -= k; match -= k; mlen += k;
+                if (k < 64) break;
+            }
+            rep2 = rep1; rep1 = offset; off_base = offset + 3;
+            if (ev_s < 4 && lane == 0) tl[ev_hl1] = ip1 + 2;
+        }
+        store_seq(S, s, anchor, ip - anchor, off_base, mlen, lane);
+        ip += mlen; anchor = ip;
+        if (int64_t(ip) <= ilimit) {
+            const uint64_t wa = ld8(s + cur0), wb = ld8(s + ip - 2), wc = ld8(s + ip - 1);
+            if (lane == 0) {
+                tl[HL(wa)] = cur0 + 2; tl[HL(wb)] = ip;
+                ts[zhash(wa, hs_log, mls)] = cur0 + 2; ts[zhash(wc, hs_log, mls)] = ip + 1;
+            }
+            while (int64_t(ip) <= ilimit && ((rep2 > 0) & (ld4(s + ip) == ld4(s + ip - rep2)))) {
+                const uint32_t rlen = count_fwd(s, ip + 4, ip + 4 - rep2, end, lane) + 4;
+                const uint32_t t = rep2; rep2 = rep1; rep1 = t;
+                const uint64_t wi = ld8(s + ip);
+                if (lane == 0) { ts[zhash(wi, hs_log, mls)] = ip + 2; tl[HL(wi)] = ip + 2; }
+                store_seq(S, s, anchor, 0, 1, rlen, lane);
+                ip += rlen; anchor = ip;
+            }
+        }
+    }
+    saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;
+    rep[0] = rep1 ? rep1 : saved1;
+    rep[1] = rep2 ? rep2 : saved2;
+    return end - anchor;
+}
+
 // ------------------------------------------------------------------------------------------------ frame
-__device__ __forceinline__ Params level_params(uint32_t n)
+__device__ __forceinline__ Params level_params(uint32_t n, int level)
 {
     Params p;
-    uint32_t wlog, hlog;
-    if (n <= 16 * 1024) { wlog = 14; hlog = 15; p.mml = 5; }
-    else if (n <= 128 * 1024) { wlog = 17; hlog = 13; p.mml = 6; }
-    else if (n <= 256 * 1024) { wlog = 18; hlog = 14; p.mml = 6; }
-    else { wlog = 19; hlog = 14; p.mml = 7; }
+    uint32_t wlog, hlog, clog;
+    if (level == 3) {                                   // clevels.h rows of level 3 (ZSTD_dfast)
+        if (n <= 16 * 1024) { wlog = 14; clog = 14; hlog = 15; p.mml = 4; }
+        else if (n <= 128 * 1024) { wlog = 17; clog = 15; hlog = 16; p.mml = 5; }
+        else if (n <= 256 * 1024) { wlog = 18; clog = 16; hlog = 16; p.mml = 4; }
+        else { wlog = 21; clog = 16; hlog = 17; p.mml = 5; }
+        p.strat = 2;
+    } else {                                            // level 1 (ZSTD_fast)
+        if (n <= 16 * 1024) { wlog = 14; clog = 14; hlog = 15; p.mml = 5; }
+        else if (n <= 128 * 1024) { wlog = 17; clog = 12; hlog = 13; p.mml = 6; }
+        else if (n <= 256 * 1024) { wlog = 18; clog = 13; hlog = 14; p.mml = 6; }
+        else { wlog = 19; clog = 13; hlog = 14; p.mml = 7; }
+        p.strat = 1;
+    }
     const uint32_t src_log = n < 64 ? 6u : uint32_t(hibit(n - 1)) + 1;
     if (wlog > src_log) wlog = src_log;
     if (hlog > wlog + 1) hlog = wlog + 1;
+    if (clog > wlog) clog = wlog;
     if (wlog < 10) wlog = 10;
-    p.wlog = wlog; p.hlog = hlog; p.tlen = 0;
+    p.wlog = wlog; p.hlog = hlog; p.clog = clog; p.tlen = 0;
     return p;
 }
 
@@ -1057,9 +1196,10 @@ __device__ __forceinline__ bool is_rle(const uint8_t* s, uint32_t n, int lane)
 }
 
 // ZSTD_compress(dst, cap, src, n, 1); returns the frame size or a negative ZSTD error number
-__device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* work, bool serial, int lane)
+__device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* work, int level, bool serial, int lane)
 {
-    const Params P = level_params(n);
+    const Params P = level_params(n, level);
+    uint32_t* const tab_s = reinterpret_cast<uint32_t*>(work + kLongBytes);
     uint32_t* const tab = reinterpret_cast<uint32_t*>(work);
     SeqStore S;
     S.ll = reinterpret_cast<uint32_t*>(work + kTabBytes); S.ml = S.ll + kSeqCap; S.off = S.ml + kSeqCap;
@@ -1089,6 +1229,11 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
         uint4* t4 = reinterpret_cast<uint4*>(tab);
         const uint32_t n16 = (4u << P.hlog) / 16;
         for (uint32_t i = lane; i < n16; i += 64) t4[i] = make_uint4(0, 0, 0, 0);
+        if (P.strat == 2) {
+            uint4* s4 = reinterpret_cast<uint4*>(tab_s);
+            const uint32_t m16 = (4u << P.clog) / 16;
+            for (uint32_t i = lane; i < m16; i += 64) s4[i] = make_uint4(0, 0, 0, 0);
+        }
         for (int i = lane; i < 1024; i += 64) L.score[i] = 0xFFFFFFFFu;
         for (int i = lane; i < 256; i += 64) { L.huf[0][i] = 0; L.huf[1][i] = 0; }
     }
@@ -1112,7 +1257,8 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
             S.nseq = 0; S.nlit = 0;
             ne.rep[0] = pe.rep[0]; ne.rep[1] = pe.rep[1]; ne.rep[2] = pe.rep[2];
             ZPH(t_out);
-            const uint32_t tail = fast_block(L, S, tab, P, ne.rep, src, pos, pos + len, n, serial, lane);
+            const uint32_t tail = P.strat == 2 ? dfast_block(L, S, tab, tab_s, P, ne.rep, src, pos, pos + len, lane)
+                                               : fast_block(L, S, tab, P, ne.rep, src, pos, pos + len, n, serial, lane);
             copy_bytes(S.lit + S.nlit, src + pos + len - tail, tail, lane);
             S.nlit += tail;
             ZPH(t_mf);
@@ -1121,7 +1267,7 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
             c = lsz;
             ZPH(t_lit);
             if (lsz >= 0) {
-                const int ssz = encode_sequences(L, out + lsz, bcap - uint32_t(lsz), S, lane);
+                const int ssz = encode_sequences(L, out + lsz, bcap - uint32_t(lsz), S, P.strat, lane);
                 c = ssz <= 0 ? ssz : lsz + ssz;
             }
             ZPH(t_seq);
@@ -1153,7 +1299,7 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
 // container_mode 1: native/4mc.c:467-489 (capacity n-1; an error stores the block raw)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void zstd_encode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks, uint32_t nblocks,
-                        uint8_t* work_base, int container_mode, int serial)
+                        uint8_t* work_base, int container_mode, int level, int serial)
 {
     __shared__ ZLds L;
     const uint32_t b = blockIdx.x;
@@ -1164,7 +1310,7 @@ void zstd_encode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
     uint8_t* dst = dst_base + blk.dst_off;
     const uint32_t n = blk.src_len;
     const uint32_t cap = container_mode ? (n ? n - 1 : 0) : blk.dst_cap;
-    int r = zstd_encode_frame(L, src, n, dst, cap, work_base + size_t(b) * kWorkBytes, serial != 0, lane);
+    int r = zstd_encode_frame(L, src, n, dst, cap, work_base + size_t(b) * kWorkBytes, level, serial != 0, lane);
     if (container_mode && r <= 0) { copy_bytes(dst, src, n, lane); r = int(n); }
     if (lane == 0) blocks[b].result = r;
 }
@@ -1174,11 +1320,11 @@ void zstd_encode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
 extern "C" size_t fourmc_zstd_enc_work_bytes(uint32_t n) { return size_t(n) * kWorkBytes; }
 
 extern "C" hipError_t fourmc_launch_zstd_encode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
-                                                void* d_work, int container_mode, int serial, hipStream_t stream)
+                                                void* d_work, int container_mode, int level, int serial, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(zstd_encode_kernel, dim3(n), dim3(64), 0, stream,
                        static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n,
-                       static_cast<uint8_t*>(d_work), container_mode, serial);
+                       static_cast<uint8_t*>(d_work), container_mode, level, serial);
     return hipGetLastError();
 }

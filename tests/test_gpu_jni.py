@@ -34,6 +34,7 @@ def test_jni_entry_points_through_mock_env(gpu, tmp_path):
         "Lz4_compressBytesDirectMC": helpers.orc_compress_mc(data, -1),
         "Lz4_compressBytesDirectHC": helpers.orc_compress_hc(data, 4, bound),
         "Zstd_compressBytesDirect": helpers.orc_zstd_compress(data, 1),
+        "Zstd_compressBytesDirectMC": helpers.orc_zstd_compress(data, 3),      # zstd level 3 (jniZstdCompressor.c:126)
         "Zstd_compressBytesDirectHC": helpers.orc_zstd_compress(data, 1),      # the driver passes level 1
     }
     for name, (wr, wbytes) in want.items():
@@ -42,8 +43,8 @@ def test_jni_entry_points_through_mock_env(gpu, tmp_path):
         assert np.array_equal(np.fromfile(tmp_path / (name + ".bin"), dtype=np.uint8), wbytes), name
         d, rest = out[name + "_roundtrip"]
         assert d == n and "same=1" in rest and "clen_after=0" in rest, (name, d, rest)
-    # zstd level 3 is not on the device: error code returned AND InternalError thrown, buffer length untouched
-    r3, rest = out["Zstd_compressBytesDirectMC"]
+    # a zstd level that is not on the device: error code returned AND InternalError thrown, buffer length untouched
+    r6, rest = out["Zstd_compressBytesDirectHC6"]
     assert "java/lang/InternalError: ZSTD_compress returned: " in rest and ("ulen_after=%d" % n) in rest
     for codec, fn in (("Lz4", "LZ4_decompress_safe"), ("Zstd", "LZ4_decompress_safe")):   # zstd reuses the text (jniZstdDecompressor.c:96)
         d, rest = out[codec + "_decompress_garbage"]

@@ -1,4 +1,4 @@
-"""GPU: ZSTD level-1 frame encode (4mz "fast") byte parity against the oracle port
+"""GPU: ZSTD level-1 / level-3 frame encode (4mz "fast" / "medium") byte parity against the oracle port
 (oracle/zstd_enc_port.c, itself pinned to the reference's ZSTD_compress) and the reference CLI's
 `4mc -z -1` golden manifest; every frame also decodes back on the GPU."""
 import hashlib
@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def _encode(gpu, srcs, caps):
+def _encode(gpu, srcs, caps, level=1):
     offs, pos = [], 0
     for s in srcs:
         offs.append(pos); pos += len(s) + 5
@@ -28,7 +28,7 @@ def _encode(gpu, srcs, caps):
         dsts.append(dpos); dpos += c + 40
     batch = gpu.DeviceBatch(gpu.make_blocks(offs, dsts, [len(s) for s in srcs], caps))
     d_out = torch.full((dpos + 64,), 0x5A, dtype=torch.uint8, device="cuda")
-    gpu.zstd_compress(torch.from_numpy(buf).cuda(), d_out, batch, 1)
+    gpu.zstd_compress(torch.from_numpy(buf).cuda(), d_out, batch, level)
     torch.cuda.synchronize()
     res = batch.download()["result"]
     out = d_out.cpu().numpy()
@@ -38,46 +38,51 @@ def _encode(gpu, srcs, caps):
     return res, [out[d:d + max(int(r), 0)] for d, r in zip(dsts, res)]
 
 
-def _check(gpu, names, srcs, caps, tag):
-    res, outs = _encode(gpu, srcs, caps)
+def _check(gpu, names, srcs, caps, tag, level=1):
+    res, outs = _encode(gpu, srcs, caps, level)
     for k, s, cap, r, o in zip(names, srcs, caps, res, outs):
-        want_r, want = helpers.orc_zstd_compress(s, 1, cap)
-        assert int(r) == want_r, (tag, k, len(s), cap, int(r), want_r)
+        want_r, want = helpers.orc_zstd_compress(s, level, cap)
+        assert int(r) == want_r, (tag, level, k, len(s), cap, int(r), want_r)
         assert np.array_equal(o, want), (tag, k, len(s), cap)
 
 
-def test_zstd1_bytes_identical_edge_inputs(gpu):
+@pytest.mark.parametrize("level", [1, 3])
+def test_zstd_bytes_identical_edge_inputs(gpu, level):
     inputs = helpers.edge_inputs()
     names = list(inputs)
     srcs = [inputs[k] for k in names]
-    _check(gpu, names, srcs, [helpers.zstd_bound(len(s)) for s in srcs], "bound")
-    _check(gpu, names, srcs, [max(len(s) - 1, 0) for s in srcs], "n-1")          # the capacity 4mz passes
-    _check(gpu, names, srcs, [len(s) // 3 for s in srcs], "n/3")                  # mostly dstSize_tooSmall
+    _check(gpu, names, srcs, [helpers.zstd_bound(len(s)) for s in srcs], "bound", level)
+    _check(gpu, names, srcs, [max(len(s) - 1, 0) for s in srcs], "n-1", level)   # the capacity 4mz passes
+    _check(gpu, names, srcs, [len(s) // 3 for s in srcs], "n/3", level)           # mostly dstSize_tooSmall
 
 
-def test_zstd1_size_classes_and_tails(gpu):
+@pytest.mark.parametrize("level", [1, 3])
+def test_zstd_size_classes_and_tails(gpu, level):
     """Level-table size classes (16 KiB / 128 KiB / 256 KiB), 128 KiB sub-block boundaries and tails."""
     rng = np.random.default_rng(5)
     src = helpers.corpus(3 * B, first_block=5)
     sizes = [7, 8, 18, 19, 20, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 16383, 16384, 16385, 65791, 65792,
-             131071, 131072, 131073, 131078, 131079, 131080, 262144, 262145, 262151, 393216 + 3, 524288, 524289, 1500001]
+             131071, 131072, 131073, 131078, 131079, 131080, 262144, 262145, 262151, 393216 + 3, 524288, 524289, 1500001,
+             2 * 1024 * 1024 + 77, 3 * 1024 * 1024]
     srcs = [src[int(o): int(o) + n].copy() for n, o in zip(sizes, rng.integers(0, B, len(sizes)))]
     names = ["n=%d" % n for n in sizes]
-    _check(gpu, names, srcs, [max(n - 1, 0) for n in sizes], "n-1")
-    _check(gpu, names, srcs, [helpers.zstd_bound(n) for n in sizes], "bound")
+    _check(gpu, names, srcs, [max(n - 1, 0) for n in sizes], "n-1", level)
+    _check(gpu, names, srcs, [helpers.zstd_bound(n) for n in sizes], "bound", level)
 
 
-def test_zstd1_capacity_sweep(gpu):
+@pytest.mark.parametrize("level", [1, 3])
+def test_zstd_capacity_sweep(gpu, level):
     """Capacities around the real frame size: every overflow rule of the bit and byte writers."""
     src = helpers.corpus(B, first_block=2)
     for n in (100, 1000, 20000, 140000):
         d = src[7 * n: 8 * n]
-        c, _ = helpers.orc_zstd_compress(d, 1, helpers.zstd_bound(n))
+        c, _ = helpers.orc_zstd_compress(d, level, helpers.zstd_bound(n))
         caps = list(range(max(0, c - 24), c + 10))
-        _check(gpu, ["cap=%d" % x for x in caps], [d] * len(caps), caps, "tight n=%d" % n)
+        _check(gpu, ["cap=%d" % x for x in caps], [d] * len(caps), caps, "tight n=%d" % n, level)
 
 
-def test_zstd1_corpus_blocks_golden_manifest_and_roundtrip(gpu):
+@pytest.mark.parametrize("level,key", [(1, "4mz-1"), (3, "4mz-2")])
+def test_zstd_corpus_blocks_golden_manifest_and_roundtrip(gpu, level, key):
     m = json.load(open(os.path.join(G, "corpus_manifest.json")))
     n = m["corpus"]["bytes"]
     data = helpers.corpus(n)
@@ -88,10 +93,10 @@ def test_zstd1_corpus_blocks_golden_manifest_and_roundtrip(gpu):
     batch = gpu.DeviceBatch(blocks)
     d_src = torch.from_numpy(data).cuda()
     d_dst = torch.zeros(nb * (B + 64), dtype=torch.uint8, device="cuda")
-    gpu.encode_blocks(d_src, d_dst, batch, codec=gpu.CODEC_ZSTD, level=1)
+    gpu.encode_blocks(d_src, d_dst, batch, codec=gpu.CODEC_ZSTD, level=level)
     torch.cuda.synchronize()
     got = batch.download()
-    want = m["levels"]["4mz-1"]["blocks"]
+    want = m["levels"][key]["blocks"]
     for b, (u, c, x) in enumerate(want):
         assert (int(got["src_len"][b]), int(got["result"][b]), int(got["xxh32"][b])) == (u, c, x), b
     # decode the encoded payloads back on the GPU
@@ -107,22 +112,23 @@ def test_zstd1_corpus_blocks_golden_manifest_and_roundtrip(gpu):
     assert torch.equal(d_back[:n], d_src)
 
 
-def test_cli_4mz_fast_file_equals_reference(gpu, tmp_path):
-    """`4mc -z -1 file` writes the reference CLI's .4mz bytes; -z -2 (zstd level 3) fails loudly, no CPU fallback."""
+@pytest.mark.parametrize("flag,key", [("-1", "4mz-1"), ("-2", "4mz-2")])
+def test_cli_4mz_file_equals_reference(gpu, tmp_path, flag, key):
+    """`4mc -z -1|-2 file` writes the reference CLI's .4mz bytes; -z -3 (zstd level 6) fails loudly, no CPU fallback."""
     import subprocess
     m = json.load(open(os.path.join(G, "corpus_manifest.json")))
     data = helpers.corpus(m["corpus"]["bytes"])
     src = tmp_path / "c.bin"; src.write_bytes(data.tobytes())
     out = tmp_path / "c.4mz"
-    r = subprocess.run([gpu.cli_path(), "-z", "-1", "-f", str(src), str(out)], capture_output=True)
+    r = subprocess.run([gpu.cli_path(), "-z", flag, "-f", str(src), str(out)], capture_output=True)
     assert r.returncode == 0, r.stderr
     img = out.read_bytes()
-    assert len(img) == m["levels"]["4mz-1"]["file_bytes"]
-    assert hashlib.sha256(img).hexdigest() == m["levels"]["4mz-1"]["sha256"], "file differs from the reference CLI's"
+    assert len(img) == m["levels"][key]["file_bytes"]
+    assert hashlib.sha256(img).hexdigest() == m["levels"][key]["sha256"], "file differs from the reference CLI's"
     back = tmp_path / "back.bin"
     assert subprocess.run([gpu.cli_path(), "-d", "-z", "-f", str(out), str(back)], capture_output=True).returncode == 0
     assert back.read_bytes() == data.tobytes()
-    r = subprocess.run([gpu.cli_path(), "-z", "-2", "-f", str(src), str(tmp_path / "c2.4mz")], capture_output=True)
+    r = subprocess.run([gpu.cli_path(), "-z", "-3", "-f", str(src), str(tmp_path / "c2.4mz")], capture_output=True)
     assert r.returncode != 0 and b"not on the device" in r.stderr
 
 
@@ -140,5 +146,9 @@ def test_host_zstd_compress_entry_point(gpu):
     out = np.zeros(64, np.uint8)
     r = L.fourmc_ZSTD_compress(out.ctypes.data, 30, d.ctypes.data, 1000, 1)
     assert r == (1 << 64) - 70                                     # (size_t)-ZSTD_error_dstSize_tooSmall
-    r = L.fourmc_ZSTD_compress(out.ctypes.data, 64, d.ctypes.data, 10, 3)
-    assert r > (1 << 64) - 120                                     # level 3: ZSTD_isError(), no CPU fallback
+    r = L.fourmc_ZSTD_compress(out.ctypes.data, 64, d.ctypes.data, 10, 6)
+    assert r > (1 << 64) - 120                                     # level 6: ZSTD_isError(), no CPU fallback
+    out = np.zeros(helpers.zstd_bound(300000) + 64, np.uint8)
+    r = L.fourmc_ZSTD_compress(out.ctypes.data, 1 << 30, d.ctypes.data, 300000, 3)
+    want_r, want = helpers.orc_zstd_compress(d, 3)
+    assert r == want_r and np.array_equal(out[:r], want)

@@ -8,11 +8,12 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers
 p = importlib.import_module("4mc_amd"); p.gpu_init(0)
 B = p.BLOCKSIZE
+LEVEL = int(os.environ.get("ZLEVEL", "1"))
 names = ["text", "binary", "pcm6", "sdf", "binary", "db", "text", "code", "pcm11", "dict", "xml", "random"]
 def t(fn):
     s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
     fn(); torch.cuda.synchronize(); s.record(); fn(); e.record(); torch.cuda.synchronize(); return s.elapsed_time(e)
-ENC_WORK, ENC_CTR = 754880, 131072 + 3 * 131328 + 3 * 32832 + 64 + 131072 + 64     # zstd_encode.hip: kWorkBytes, counters behind the literal buffer
+ENC_WORK, ENC_CTR = 1410240, 786432 + 3 * 131328 + 3 * 32832 + 64 + 131072 + 64     # zstd_encode.hip: kWorkBytes, counters behind the literal buffer
 DEC_WORK, DEC_CTR = 131072 + 64, 131072                                                 # zstd_decode.hip
 def counters(work, off, names):
     import ctypes as C
@@ -24,7 +25,7 @@ def run(src, nb, tag):
     offs = np.arange(nb, dtype=np.uint64) * B; lens = np.full(nb, B, np.uint32)
     enc = p.DeviceBatch(p.make_blocks(offs, offs, lens, lens))
     stage = torch.empty(nb * B, dtype=torch.uint8, device="cuda")
-    te = t(lambda: p.encode_blocks(src, stage, enc, codec=p.CODEC_ZSTD, level=1))
+    te = t(lambda: p.encode_blocks(src, stage, enc, codec=p.CODEC_ZSTD, level=LEVEL))
     r = enc.download()
     dec = p.DeviceBatch(p.make_blocks(offs, offs, r["result"].astype(np.uint32), lens, r["xxh32"]))
     out = torch.empty(nb * B + 64, dtype=torch.uint8, device="cuda")
