@@ -23,7 +23,8 @@ class EngineError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libhadoop-4mc.so")
+    # FOURMC_LIB: load an alternative build (profiling variants, tools/k2_phases.py); default = the in-tree library
+    return os.environ.get("FOURMC_LIB") or os.path.join(_HERE, "lib", "libhadoop-4mc.so")
 
 
 def cli_path():

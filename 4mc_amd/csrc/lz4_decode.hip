@@ -273,6 +273,12 @@ __device__ __forceinline__ int lz4_decode_block_fast(const uint8_t* src, int csi
     // store outstanding) and never for a store acknowledgement.  Sources that fall into the
     // pending step are forwarded from its registers.
     uint32_t pv = 0; int p_base = 0, p_n = 0;
+#ifdef K2_PROF   // one-off phase profile of the batch decoder (side build, make prof): cycles per phase, printed by block 0
+    uint64_t pt_parse = 0, pt_map = 0, pt_copy = 0, pt_gen = 0, pt0 = __builtin_readcyclecounter(), pt1; uint32_t n_batch = 0, n_step = 0, n_gen = 0;
+#define K1PH(acc) do { pt1 = __builtin_readcyclecounter(); acc += pt1 - pt0; pt0 = pt1; } while (0)
+#else
+#define K1PH(acc) do { } while (0)
+#endif
 
     for (;;) {
         // ---------------------------------------------------------------- batch of sequences inside one window
@@ -300,6 +306,7 @@ __device__ __forceinline__ int lz4_decode_block_fast(const uint8_t* src, int csi
                 tokmask |= 1ull << pos;
                 pos = uint32_t(__builtin_amdgcn_readlane(int(nxt), int(pos)));
             }
+            K1PH(pt_parse);
             if (tokmask) {
                 bool is_tok = (tokmask >> lane) & 1;
                 uint32_t sz = is_tok ? L + ml : 0;
@@ -323,6 +330,7 @@ __device__ __forceinline__ int lz4_decode_block_fast(const uint8_t* src, int csi
                 if (is_tok) own[ostart] = uint8_t(lane + 1);
                 uint32_t carry = 0;
                 if (p_n == 0) p_base = op;
+                K1PH(pt_map);
                 for (uint32_t c0 = 0; c0 < T; c0 += 64) {
                     const uint32_t o = c0 + lane;
                     const bool live = o < T;
@@ -363,6 +371,10 @@ __device__ __forceinline__ int lz4_decode_block_fast(const uint8_t* src, int csi
                 }
                 op += int(T);
                 ip += int(pos);
+#ifdef K2_PROF
+                n_batch++; n_step += (T + 63) / 64;
+#endif
+                K1PH(pt_copy);
                 continue;
             }
         }
@@ -371,6 +383,13 @@ __device__ __forceinline__ int lz4_decode_block_fast(const uint8_t* src, int csi
         p_n = 0; p_base = 0;
         if (ip >= iend) return kRetry;
         if (ip < s.la_pos || ip + 24 > s.la_pos + 64) s.reload(ip);
+#ifdef K2_PROF
+        n_gen++;
+        if (ip + 64 >= iend && lane == 0) {      // tools/k2_phases.py leaves 64 spare bytes behind the output
+            uint64_t* c = reinterpret_cast<uint64_t*>(dst + cap);
+            c[0] = pt_parse; c[1] = pt_map; c[2] = pt_copy; c[3] = pt_gen; c[4] = n_batch; c[5] = n_step; c[6] = n_gen;
+        }
+#endif
         const uint32_t token = s.get(ip); ip++;
         int lit = int(token >> 4), mlen = int(token & 15);
         if (lit == 15) { if (!more_len(s, ip, iend - 15, true, lit)) return kRetry; }
@@ -388,6 +407,7 @@ __device__ __forceinline__ int lz4_decode_block_fast(const uint8_t* src, int csi
         if (off == 0 || off > op || op + mlen > oend - 5) return kRetry;
         copy_match(dst, op, off, mlen, lane);
         op += mlen;
+        K1PH(pt_gen);
     }
 }
 

@@ -69,6 +69,12 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                                 uint32_t* tab32, uint32_t* score, const int lane)
 {
     uint16_t* tab16 = reinterpret_cast<uint16_t*>(tab32);
+#ifdef K2_PROF   // one-off phase profile (tools/k2_phases.py builds a side library with -DK2_PROF): cycles per phase
+    uint64_t pt_search = 0, pt_ext = 0, pt_match = 0, pt0 = __builtin_readcyclecounter(), pt1;
+#define K2PH(acc) do { pt1 = __builtin_readcyclecounter(); acc += pt1 - pt0; pt0 = pt1; } while (0)
+#else
+#define K2PH(acc) do { } while (0)
+#endif
     const bool limited = cap < n + n / 255 + 16;                       // lz4.c:1352
     uint32_t op = 0, anchor = 0;
 
@@ -166,6 +172,7 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                 k0 = U(k0 + e);
                 if (e == int(width) && width < 64) width *= 2;
             }
+            K2PH(pt_search);
             // ------------------------------------------------------------ catch up (lz4.c:1080)
             {
                 // forward bytes already known from the hit registers (relative to the ORIGINAL ip)
@@ -215,6 +222,7 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                     } else copy_bytes(dst + op, src + anchor, lit, lane);
                     op += lit;
                 }
+                K2PH(pt_ext);
                 for (;;) {   // _next_match (lz4.c:1109-1200)
                     const uint32_t off = ip - cand;
                     if (lane == 0) { dst[op] = uint8_t(off); dst[op + 1] = uint8_t(off >> 8); }
@@ -293,6 +301,7 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                 }
             }
             sp = U(ip + 1); anchor = U(anchor); op = U(op);
+            K2PH(pt_match);
         }
     }
 last_literals:
@@ -310,6 +319,9 @@ last_literals:
         copy_bytes(dst + op, src + anchor, run, lane);
         op += run;
     }
+#ifdef K2_PROF
+    if (lane == 0 && n == (4 << 20)) { uint64_t* c = reinterpret_cast<uint64_t*>(dst + n - 32); c[0] = pt_search; c[1] = pt_ext; c[2] = pt_match; }
+#endif
     return int(op);
 }
 

@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=int(os.environ.get("FOURMC_BENCH_BLOCKS", 2048)),
                     help="4 MiB blocks per GPU (2048 = 8 GiB, BASELINE configs[1])")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configs (4mz Fast/Medium, 4mc High) timed after the headline")
     args = ap.parse_args()
 
     import torch
@@ -204,6 +205,27 @@ def main():
         return {"lz4_encode": enc_total - x_out, "xxh32_out": x_out, "pack": pack,
                 "xxh32_verify": x_ver, "lz4_decode": dec_total - x_ver}
 
+    def other_configs():
+        """BASELINE configs[2] (4mz Fast = zstd level 1) and configs[3] (4mc High = LZ4 HC level 4), plus 4mz Medium
+        (zstd level 3), on the same resident corpus: one launch each, HIP events on the launch stream; every
+        compressed batch is decoded back and compared.  Reported beside the headline, never part of `value`."""
+        out = {}
+        def timed(fn):
+            a, b = ev(), ev()
+            torch.cuda.synchronize(); a.record(); fn(); b.record(); torch.cuda.synchronize()
+            return a.elapsed_time(b)
+        for name, codec, level in (("4mz_fast_zstd1", p.CODEC_ZSTD, 1), ("4mz_medium_zstd3", p.CODEC_ZSTD, 3), ("4mc_high_lz4hc4", p.CODEC_LZ4_HC, 4)):
+            eb = p.DeviceBatch(p.make_blocks(offs, offs, lens, lens), dev)
+            t_enc = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_encode_blocks(d_src.data_ptr(), d_stage.data_ptr(), eb.ptr, nb, codec, level, sp), name))
+            r = eb.download()
+            cs = r["result"].astype(np.int64)
+            db = p.DeviceBatch(p.make_blocks(offs, offs, r["result"].astype(np.uint32), lens, r["xxh32"]), dev)
+            t_dec = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_stage.data_ptr(), d_out.data_ptr(), db.ptr, nb, codec, sp), name))
+            assert bool(torch.equal(d_out[: nb * B], d_src)), name + ": round trip failed"
+            out[name] = {"compress_GBps": round(nb * B / t_enc / 1e6, 3), "decompress_GBps": round(nb * B / t_dec / 1e6, 3),
+                         "ratio": round(nb * B / float((cs + 12).sum()), 4), "encode_blocks_ms": round(t_enc, 2), "decode_blocks_ms": round(t_dec, 2)}
+        return out
+
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
@@ -272,6 +294,8 @@ def main():
             "roofline": roof(dom, alg),
             "roofline_decode": roof("lz4_decode", alg_dec),
         }
+        if world == 1 and not args.no_extras:
+            line["other_configs"] = other_configs()
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(helpers, base, base_blocks)
         else:

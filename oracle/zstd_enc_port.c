@@ -3,8 +3,9 @@
  * native/zstd) for the one-shot, no-dictionary, known-size call 4mz makes per block
  * (native/4mc.c:467: ZSTD_compress(out+12, n-1, in, n, level)).  TEST INFRASTRUCTURE, NOT PRODUCT.
  *
- * Covered: strategy ZSTD_fast (4mz "fast" = zstd level 1) and ZSTD_dfast (4mz "medium" = zstd level 3),
- * every size class of the level table.  Other levels return ORC_ZSTD_UNSUPPORTED.
+ * Covered: ZSTD_fast (4mz "fast" = zstd level 1), ZSTD_dfast ("medium" = level 3), ZSTD_lazy / lazy2 with the row-hash
+ * and hash-chain match finders ("high" = level 6: every size class; "ultra" = level 12: inputs > 256 KiB only - its
+ * smaller size classes use btlazy2 / btopt, which are not restated).  Anything else returns ORC_ZSTD_UNSUPPORTED.
  *
  *   parameters   ZSTD_getCParams_internal        compress/zstd_compress.c:6465-6488, clevels.h:25-130,
  *                ZSTD_adjustCParams_internal     compress/zstd_compress.c:1335-1399
@@ -75,6 +76,7 @@ typedef struct {
     uint32_t dbits[64];          /* deltaNbBits   */
     int32_t  dfind[64];          /* deltaFindState */
     uint32_t log;
+    uint32_t maxsym;             /* ZSTD_getFSEMaxSymbolValue */
 } fse_ct;
 
 static unsigned hist(uint32_t* count, unsigned* max_sym, const uint8_t* s, size_t n)   /* hist.c:31-60 */
@@ -225,7 +227,7 @@ static void fse_build(fse_ct* ct, const int16_t* norm, unsigned max_sym, uint32_
     uint16_t cumul[66];
     uint8_t symbol_at[1 << 9];
     uint32_t high = size - 1, pos = 0, total = 0;
-    ct->log = log;
+    ct->log = log; ct->maxsym = max_sym;
     cumul[0] = 0;
     for (unsigned s = 0; s <= max_sym; s++) {
         if (norm[s] == -1) { cumul[s + 1] = cumul[s] + 1; symbol_at[high--] = (uint8_t)s; }
@@ -251,7 +253,7 @@ static void fse_build(fse_ct* ct, const int16_t* norm, unsigned max_sym, uint32_
 }
 
 static void fse_build_rle(fse_ct* ct, unsigned sym)
-{ ct->log = 0; ct->next[0] = ct->next[1] = 0; ct->dbits[sym] = 0; ct->dfind[sym] = 0; }
+{ ct->log = 0; ct->maxsym = sym; ct->next[0] = ct->next[1] = 0; ct->dbits[sym] = 0; ct->dfind[sym] = 0; }
 
 static uint32_t fse_first_state(const fse_ct* ct, unsigned sym)              /* FSE_initCState2 */
 {
@@ -539,7 +541,7 @@ static int64_t huf_compress(uint8_t* dst, size_t cap, const uint8_t* src, size_t
 }
 
 /* ------------------------------------------------------------------------------------------------ literals */
-typedef struct { huf_ct huf; int huf_repeat; uint32_t rep[3]; } zentropy;
+typedef struct { huf_ct huf; int huf_repeat; uint32_t rep[3]; fse_ct fse[3]; int fse_repeat[3]; /* ll, of, ml */ } zentropy;
 
 static int64_t raw_literals(uint8_t* dst, size_t cap, const uint8_t* src, size_t n, int rle)
 {
@@ -555,7 +557,7 @@ static int64_t raw_literals(uint8_t* dst, size_t cap, const uint8_t* src, size_t
 }
 
 static int64_t compress_literals(const zentropy* prev, zentropy* next, uint8_t* dst, size_t cap,
-                                 const uint8_t* src, size_t n, int suspect)
+                                 const uint8_t* src, size_t n, int suspect, uint32_t strat)
 {
     const size_t min_gain = (n >> 6) + 2, lh = 3 + (n >= 1024) + (n >= 16384);
     int single = n < 256, repeat = prev->huf_repeat, type = 2;
@@ -564,7 +566,7 @@ static int64_t compress_literals(const zentropy* prev, zentropy* next, uint8_t* 
     if (n <= (size_t)(prev->huf_repeat == REP_VALID ? 6 : 63)) return raw_literals(dst, cap, src, n, 0);
     if (cap < lh + 1) return ERR_TOOSMALL;
     if (repeat == REP_VALID && lh == 3) single = 1;
-    c = huf_compress(dst + lh, cap - lh, src, n, !single, &next->huf, &repeat, n <= 1024 /* strategy < lazy */, suspect);
+    c = huf_compress(dst + lh, cap - lh, src, n, !single, &next->huf, &repeat, strat < 4 /* ZSTD_lazy */ && n <= 1024, suspect);
     if (repeat != REP_NONE) type = 3;
     if (c <= 0 || (size_t)c >= n - min_gain) { next->huf = prev->huf; return raw_literals(dst, cap, src, n, 0); }
     if (c == 1) { next->huf = prev->huf; return raw_literals(dst, cap, src, n, 1); }
@@ -602,25 +604,96 @@ static unsigned ml_code(uint32_t v)
     return 42;
 }
 
-/* ZSTD_selectEncodingType, strategy < lazy, no dictionary (repeat mode is never "valid") */
-static uint32_t g_unused;
-static int select_type(const uint32_t* count, unsigned max, size_t most, size_t nseq, uint32_t def_log, int def_ok, uint32_t strat)
+/* floor(-log2(i / 256) * 256): kInverseProbabilityLog256 of zstd_compress_sequences.c:19-42 */
+static unsigned inv_prob_log256(unsigned i)
 {
-    (void)count; (void)max; (void)g_unused;
-    if (most == nseq) return (def_ok && nseq <= 2) ? 0 : 1;
-    if (def_ok) {
-        const size_t dyn_min = (((size_t)1 << def_log) * (10 - strat)) >> 3;      /* ZSTD_fast = 1, ZSTD_dfast = 2 */
-        if (nseq < dyn_min || most < (nseq >> (def_log - 1))) return 0;
+    static unsigned tab[256];
+    if (!tab[1]) {
+        /* fixed point log2 by repeated squaring, exact enough for 11 fractional bits over 1..255 */
+        for (unsigned v = 1; v < 256; v++) {
+            uint64_t x = (uint64_t)v << 56;                 /* v / 256 in 0.64 fixed point */
+            unsigned ip = 0, r = 0;
+            while (!(x >> 63)) { x <<= 1; ip++; }           /* v/256 = 2^-(ip+1) * m, m in [1,2) held as 1.63 fixed point */
+            for (int k = 0; k < 24; k++) {                  /* fractional bits of log2(m) */
+                const __uint128_t sq = (__uint128_t)x * x;
+                x = (uint64_t)(sq >> 63);
+                r <<= 1;
+                if ((sq >> 127) & 1) { r |= 1; x = (uint64_t)(sq >> 64); }   /* m^2 >= 2: bit set, halve */
+            }
+            /* -log2(v/256) = ip + 1 - frac, frac = r / 2^24 */
+            {
+                const uint64_t neg = ((uint64_t)(ip + 1) << 24) - r;     /* 24 fractional bits */
+                tab[v] = (unsigned)(neg >> 16);                    /* * 256, floor */
+            }
+        }
     }
+    return tab[i];
+}
+
+#define COST_ERR ((size_t)-1)
+
+/* ZSTD_fseBitCost (:100-128) with FSE_bitCost (common/fse.h:570-586) */
+static size_t fse_bit_cost(const fse_ct* ct, const uint32_t* count, unsigned max)
+{
+    size_t cost = 0;
+    if (ct->maxsym < max) return COST_ERR;
+    for (unsigned s = 0; s <= max; s++) {
+        const uint32_t log = ct->log, bad = (log + 1) << 8;
+        const uint32_t min_bits = ct->dbits[s] >> 16, threshold = (min_bits + 1) << 16;
+        const uint32_t delta = threshold - (ct->dbits[s] + (1u << log));
+        const uint32_t bits = (min_bits + 1) * 256 - ((delta << 8) >> log);
+        if (!count[s]) continue;
+        if (bits >= bad) return COST_ERR;
+        cost += (size_t)count[s] * bits;
+    }
+    return cost >> 8;
+}
+
+/* ZSTD_selectEncodingType (zstd_compress_sequences.c:153-239), no dictionary: 0 basic, 1 rle, 2 compressed, 3 repeat */
+static int select_type(int* repeat, const uint32_t* count, unsigned max, size_t most, size_t nseq, uint32_t fse_log,
+                       const fse_ct* prev, const int16_t* def_norm, uint32_t def_log, int def_ok, uint32_t strat)
+{
+    if (most == nseq) { *repeat = REP_NONE; return (def_ok && nseq <= 2) ? 0 : 1; }
+    if (strat < 4) {                                               /* < ZSTD_lazy */
+        if (def_ok) {
+            const size_t dyn_min = (((size_t)1 << def_log) * (10 - strat)) >> 3;
+            if (*repeat == REP_VALID && nseq < 1000) return 3;
+            if (nseq < dyn_min || most < (nseq >> (def_log - 1))) { *repeat = REP_NONE; return 0; }
+        }
+    } else {
+        size_t basic = COST_ERR, rep = COST_ERR, nc, comp = 0;
+        if (def_ok) {                                              /* ZSTD_crossEntropyCost */
+            basic = 0;
+            for (unsigned s = 0; s <= max; s++) basic += (size_t)count[s] * inv_prob_log256((unsigned)(def_norm[s] != -1 ? def_norm[s] : 1) << (8 - def_log));
+            basic >>= 8;
+        }
+        if (*repeat != REP_NONE) rep = fse_bit_cost(prev, count, max);
+        {                                                          /* ZSTD_NCountCost + ZSTD_entropyCost */
+            uint8_t tmp[512]; int16_t norm[53];
+            const uint32_t log = fse_optimal_log(fse_log, nseq, max, 2);
+            fse_normalize(norm, log, count, nseq, max, nseq >= 2048);
+            nc = (size_t)fse_write_ncount(tmp, sizeof tmp, norm, max, log);
+            for (unsigned s = 0; s <= max; s++) {
+                unsigned q = (unsigned)((256 * (uint64_t)count[s]) / nseq);
+                if (count[s] && !q) q = 1;
+                comp += (size_t)count[s] * inv_prob_log256(q);
+            }
+            comp = (nc << 3) + (comp >> 8);
+        }
+        if (basic <= rep && basic <= comp) { *repeat = REP_NONE; return 0; }
+        if (rep <= comp) return 3;
+    }
+    *repeat = REP_CHECK;
     return 2;
 }
 
 /* ZSTD_buildCTable: bytes of table description written, or ERR_* */
-static int build_seq_table(uint8_t* dst, size_t cap, fse_ct* ct, uint32_t fse_log, int type, uint32_t* count, unsigned max,
+static int build_seq_table(uint8_t* dst, size_t cap, fse_ct* ct, const fse_ct* prev, uint32_t fse_log, int type, uint32_t* count, unsigned max,
                            const uint8_t* codes, size_t nseq, const int16_t* def_norm, uint32_t def_log, unsigned def_max)
 {
     if (type == 1) { fse_build_rle(ct, max); if (!cap) return ERR_TOOSMALL; dst[0] = codes[0]; return 1; }
     if (type == 0) { fse_build(ct, def_norm, def_max, def_log); return 0; }
+    if (type == 3) { *ct = *prev; return 0; }
     {
         int16_t norm[53];
         size_t n1 = nseq;
@@ -637,16 +710,17 @@ static int build_seq_table(uint8_t* dst, size_t cap, fse_ct* ct, uint32_t fse_lo
 }
 
 /* sequences section after the literals; returns bytes or 0 / ERR_* (ZSTD_entropyCompressSeqStore_internal tail) */
-static int64_t encode_sequences(uint8_t* dst, size_t cap, const zseq* seq, size_t nseq, uint8_t* llc, uint8_t* ofc, uint8_t* mlc, uint32_t strat)
+static int64_t encode_sequences(uint8_t* dst, size_t cap, const zseq* seq, size_t nseq, uint8_t* llc, uint8_t* ofc, uint8_t* mlc, uint32_t strat,
+                                const zentropy* pe, zentropy* ne)
 {
     size_t o = 0, last_count = 0;
-    fse_ct ll, of, ml;
+    fse_ct* const ll = &ne->fse[0]; fse_ct* const of = &ne->fse[1]; fse_ct* const ml = &ne->fse[2];
     uint32_t count[64];
     if (cap < 4) return ERR_TOOSMALL;
     if (nseq < 128) dst[o++] = (uint8_t)nseq;
     else if (nseq < 0x7F00) { dst[o++] = (uint8_t)((nseq >> 8) + 0x80); dst[o++] = (uint8_t)nseq; }
     else { dst[o++] = 0xFF; dst[o++] = (uint8_t)(nseq - 0x7F00); dst[o++] = (uint8_t)((nseq - 0x7F00) >> 8); }
-    if (!nseq) return (int64_t)o;
+    if (!nseq) { memcpy(ne->fse, pe->fse, sizeof ne->fse); memcpy(ne->fse_repeat, pe->fse_repeat, sizeof ne->fse_repeat); return (int64_t)o; }
     for (size_t i = 0; i < nseq; i++) { llc[i] = (uint8_t)ll_code(seq[i].ll); ofc[i] = (uint8_t)hibit(seq[i].off); mlc[i] = (uint8_t)ml_code(seq[i].ml); }
     {
         uint8_t* const head = dst + o++;
@@ -654,43 +728,46 @@ static int64_t encode_sequences(uint8_t* dst, size_t cap, const zseq* seq, size_
         unsigned max;
         size_t most;
         max = 35; most = hist(count, &max, llc, nseq);
-        tll = select_type(count, max, most, nseq, 6, 1, strat);
-        r = build_seq_table(dst + o, cap - o, &ll, 9, tll, count, max, llc, nseq, kLLNorm, 6, 35);
+        ne->fse_repeat[0] = pe->fse_repeat[0];
+        tll = select_type(&ne->fse_repeat[0], count, max, most, nseq, 9, &pe->fse[0], kLLNorm, 6, 1, strat);
+        r = build_seq_table(dst + o, cap - o, ll, &pe->fse[0], 9, tll, count, max, llc, nseq, kLLNorm, 6, 35);
         if (r < 0) return r;
         if (tll == 2) last_count = (size_t)r;
         o += (size_t)r;
         max = 31; most = hist(count, &max, ofc, nseq);
-        tof = select_type(count, max, most, nseq, 5, max <= 28, strat);
-        r = build_seq_table(dst + o, cap - o, &of, 8, tof, count, max, ofc, nseq, kOFNorm, 5, 28);
+        ne->fse_repeat[1] = pe->fse_repeat[1];
+        tof = select_type(&ne->fse_repeat[1], count, max, most, nseq, 8, &pe->fse[1], kOFNorm, 5, max <= 28, strat);
+        r = build_seq_table(dst + o, cap - o, of, &pe->fse[1], 8, tof, count, max, ofc, nseq, kOFNorm, 5, 28);
         if (r < 0) return r;
         if (tof == 2) last_count = (size_t)r;
         o += (size_t)r;
         max = 52; most = hist(count, &max, mlc, nseq);
-        tml = select_type(count, max, most, nseq, 6, 1, strat);
-        r = build_seq_table(dst + o, cap - o, &ml, 9, tml, count, max, mlc, nseq, kMLNorm, 6, 52);
+        ne->fse_repeat[2] = pe->fse_repeat[2];
+        tml = select_type(&ne->fse_repeat[2], count, max, most, nseq, 9, &pe->fse[2], kMLNorm, 6, 1, strat);
+        r = build_seq_table(dst + o, cap - o, ml, &pe->fse[2], 9, tml, count, max, mlc, nseq, kMLNorm, 6, 52);
         if (r < 0) return r;
         if (tml == 2) last_count = (size_t)r;
         o += (size_t)r;
-        *head = (uint8_t)((tll << 6) + (tof << 4) + (tml << 2));
+        *head = (uint8_t)((tll << 6) + (tof << 4) + (tml << 2));      /* set_basic 0, set_rle 1, set_compressed 2, set_repeat 3 */
     }
     {   /* ZSTD_encodeSequences_body: last sequence first */
         bitw w;
         size_t i = nseq - 1, bytes;
         uint32_t sml, sof, sll;
         if (!bw_init(&w, dst + o, cap - o)) return ERR_TOOSMALL;
-        sml = fse_first_state(&ml, mlc[i]); sof = fse_first_state(&of, ofc[i]); sll = fse_first_state(&ll, llc[i]);
+        sml = fse_first_state(ml, mlc[i]); sof = fse_first_state(of, ofc[i]); sll = fse_first_state(ll, llc[i]);
         bw_put(&w, seq[i].ll, kLLBits[llc[i]]);
         bw_put(&w, seq[i].ml, kMLBits[mlc[i]]);
         bw_put(&w, seq[i].off, ofc[i]);
         while (i-- > 0) {
-            sof = fse_encode(&w, &of, sof, ofc[i]);
-            sml = fse_encode(&w, &ml, sml, mlc[i]);
-            sll = fse_encode(&w, &ll, sll, llc[i]);
+            sof = fse_encode(&w, of, sof, ofc[i]);
+            sml = fse_encode(&w, ml, sml, mlc[i]);
+            sll = fse_encode(&w, ll, sll, llc[i]);
             bw_put(&w, seq[i].ll, kLLBits[llc[i]]);
             bw_put(&w, seq[i].ml, kMLBits[mlc[i]]);
             bw_put(&w, seq[i].off, ofc[i]);
         }
-        bw_put(&w, sml, ml.log); bw_put(&w, sof, of.log); bw_put(&w, sll, ll.log);
+        bw_put(&w, sml, ml->log); bw_put(&w, sof, of->log); bw_put(&w, sll, ll->log);
         bytes = bw_close(&w);
         if (!bytes) return ERR_TOOSMALL;
         o += bytes;
@@ -702,7 +779,9 @@ static int64_t encode_sequences(uint8_t* dst, size_t cap, const zseq* seq, size_
 /* ------------------------------------------------------------------------------------------------ match finder */
 typedef struct {
     uint32_t* table;              /* fast: the hash table; dfast: the long (8-byte) hash table */
-    uint32_t* small;              /* dfast: the short hash table (the reference's chainTable) */
+    uint32_t* small;              /* dfast: the short hash table; lazy with hash chains: the chain table */
+    uint8_t*  tags;               /* row match finder: tag table, 2 bytes per hash-table entry (head byte + tags at +16) */
+    uint32_t  hash_cache[8], next_to_update, low_limit, dict_limit;   /* window.lowLimit / dictLimit as indices */
     zparams   p;
     zseq*     seq;  size_t nseq;
     uint8_t*  lit;  size_t nlit;
@@ -906,13 +985,210 @@ cleanup:
     return end - anchor;
 }
 
+/* ------------------------------------------------------------------------------------------------ lazy parsers
+ * ZSTD_compressBlock_lazy_generic (compress/zstd_lazy.c:1486-1737, noDict) with the row-hash match finder
+ * (ZSTD_RowFindBestMatch :1139-1250, row update :885-946, hash cache :842-883) or the hash-chain one
+ * (ZSTD_HcFindBestMatch :649-730).  Which one: ZSTD_resolveRowMatchFinderMode (zstd_compress.c:232-248). */
+static uint32_t lz_mls(const zmatch* m) { return m->p.mml < 4 ? 4 : m->p.mml > 6 ? 6 : m->p.mml; }
+static uint32_t lz_rowlog(const zmatch* m) { return m->p.slog < 4 ? 4 : m->p.slog > 6 ? 6 : m->p.slog; }
+static uint32_t row_hash(const zmatch* m, const uint8_t* s, uint32_t idx)
+{ return zhash(s + idx - 2, m->p.hlog - lz_rowlog(m) + 8, lz_mls(m)); }
+
+static void row_fill_cache(zmatch* m, const uint8_t* s, uint32_t idx, int64_t limit_pos)
+{
+    const int64_t at = (int64_t)idx - 2;
+    const uint32_t n = at > limit_pos ? 0 : (uint32_t)(limit_pos - at + 1);
+    const uint32_t lim = idx + (n < 8 ? n : 8);
+    for (; idx < lim; idx++) m->hash_cache[idx & 7] = row_hash(m, s, idx);
+}
+
+static uint32_t row_next_hash(zmatch* m, const uint8_t* s, uint32_t idx)
+{
+    const uint32_t fresh = row_hash(m, s, idx + 8), h = m->hash_cache[idx & 7];
+    m->hash_cache[idx & 7] = fresh;
+    return h;
+}
+
+static void row_insert(zmatch* m, uint32_t hash, uint32_t idx)
+{
+    const uint32_t rowlog = lz_rowlog(m), mask = (1u << rowlog) - 1, rel = (hash >> 8) << rowlog;
+    uint8_t* const tag_row = m->tags + 2 * (size_t)rel;
+    const uint32_t pos = (tag_row[0] - 1u) & mask;
+    tag_row[0] = (uint8_t)pos;
+    tag_row[16 + pos] = (uint8_t)hash;
+    m->table[rel + pos] = idx;
+}
+
+static void row_update(zmatch* m, const uint8_t* s, uint32_t target)         /* ZSTD_row_update_internal, useCache = 1 */
+{
+    uint32_t idx = m->next_to_update;
+    if (target - idx > 384) {
+        for (const uint32_t bound = idx + 96; idx < bound; idx++) row_insert(m, row_next_hash(m, s, idx), idx);
+        idx = target - 32;
+        row_fill_cache(m, s, idx, (int64_t)target - 2 + 1);
+    }
+    for (; idx < target; idx++) row_insert(m, row_next_hash(m, s, idx), idx);
+    m->next_to_update = target;
+}
+
+static uint32_t lz_low_limit(const zmatch* m, uint32_t curr)
+{
+    const uint32_t max_dist = 1u << m->p.wlog;
+    return curr - m->low_limit > max_dist ? curr - max_dist : m->low_limit;
+}
+
+static size_t row_search(zmatch* m, const uint8_t* s, size_t ip, size_t end, uint32_t* ofb)
+{
+    const uint32_t curr = (uint32_t)ip + 2, low = lz_low_limit(m, curr);
+    const uint32_t rowlog = lz_rowlog(m), entries = 1u << rowlog, mask = entries - 1;
+    uint32_t attempts = 1u << (m->p.slog < rowlog ? m->p.slog : rowlog);
+    uint32_t cand[64], ncand = 0;
+    size_t ml = 3;
+    row_update(m, s, curr);
+    {
+        const uint32_t hash = row_next_hash(m, s, curr), rel = (hash >> 8) << rowlog, tag = hash & 255;
+        uint8_t* const tag_row = m->tags + 2 * (size_t)rel;
+        const uint32_t head = tag_row[0] & mask;
+        for (uint32_t i = 0; i < entries && attempts > 0; i++) {        /* newest first: the rotated SSE match mask */
+            const uint32_t pos = (head + i) & mask;
+            if (tag_row[16 + pos] != tag) continue;
+            if (m->table[rel + pos] < low) break;
+            cand[ncand++] = m->table[rel + pos];
+            attempts--;
+        }
+        {   /* the current position goes in as well (:1229-1234) */
+            const uint32_t pos = (tag_row[0] - 1u) & mask;
+            tag_row[0] = (uint8_t)pos; tag_row[16 + pos] = (uint8_t)tag;
+            m->table[rel + pos] = m->next_to_update++;
+        }
+    }
+    for (uint32_t k = 0; k < ncand; k++) {
+        const size_t match = cand[k] - 2;
+        size_t cur = 0;
+        if (s[match + ml] == s[ip + ml]) cur = count_eq(s, ip, match, end);
+        if (cur > ml) { ml = cur; *ofb = curr - cand[k] + 3; if (ip + cur == end) break; }
+    }
+    return ml;
+}
+
+static size_t hc_search(zmatch* m, const uint8_t* s, size_t ip, size_t end, uint32_t* ofb)
+{
+    const uint32_t curr = (uint32_t)ip + 2, low = lz_low_limit(m, curr), mls = lz_mls(m);
+    const uint32_t chain_size = 1u << m->p.clog, cmask = chain_size - 1;
+    const uint32_t min_chain = curr > chain_size ? curr - chain_size : 0;
+    uint32_t attempts = 1u << m->p.slog, idx = m->next_to_update, mi;
+    size_t ml = 3;
+    for (; idx < curr; idx++) {                                       /* ZSTD_insertAndFindFirstIndex_internal */
+        const uint32_t h = zhash(s + idx - 2, m->p.hlog, mls);
+        m->small[idx & cmask] = m->table[h];
+        m->table[h] = idx;
+    }
+    m->next_to_update = curr;
+    mi = m->table[zhash(s + ip, m->p.hlog, mls)];
+    for (; (mi >= low) & (attempts > 0); attempts--) {
+        const size_t match = mi - 2;
+        size_t cur = 0;
+        if (s[match + ml] == s[ip + ml]) cur = count_eq(s, ip, match, end);
+        if (cur > ml) { ml = cur; *ofb = curr - mi + 3; if (ip + cur == end) break; }
+        if (mi <= min_chain) break;
+        mi = m->small[mi & cmask];
+    }
+    return ml;
+}
+
+static size_t lazy_block(zmatch* m, uint32_t rep[3], const uint8_t* s, size_t start, size_t end, int depth, int use_row)
+{
+    const int64_t ilimit = (int64_t)end - 8 - (use_row ? 8 : 0);
+    const uint32_t prefix_idx = m->dict_limit;
+    const size_t prefix = prefix_idx - 2;
+    size_t ip = start, anchor = start;
+    uint32_t rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0;
+#define SEARCH(pos_, ofb_) (use_row ? row_search(m, s, (pos_), end, (ofb_)) : hc_search(m, s, (pos_), end, (ofb_)))
+    ip += (ip == prefix);
+    {
+        const uint32_t c = (uint32_t)ip + 2, max_dist = 1u << m->p.wlog;
+        const uint32_t low = c - m->dict_limit > max_dist ? c - max_dist : m->dict_limit;
+        const uint32_t max_rep = c - low;
+        if (rep2 > max_rep) { saved2 = rep2; rep2 = 0; }
+        if (rep1 > max_rep) { saved1 = rep1; rep1 = 0; }
+    }
+    if (use_row) row_fill_cache(m, s, m->next_to_update, ilimit);
+    while ((int64_t)ip < ilimit) {
+        size_t ml = 0, at = ip + 1;
+        uint32_t ofb = 1;
+        if ((rep1 > 0) & (rd32(s + ip + 1 - rep1) == rd32(s + ip + 1))) {
+            ml = count_eq(s, ip + 1 + 4, ip + 1 + 4 - rep1, end) + 4;
+            if (depth == 0) goto store;
+        }
+        {
+            uint32_t found = 999999999;
+            const size_t ml2 = SEARCH(ip, &found);
+            if (ml2 > ml) { ml = ml2; at = ip; ofb = found; }
+        }
+        if (ml < 4) { ip += ((ip - anchor) >> 8) + 1; continue; }
+        if (depth >= 1)
+            while ((int64_t)ip < ilimit) {
+                ip++;
+                if ((rep1 > 0) & (rd32(s + ip) == rd32(s + ip - rep1))) {
+                    const size_t mr = count_eq(s, ip + 4, ip + 4 - rep1, end) + 4;
+                    const int g2 = (int)(mr * 3), g1 = (int)(ml * 3 - (size_t)hibit(ofb) + 1);
+                    if (mr >= 4 && g2 > g1) { ml = mr; ofb = 1; at = ip; }
+                }
+                {
+                    uint32_t cand = 999999999;
+                    const size_t ml2 = SEARCH(ip, &cand);
+                    const int g2 = (int)(ml2 * 4 - (size_t)hibit(cand)), g1 = (int)(ml * 4 - (size_t)hibit(ofb) + 4);
+                    if (ml2 >= 4 && g2 > g1) { ml = ml2; ofb = cand; at = ip; continue; }
+                }
+                if (depth == 2 && (int64_t)ip < ilimit) {
+                    ip++;
+                    if ((rep1 > 0) & (rd32(s + ip) == rd32(s + ip - rep1))) {
+                        const size_t mr = count_eq(s, ip + 4, ip + 4 - rep1, end) + 4;
+                        const int g2 = (int)(mr * 4), g1 = (int)(ml * 4 - (size_t)hibit(ofb) + 1);
+                        if (mr >= 4 && g2 > g1) { ml = mr; ofb = 1; at = ip; }
+                    }
+                    {
+                        uint32_t cand = 999999999;
+                        const size_t ml2 = SEARCH(ip, &cand);
+                        const int g2 = (int)(ml2 * 4 - (size_t)hibit(cand)), g1 = (int)(ml * 4 - (size_t)hibit(ofb) + 7);
+                        if (ml2 >= 4 && g2 > g1) { ml = ml2; ofb = cand; at = ip; continue; }
+                    }
+                }
+                break;
+            }
+        if (ofb > 3) {
+            const uint32_t off = ofb - 3;
+            while (at > anchor && at - off > prefix && s[at - 1] == s[at - off - 1]) { at--; ml++; }
+            rep2 = rep1; rep1 = off;
+        }
+    store:
+        store_seq(m, s, anchor, at - anchor, ofb, ml);
+        anchor = ip = at + ml;
+        while (((int64_t)ip <= ilimit) & (rep2 > 0) && rd32(s + ip) == rd32(s + ip - rep2)) {
+            const uint32_t t = rep2;
+            ml = count_eq(s, ip + 4, ip + 4 - rep2, end) + 4;
+            rep2 = rep1; rep1 = t;
+            store_seq(m, s, anchor, 0, 1, ml);
+            ip += ml; anchor = ip;
+        }
+    }
+#undef SEARCH
+    saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;
+    rep[0] = rep1 ? rep1 : saved1;
+    rep[1] = rep2 ? rep2 : saved2;
+    return end - anchor;
+}
+
 /* ------------------------------------------------------------------------------------------------ frame */
+/* clevels.h rows of the levels 4mz uses; strat: 1 fast, 2 dfast, 4 lazy, 5 lazy2, 0 = a strategy this port does not restate */
 static zparams level_params(int level, size_t n)
 {
-    static const zparams rows[2][4] = {            /* clevels.h, tables for > 256 KB, <= 256 KB, <= 128 KB, <= 16 KB */
-        {{19, 13, 14, 1, 7, 0, 1}, {18, 13, 14, 1, 6, 0, 1}, {17, 12, 13, 1, 6, 0, 1}, {14, 14, 15, 1, 5, 0, 1}},   /* level 1: fast  */
-        {{21, 16, 17, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {17, 15, 16, 2, 5, 0, 2}, {14, 14, 15, 2, 4, 0, 2}}};  /* level 3: dfast */
-    zparams p = rows[level == 3][(n <= 256 * 1024) + (n <= 128 * 1024) + (n <= 16 * 1024)];
+    static const zparams rows[4][4] = {            /* tables for > 256 KB, <= 256 KB, <= 128 KB, <= 16 KB */
+        {{19, 13, 14, 1, 7, 0, 1}, {18, 13, 14, 1, 6, 0, 1}, {17, 12, 13, 1, 6, 0, 1}, {14, 14, 15, 1, 5, 0, 1}},     /* level 1  */
+        {{21, 16, 17, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {17, 15, 16, 2, 5, 0, 2}, {14, 14, 15, 2, 4, 0, 2}},     /* level 3  */
+        {{21, 18, 19, 3, 5, 4, 4}, {18, 18, 19, 3, 5, 4, 4}, {17, 16, 17, 3, 4, 4, 4}, {14, 14, 14, 4, 4, 8, 5}},     /* level 6  */
+        {{22, 22, 23, 6, 5, 32, 5}, {18, 19, 19, 7, 4, 12, 0}, {17, 18, 17, 7, 4, 12, 0}, {14, 15, 14, 4, 3, 24, 0}}};/* level 12: btlazy2 / btopt below 256 KB */
+    zparams p = rows[level == 3 ? 1 : level == 6 ? 2 : level == 12 ? 3 : 0][(n <= 256 * 1024) + (n <= 128 * 1024) + (n <= 16 * 1024)];
     const uint32_t src_log = n < 64 ? 6 : (uint32_t)hibit((uint32_t)(n - 1)) + 1;
     if (p.wlog > src_log) p.wlog = src_log;
     if (p.hlog > p.wlog + 1) p.hlog = p.wlog + 1;
@@ -933,8 +1209,9 @@ int64_t orc_zstd_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap
     size_t o = 0, pos = 0, block;
     int64_t result;
     uint8_t *llc, *ofc, *mlc;
-    if (level != 1 && level != 3) return ORC_ZSTD_UNSUPPORTED;
+    if (level != 1 && level != 3 && level != 6 && level != 12) return ORC_ZSTD_UNSUPPORTED;
     p = level_params(level, n);
+    if (!p.strat) return ORC_ZSTD_UNSUPPORTED;
     if (cap < 18) return ERR_TOOSMALL;
     {   /* frame header: magic, descriptor, [window], content size */
         const uint32_t wsize = 1u << p.wlog;
@@ -958,6 +1235,9 @@ int64_t orc_zstd_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap
     m.p = p;
     m.table = (uint32_t*)calloc((size_t)1 << p.hlog, 4);
     m.small = (uint32_t*)calloc((size_t)1 << p.clog, 4);
+    m.tags = (uint8_t*)calloc((size_t)2 << p.hlog, 1);
+    m.next_to_update = m.low_limit = m.dict_limit = 2;                /* ZSTD_WINDOW_START_INDEX */
+    memset(m.hash_cache, 0, sizeof m.hash_cache);
     m.seq = (zseq*)malloc((BLOCK_MAX / 3 + 1) * sizeof(zseq));
     m.lit = (uint8_t*)malloc(BLOCK_MAX + 64);
     llc = (uint8_t*)malloc(3 * (BLOCK_MAX / 3 + 1)); ofc = llc + BLOCK_MAX / 3 + 1; mlc = ofc + BLOCK_MAX / 3 + 1;
@@ -973,18 +1253,31 @@ int64_t orc_zstd_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap
         int64_t c = 0;
         if (cap - o < 3 + 2 + 1) { result = ERR_TOOSMALL; break; }
         bcap = cap - o - 3;
+        {   /* ZSTD_window_enforceMaxDist(window, block START, ...) and the nextToUpdate floor (zstd_compress.c:4017-4021) */
+            const uint32_t start_idx = (uint32_t)pos + 2, max_dist = 1u << p.wlog;
+            if (start_idx > max_dist) {
+                if (m.low_limit < start_idx - max_dist) m.low_limit = start_idx - max_dist;
+                if (m.dict_limit < m.low_limit) m.dict_limit = m.low_limit;
+            }
+            if (m.next_to_update < m.low_limit) m.next_to_update = m.low_limit;
+        }
         if (len >= 7) {
             uint8_t* const out = dst + o + 3;
             size_t tail;
             int64_t lsz, ssz;
             m.nseq = 0; m.nlit = 0;
             memcpy(next->rep, prev->rep, sizeof next->rep);
-            tail = p.strat == 2 ? dfast_block(&m, next->rep, src, pos, pos + len) : fast_block(&m, next->rep, src, pos, pos + len);
+            {   /* limited catch-up after a very long match (ZSTD_buildSeqStore, zstd_compress.c:2890-2896) */
+                const uint32_t curr = (uint32_t)pos + 2;
+                if (curr > m.next_to_update + 384) { const uint32_t gap = curr - m.next_to_update - 384; m.next_to_update = curr - (gap < 192 ? gap : 192); }
+            }
+            if (p.strat >= 4) tail = lazy_block(&m, next->rep, src, pos, pos + len, p.strat == 5 ? 2 : 1, p.wlog > 14);
+            else tail = p.strat == 2 ? dfast_block(&m, next->rep, src, pos, pos + len) : fast_block(&m, next->rep, src, pos, pos + len);
             memcpy(m.lit + m.nlit, src + pos + len - tail, tail); m.nlit += tail;
-            lsz = compress_literals(prev, next, out, bcap, m.lit, m.nlit, m.nseq == 0 || m.nlit / m.nseq >= 20);
+            lsz = compress_literals(prev, next, out, bcap, m.lit, m.nlit, m.nseq == 0 || m.nlit / m.nseq >= 20, p.strat);
             c = lsz;
             if (lsz >= 0) {
-                ssz = encode_sequences(out + lsz, bcap - (size_t)lsz, m.seq, m.nseq, llc, ofc, mlc, p.strat);
+                ssz = encode_sequences(out + lsz, bcap - (size_t)lsz, m.seq, m.nseq, llc, ofc, mlc, p.strat, prev, next);
                 c = ssz <= 0 ? ssz : lsz + ssz;
             }
             if (c == ERR_TOOSMALL && len <= bcap) c = 0;
@@ -1006,7 +1299,7 @@ int64_t orc_zstd_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap
         }
         pos += len; first = 0;
     }
-    free(m.table); free(m.small); free(m.seq); free(m.lit); free(llc);
+    free(m.table); free(m.small); free(m.tags); free(m.seq); free(m.lit); free(llc);
     return result < 0 ? result : (int64_t)o;
 }
 
