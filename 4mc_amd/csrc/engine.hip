@@ -180,9 +180,9 @@ static int zstd_enc_serial() { const char* e = getenv("FOURMC_ZSTD_SERIAL"); ret
 int fourmc_gpu_zstd_compress(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, int level, void* stream)
 {
     if (int r = ensure_device()) return r;
-    if (level != 1 && level != 3) { snprintf(g_err, sizeof g_err, "ZSTD level %d not on the device (levels 1 and 3 are)", level); return FOURMC_EUNSUP; }
+    if (level != 1 && level != 3 && level != 6) { snprintf(g_err, sizeof g_err, "ZSTD level %d not on the device (levels 1, 3 and 6 are)", level); return FOURMC_EUNSUP; }
     void* work = nullptr;
-    if (int r = zstd_scratch_bytes(fourmc_zstd_enc_work_bytes(n), &work)) return r;
+    if (int r = zstd_scratch_bytes(fourmc_zstd_enc_work_bytes(n, level), &work)) return r;
     HIP_TRY(fourmc_launch_zstd_encode(d_src, d_dst, d_blocks, n, work, 0, level, zstd_enc_serial(), static_cast<hipStream_t>(stream)));
     return FOURMC_OK;
 }
@@ -215,9 +215,9 @@ int fourmc_gpu_4mc_encode_blocks(const void* d_src, void* d_dst, fourmc_block* d
         return FOURMC_OK;
     }
     if (codec == FOURMC_CODEC_ZSTD) {
-        if (level != 1 && level != 3) { snprintf(g_err, sizeof g_err, "ZSTD level %d not on the device (4mz fast = 1 and medium = 3 are)", level); return FOURMC_EUNSUP; }
+        if (level != 1 && level != 3 && level != 6) { snprintf(g_err, sizeof g_err, "ZSTD level %d not on the device (4mz fast = 1, medium = 3 and high = 6 are)", level); return FOURMC_EUNSUP; }
         void* work = nullptr;
-        if (int r = zstd_scratch_bytes(fourmc_zstd_enc_work_bytes(n), &work)) return r;
+        if (int r = zstd_scratch_bytes(fourmc_zstd_enc_work_bytes(n, level), &work)) return r;
         HIP_TRY(fourmc_launch_zstd_encode(d_src, d_dst, d_blocks, n, work, 1, level, zstd_enc_serial(), s));
         HIP_TRY(fourmc_launch_xxh32(d_dst, d_blocks, n, 0, FOURMC_HASH_DST_RESULT, s));
         return FOURMC_OK;

@@ -7,7 +7,7 @@
  * names and error contract as the LZ4 pair; codec results follow zstd's size_t convention
  * (error <=> value > (size_t)-ZSTD_error_maxCode, native/zstd/common/error_private.h).
  * decompressBytesDirect (any level) and compressBytesDirect (zstd level 1) run on the device;
- * compressBytesDirectMC (zstd level 3) and HC(1|3) run on the device; other HC levels fail LOUDLY with
+ * compressBytesDirectMC (zstd level 3) and HC(1|3|6) run on the device; other HC levels fail LOUDLY with
  * java/lang/InternalError("ZSTD_compress returned: <error code>") — there is no CPU fallback.
  *
  * Streaming classes (native/jniZstd.c, native/jniZStreamCompressor.c, native/jniZStreamDecompressor.c)

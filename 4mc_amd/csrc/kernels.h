@@ -31,7 +31,7 @@ hipError_t fourmc_launch_lz4mc_encode(const void* d_src, void* d_dst, fourmc_blo
 size_t     fourmc_zstd_scratch_bytes(uint32_t n);
 hipError_t fourmc_launch_zstd_decode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                      void* d_scratch, int container_mode, hipStream_t stream);
-size_t     fourmc_zstd_enc_work_bytes(uint32_t n);
+size_t     fourmc_zstd_enc_work_bytes(uint32_t n, int level);
 hipError_t fourmc_launch_zstd_encode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                      void* d_work, int container_mode, int level, int serial, hipStream_t stream);
 hipError_t fourmc_launch_xxh32(const void* d_base, fourmc_block* d_blocks, uint32_t n,

@@ -37,13 +37,20 @@ namespace {
 constexpr int      kErrGeneric = -1, kErrTooSmall = -70;     // ZSTD_error_GENERIC / _dstSize_tooSmall
 constexpr uint32_t kSub    = 128 * 1024;                     // ZSTD_BLOCKSIZE_MAX
 constexpr uint32_t kSeqCap = 32768 + 64;
-constexpr size_t   kLongBytes = size_t(4) << 17;                   // level 1: the hash table (<= 2^15 entries); level 3: long-hash table
-constexpr size_t   kTabBytes  = kLongBytes + (size_t(4) << 16);   // + level 3's short-hash table
 constexpr size_t   kSeqBytes  = size_t(kSeqCap) * 4;
 constexpr size_t   kCodeBytes = kSeqCap;
 constexpr size_t   kLitPad    = 64;
 constexpr size_t   kLitBytes  = kLitPad + kSub + 192;
-constexpr size_t   kWorkBytes = kTabBytes + 3 * kSeqBytes + 3 * kCodeBytes + kLitBytes;
+// per-block workspace: [sequence store | codes | literal buffer (+ profile counters) | previous FSE tables | scratch] [tables]
+constexpr size_t   kOffCodes  = 3 * kSeqBytes;
+constexpr size_t   kOffLit    = kOffCodes + 3 * kCodeBytes;
+constexpr size_t   kOffPrev   = kOffLit + kLitBytes;                 // 3 x FseCt of the last confirmed block (lazy strategies)
+constexpr size_t   kOffTmp    = kOffPrev + 4736;                     // 512 B: FSE_writeNCount trial output (ZSTD_NCountCost)
+constexpr size_t   kStoreBytes = kOffTmp + 512 + 192;
+static_assert(kStoreBytes % 64 == 0, "tables start 64-byte aligned");
+// tables by level: 1 -> hash table (<= 2^15 x u32); 3 -> long 2^17 + short 2^16; 6 -> rows 2^19 x u32 + tags 2^19 x u16
+__host__ __device__ constexpr size_t table_bytes(int level)
+{ return level == 6 ? (size_t(4) << 19) + (size_t(2) << 19) : level == 3 ? (size_t(4) << 17) + (size_t(4) << 16) : (size_t(4) << 15); }
 
 struct __attribute__((packed, aligned(1))) S4B { uint32_t v; };
 __device__ __forceinline__ void st4(uint8_t* p, uint32_t v) { reinterpret_cast<S4B*>(p)->v = v; }
@@ -67,7 +74,7 @@ __device__ __forceinline__ uint32_t scan_add(uint32_t v)          // wave64 incl
     return v;
 }
 
-struct FseCt { uint16_t next[512]; uint32_t dbits[64]; int32_t dfind[64]; uint32_t log; };
+struct FseCt { uint16_t next[512]; uint32_t dbits[64]; int32_t dfind[64]; uint32_t log, maxsym; };
 
 struct ZLds {
     uint32_t count[256];
@@ -263,7 +270,7 @@ __device__ __forceinline__ void fse_build(ZLds& L, FseCt& ct, uint32_t max_sym, 
 {
     const uint32_t size = 1u << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
     uint32_t high = size - 1, pos = 0, total = 0;
-    ct.log = log;
+    ct.log = log; ct.maxsym = max_sym;
     L.cumul[0] = 0;
     for (uint32_t s = 0; s <= max_sym; s++) {
         const int n = L.norm[s];
@@ -631,11 +638,11 @@ __device__ __forceinline__ int raw_literals(uint8_t* dst, uint32_t cap, const ui
     return int(n + fl);
 }
 
-struct Entropy { int huf_repeat; uint32_t rep[3]; };       // per-block-state besides the LDS literal table
+struct Entropy { int huf_repeat; uint32_t rep[3]; int fse_repeat[3]; };       // per-block state besides the LDS literal table and the FSE tables
 
-// ZSTD_compressLiterals (strategy fast)
+// ZSTD_compressLiterals
 __device__ __forceinline__ int compress_literals(ZLds& L, int prev, const Entropy& pe, Entropy& ne, uint8_t* dst, uint32_t cap,
-                                                 const uint8_t* lit, uint32_t n, bool suspect, int lane)
+                                                 const uint8_t* lit, uint32_t n, bool suspect, uint32_t strat, int lane)
 {
     const uint32_t min_gain = (n >> 6) + 2, lh = 3 + (n >= 1024) + (n >= 16384);
     bool single = n < 256;
@@ -647,7 +654,7 @@ __device__ __forceinline__ int compress_literals(ZLds& L, int prev, const Entrop
     if (n <= uint32_t(pe.huf_repeat == kRepValid ? 6 : 63)) return raw_literals(dst, cap, lit, n, false, lane);
     if (cap < lh + 1) return kErrTooSmall;
     if (repeat == kRepValid && lh == 3) single = true;
-    const int c = huf_compress(L, ntab, dst + lh, cap - lh, lit, n, !single, repeat, n <= 1024, suspect, lane);
+    const int c = huf_compress(L, ntab, dst + lh, cap - lh, lit, n, !single, repeat, strat < 4 && n <= 1024, suspect, lane);
     if (repeat != kRepNone) type = 3;
     if (c <= 0 || uint32_t(c) >= n - min_gain) { for (int i = lane; i < 256; i += 64) ntab[i] = ptab[i]; return raw_literals(dst, cap, lit, n, false, lane); }
     if (c == 1) { for (int i = lane; i < 256; i += 64) ntab[i] = ptab[i]; return raw_literals(dst, cap, lit, n, true, lane); }
@@ -690,24 +697,106 @@ __device__ __forceinline__ int default_norm(int which, uint32_t s)       // LL_d
     return s == 0 ? 1 : s == 1 ? 4 : s == 2 ? 3 : (s >= 3 && s <= 8) ? 2 : s >= 46 ? -1 : 1;
 }
 
-// ZSTD_selectEncodingType for strategy fast without dictionary: 0 basic, 1 rle, 2 compressed
-__device__ __forceinline__ int select_type(uint32_t most, uint32_t nseq, uint32_t def_log, bool def_ok, uint32_t strat)
+// floor(-log2(i / 256) * 256), i in 1..255 (kInverseProbabilityLog256, zstd_compress_sequences.c:19-42), computed at
+// compile time: exponent + 24 fractional bits of log2 by repeated squaring
+struct InvLog { uint16_t v[256]; };
+constexpr InvLog make_inv_log()
 {
-    if (most == nseq) return (def_ok && nseq <= 2) ? 0 : 1;
-    if (def_ok) {
-        const uint32_t dyn_min = ((1u << def_log) * (10u - strat)) >> 3;      // ZSTD_fast = 1, ZSTD_dfast = 2
-        if (nseq < dyn_min || most < (nseq >> (def_log - 1))) return 0;
+    InvLog t{};
+    for (unsigned i = 1; i < 256; i++) {
+        unsigned long long x = (unsigned long long)i << 56; unsigned ip = 0, r = 0;
+        while (!(x >> 63)) { x <<= 1; ip++; }
+        for (int k = 0; k < 24; k++) {
+            const __uint128_t sq = (__uint128_t)x * x;
+            r <<= 1;
+            if ((sq >> 127) & 1) { r |= 1; x = (unsigned long long)(sq >> 64); } else x = (unsigned long long)(sq >> 63);
+        }
+        t.v[i] = uint16_t((((unsigned long long)(ip + 1) << 24) - r) >> 16);
     }
+    return t;
+}
+__constant__ InvLog kInvLog = make_inv_log();
+
+constexpr uint32_t kCostErr = 0xFFFFFFFFu;
+
+// ZSTD_fseBitCost of the previous block's table (kept in the HBM workspace) for the histogram in L.count
+__device__ __forceinline__ uint32_t fse_bit_cost(ZLds& L, const FseCt* prev, uint32_t max, int lane)
+{
+    if (prev->maxsym < max) return kCostErr;
+    const uint32_t log = prev->log, badc = (log + 1) << 8;
+    uint32_t cost = 0; bool bad = false;
+    for (uint32_t sy = lane; sy <= max; sy += 64) {
+        const uint32_t d = prev->dbits[sy], c = L.count[sy];
+        const uint32_t min_bits = d >> 16, threshold = (min_bits + 1) << 16;
+        const uint32_t delta = threshold - (d + (1u << log));
+        const uint32_t bits = (min_bits + 1) * 256 - ((delta << 8) >> log);
+        if (c) { if (bits >= badc) bad = true; cost += c * bits; }
+    }
+    if (__ballot(bad)) return kCostErr;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) cost += uint32_t(__shfl_xor(int(cost), d));
+    return cost >> 8;
+}
+
+// ZSTD_selectEncodingType (zstd_compress_sequences.c:153-239), no dictionary: 0 basic, 1 rle, 2 compressed, 3 repeat
+__device__ __forceinline__ int select_type(ZLds& L, int& repeat, int which, uint32_t most, uint32_t max, uint32_t nseq, uint32_t fse_log,
+                                           const FseCt* prev, uint8_t* tmp, uint32_t def_log, bool def_ok, uint32_t strat, int lane)
+{
+    if (most == nseq) { repeat = kRepNone; return (def_ok && nseq <= 2) ? 0 : 1; }
+    if (strat < 4) {
+        if (def_ok) {
+            const uint32_t dyn_min = ((1u << def_log) * (10u - strat)) >> 3;      // ZSTD_fast = 1, ZSTD_dfast = 2
+            if (repeat == kRepValid && nseq < 1000) return 3;
+            if (nseq < dyn_min || most < (nseq >> (def_log - 1))) { repeat = kRepNone; return 0; }
+        }
+    } else {
+        uint32_t basic = kCostErr, rep = kCostErr, comp = 0;
+        if (def_ok) {                                              // ZSTD_crossEntropyCost
+            uint32_t c = 0;
+            for (uint32_t sy = lane; sy <= max; sy += 64) {
+                const int dn = default_norm(which, sy);
+                c += L.count[sy] * kInvLog.v[uint32_t(dn != -1 ? dn : 1) << (8 - def_log)];
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) c += uint32_t(__shfl_xor(int(c), d));
+            basic = c >> 8;
+        }
+        if (repeat != kRepNone) rep = fse_bit_cost(L, prev, max, lane);
+        {                                                          // ZSTD_NCountCost + ZSTD_entropyCost
+            const uint32_t log = fse_optimal_log(fse_log, nseq, max, 2);
+            fse_normalize(L, log, nseq, max, nseq >= 2048);
+            const int nc = fse_write_ncount(L, tmp, 512, max, log, lane);
+            uint32_t c = 0;
+            for (uint32_t sy = lane; sy <= max; sy += 64) {
+                const uint32_t cnt = L.count[sy];
+                uint32_t q = uint32_t((256ull * cnt) / nseq);
+                if (cnt && !q) q = 1;
+                c += cnt * kInvLog.v[q];
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) c += uint32_t(__shfl_xor(int(c), d));
+            comp = (uint32_t(nc) << 3) + (c >> 8);
+        }
+        if (basic <= rep && basic <= comp) { repeat = kRepNone; return 0; }
+        if (rep <= comp) return 3;
+    }
+    repeat = kRepCheck;
     return 2;
 }
 
 // ZSTD_buildCTable for table `which` (0 ll, 1 of, 2 ml): bytes of description or kErr*
 __device__ __forceinline__ int build_seq_table(ZLds& L, int which, uint8_t* dst, uint32_t cap, uint32_t fse_log, int type, uint32_t max,
-                                               const uint8_t* codes, uint32_t nseq, uint32_t def_log, uint32_t def_max, int lane)
+                                               const uint8_t* codes, uint32_t nseq, uint32_t def_log, uint32_t def_max, const FseCt* prev, int lane)
 {
     FseCt& ct = L.ct[which];
+    if (type == 3) {                                               // set_repeat: the previous block's table
+        const uint32_t* from = reinterpret_cast<const uint32_t*>(prev);
+        uint32_t* to = reinterpret_cast<uint32_t*>(&ct);
+        for (uint32_t i = lane; i < sizeof(FseCt) / 4; i += 64) to[i] = from[i];
+        return 0;
+    }
     if (type == 1) {
-        if (lane == 0) { ct.log = 0; ct.next[0] = 0; ct.next[1] = 0; ct.dbits[max] = 0; ct.dfind[max] = 0; }
+        if (lane == 0) { ct.log = 0; ct.maxsym = max; ct.next[0] = 0; ct.next[1] = 0; ct.dbits[max] = 0; ct.dfind[max] = 0; }
         if (!cap) return kErrTooSmall;
         if (lane == 0) dst[0] = codes[0];
         return 1;
@@ -732,8 +821,11 @@ __device__ __forceinline__ int build_seq_table(ZLds& L, int which, uint8_t* dst,
 struct SeqStore { uint32_t *ll, *ml, *off; uint8_t *llc, *ofc, *mlc; uint8_t* lit; uint32_t nseq, nlit; };
 
 // sequences section (tail of ZSTD_entropyCompressSeqStore_internal); bytes, 0 or kErr*
-__device__ __forceinline__ int encode_sequences(ZLds& L, uint8_t* dst, uint32_t cap, const SeqStore& S, uint32_t strat, int lane)
+__device__ __forceinline__ int encode_sequences(ZLds& L, uint8_t* dst, uint32_t cap, const SeqStore& S, uint32_t strat,
+                                                const Entropy& pe, Entropy& ne, const FseCt* prevfse, uint8_t* tmp, bool& tables_built, int lane)
 {
+    tables_built = false;
+    ne.fse_repeat[0] = pe.fse_repeat[0]; ne.fse_repeat[1] = pe.fse_repeat[1]; ne.fse_repeat[2] = pe.fse_repeat[2];
     const uint32_t nseq = S.nseq;
     uint32_t o = 0, last_count = 0;
     if (cap < 4) return kErrTooSmall;
@@ -748,20 +840,21 @@ __device__ __forceinline__ int encode_sequences(ZLds& L, uint8_t* dst, uint32_t 
         uint8_t* const head = dst + o++;
         uint32_t most, max;
         hist_bytes(L, S.llc, nseq, most, max, lane);
-        const int tll = select_type(most, nseq, 6, true, strat);
-        int r = build_seq_table(L, 0, dst + o, cap - o, 9, tll, max, S.llc, nseq, 6, 35, lane);
+        const int tll = select_type(L, ne.fse_repeat[0], 0, most, max, nseq, 9, prevfse + 0, tmp, 6, true, strat, lane);
+        int r = build_seq_table(L, 0, dst + o, cap - o, 9, tll, max, S.llc, nseq, 6, 35, prevfse + 0, lane);
         if (r < 0) return r;
         if (tll == 2) last_count = uint32_t(r);
         o += uint32_t(r);
         hist_bytes(L, S.ofc, nseq, most, max, lane);
-        const int tof = select_type(most, nseq, 5, max <= 28, strat);
-        r = build_seq_table(L, 1, dst + o, cap - o, 8, tof, max, S.ofc, nseq, 5, 28, lane);
+        const int tof = select_type(L, ne.fse_repeat[1], 1, most, max, nseq, 8, prevfse + 1, tmp, 5, max <= 28, strat, lane);
+        r = build_seq_table(L, 1, dst + o, cap - o, 8, tof, max, S.ofc, nseq, 5, 28, prevfse + 1, lane);
         if (r < 0) return r;
         if (tof == 2) last_count = uint32_t(r);
         o += uint32_t(r);
         hist_bytes(L, S.mlc, nseq, most, max, lane);
-        const int tml = select_type(most, nseq, 6, true, strat);
-        r = build_seq_table(L, 2, dst + o, cap - o, 9, tml, max, S.mlc, nseq, 6, 52, lane);
+        const int tml = select_type(L, ne.fse_repeat[2], 2, most, max, nseq, 9, prevfse + 2, tmp, 6, true, strat, lane);
+        r = build_seq_table(L, 2, dst + o, cap - o, 9, tml, max, S.mlc, nseq, 6, 52, prevfse + 2, lane);
+        tables_built = true;
         if (r < 0) return r;
         if (tml == 2) last_count = uint32_t(r);
         o += uint32_t(r);
@@ -811,7 +904,7 @@ __device__ __forceinline__ int encode_sequences(ZLds& L, uint8_t* dst, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------ match finder
-struct Params { uint32_t wlog, hlog, clog, mml, tlen, strat; };
+struct Params { uint32_t wlog, hlog, clog, slog, mml, tlen, strat; };
 
 __device__ __forceinline__ uint32_t zhash(uint64_t v, uint32_t hlog, uint32_t mls)
 {
@@ -1160,12 +1253,233 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
     return end - anchor;
 }
 
+
+// ------------------------------------------------------------------------------------------------ lazy parsers (level 6)
+// ZSTD_compressBlock_lazy_generic (compress/zstd_lazy.c:1486-1737, noDict) with the row-hash match finder
+// (ZSTD_RowFindBestMatch :1139-1250, ZSTD_row_update_internal :915-946) or, for windows <= 2^14, hash chains
+// (ZSTD_HcFindBestMatch :649-730).  The parse is serial by definition (every search sees the rows as the previous
+// insertions left them); the wave parallelises inside a search: a row's 16-64 tags are compared in one step, all
+// candidates are measured at once (one per lane), skipped positions enter their rows in conflict-free rounds.
+// The reference's 8-entry hash cache only prefetches: the cached value always equals the hash of its position.
+struct LazyState { uint32_t* tab; uint32_t* chain; uint8_t* tags; uint32_t ntu, low_limit, dict_limit; };
+
+__device__ __forceinline__ uint32_t lz_low(const LazyState& Z, const Params& P, uint32_t curr)
+{ const uint32_t md = 1u << P.wlog; return curr - Z.low_limit > md ? curr - md : Z.low_limit; }
+
+// common prefix length of s[a..] and s[b..] (a > b), a stops at lim; per lane, for short candidates: up to 32 bytes
+__device__ __forceinline__ uint32_t lane_count32(const uint8_t* s, uint32_t a, uint32_t b, uint32_t lim, uint32_t n_total)
+{
+    const uint32_t room = lim - a;
+    if (a + 32 <= n_total) {
+        const U16B x0 = *reinterpret_cast<const U16B*>(s + a), y0 = *reinterpret_cast<const U16B*>(s + b);
+        const U16B x1 = *reinterpret_cast<const U16B*>(s + a + 16), y1 = *reinterpret_cast<const U16B*>(s + b + 16);
+        const uint64_t d0 = x0.a ^ y0.a, d1 = x0.b ^ y0.b, d2 = x1.a ^ y1.a, d3 = x1.b ^ y1.b;
+        const uint32_t eq = d0 ? uint32_t(__builtin_ctzll(d0) >> 3) : d1 ? 8u + uint32_t(__builtin_ctzll(d1) >> 3)
+                          : d2 ? 16u + uint32_t(__builtin_ctzll(d2) >> 3) : d3 ? 24u + uint32_t(__builtin_ctzll(d3) >> 3) : 32u;
+        return min(eq, room);
+    }
+    uint32_t k = 0;
+    while (k < 32 && k < room && s[a + k] == s[b + k]) k++;
+    return k;
+}
+
+// best of the candidate list held one per lane (cand != 0): longest, first in list order on ties; returns ml (3 = none)
+__device__ __forceinline__ uint32_t best_candidate(const uint8_t* s, uint32_t ip, uint32_t end, uint32_t n_total, uint32_t cand, bool has,
+                                                   uint32_t order, uint32_t curr, uint32_t& ofb, int lane)
+{
+    uint32_t cnt = has ? lane_count32(s, ip, cand - 2, end, n_total) : 0u;
+    for (unsigned long long todo = __ballot(has && cnt == 32 && ip + 32 < end); todo; todo &= todo - 1) {
+        const int l = __builtin_ctzll(todo);
+        const uint32_t extra = count_fwd(s, ip + 32, rl(cand, l) - 2 + 32, end, lane);
+        if (lane == l) cnt += extra;
+    }
+    uint32_t key = (has && cnt > 3) ? ((cnt << 6) | (63u - order)) : 0u;
+    key = wave_max(key);
+    if (!key) return 3;
+    const unsigned long long who = __ballot(has && ((cnt << 6) | (63u - order)) == key);
+    ofb = curr - rl(cand, uint32_t(__builtin_ctzll(who))) + 3;
+    return key >> 6;
+}
+
+// rows: positions [from, to) enter their rows in index order (ZSTD_row_update_internalImpl)
+__device__ __forceinline__ void row_insert_range(ZLds& L, LazyState& Z, const Params& P, const uint8_t* s, uint32_t from, uint32_t to, int lane)
+{
+    const uint32_t rowlog = min(max(P.slog, 4u), 6u), mask = (1u << rowlog) - 1, hbits = P.hlog - rowlog + 8, mls = min(max(P.mml, 4u), 6u);
+    for (uint32_t base = from; base < to; base += 64) {
+        const uint32_t idx = base + lane;
+        bool todo = idx < to;
+        const uint32_t hash = todo ? zhash(ld8(s + idx - 2), hbits, mls) : 0u;
+        const uint32_t rel = (hash >> 8) << rowlog;
+        uint32_t* const sc = &L.score[(hash >> 8) & 1023];
+        while (__ballot(todo)) {                                   // same-row insertions keep their order: lowest lane first
+            if (todo) atomicMin(sc, uint32_t(lane));
+            const bool mine = todo && *sc == uint32_t(lane);
+            if (mine) {
+                uint8_t* const tag_row = Z.tags + 2 * size_t(rel);
+                const uint32_t pos = (uint32_t(tag_row[0]) - 1u) & mask;
+                tag_row[0] = uint8_t(pos); tag_row[16 + pos] = uint8_t(hash);
+                Z.tab[rel + pos] = idx;
+                *sc = 0xFFFFFFFFu;
+                todo = false;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t row_search(ZLds& L, LazyState& Z, const Params& P, const uint8_t* s, uint32_t ip, uint32_t end,
+                                               uint32_t n_total, uint32_t& ofb, int lane)
+{
+    const uint32_t curr = ip + 2, low = lz_low(Z, P, curr);
+    const uint32_t rowlog = min(max(P.slog, 4u), 6u), entries = 1u << rowlog, mask = entries - 1, mls = min(max(P.mml, 4u), 6u);
+    const uint32_t attempts = 1u << min(P.slog, rowlog);
+    {   // ZSTD_row_update_internal: catch up to curr (skipping the middle of long gaps)
+        uint32_t idx = Z.ntu;
+        if (curr - idx > 384) { row_insert_range(L, Z, P, s, idx, idx + 96, lane); idx = curr - 32; }
+        row_insert_range(L, Z, P, s, idx, curr, lane);
+        Z.ntu = curr;
+    }
+    const uint32_t hash = zhash(ld8(s + ip), P.hlog - rowlog + 8, mls), rel = (hash >> 8) << rowlog, tag = hash & 255;
+    uint8_t* const tag_row = Z.tags + 2 * size_t(rel);
+    const uint32_t head_byte = tag_row[0], head = head_byte & mask;
+    // lane i looks at the i-th newest entry (the rotated match mask of the reference)
+    const uint32_t pos = (head + uint32_t(lane)) & mask;
+    const bool in_row = uint32_t(lane) < entries;
+    const uint32_t e = in_row ? Z.tab[rel + pos] : 0u;
+    const bool valid = in_row && tag_row[16 + pos] == tag;
+    unsigned long long vm = __ballot(valid);
+    const unsigned long long stop = __ballot(valid && e < low);
+    if (stop) vm &= (1ull << __builtin_ctzll(stop)) - 1;
+    const uint32_t rank = uint32_t(__builtin_popcountll(vm & ((1ull << lane) - 1)));
+    const bool has = ((vm >> lane) & 1) && rank < attempts;
+    if (lane == 0) {                                               // the current position goes in as well (:1229-1234)
+        const uint32_t p0 = (head_byte - 1u) & mask;
+        tag_row[0] = uint8_t(p0); tag_row[16 + p0] = uint8_t(tag); Z.tab[rel + p0] = curr;
+    }
+    Z.ntu = curr + 1;
+    return best_candidate(s, ip, end, n_total, e, has, rank, curr, ofb, lane);
+}
+
+__device__ __forceinline__ uint32_t hc_search(LazyState& Z, const Params& P, const uint8_t* s, uint32_t ip, uint32_t end,
+                                              uint32_t n_total, uint32_t& ofb, int lane)
+{
+    const uint32_t curr = ip + 2, low = lz_low(Z, P, curr), mls = min(max(P.mml, 4u), 6u);
+    const uint32_t chain_size = 1u << P.clog, cmask = chain_size - 1, min_chain = curr > chain_size ? curr - chain_size : 0;
+    for (uint32_t idx = Z.ntu; idx < curr; idx++) {                // ZSTD_insertAndFindFirstIndex_internal (small inputs only: serial)
+        const uint32_t h = zhash(ld8(s + idx - 2), P.hlog, mls);
+        const uint32_t old = Z.tab[h];
+        if (lane == 0) { Z.chain[idx & cmask] = old; Z.tab[h] = idx; }
+    }
+    Z.ntu = curr;
+    uint32_t mi = Z.tab[zhash(ld8(s + ip), P.hlog, mls)], cand = 0, n = 0;
+    const uint32_t attempts = 1u << P.slog;                        // <= 16 here: candidates gathered one per lane
+    while (mi >= low && n < attempts) {
+        if (uint32_t(lane) == n) cand = mi;
+        n++;
+        if (mi <= min_chain) break;
+        mi = Z.chain[mi & cmask];
+    }
+    return best_candidate(s, ip, end, n_total, cand, uint32_t(lane) < n, uint32_t(lane), curr, ofb, lane);
+}
+
+__device__ __forceinline__ uint32_t lazy_block(ZLds& L, SeqStore& S, LazyState& Z, const Params& P, uint32_t rep[3],
+                                               const uint8_t* s, uint32_t start, uint32_t end, uint32_t n_total, int lane)
+{
+    const bool use_row = P.wlog > 14;
+    const uint32_t depth = P.strat == 5 ? 2u : 1u;
+    const int64_t ilimit = int64_t(end) - 8 - (use_row ? 8 : 0);
+    const uint32_t prefix_idx = Z.dict_limit, prefix = prefix_idx - 2;
+    uint32_t ip = start, anchor = start;
+    uint32_t rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0;
+    auto search = [&](uint32_t at, uint32_t& ofb) -> uint32_t {
+        return use_row ? row_search(L, Z, P, s, at, end, n_total, ofb, lane) : hc_search(Z, P, s, at, end, n_total, ofb, lane);
+    };
+    ip += (ip == prefix) ? 1 : 0;
+    {
+        const uint32_t c = ip + 2, md = 1u << P.wlog;
+        const uint32_t low = c - Z.dict_limit > md ? c - md : Z.dict_limit;
+        const uint32_t max_rep = c - low;
+        if (rep2 > max_rep) { saved2 = rep2; rep2 = 0; }
+        if (rep1 > max_rep) { saved1 = rep1; rep1 = 0; }
+    }
+    while (int64_t(ip) < ilimit) {
+        uint32_t ml = 0, at = ip + 1, ofb = 1;
+        if ((rep1 > 0) & (ld4(s + ip + 1 - rep1) == ld4(s + ip + 1)))
+            ml = count_fwd(s, ip + 1 + 4, ip + 1 + 4 - rep1, end, lane) + 4;
+        {
+            uint32_t found = 999999999;
+            const uint32_t ml2 = search(ip, found);
+            if (ml2 > ml) { ml = ml2; at = ip; ofb = found; }
+        }
+        if (ml < 4) { ip += ((ip - anchor) >> 8) + 1; continue; }
+        while (int64_t(ip) < ilimit) {                              // depth >= 1
+            ip++;
+            if ((rep1 > 0) & (ld4(s + ip) == ld4(s + ip - rep1))) {
+                const uint32_t mr = count_fwd(s, ip + 4, ip + 4 - rep1, end, lane) + 4;
+                const int g2 = int(mr * 3), g1 = int(ml * 3 - uint32_t(hibit(ofb)) + 1);
+                if (mr >= 4 && g2 > g1) { ml = mr; ofb = 1; at = ip; }
+            }
+            {
+                uint32_t cand = 999999999;
+                const uint32_t ml2 = search(ip, cand);
+                const int g2 = int(ml2 * 4 - uint32_t(hibit(cand))), g1 = int(ml * 4 - uint32_t(hibit(ofb)) + 4);
+                if (ml2 >= 4 && g2 > g1) { ml = ml2; ofb = cand; at = ip; continue; }
+            }
+            if (depth == 2 && int64_t(ip) < ilimit) {
+                ip++;
+                if ((rep1 > 0) & (ld4(s + ip) == ld4(s + ip - rep1))) {
+                    const uint32_t mr = count_fwd(s, ip + 4, ip + 4 - rep1, end, lane) + 4;
+                    const int g2 = int(mr * 4), g1 = int(ml * 4 - uint32_t(hibit(ofb)) + 1);
+                    if (mr >= 4 && g2 > g1) { ml = mr; ofb = 1; at = ip; }
+                }
+                {
+                    uint32_t cand = 999999999;
+                    const uint32_t ml2 = search(ip, cand);
+                    const int g2 = int(ml2 * 4 - uint32_t(hibit(cand))), g1 = int(ml * 4 - uint32_t(hibit(ofb)) + 7);
+                    if (ml2 >= 4 && g2 > g1) { ml = ml2; ofb = cand; at = ip; continue; }
+                }
+            }
+            break;
+        }
+        if (ofb > 3) {
+            const uint32_t off = ofb - 3;
+            for (;;) {                                             // catch up, 64 bytes per step
+                const uint32_t room = min(at - anchor, at - off - prefix);
+                const bool same = uint32_t(lane) < room && s[at - 1 - lane] == s[at - off - 1 - lane];
+                const unsigned long long bad = ~__ballot(same);
+                const uint32_t k = bad ? uint32_t(__builtin_ctzll(bad)) : 64u;
+                at -= k; ml += k;
+                if (k < 64) break;
+            }
+            rep2 = rep1; rep1 = off;
+        }
+        store_seq(S, s, anchor, at - anchor, ofb, ml, lane);
+        anchor = ip = at + ml;
+        while ((int64_t(ip) <= ilimit) & (rep2 > 0) && ld4(s + ip) == ld4(s + ip - rep2)) {
+            const uint32_t t = rep2;
+            ml = count_fwd(s, ip + 4, ip + 4 - rep2, end, lane) + 4;
+            rep2 = rep1; rep1 = t;
+            store_seq(S, s, anchor, 0, 1, ml, lane);
+            ip += ml; anchor = ip;
+        }
+    }
+    saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;
+    rep[0] = rep1 ? rep1 : saved1;
+    rep[1] = rep2 ? rep2 : saved2;
+    return end - anchor;
+}
+
 // ------------------------------------------------------------------------------------------------ frame
 __device__ __forceinline__ Params level_params(uint32_t n, int level)
 {
     Params p;
     uint32_t wlog, hlog, clog;
-    if (level == 3) {                                   // clevels.h rows of level 3 (ZSTD_dfast)
+    p.slog = 1;
+    if (level == 6) {                                   // clevels.h rows of level 6 (ZSTD_lazy; lazy2 for <= 16 KB)
+        if (n <= 16 * 1024) { wlog = 14; clog = 14; hlog = 14; p.slog = 4; p.mml = 4; p.strat = 5; }
+        else if (n <= 128 * 1024) { wlog = 17; clog = 16; hlog = 17; p.slog = 3; p.mml = 4; p.strat = 4; }
+        else if (n <= 256 * 1024) { wlog = 18; clog = 18; hlog = 19; p.slog = 3; p.mml = 5; p.strat = 4; }
+        else { wlog = 21; clog = 18; hlog = 19; p.slog = 3; p.mml = 5; p.strat = 4; }
+    } else if (level == 3) {                                   // clevels.h rows of level 3 (ZSTD_dfast)
         if (n <= 16 * 1024) { wlog = 14; clog = 14; hlog = 15; p.mml = 4; }
         else if (n <= 128 * 1024) { wlog = 17; clog = 15; hlog = 16; p.mml = 5; }
         else if (n <= 256 * 1024) { wlog = 18; clog = 16; hlog = 16; p.mml = 4; }
@@ -1199,12 +1513,18 @@ __device__ __forceinline__ bool is_rle(const uint8_t* s, uint32_t n, int lane)
 __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* work, int level, bool serial, int lane)
 {
     const Params P = level_params(n, level);
-    uint32_t* const tab_s = reinterpret_cast<uint32_t*>(work + kLongBytes);
-    uint32_t* const tab = reinterpret_cast<uint32_t*>(work);
+    uint32_t* const tab = reinterpret_cast<uint32_t*>(work + kStoreBytes);
+    uint32_t* const tab_s = reinterpret_cast<uint32_t*>(work + kStoreBytes + (size_t(4) << 17));      // level 3: short-hash table
     SeqStore S;
-    S.ll = reinterpret_cast<uint32_t*>(work + kTabBytes); S.ml = S.ll + kSeqCap; S.off = S.ml + kSeqCap;
-    S.llc = work + kTabBytes + 3 * kSeqBytes; S.ofc = S.llc + kCodeBytes; S.mlc = S.ofc + kCodeBytes;
-    S.lit = S.mlc + kCodeBytes + kLitPad;
+    S.ll = reinterpret_cast<uint32_t*>(work); S.ml = S.ll + kSeqCap; S.off = S.ml + kSeqCap;
+    S.llc = work + kOffCodes; S.ofc = S.llc + kCodeBytes; S.mlc = S.ofc + kCodeBytes;
+    S.lit = work + kOffLit + kLitPad;
+    FseCt* const prevfse = reinterpret_cast<FseCt*>(work + kOffPrev);
+    uint8_t* const tmp = work + kOffTmp;
+    LazyState Z;
+    Z.tab = tab; Z.ntu = 2; Z.low_limit = 2; Z.dict_limit = 2;
+    Z.tags = reinterpret_cast<uint8_t*>(tab) + (size_t(4) << P.hlog);                                   // rows: tag table behind the entries
+    Z.chain = tab + (size_t(1) << P.hlog);                                                              // hash chains: chain table there
     uint32_t o = 0;
     if (cap < 18) return kErrTooSmall;
     {
@@ -1234,6 +1554,11 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
             const uint32_t m16 = (4u << P.clog) / 16;
             for (uint32_t i = lane; i < m16; i += 64) s4[i] = make_uint4(0, 0, 0, 0);
         }
+        if (P.strat >= 4) {                                    // tag table (2 bytes per entry) or chain table (4 bytes per entry)
+            uint4* s4 = reinterpret_cast<uint4*>(Z.tags);
+            const uint32_t m16 = P.wlog > 14 ? (2u << P.hlog) / 16 : (4u << P.clog) / 16;
+            for (uint32_t i = lane; i < m16; i += 64) s4[i] = make_uint4(0, 0, 0, 0);
+        }
         for (int i = lane; i < 1024; i += 64) L.score[i] = 0xFFFFFFFFu;
         for (int i = lane; i < 256; i += 64) { L.huf[0][i] = 0; L.huf[1][i] = 0; }
     }
@@ -1242,6 +1567,7 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
 #define ZPH(acc) do { t1 = __builtin_readcyclecounter(); acc += t1 - t0; t0 = t1; } while (0)
     Entropy pe, ne;
     pe.huf_repeat = kRepNone; pe.rep[0] = 1; pe.rep[1] = 4; pe.rep[2] = 8;
+    pe.fse_repeat[0] = pe.fse_repeat[1] = pe.fse_repeat[2] = kRepNone;
     ne = pe;
     int cur = 0;
     bool first = true;
@@ -1253,21 +1579,30 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
         if (cap - o < 3 + 2 + 1) return kErrTooSmall;
         const uint32_t bcap = cap - o - 3;
         uint8_t* const out = dst + o + 3;
+        {   // ZSTD_window_enforceMaxDist(window, block START) and the nextToUpdate floor (zstd_compress.c:4017-4021)
+            const uint32_t start_idx = pos + 2, md = 1u << P.wlog;
+            if (start_idx > md) { Z.low_limit = max(Z.low_limit, start_idx - md); Z.dict_limit = max(Z.dict_limit, Z.low_limit); }
+            Z.ntu = max(Z.ntu, Z.low_limit);
+        }
+        bool tables_built = false;
         if (len >= 7) {
             S.nseq = 0; S.nlit = 0;
             ne.rep[0] = pe.rep[0]; ne.rep[1] = pe.rep[1]; ne.rep[2] = pe.rep[2];
             ZPH(t_out);
-            const uint32_t tail = P.strat == 2 ? dfast_block(L, S, tab, tab_s, P, ne.rep, src, pos, pos + len, lane)
-                                               : fast_block(L, S, tab, P, ne.rep, src, pos, pos + len, n, serial, lane);
+            if (pos + 2 > Z.ntu + 384) { const uint32_t gap = pos + 2 - Z.ntu - 384; Z.ntu = pos + 2 - min(gap, 192u); }   // ZSTD_buildSeqStore :2890-2896
+            uint32_t tail;
+            if (P.strat >= 4) tail = lazy_block(L, S, Z, P, ne.rep, src, pos, pos + len, n, lane);
+            else tail = P.strat == 2 ? dfast_block(L, S, tab, tab_s, P, ne.rep, src, pos, pos + len, lane)
+                                     : fast_block(L, S, tab, P, ne.rep, src, pos, pos + len, n, serial, lane);
             copy_bytes(S.lit + S.nlit, src + pos + len - tail, tail, lane);
             S.nlit += tail;
             ZPH(t_mf);
             const bool suspect = S.nseq == 0 || S.nlit / S.nseq >= 20;
-            const int lsz = compress_literals(L, cur, pe, ne, out, bcap, S.lit, S.nlit, suspect, lane);
+            const int lsz = compress_literals(L, cur, pe, ne, out, bcap, S.lit, S.nlit, suspect, P.strat, lane);
             c = lsz;
             ZPH(t_lit);
             if (lsz >= 0) {
-                const int ssz = encode_sequences(L, out + lsz, bcap - uint32_t(lsz), S, P.strat, lane);
+                const int ssz = encode_sequences(L, out + lsz, bcap - uint32_t(lsz), S, P.strat, pe, ne, prevfse, tmp, tables_built, lane);
                 c = ssz <= 0 ? ssz : lsz + ssz;
             }
             ZPH(t_seq);
@@ -1275,7 +1610,14 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
             if (c < 0) return c;
             if (c > 0 && uint32_t(c) >= len - ((len >> 6) + 2)) c = 0;
             if (!first && c < 25 && is_rle(src + pos, len, lane)) { c = 1; if (lane == 0) out[0] = src[pos]; }
-            if (c > 1) { cur ^= 1; pe = ne; }
+            if (c > 1) {                                           // ZSTD_blockState_confirmRepcodesAndEntropyTables
+                cur ^= 1; pe = ne;
+                if (tables_built && P.strat >= 4) {                // keep this block's FSE tables for the next block's repeat mode
+                    const uint32_t* from = reinterpret_cast<const uint32_t*>(&L.ct[0]);
+                    uint32_t* to = reinterpret_cast<uint32_t*>(prevfse);
+                    for (uint32_t i = lane; i < 3 * sizeof(FseCt) / 4; i += 64) to[i] = from[i];
+                }
+            }
         }
         if (c == 0) {
             const uint32_t h = last + (len << 3);
@@ -1310,14 +1652,14 @@ void zstd_encode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
     uint8_t* dst = dst_base + blk.dst_off;
     const uint32_t n = blk.src_len;
     const uint32_t cap = container_mode ? (n ? n - 1 : 0) : blk.dst_cap;
-    int r = zstd_encode_frame(L, src, n, dst, cap, work_base + size_t(b) * kWorkBytes, level, serial != 0, lane);
+    int r = zstd_encode_frame(L, src, n, dst, cap, work_base + size_t(b) * (kStoreBytes + table_bytes(level)), level, serial != 0, lane);
     if (container_mode && r <= 0) { copy_bytes(dst, src, n, lane); r = int(n); }
     if (lane == 0) blocks[b].result = r;
 }
 
 } // namespace
 
-extern "C" size_t fourmc_zstd_enc_work_bytes(uint32_t n) { return size_t(n) * kWorkBytes; }
+extern "C" size_t fourmc_zstd_enc_work_bytes(uint32_t n, int level) { return size_t(n) * (kStoreBytes + table_bytes(level)); }
 
 extern "C" hipError_t fourmc_launch_zstd_encode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                                 void* d_work, int container_mode, int level, int serial, hipStream_t stream)

@@ -113,8 +113,8 @@ int main(int argc, char** argv)
             obj_t co = {{{"finish", 0, 0, 0}, {"finished", 0, 0, 0}, {"uncompressedDirectBuf", 1, 0, raw}, {"uncompressedDirectBufLen", 0, n, 0},
                          {"compressedDirectBuf", 1, 0, comp}, {"directBufferSize", 0, cap, 0}}, 6};
             g_thrown[0] = 0;
-            jint r = ((call1_fn)sym(lib, ccls, "compressBytesDirectHC"))(&env, &co, 6);
-            printf("Zstd_compressBytesDirectHC6 %d %s | ulen_after=%d\n", r, g_thrown[0] ? g_thrown : "-", co.f[3].ival);
+            jint r = ((call1_fn)sym(lib, ccls, "compressBytesDirectHC"))(&env, &co, 12);
+            printf("Zstd_compressBytesDirectHC12 %d %s | ulen_after=%d\n", r, g_thrown[0] ? g_thrown : "-", co.f[3].ival);
         }
         {   /* corrupt input: the decompressor throws InternalError and returns the codec's error */
             obj_t dob = {{{"finished", 0, 0, 0}, {"compressedDirectBuf", 1, 0, raw}, {"compressedDirectBufLen", 0, n > 1000 ? 1000 : n, 0},

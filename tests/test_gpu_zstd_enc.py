@@ -1,4 +1,4 @@
-"""GPU: ZSTD level-1 / level-3 frame encode (4mz "fast" / "medium") byte parity against the oracle port
+"""GPU: ZSTD level-1 / 3 / 6 frame encode (4mz "fast" / "medium" / "high") byte parity against the oracle port
 (oracle/zstd_enc_port.c, itself pinned to the reference's ZSTD_compress) and the reference CLI's
 `4mc -z -1` golden manifest; every frame also decodes back on the GPU."""
 import hashlib
@@ -46,7 +46,7 @@ def _check(gpu, names, srcs, caps, tag, level=1):
         assert np.array_equal(o, want), (tag, k, len(s), cap)
 
 
-@pytest.mark.parametrize("level", [1, 3])
+@pytest.mark.parametrize("level", [1, 3, 6])
 def test_zstd_bytes_identical_edge_inputs(gpu, level):
     inputs = helpers.edge_inputs()
     names = list(inputs)
@@ -56,7 +56,7 @@ def test_zstd_bytes_identical_edge_inputs(gpu, level):
     _check(gpu, names, srcs, [len(s) // 3 for s in srcs], "n/3", level)           # mostly dstSize_tooSmall
 
 
-@pytest.mark.parametrize("level", [1, 3])
+@pytest.mark.parametrize("level", [1, 3, 6])
 def test_zstd_size_classes_and_tails(gpu, level):
     """Level-table size classes (16 KiB / 128 KiB / 256 KiB), 128 KiB sub-block boundaries and tails."""
     rng = np.random.default_rng(5)
@@ -70,7 +70,7 @@ def test_zstd_size_classes_and_tails(gpu, level):
     _check(gpu, names, srcs, [helpers.zstd_bound(n) for n in sizes], "bound", level)
 
 
-@pytest.mark.parametrize("level", [1, 3])
+@pytest.mark.parametrize("level", [1, 3, 6])
 def test_zstd_capacity_sweep(gpu, level):
     """Capacities around the real frame size: every overflow rule of the bit and byte writers."""
     src = helpers.corpus(B, first_block=2)
@@ -81,7 +81,7 @@ def test_zstd_capacity_sweep(gpu, level):
         _check(gpu, ["cap=%d" % x for x in caps], [d] * len(caps), caps, "tight n=%d" % n, level)
 
 
-@pytest.mark.parametrize("level,key", [(1, "4mz-1"), (3, "4mz-2")])
+@pytest.mark.parametrize("level,key", [(1, "4mz-1"), (3, "4mz-2"), (6, "4mz-3")])
 def test_zstd_corpus_blocks_golden_manifest_and_roundtrip(gpu, level, key):
     m = json.load(open(os.path.join(G, "corpus_manifest.json")))
     n = m["corpus"]["bytes"]
@@ -112,9 +112,9 @@ def test_zstd_corpus_blocks_golden_manifest_and_roundtrip(gpu, level, key):
     assert torch.equal(d_back[:n], d_src)
 
 
-@pytest.mark.parametrize("flag,key", [("-1", "4mz-1"), ("-2", "4mz-2")])
+@pytest.mark.parametrize("flag,key", [("-1", "4mz-1"), ("-2", "4mz-2"), ("-3", "4mz-3")])
 def test_cli_4mz_file_equals_reference(gpu, tmp_path, flag, key):
-    """`4mc -z -1|-2 file` writes the reference CLI's .4mz bytes; -z -3 (zstd level 6) fails loudly, no CPU fallback."""
+    """`4mc -z -1|-2|-3 file` writes the reference CLI's .4mz bytes; -z -4 (zstd level 12) fails loudly, no CPU fallback."""
     import subprocess
     m = json.load(open(os.path.join(G, "corpus_manifest.json")))
     data = helpers.corpus(m["corpus"]["bytes"])
@@ -128,7 +128,7 @@ def test_cli_4mz_file_equals_reference(gpu, tmp_path, flag, key):
     back = tmp_path / "back.bin"
     assert subprocess.run([gpu.cli_path(), "-d", "-z", "-f", str(out), str(back)], capture_output=True).returncode == 0
     assert back.read_bytes() == data.tobytes()
-    r = subprocess.run([gpu.cli_path(), "-z", "-3", "-f", str(src), str(tmp_path / "c2.4mz")], capture_output=True)
+    r = subprocess.run([gpu.cli_path(), "-z", "-4", "-f", str(src), str(tmp_path / "c2.4mz")], capture_output=True)
     assert r.returncode != 0 and b"not on the device" in r.stderr
 
 
@@ -146,9 +146,10 @@ def test_host_zstd_compress_entry_point(gpu):
     out = np.zeros(64, np.uint8)
     r = L.fourmc_ZSTD_compress(out.ctypes.data, 30, d.ctypes.data, 1000, 1)
     assert r == (1 << 64) - 70                                     # (size_t)-ZSTD_error_dstSize_tooSmall
-    r = L.fourmc_ZSTD_compress(out.ctypes.data, 64, d.ctypes.data, 10, 6)
-    assert r > (1 << 64) - 120                                     # level 6: ZSTD_isError(), no CPU fallback
+    r = L.fourmc_ZSTD_compress(out.ctypes.data, 64, d.ctypes.data, 10, 12)
+    assert r > (1 << 64) - 120                                     # level 12: ZSTD_isError(), no CPU fallback
     out = np.zeros(helpers.zstd_bound(300000) + 64, np.uint8)
-    r = L.fourmc_ZSTD_compress(out.ctypes.data, 1 << 30, d.ctypes.data, 300000, 3)
-    want_r, want = helpers.orc_zstd_compress(d, 3)
-    assert r == want_r and np.array_equal(out[:r], want)
+    for lvl in (3, 6):
+        r = L.fourmc_ZSTD_compress(out.ctypes.data, 1 << 30, d.ctypes.data, 300000, lvl)
+        want_r, want = helpers.orc_zstd_compress(d, lvl)
+        assert r == want_r and np.array_equal(out[:r], want), lvl

@@ -13,7 +13,8 @@ names = ["text", "binary", "pcm6", "sdf", "binary", "db", "text", "code", "pcm11
 def t(fn):
     s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
     fn(); torch.cuda.synchronize(); s.record(); fn(); e.record(); torch.cuda.synchronize(); return s.elapsed_time(e)
-ENC_WORK, ENC_CTR = 1410240, 786432 + 3 * 131328 + 3 * 32832 + 64 + 131072 + 64     # zstd_encode.hip: kWorkBytes, counters behind the literal buffer
+ENC_CTR = 3 * 131328 + 3 * 32832 + 64 + 131072 + 64                                    # zstd_encode.hip: kOffLit + kLitPad + kSub + 64
+ENC_WORK = 0     
 DEC_WORK, DEC_CTR = 131072 + 64, 131072                                                 # zstd_decode.hip
 def counters(work, off, names):
     import ctypes as C
