@@ -5,6 +5,7 @@
 // fails with FOURMC_ENODEV (the product must fail loudly rather than fall back).
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <vector>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -175,12 +176,29 @@ int fourmc_gpu_zstd_decompress(const void* d_src, void* d_dst, fourmc_block* d_b
     return FOURMC_OK;
 }
 
+// zstd level 12 is on the device for inputs > 256 KiB only (below that the reference switches to btlazy2 / btopt):
+// refuse the whole batch rather than emit anything the reference would not
+static int zstd_level_ok(const fourmc_block* d_blocks, uint32_t n, int level, hipStream_t s)
+{
+    if (level == 1 || level == 3 || level == 6) return FOURMC_OK;
+    if (level != 12) { snprintf(g_err, sizeof g_err, "ZSTD level %d not on the device (levels 1, 3, 6 and 12 are)", level); return FOURMC_EUNSUP; }
+    std::vector<fourmc_block> h(n);
+    HIP_TRY(hipMemcpyAsync(h.data(), d_blocks, n * sizeof(fourmc_block), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (uint32_t b = 0; b < n; b++)
+        if (h[b].src_len <= 256u * 1024u) {
+            snprintf(g_err, sizeof g_err, "ZSTD level 12 not on the device for inputs <= 256 KiB (block %u has %u bytes; the reference uses btlazy2/btopt there)", b, h[b].src_len);
+            return FOURMC_EUNSUP;
+        }
+    return FOURMC_OK;
+}
+
 static int zstd_enc_serial() { const char* e = getenv("FOURMC_ZSTD_SERIAL"); return e && *e == '1'; }
 
 int fourmc_gpu_zstd_compress(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, int level, void* stream)
 {
     if (int r = ensure_device()) return r;
-    if (level != 1 && level != 3 && level != 6) { snprintf(g_err, sizeof g_err, "ZSTD level %d not on the device (levels 1, 3 and 6 are)", level); return FOURMC_EUNSUP; }
+    if (int r = zstd_level_ok(d_blocks, n, level, static_cast<hipStream_t>(stream))) return r;
     void* work = nullptr;
     if (int r = zstd_scratch_bytes(fourmc_zstd_enc_work_bytes(n, level), &work)) return r;
     HIP_TRY(fourmc_launch_zstd_encode(d_src, d_dst, d_blocks, n, work, 0, level, zstd_enc_serial(), static_cast<hipStream_t>(stream)));
@@ -215,7 +233,7 @@ int fourmc_gpu_4mc_encode_blocks(const void* d_src, void* d_dst, fourmc_block* d
         return FOURMC_OK;
     }
     if (codec == FOURMC_CODEC_ZSTD) {
-        if (level != 1 && level != 3 && level != 6) { snprintf(g_err, sizeof g_err, "ZSTD level %d not on the device (4mz fast = 1, medium = 3 and high = 6 are)", level); return FOURMC_EUNSUP; }
+        if (int r = zstd_level_ok(d_blocks, n, level, s)) return r;
         void* work = nullptr;
         if (int r = zstd_scratch_bytes(fourmc_zstd_enc_work_bytes(n, level), &work)) return r;
         HIP_TRY(fourmc_launch_zstd_encode(d_src, d_dst, d_blocks, n, work, 1, level, zstd_enc_serial(), s));

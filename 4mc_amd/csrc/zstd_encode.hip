@@ -48,9 +48,10 @@ constexpr size_t   kOffPrev   = kOffLit + kLitBytes;                 // 3 x FseC
 constexpr size_t   kOffTmp    = kOffPrev + 4736;                     // 512 B: FSE_writeNCount trial output (ZSTD_NCountCost)
 constexpr size_t   kStoreBytes = kOffTmp + 512 + 192;
 static_assert(kStoreBytes % 64 == 0, "tables start 64-byte aligned");
-// tables by level: 1 -> hash table (<= 2^15 x u32); 3 -> long 2^17 + short 2^16; 6 -> rows 2^19 x u32 + tags 2^19 x u16
+// tables by level: 1 -> hash table (<= 2^15 x u32); 3 -> long 2^17 + short 2^16; 6 -> rows 2^19 x u32 + tags 2^19 x u16;
+// 12 (inputs > 256 KiB only) -> rows 2^23 x u32 + tags 2^23 x u16
 __host__ __device__ constexpr size_t table_bytes(int level)
-{ return level == 6 ? (size_t(4) << 19) + (size_t(2) << 19) : level == 3 ? (size_t(4) << 17) + (size_t(4) << 16) : (size_t(4) << 15); }
+{ return level == 12 ? (size_t(4) << 23) + (size_t(2) << 23) : level == 6 ? (size_t(4) << 19) + (size_t(2) << 19) : level == 3 ? (size_t(4) << 17) + (size_t(4) << 16) : (size_t(4) << 15); }
 
 struct __attribute__((packed, aligned(1))) S4B { uint32_t v; };
 __device__ __forceinline__ void st4(uint8_t* p, uint32_t v) { reinterpret_cast<S4B*>(p)->v = v; }
@@ -1474,7 +1475,9 @@ __device__ __forceinline__ Params level_params(uint32_t n, int level)
     Params p;
     uint32_t wlog, hlog, clog;
     p.slog = 1;
-    if (level == 6) {                                   // clevels.h rows of level 6 (ZSTD_lazy; lazy2 for <= 16 KB)
+    if (level == 12) {                                  // clevels.h level 12, > 256 KB row only (ZSTD_lazy2); smaller inputs use btlazy2 / btopt
+        wlog = 22; clog = 22; hlog = 23; p.slog = 6; p.mml = 5; p.strat = 5;
+    } else if (level == 6) {                                   // clevels.h rows of level 6 (ZSTD_lazy; lazy2 for <= 16 KB)
         if (n <= 16 * 1024) { wlog = 14; clog = 14; hlog = 14; p.slog = 4; p.mml = 4; p.strat = 5; }
         else if (n <= 128 * 1024) { wlog = 17; clog = 16; hlog = 17; p.slog = 3; p.mml = 4; p.strat = 4; }
         else if (n <= 256 * 1024) { wlog = 18; clog = 18; hlog = 19; p.slog = 3; p.mml = 5; p.strat = 4; }
@@ -1512,6 +1515,7 @@ __device__ __forceinline__ bool is_rle(const uint8_t* s, uint32_t n, int lane)
 // ZSTD_compress(dst, cap, src, n, 1); returns the frame size or a negative ZSTD error number
 __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* work, int level, bool serial, int lane)
 {
+    if (level == 12 && n <= 256 * 1024) return kErrGeneric;      // refused by the engine before launch; never silently stored
     const Params P = level_params(n, level);
     uint32_t* const tab = reinterpret_cast<uint32_t*>(work + kStoreBytes);
     uint32_t* const tab_s = reinterpret_cast<uint32_t*>(work + kStoreBytes + (size_t(4) << 17));      // level 3: short-hash table

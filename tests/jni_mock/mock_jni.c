@@ -113,7 +113,7 @@ int main(int argc, char** argv)
             obj_t co = {{{"finish", 0, 0, 0}, {"finished", 0, 0, 0}, {"uncompressedDirectBuf", 1, 0, raw}, {"uncompressedDirectBufLen", 0, n, 0},
                          {"compressedDirectBuf", 1, 0, comp}, {"directBufferSize", 0, cap, 0}}, 6};
             g_thrown[0] = 0;
-            jint r = ((call1_fn)sym(lib, ccls, "compressBytesDirectHC"))(&env, &co, 12);
+            jint r = ((call1_fn)sym(lib, ccls, "compressBytesDirectHC"))(&env, &co, 9);
             printf("Zstd_compressBytesDirectHC12 %d %s | ulen_after=%d\n", r, g_thrown[0] ? g_thrown : "-", co.f[3].ival);
         }
         {   /* corrupt input: the decompressor throws InternalError and returns the codec's error */

@@ -129,7 +129,7 @@ def test_cli_4mz_file_equals_reference(gpu, tmp_path, flag, key):
     assert subprocess.run([gpu.cli_path(), "-d", "-z", "-f", str(out), str(back)], capture_output=True).returncode == 0
     assert back.read_bytes() == data.tobytes()
     r = subprocess.run([gpu.cli_path(), "-z", "-4", "-f", str(src), str(tmp_path / "c2.4mz")], capture_output=True)
-    assert r.returncode != 0 and b"not on the device" in r.stderr
+    assert r.returncode != 0 and b"not on the device" in r.stderr          # the corpus ends in a 123457-byte block
 
 
 def test_host_zstd_compress_entry_point(gpu):
@@ -146,10 +146,47 @@ def test_host_zstd_compress_entry_point(gpu):
     out = np.zeros(64, np.uint8)
     r = L.fourmc_ZSTD_compress(out.ctypes.data, 30, d.ctypes.data, 1000, 1)
     assert r == (1 << 64) - 70                                     # (size_t)-ZSTD_error_dstSize_tooSmall
-    r = L.fourmc_ZSTD_compress(out.ctypes.data, 64, d.ctypes.data, 10, 12)
-    assert r > (1 << 64) - 120                                     # level 12: ZSTD_isError(), no CPU fallback
+    r = L.fourmc_ZSTD_compress(out.ctypes.data, 64, d.ctypes.data, 10, 9)
+    assert r > (1 << 64) - 120                                     # level 9: ZSTD_isError(), no CPU fallback
     out = np.zeros(helpers.zstd_bound(300000) + 64, np.uint8)
     for lvl in (3, 6):
         r = L.fourmc_ZSTD_compress(out.ctypes.data, 1 << 30, d.ctypes.data, 300000, lvl)
         want_r, want = helpers.orc_zstd_compress(d, lvl)
         assert r == want_r and np.array_equal(out[:r], want), lvl
+
+
+def test_zstd12_full_blocks_golden_manifest_and_small_inputs_refused(gpu, tmp_path):
+    """4mz Ultra (zstd level 12, lazy2 + 64-entry rows) is on the device for inputs > 256 KiB: the 12 full corpus
+    blocks equal the reference CLI's manifest; smaller inputs (btlazy2 / btopt in the reference) are refused loudly."""
+    import subprocess
+    m = json.load(open(os.path.join(G, "corpus_manifest.json")))
+    nb = 12
+    data = helpers.corpus(nb * B)
+    blocks = gpu.make_blocks([b * B for b in range(nb)], [b * (B + 64) for b in range(nb)], [B] * nb, [B] * nb)
+    batch = gpu.DeviceBatch(blocks)
+    d_src = torch.from_numpy(data).cuda()
+    d_dst = torch.zeros(nb * (B + 64), dtype=torch.uint8, device="cuda")
+    gpu.encode_blocks(d_src, d_dst, batch, codec=gpu.CODEC_ZSTD, level=12)
+    torch.cuda.synchronize()
+    got = batch.download()
+    for b, (u, c, x) in enumerate(m["levels"]["4mz-4"]["blocks"][:nb]):
+        assert (int(got["src_len"][b]), int(got["result"][b]), int(got["xxh32"][b])) == (u, c, x), b
+    # raw frames against the oracle on a few sizes just above the 256 KiB class boundary, incl. a capacity that fails
+    src = helpers.corpus(2 * B, first_block=21)
+    sizes = [262145, 300001, 1000003, 2 * 1024 * 1024 + 5]
+    _check(gpu, ["n=%d" % n for n in sizes], [src[n: 2 * n].copy() for n in sizes], [n - 1 for n in sizes], "n-1", 12)
+    _check(gpu, ["n=%d" % n for n in sizes], [src[n: 2 * n].copy() for n in sizes], [n // 4 for n in sizes], "n/4", 12)
+    # small input: refused (never a silently different payload)
+    small = gpu.DeviceBatch(gpu.make_blocks([0], [0], [200000], [200000]))
+    with pytest.raises(gpu.EngineError, match="not on the device"):
+        gpu.zstd_compress(d_src, d_dst, small, 12)
+    # CLI: a file of whole blocks compresses and round-trips; the full corpus (123457-byte tail) is refused up front
+    f = tmp_path / "whole.bin"; f.write_bytes(data[: 3 * B].tobytes())
+    out = tmp_path / "whole.4mz"
+    assert subprocess.run([gpu.cli_path(), "-z", "-4", "-f", str(f), str(out)], capture_output=True).returncode == 0
+    back = tmp_path / "whole.back"
+    assert subprocess.run([gpu.cli_path(), "-d", "-z", "-f", str(out), str(back)], capture_output=True).returncode == 0
+    assert back.read_bytes() == data[: 3 * B].tobytes()
+    g = tmp_path / "tail.bin"; g.write_bytes(helpers.corpus(B + 123457).tobytes())
+    r = subprocess.run([gpu.cli_path(), "-z", "-4", "-f", str(g), str(tmp_path / "tail.4mz")], capture_output=True)
+    assert r.returncode == 1 and b"not on the device" in r.stderr and not (tmp_path / "tail.4mz").exists()
