@@ -95,9 +95,14 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
         // words of the following searches, the extension bytes around a hit, short literal runs and the
         // ip-2 / ip refill after a match.
         Q16 W = {0, 0, 0, 0}; uint32_t wsp = 0; bool wvalid = false;
+        // After a match the reference refills ip-2, re-tests ip at once (lz4.c:1207-1259) and only then starts the
+        // next search at ip+1.  Here that re-test is lane 0 of the next search's first batch (`retest`): same table
+        // order (ip-2, then ip, then ip+1 ...), one candidate round trip instead of two.
+        bool retest = false;
         for (;;) {
             // ------------------------------------------------------------ search (lz4.c:1014-1076)
             uint32_t ip, cand;
+            bool rt_hit = false;
             uint64_t e_ipx = 0, e_cx = 0; uint32_t e_ipb = 0, e_cb = 0; bool e_regs = false;   // extension data of the hit
             // Probe width: candidate checks are random 64 KiB-window gathers (one cache line each), the
             // real cost of a batch.  In compressible data a match turns up within a few probes, so a
@@ -132,9 +137,14 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                     ipb = q.d0; v8 = u64(q.d1, q.d2); ipx = u64(q.d2, q.d3);
                 } else v8 = ld8(src + rp);
                 const uint32_t h = hash_of<U32TAB>(v8);
+                // re-test batch: position sp-2 enters the table first; its 8 bytes are bytes 2..9 of lane 0's 16
+                const bool rt = retest && k0 == 0;
+                uint32_t h2 = 0xFFFFFFFFu;
+                if (rt) h2 = rl(hash_of<U32TAB>(u64(__builtin_amdgcn_alignbit(uint32_t(v8), ipb, 16), __builtin_amdgcn_alignbit(uint32_t(v8 >> 32), uint32_t(v8), 16))), 0);
                 uint32_t c = 0, cw = 0; uint64_t cx = 0; uint32_t cb = 0; bool shared = false, cregs = false;
                 if (act) {
                     c = tab_get(h);
+                    if (h == h2) c = sp - 2;                           // the refill of ip-2 comes before every probe of this batch
                     // scoreboard: does an earlier lane of this batch touch the same (folded) slot?
                     uint32_t* sc = &score[h & (kScore - 1)];
                     atomicMin(sc, uint32_t(lane));
@@ -153,7 +163,8 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                 const unsigned long long ev = (m_term | m_hit) & ((cut >= 64) ? ~0ull : ((1ull << cut) - 1));
                 const int e = ev ? __builtin_ctzll(ev) : cut;
                 const bool e_is_hit = ev && ((m_hit >> e) & 1) && !((m_term >> e) & 1);
-                // commit table writes of the probes that really happen
+                // commit table writes of the probes that really happen (after the ip-2 refill of a re-test batch)
+                if (rt && lane == 0) tab_put(h2, sp - 2);
                 if (lane < e || (lane == e && e_is_hit)) tab_put(h, pos);
                 if (ev) {
                     if (!e_is_hit) goto last_literals;
@@ -165,13 +176,14 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                         e_cx  = u64(rl(uint32_t(cx), e), rl(uint32_t(cx >> 32), e));
                         e_ipb = rl(ipb, e); e_cb = rl(cb, e);
                     }
-                    // literal run [anchor, ip) straight from the batch registers: possible when the search
-                    // began right behind the previous sequence and the hit is in its first, stride-1 batch
+                    rt_hit = rt && e == 0;                            // the immediate re-test hit: no literals, no catch-up
                     break;
                 }
                 k0 = U(k0 + e);
+                if (rt) { sp = U(sp + 1); k0 = U(k0 - 1); retest = false; }   // the search proper starts one past the re-test
                 if (e == int(width) && width < 64) width *= 2;
             }
+            retest = false;
             K2PH(pt_search);
             // ------------------------------------------------------------ catch up (lz4.c:1080)
             {
@@ -184,6 +196,9 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                     fwd_known = min(eq, room);
                     fwd_done = (eq < 8) || (room <= 8);
                 }
+                uint32_t token_pos, tok;      // the token byte is written once both nibbles are known
+                if (rt_hit) { token_pos = op++; tok = 0; }             // lz4.c:1250-1256: zero literals, straight to _next_match
+                else {
                 const uint32_t maxback = min(ip - anchor, cand);
                 uint32_t back = 0; bool more = maxback > 0;
                 if (e_regs && more && cand >= 4) {                     // first 4 bytes from registers
@@ -206,7 +221,6 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                 // the new ip+4, so the `back` bytes just walked over are already part of it
                 if (e_regs) fwd_known += back;
                 // ---------------------------------------------------------- literals (lz4.c:1083-1107)
-                uint32_t token_pos, tok;      // the token byte is written once both nibbles are known
                 {
                     const uint32_t lit = ip - anchor;
                     token_pos = op++;
@@ -222,8 +236,9 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                     } else copy_bytes(dst + op, src + anchor, lit, lane);
                     op += lit;
                 }
+                }
                 K2PH(pt_ext);
-                for (;;) {   // _next_match (lz4.c:1109-1200)
+                {   // _next_match (lz4.c:1109-1200)
                     const uint32_t off = ip - cand;
                     if (lane == 0) { dst[op] = uint8_t(off); dst[op + 1] = uint8_t(off >> 8); }
                     op += 2;
@@ -263,44 +278,10 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                     if (lane == 0) dst[token_pos] = uint8_t(tok + tok_add);
                     anchor = ip; op = U(op);
                     if (ip >= lim) goto last_literals;
-                    // refill ip-2, then test ip immediately (lz4.c:1207-1259)
-                    // [ip-2, ip+14) in one (wave-uniform) load: hash words of ip-2 and ip, forward bytes of ip
-                    uint64_t w2, w0, nx = 0; bool nregs = false;
-                    if (wvalid && ip >= wsp && ip < wsp + 64) {
-                        // lane ip-wsp holds [ip-4, ip+12): ip-2 is its byte 2, ip byte 4, ip+4 byte 8
-                        const int l = int(ip - wsp);
-                        const uint32_t a0 = rl(W.d0, l), a1 = rl(W.d1, l), a2 = rl(W.d2, l), a3 = rl(W.d3, l);
-                        w2 = u64(__builtin_amdgcn_alignbit(a1, a0, 16), __builtin_amdgcn_alignbit(a2, a1, 16));
-                        w0 = u64(a1, a2); nx = u64(a2, a3);
-                        nregs = true;
-                    } else if (ip + 14 <= un) {
-                        const Q16 q = ld16(src + ip - 2);
-                        w2 = u64(q.d0, q.d1);
-                        w0 = u64(__builtin_amdgcn_alignbit(q.d1, q.d0, 16), __builtin_amdgcn_alignbit(q.d2, q.d1, 16));
-                        nx = u64(__builtin_amdgcn_alignbit(q.d2, q.d1, 16), __builtin_amdgcn_alignbit(q.d3, q.d2, 16));
-                        nregs = true;
-                    } else { w2 = ld8(src + ip - 2); w0 = ld8(src + ip); }
-                    if (lane == 0) tab_put(hash_of<U32TAB>(w2), ip - 2);
-                    const uint32_t h = hash_of<U32TAB>(w0);
-                    cand = uint32_t(__builtin_amdgcn_readfirstlane(int(tab_get(h))));
-                    if (lane == 0) tab_put(h, ip);
-                    const uint32_t cw = ld4(src + cand);
-                    uint64_t cx = 0;
-                    if (nregs) cx = ld8(src + cand + 4);
-                    const bool again = (!U32TAB || cand + kMaxDist >= ip) && cw == uint32_t(w0);
-                    if (!__builtin_amdgcn_readfirstlane(int(again))) break;
-                    token_pos = op++; tok = 0;
-                    fwd_known = 0; fwd_done = false;
-                    if (nregs) {
-                        const uint64_t x = nx ^ cx;
-                        const uint32_t eq = x ? uint32_t(__builtin_ctzll(x) >> 3) : 8u;
-                        const uint32_t room = matchlimit - (ip + 4);
-                        fwd_known = min(eq, room);
-                        fwd_done = (eq < 8) || (room <= 8);
-                    }
+                    // the refill of ip-2 and the immediate re-test of ip (lz4.c:1207-1259) ride on the next batch
                 }
             }
-            sp = U(ip + 1); anchor = U(anchor); op = U(op);
+            sp = U(ip); retest = true; anchor = U(anchor); op = U(op);
             K2PH(pt_match);
         }
     }
