@@ -35,17 +35,32 @@ constexpr uint32_t kIdx0 = 65536;            // table index of position 0 (LZ4HC
 constexpr uint32_t kMaxDist = 65535;
 constexpr int      kMinMatch = 4, kMfLimit = 12, kLastLit = 5, kOptimalML = 18;
 constexpr int      kScore = 1024;
-constexpr size_t   kWorkBytes = (size_t(4) << kHashLog) + 2 * 65536;     // per block: heads + chain
+constexpr uint32_t kChainMask = 0x1FFFF;     // chain deltas of the last 128 Ki positions (the reference keeps 64 Ki): room for
+                                             // inserting up to 64 Ki positions AHEAD of the search position
+constexpr int      kWinK = 8;                // candidates cached per position of the look-ahead window
+constexpr size_t   kWorkBytes = (size_t(4) << kHashLog) + 2 * (size_t(kChainMask) + 1);     // per block: heads + chain
 
 __device__ __forceinline__ uint32_t hc_hash(uint32_t v) { return (v * 2654435761u) >> (32 - kHashLog); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// look-ahead window (LDS): for 64 consecutive positions, the first kWinK chain candidates with their measured lengths
+struct HCWin {
+    uint32_t cand[64 * kWinK];   // table index of the candidate
+    uint8_t  fl[64 * kWinK];     // equal bytes after the first 4 (0..32); 0xFF: the first 4 bytes differ
+    uint8_t  bl[64 * kWinK];     // equal bytes before (0..16)
+    uint32_t next[64];           // chain continuation after the cached candidates (0: chain ended)
+    uint8_t  nc[64];             // cached candidates of the position
+};
+
 struct HC {
     const uint8_t* src;
     uint32_t* heads;       // [32768]
-    uint16_t* chain;       // [65536]
+    uint16_t* chain;       // [131072]
     uint32_t* score;       // LDS [kScore], all 0xFFFFFFFF between uses
-    uint32_t  ntu;         // next position to insert
+    HCWin*    win;         // LDS
+    uint32_t  ntu;         // next position to insert (runs AHEAD of the search position)
+    uint32_t  wbase;       // first position of the window, 0xFFFFFFFF: none
+    uint32_t  n, matchlimit, mflimit;
     int       lane;
 };
 
@@ -64,7 +79,7 @@ __device__ __forceinline__ void hc_insert(HC& c, uint32_t upto)
             if (win) {
                 uint32_t delta = idx - c.heads[h];
                 if (delta > kMaxDist) delta = kMaxDist;
-                c.chain[idx & 0xFFFF] = uint16_t(delta);
+                c.chain[idx & kChainMask] = uint16_t(delta);
                 c.heads[h] = idx;
                 *sc = 0xFFFFFFFFu;
                 pending = false;
@@ -110,64 +125,161 @@ __device__ __forceinline__ uint32_t wave_count_back(const uint8_t* s, uint32_t a
     }
 }
 
+__device__ __forceinline__ uint32_t eq16_fwd(const U16B& x, const U16B& y)
+{
+    const uint64_t d0 = x.a ^ y.a, d1 = x.b ^ y.b;
+    return d0 ? uint32_t(__builtin_ctzll(d0) >> 3) : (d1 ? 8u + uint32_t(__builtin_ctzll(d1) >> 3) : 16u);
+}
+__device__ __forceinline__ uint32_t eq16_back(const U16B& x, const U16B& y)      // both end just before the compared positions
+{
+    const uint64_t d1 = x.b ^ y.b, d0 = x.a ^ y.a;
+    return d1 ? uint32_t(__builtin_clzll(d1) >> 3) : (d0 ? 8u + uint32_t(__builtin_clzll(d0) >> 3) : 16u);
+}
+
+// Look-ahead window.  Every position enters the tables (LZ4HC_Insert inserts them all, in order, whatever the parse
+// does), so the chain of position q is a function of the input alone: its first candidate is q - chain[q], the delta
+// recorded when q itself was inserted.  That lets the wave walk the chains of 64 consecutive positions AT ONCE (one
+// per lane, kWinK dependent steps for all of them together) and measure every candidate on the way, instead of one
+// dependent chain step per memory round trip.  The serial parser below then reads its searches out of LDS.
+__device__ __forceinline__ void hc_build_window(HC& c, uint32_t wb, int attempts)
+{
+    const uint8_t* s = c.src;
+    const int lane = c.lane;
+    hc_insert(c, min(wb + 64u, c.n - 3u));
+    const uint32_t q = wb + lane;
+    const bool act = q <= c.mflimit;                                  // no search starts beyond mflimit
+    const uint32_t qi = q + kIdx0, lowest = (kIdx0 + 65536 > qi) ? kIdx0 : qi - kMaxDist;
+    const uint32_t pat = ld4(s + (act ? q : 0u));
+    const bool wide_f = act && q + 36 <= c.n, wide_b = act && q >= 16;
+    U16B f0 = {0, 0}, f1 = {0, 0}, b0 = {0, 0};
+    if (wide_f) { f0 = *reinterpret_cast<const U16B*>(s + q + 4); f1 = *reinterpret_cast<const U16B*>(s + q + 20); }
+    if (wide_b) b0 = *reinterpret_cast<const U16B*>(s + q - 16);
+    const uint32_t fcap = act ? min(32u, c.matchlimit - (q + 4)) : 0u;
+    uint32_t mi = 0; bool go = false;
+    if (act) {
+        const uint32_t d = c.chain[qi & kChainMask];
+        mi = qi - d;
+        go = mi >= lowest;
+        // a delta of 65535 is either that distance or "further" (capped at insertion): it is the former iff the
+        // position there carries our hash
+        if (go && d == kMaxDist) go = hc_hash(ld4(s + (mi - kIdx0))) == hc_hash(pat);
+    }
+    uint32_t cnt = 0;
+    const int K = attempts < kWinK ? attempts : kWinK;
+    for (int k = 0; k < K; k++) {
+        if (!__ballot(go)) break;
+        if (go) {
+            const uint32_t m = mi - kIdx0;
+            const uint32_t d = c.chain[mi & kChainMask];
+            const uint32_t c4 = ld4(s + m);
+            uint32_t fl = 0xFF, bl = 0;
+            if (c4 == pat) {
+                if (wide_f) {
+                    const U16B g0 = *reinterpret_cast<const U16B*>(s + m + 4);
+                    uint32_t e = eq16_fwd(f0, g0);
+                    if (e == 16) { const U16B g1 = *reinterpret_cast<const U16B*>(s + m + 20); e += eq16_fwd(f1, g1); }
+                    fl = min(e, fcap);
+                } else { fl = 0; while (fl < fcap && s[q + 4 + fl] == s[m + 4 + fl]) fl++; }
+                if (wide_b && m >= 16) bl = eq16_back(b0, *reinterpret_cast<const U16B*>(s + m - 16));
+                else { const uint32_t bc = min(16u, min(q, m)); while (bl < bc && s[q - 1 - bl] == s[m - 1 - bl]) bl++; }
+            }
+            c.win->cand[lane * kWinK + k] = mi; c.win->fl[lane * kWinK + k] = uint8_t(fl); c.win->bl[lane * kWinK + k] = uint8_t(bl);
+            cnt++;
+            mi -= d;
+            go = mi >= lowest;
+        }
+    }
+    c.win->nc[lane] = uint8_t(cnt);
+    c.win->next[lane] = go ? mi : 0u;
+    c.wbase = wb;
+}
+
 // LZ4HC_InsertAndGetWiderMatch (lz4hc.c:239-447), no dictionary, no pattern analysis, no chain swap.
 __device__ __forceinline__ int hc_wider(HC& c, uint32_t ip, uint32_t low, uint32_t high, int longest,
                                         uint32_t& mpos, uint32_t& spos, int attempts)
 {
     const uint8_t* s = c.src;
     const int lane = c.lane;
-    hc_insert(c, ip);
+    if (c.wbase == 0xFFFFFFFFu || ip - c.wbase >= 64u) hc_build_window(c, ip, attempts);
+    const uint32_t j = ip - c.wbase;
     const uint32_t ip_idx = ip + kIdx0;
     const uint32_t lowest = (kIdx0 + 65536 > ip_idx) ? kIdx0 : ip_idx - kMaxDist;
     const uint32_t lookback = ip - low;
     const uint32_t pattern = ld4(s + ip);
-    uint32_t mi = uint32_t(uni(int(c.heads[hc_hash(pattern)])));
-    while (mi >= lowest && attempts > 0) {
-        // ---- collect up to 64 candidates of the chain (serial pointer chase)
-        uint32_t cand = 0; int nc = 0;
-        while (mi >= lowest && attempts > 0 && nc < 64) {
-            if (lane == nc) cand = mi;
-            nc++; attempts--;
-            mi -= uint32_t(uni(int(c.chain[mi & 0xFFFF])));
-        }
-        // ---- measure them, one per lane
-        const uint32_t m = cand - kIdx0;
-        bool live = lane < nc && ld4(s + (lane < nc ? m : 0u)) == pattern;
-        uint32_t fl = 0; bool more_f = false;
-        if (live) {                                           // forward: up to 32 bytes here
-            uint32_t a = ip + kMinMatch, b = m + kMinMatch;
-            more_f = true;
-            for (int it = 0; it < 4; it++) {
-                if (a + 8 > high) { while (a < high && s[a] == s[b]) { a++; b++; fl++; } more_f = false; break; }
-                const uint64_t x = ld8(s + a) ^ ld8(s + b);
-                if (x) { fl += uint32_t(__builtin_ctzll(x) >> 3); more_f = false; break; }
-                a += 8; b += 8; fl += 8;
+    int nc = int(c.win->nc[j]);
+    uint32_t mi = c.win->next[j];
+    if (nc == 0) return longest;                                      // empty chain (the common case in incompressible data)
+    attempts -= nc;
+    bool from_window = true;
+    for (;;) {
+        uint32_t m = 0, fl = 0, bk = 0; bool live = false, more_f = false, more_b = false;
+        if (from_window) {
+            // ---- the cached candidates: measured when the window was built; only limits that depend on the parse remain
+            if (lane < nc) {
+                const uint32_t f = c.win->fl[j * kWinK + lane], b = c.win->bl[j * kWinK + lane];
+                m = c.win->cand[j * kWinK + lane] - kIdx0;
+                live = f != 0xFF;
+                if (live) {
+                    fl = f; more_f = (f == 32) && (ip + kMinMatch + 32 < high);
+                    const uint32_t maxb = min(lookback, m);
+                    bk = min(b, maxb); more_b = (b == 16) && (maxb > 16);
+                }
             }
-        }
-        uint32_t bk = 0; bool more_b = false;
-        if (live && lookback) {                               // backward: up to 32 bytes here
-            const uint32_t maxb = min(lookback, m);
-            more_b = true;
-            for (int it = 0; it < 4; it++) {
-                if (bk + 8 > maxb) { while (bk < maxb && s[ip - bk - 1] == s[m - bk - 1]) bk++; more_b = false; break; }
-                const uint64_t x = ld8(s + ip - bk - 8) ^ ld8(s + m - bk - 8);
-                if (x) { bk += uint32_t(__builtin_clzll(x) >> 3); more_b = false; break; }
-                bk += 8;
+            for (unsigned long long todo = __ballot(more_f); todo; todo &= todo - 1) {
+                const int l = __builtin_ctzll(todo);
+                const uint32_t mm = uint32_t(__builtin_amdgcn_readlane(int(m), l));
+                const uint32_t extra = wave_count_fwd(s, ip + kMinMatch + 32, mm + kMinMatch + 32, high, lane);
+                if (lane == l) fl += extra;
             }
-        }
-        // ---- candidates still equal after 32 bytes: finish each with the whole wavefront
-        for (unsigned long long todo = __ballot(more_f); todo; todo &= todo - 1) {
-            const int l = __builtin_ctzll(todo);
-            const uint32_t mm = uint32_t(__builtin_amdgcn_readlane(int(m), l));
-            const uint32_t extra = wave_count_fwd(s, ip + kMinMatch + 32, mm + kMinMatch + 32, high, lane);
-            if (lane == l) fl += extra;
-        }
-        for (unsigned long long todo = __ballot(more_b); todo; todo &= todo - 1) {
-            const int l = __builtin_ctzll(todo);
-            const uint32_t mm = uint32_t(__builtin_amdgcn_readlane(int(m), l));
-            const uint32_t maxb = min(lookback, mm);
-            const uint32_t extra = wave_count_back(s, ip - 32, mm - 32, maxb - 32, lane);
-            if (lane == l) bk += extra;
+            for (unsigned long long todo = __ballot(more_b); todo; todo &= todo - 1) {
+                const int l = __builtin_ctzll(todo);
+                const uint32_t mm = uint32_t(__builtin_amdgcn_readlane(int(m), l));
+                const uint32_t extra = wave_count_back(s, ip - 16, mm - 16, min(lookback, mm) - 16, lane);
+                if (lane == l) bk += extra;
+            }
+        } else {
+            // ---- levels with more attempts than the window caches: the rest of the chain, 64 candidates per step
+            uint32_t cand = 0; nc = 0;
+            while (mi >= lowest && attempts > 0 && nc < 64) {
+                if (lane == nc) cand = mi;
+                nc++; attempts--;
+                mi -= uint32_t(uni(int(c.chain[mi & kChainMask])));
+            }
+            m = cand - kIdx0;
+            live = lane < nc && ld4(s + (lane < nc ? m : 0u)) == pattern;
+            if (live) {                                           // forward: up to 32 bytes here
+                uint32_t a = ip + kMinMatch, b = m + kMinMatch;
+                more_f = true;
+                for (int it = 0; it < 4; it++) {
+                    if (a + 8 > high) { while (a < high && s[a] == s[b]) { a++; b++; fl++; } more_f = false; break; }
+                    const uint64_t x = ld8(s + a) ^ ld8(s + b);
+                    if (x) { fl += uint32_t(__builtin_ctzll(x) >> 3); more_f = false; break; }
+                    a += 8; b += 8; fl += 8;
+                }
+            }
+            if (live && lookback) {                               // backward: up to 32 bytes here
+                const uint32_t maxb = min(lookback, m);
+                more_b = true;
+                for (int it = 0; it < 4; it++) {
+                    if (bk + 8 > maxb) { while (bk < maxb && s[ip - bk - 1] == s[m - bk - 1]) bk++; more_b = false; break; }
+                    const uint64_t x = ld8(s + ip - bk - 8) ^ ld8(s + m - bk - 8);
+                    if (x) { bk += uint32_t(__builtin_clzll(x) >> 3); more_b = false; break; }
+                    bk += 8;
+                }
+            }
+            for (unsigned long long todo = __ballot(more_f); todo; todo &= todo - 1) {
+                const int l = __builtin_ctzll(todo);
+                const uint32_t mm = uint32_t(__builtin_amdgcn_readlane(int(m), l));
+                const uint32_t extra = wave_count_fwd(s, ip + kMinMatch + 32, mm + kMinMatch + 32, high, lane);
+                if (lane == l) fl += extra;
+            }
+            for (unsigned long long todo = __ballot(more_b); todo; todo &= todo - 1) {
+                const int l = __builtin_ctzll(todo);
+                const uint32_t mm = uint32_t(__builtin_amdgcn_readlane(int(m), l));
+                const uint32_t maxb = min(lookback, mm);
+                const uint32_t extra = wave_count_back(s, ip - 32, mm - 32, maxb - 32, lane);
+                if (lane == l) bk += extra;
+            }
         }
         // ---- running "ml > longest" in chain order == max length, earliest candidate wins ties
         const uint32_t ml = live ? kMinMatch + fl + bk : 0u;
@@ -181,6 +293,8 @@ __device__ __forceinline__ int hc_wider(HC& c, uint32_t ip, uint32_t low, uint32
             const uint32_t bm = uint32_t(__builtin_amdgcn_readlane(int(m), l)), bb = uint32_t(__builtin_amdgcn_readlane(int(bk), l));
             mpos = bm - bb; spos = ip - bb;
         }
+        from_window = false;
+        if (!(mi != 0 && mi >= lowest && attempts > 0)) break;
     }
     return longest;
 }
@@ -211,10 +325,11 @@ __device__ __forceinline__ bool hc_emit(const uint8_t* src, uint8_t* dst, uint32
 }
 
 __device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int cap, int attempts,
-                                  uint8_t* work, uint32_t* score, int lane)
+                                  uint8_t* work, uint32_t* score, HCWin* win, int lane)
 {
     if (uint32_t(n) > 0x7E000000u) return 0;
-    HC c; c.src = src; c.lane = lane; c.ntu = 0; c.score = score;
+    HC c; c.src = src; c.lane = lane; c.ntu = 0; c.score = score; c.win = win; c.wbase = 0xFFFFFFFFu;
+    c.n = uint32_t(n); c.matchlimit = n > kLastLit ? uint32_t(n) - kLastLit : 0u; c.mflimit = n > kMfLimit ? uint32_t(n) - kMfLimit : 0u;
     c.heads = reinterpret_cast<uint32_t*>(work);
     c.chain = reinterpret_cast<uint16_t*>(work + (size_t(4) << kHashLog));
     {   // LZ4HC_clearTables: heads = 0, chain = 0xFFFF
@@ -306,6 +421,7 @@ void lz4hc_encode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base
                          uint32_t nblocks, uint8_t* work_base, int attempts, int container_mode)
 {
     __shared__ uint32_t score[kScore];
+    __shared__ HCWin win;
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
     const fourmc_block blk = blocks[b];
@@ -313,7 +429,7 @@ void lz4hc_encode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base
     uint8_t* dst = dst_base + blk.dst_off;
     const int n = int(blk.src_len);
     const int cap = container_mode ? n - 1 : int(blk.dst_cap);
-    int r = lz4hc_encode_block(src, dst, n, cap, attempts, work_base + size_t(b) * kWorkBytes, score, threadIdx.x);
+    int r = lz4hc_encode_block(src, dst, n, cap, attempts, work_base + size_t(b) * kWorkBytes, score, &win, threadIdx.x);
     if (container_mode && r <= 0) { copy_bytes(dst, src, uint32_t(n), threadIdx.x); r = n; }
     if (threadIdx.x == 0) blocks[b].result = r;
 }
