@@ -50,6 +50,7 @@ struct HCWin {
     uint8_t  bl[64 * kWinK];     // equal bytes before (0..16)
     uint32_t next[64];           // chain continuation after the cached candidates (0: chain ended)
     uint8_t  nc[64];             // cached candidates of the position
+    uint8_t  live[64];           // 0: no candidate of the position can give a match (none shares its first 4 bytes, chain ended)
 };
 
 struct HC {
@@ -164,7 +165,7 @@ __device__ __forceinline__ void hc_build_window(HC& c, uint32_t wb, int attempts
         // position there carries our hash
         if (go && d == kMaxDist) go = hc_hash(ld4(s + (mi - kIdx0))) == hc_hash(pat);
     }
-    uint32_t cnt = 0;
+    uint32_t cnt = 0; bool any = false;
     const int K = attempts < kWinK ? attempts : kWinK;
     for (int k = 0; k < K; k++) {
         if (!__ballot(go)) break;
@@ -184,13 +185,14 @@ __device__ __forceinline__ void hc_build_window(HC& c, uint32_t wb, int attempts
                 else { const uint32_t bc = min(16u, min(q, m)); while (bl < bc && s[q - 1 - bl] == s[m - 1 - bl]) bl++; }
             }
             c.win->cand[lane * kWinK + k] = mi; c.win->fl[lane * kWinK + k] = uint8_t(fl); c.win->bl[lane * kWinK + k] = uint8_t(bl);
-            cnt++;
+            cnt++; any |= fl != 0xFF;
             mi -= d;
             go = mi >= lowest;
         }
     }
     c.win->nc[lane] = uint8_t(cnt);
     c.win->next[lane] = go ? mi : 0u;
+    c.win->live[lane] = uint8_t((any ? 1 : 0) | ((go && attempts > K) ? 2 : 0));
     c.wbase = wb;
 }
 
@@ -348,7 +350,18 @@ __device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int c
         uint32_t ref = 0, start2 = 0, ref2 = 0, start3 = 0, ref3 = 0, start0, ref0, dummy = 0;
         while (ip <= mflimit) {
             ml = hc_wider(c, ip, ip, matchlimit, kMinMatch - 1, ref, dummy, attempts);
-            if (ml < kMinMatch) { ip++; continue; }
+            if (ml < kMinMatch) {
+                // no match here: go straight to the next window position that has a candidate sharing its first four
+                // bytes - a search anywhere in between returns "none" without side effects (tables are filled ahead)
+                uint32_t nip = ip + 1;
+                if (c.wbase != 0xFFFFFFFFu && nip - c.wbase < 64u) {
+                    const uint32_t rel = nip - c.wbase;
+                    const unsigned long long m = __ballot(c.win->live[lane] != 0) >> rel;
+                    nip += m ? uint32_t(__builtin_ctzll(m)) : 64u - rel;
+                }
+                ip = nip;
+                continue;
+            }
             start0 = ip; ref0 = ref; ml0 = ml;
         search2:
             if (ip + ml <= mflimit) ml2 = hc_wider(c, ip + ml - 2, ip, matchlimit, ml, ref2, start2, attempts);
