@@ -682,6 +682,402 @@ __device__ __forceinline__ int zstd_decode_frames(const uint8_t* src, int csize,
     return op;
 }
 
+// ================================================================================================ lane-parallel path
+// A 4mz payload is ONE frame of up to 32 inner blocks whose entropy decoding is independent (tables repeat
+// only by reference, repcodes are resolved at execution).  Decoding a block's literals and sequences is a
+// serial bit/state chain - one lane's worth of work - so here LANE i decodes inner block i: all Huffman and
+// FSE chains of a frame advance together, tables live in a per-lane slot of the HBM workspace.  Execution
+// (repcode resolution + the batch copier) then runs over the blocks in order with the whole wave.
+// Anything unusual (several frames, skippable frames, > 64 blocks, too many sequences) declines and the
+// serial path above decides.
+constexpr int      kDecline  = -1000000007;
+constexpr int      kMaxInner = 64;
+constexpr uint32_t kSeqArea  = 512 * 1024;                    // sequences of one 4mc block held at once
+constexpr size_t   kV2State  = (sizeof(ZState) + 255) & ~size_t(255);
+constexpr size_t   kV2Lit    = (size_t(4) << 20) + kMaxInner * 64 + 256;
+constexpr size_t   kV2Bytes  = kMaxInner * kV2State + kV2Lit + size_t(kSeqArea) * 12 + (kBlockMax + 64);
+
+struct V2Info {                                               // LDS, aliases ZState::huf (unused on this path)
+    uint32_t off[kMaxInner], size[kMaxInner];                // block content offset / size in the payload
+    uint32_t lit_off[kMaxInner], lit_size[kMaxInner];        // regenerated literals: where (src offset or literal area) / how many
+    uint32_t nseq[kMaxInner], seq_off[kMaxInner];
+    uint8_t  type[kMaxInner], lit_kind[kMaxInner], lit_rle[kMaxInner], bad[kMaxInner];   // lit_kind: 0 in place, 1 rle, 2 literal area
+};
+static_assert(sizeof(V2Info) <= sizeof(uint16_t) * 4096, "V2Info must fit the aliased table");
+
+struct LitHdr { int ltype; uint32_t lh, lsize, lcsize; bool one; };
+__device__ __forceinline__ bool parse_lit_hdr(const uint8_t* bp, int bend, LitHdr& h)
+{
+    if (bend < 1) return false;
+    const uint32_t b0 = bp[0];
+    const int fmt = (b0 >> 2) & 3;
+    h.ltype = b0 & 3; h.one = false;
+    if (h.ltype >= 2) {
+        if (bend < 5) return false;
+        const uint32_t lhc = uint32_t(bp[0]) | (uint32_t(bp[1]) << 8) | (uint32_t(bp[2]) << 16) | (uint32_t(bp[3]) << 24);
+        if (fmt <= 1) { h.one = (fmt == 0); h.lh = 3; h.lsize = (lhc >> 4) & 0x3FF; h.lcsize = (lhc >> 14) & 0x3FF; }
+        else if (fmt == 2) { h.lh = 4; h.lsize = (lhc >> 4) & 0x3FFF; h.lcsize = lhc >> 18; }
+        else { h.lh = 5; h.lsize = (lhc >> 4) & 0x3FFFF; h.lcsize = (lhc >> 22) + (uint32_t(bp[4]) << 10); }
+        return h.lsize <= uint32_t(kBlockMax) && h.lcsize + h.lh <= uint32_t(bend);
+    }
+    if ((fmt & 1) == 0) { h.lh = 1; h.lsize = b0 >> 3; }
+    else if (fmt == 1) { if (bend < 2) return false; h.lh = 2; h.lsize = (b0 | (uint32_t(bp[1]) << 8)) >> 4; }
+    else { if (bend < 3) return false; h.lh = 3; h.lsize = (b0 | (uint32_t(bp[1]) << 8) | (uint32_t(bp[2]) << 16)) >> 4; }
+    if (h.lsize > uint32_t(kBlockMax)) return false;
+    h.lcsize = h.ltype == 0 ? h.lsize : 1;
+    return h.lh + h.lcsize <= uint32_t(bend);
+}
+
+// sequences header at bp[pos..): count, modes byte; returns false on error.  pos ends behind the modes byte (or the count if 0)
+__device__ __forceinline__ bool parse_seq_hdr(const uint8_t* bp, int bend, int& pos, int& nseq, uint32_t& modes)
+{
+    if (bend - pos < 1) return false;
+    nseq = bp[pos++]; modes = 0;
+    if (nseq == 0) return pos == bend;
+    if (nseq > 0x7F) {
+        if (nseq == 0xFF) { if (pos + 2 > bend) return false; nseq = (bp[pos] | (bp[pos + 1] << 8)) + 0x7F00; pos += 2; }
+        else { if (pos >= bend) return false; nseq = ((nseq - 0x80) << 8) + bp[pos++]; }
+    }
+    if (pos + 1 > bend) return false;
+    modes = bp[pos++];
+    return (modes & 3) == 0;
+}
+
+// builds table t (0 LL, 1 OF, 2 ML) of a block whose sequence header's table descriptions start at bp[pos]; `pos` advances.
+// mode 3 is resolved by the caller.  Returns the table log or -1.
+__device__ __forceinline__ int build_seq_table_lane(ZState* zl, const uint8_t* bp, int bend, int& pos, int t, int mode)
+{
+    uint32_t* tab = t == 0 ? zl->ll : (t == 1 ? zl->of : zl->ml);
+    const int maxsym = t == 0 ? 35 : (t == 1 ? 31 : 52), maxlog = t == 0 ? 9 : (t == 1 ? 8 : 9);
+    if (mode == 1) {
+        if (pos >= bend) return -1;
+        const uint32_t sy = bp[pos++];
+        if (int(sy) > maxsym) return -1;
+        tab[0] = sy;
+        return 0;
+    }
+    if (mode == 0) {
+        const int dlog = t == 1 ? 5 : 6, dmax = t == 0 ? 35 : (t == 1 ? 28 : 52);
+        const int16_t* d = t == 0 ? kLLDef : (t == 1 ? kOFDef : kMLDef);
+        for (int i = 0; i <= dmax; i++) zl->norm[i] = d[i];
+        build_fse(tab, zl->norm, dmax, dlog, zl->next);
+        return dlog;
+    }
+    int ms = maxsym, tl = 0;
+    const int used = read_ncount(bp + pos, bend - pos, zl->norm, &ms, &tl, maxlog);
+    if (used < 0) return -1;
+    build_fse(tab, zl->norm, ms, tl, zl->next);
+    pos += used;
+    return tl;
+}
+
+// skips the description of one table (to reach a later one in an earlier block's header); false on error
+__device__ __forceinline__ bool skip_seq_table(ZState* zl, const uint8_t* bp, int bend, int& pos, int t, int mode)
+{
+    if (mode == 1) { if (pos >= bend) return false; pos++; return true; }
+    if (mode == 2) {
+        int ms = t == 0 ? 35 : (t == 1 ? 31 : 52), tl = 0;
+        const int used = read_ncount(bp + pos, bend - pos, zl->norm, &ms, &tl, t == 1 ? 8 : 9);
+        if (used < 0) return false;
+        pos += used;
+    }
+    return true;
+}
+
+__device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csize, uint8_t* dst, int cap, uint8_t* work, ZState* z, int lane)
+{
+    V2Info* const I = reinterpret_cast<V2Info*>(z->huf);
+    ZState* const zl = reinterpret_cast<ZState*>(work + size_t(lane) * kV2State);
+    uint8_t* const litarea = work + kMaxInner * kV2State;
+    uint32_t* const seqarea = reinterpret_cast<uint32_t*>(litarea + kV2Lit);
+    // ---------------------------------------------------------------- step 0: frame header + block headers (wave-uniform)
+    if (csize < 9) return kDecline;
+    const uint32_t magic = uint32_t(src[0]) | (uint32_t(src[1]) << 8) | (uint32_t(src[2]) << 16) | (uint32_t(src[3]) << 24);
+    if (magic != 0xFD2FB528u) return kDecline;
+    const uint32_t fhd = src[4];
+    const int fcs_id = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3;
+    if ((fhd & 0x0C) || did) return kDecline;                          // reserved bit, checksum, dictionary: the serial path decides
+    const int fcs_sz = fcs_id == 0 ? single : (1 << fcs_id);
+    const int hsize = 5 + (single ? 0 : 1) + fcs_sz;
+    if (csize < hsize) return kDecline;
+    int hp = 5;
+    if (!single) { const uint32_t wb = src[hp++]; if (int(wb >> 3) + 10 > 31) return kDecline; }
+    uint64_t fcs = ~0ull;
+    if (fcs_id == 0) { if (single) fcs = src[hp++]; }
+    else { fcs = 0; for (int i = 0; i < fcs_sz; i++) fcs |= uint64_t(src[hp++]) << (8 * i); if (fcs_id == 1) fcs += 256; }
+    if (fcs != ~0ull && fcs > uint64_t(cap)) return kErr;              // dstSize_tooSmall
+    int ip = hsize, nblk = 0;
+    for (;;) {
+        if (csize - ip < 3) return kDecline;
+        const uint32_t bh = uint32_t(src[ip]) | (uint32_t(src[ip + 1]) << 8) | (uint32_t(src[ip + 2]) << 16);
+        ip += 3;
+        const int last = bh & 1, btype = (bh >> 1) & 3;
+        const uint32_t bsize = bh >> 3, content = btype == 1 ? 1u : bsize;
+        if (btype == 3 || nblk == kMaxInner || content > uint32_t(csize - ip)) return kDecline;
+        if (btype == 2 && (bsize >= uint32_t(kBlockMax) || bsize < 2)) return kDecline;
+        if (lane == 0) { I->off[nblk] = uint32_t(ip); I->size[nblk] = bsize; I->type[nblk] = uint8_t(btype); }
+        nblk++; ip += int(content);
+        if (last) break;
+    }
+    if (ip != csize) return kDecline;                                  // more frames follow
+    if (lane < 36) { z->llb[lane] = kLLBase[lane]; z->llx[lane] = kLLBits[lane]; }
+    if (lane < 53) { z->mlb[lane] = kMLBase[lane]; z->mlx[lane] = kMLBits[lane]; }
+    // ---------------------------------------------------------------- step 1a: literal / sequence headers, one block per lane
+    const bool mine = lane < nblk && I->type[lane < nblk ? lane : 0] == 2;
+    const uint8_t* const bp = src + (lane < nblk ? I->off[lane] : 0u);
+    const int bend = lane < nblk ? int(I->size[lane]) : 0;
+    LitHdr lh; lh.ltype = 0; lh.lh = 0; lh.lsize = 0; lh.lcsize = 0; lh.one = false;
+    int spos = 0, nseq = 0; uint32_t modes = 0;
+    bool bad = false;
+    if (mine) {
+        bad = !parse_lit_hdr(bp, bend, lh);
+        if (!bad) { spos = int(lh.lh + lh.lcsize); bad = !parse_seq_hdr(bp, bend, spos, nseq, modes); }
+    }
+    if (__ballot(bad)) return kErr;
+    {
+        const uint32_t need = (mine && lh.ltype >= 2) ? ((lh.lsize + 63u) & ~63u) : 0u;
+        const uint32_t loff = scan_add(need) - need, soff = scan_add(uint32_t(nseq)) - uint32_t(nseq);
+        if (uint32_t(__builtin_amdgcn_readlane(int(soff + uint32_t(nseq)), 63)) > kSeqArea) return kDecline;
+        if (uint32_t(__builtin_amdgcn_readlane(int(loff + need), 63)) > uint32_t(kV2Lit) - 256u) return kDecline;
+        if (lane < nblk) {
+            I->nseq[lane] = uint32_t(nseq); I->seq_off[lane] = soff; I->lit_size[lane] = lh.lsize;
+            I->lit_kind[lane] = uint8_t(lh.ltype == 0 ? 0 : lh.ltype == 1 ? 1 : 2);
+            I->lit_off[lane] = lh.ltype >= 2 ? loff : I->off[lane] + lh.lh;
+            I->lit_rle[lane] = (mine && lh.ltype == 1) ? bp[lh.lh] : uint8_t(0);
+        }
+        // ------------------------------------------------------------ step 1b: Huffman literals (table of this block or of the block it repeats)
+        if (mine && lh.ltype >= 2) {
+            int huf_log = 0, used = 0;
+            if (lh.ltype == 2) used = read_huf_table(zl, bp + lh.lh, int(lh.lcsize), &huf_log);
+            else {
+                int j = lane - 1, ok = 0;
+                for (; j >= 0; j--) {
+                    if (I->type[j] != 2) continue;
+                    LitHdr hj;
+                    const uint8_t* bj = src + I->off[j];
+                    if (!parse_lit_hdr(bj, int(I->size[j]), hj)) break;
+                    if (hj.ltype == 2) { ok = read_huf_table(zl, bj + hj.lh, int(hj.lcsize), &huf_log) >= 0; break; }
+                }
+                if (!ok) used = -1;
+            }
+            if (used < 0) bad = true;
+            else {
+                const uint8_t* hp8 = bp + lh.lh + used;
+                const int hlen = int(lh.lcsize) - used;
+                uint8_t* const out = litarea + loff;
+                int nstreams = 1, l1 = 0, l2 = 0, l3 = 0, seg = int(lh.lsize);
+                if (!lh.one) {
+                    if (hlen < 10 || lh.lsize < 6) bad = true;
+                    else {
+                        l1 = hp8[0] | (hp8[1] << 8); l2 = hp8[2] | (hp8[3] << 8); l3 = hp8[4] | (hp8[5] << 8);
+                        seg = (int(lh.lsize) + 3) / 4; nstreams = 4;
+                        if (hlen - 6 - l1 - l2 - l3 < 1 || 3 * seg > int(lh.lsize)) bad = true;
+                    }
+                }
+                for (int j = 0; j < nstreams && !bad; j++) {
+                    const int s_off = nstreams == 1 ? 0 : 6 + (j > 0 ? l1 : 0) + (j > 1 ? l2 : 0) + (j > 2 ? l3 : 0);
+                    const int s_len = nstreams == 1 ? hlen : (j == 0 ? l1 : (j == 1 ? l2 : (j == 2 ? l3 : hlen - 6 - l1 - l2 - l3)));
+                    const int o_off = nstreams == 1 ? 0 : seg * j, o_len = nstreams == 1 ? int(lh.lsize) : ((j == 3) ? int(lh.lsize) - 3 * seg : seg);
+                    BitsBack bs;
+                    if (!bs.init(hp8 + s_off, s_len)) { bad = true; break; }
+                    for (int i = 0; i < o_len; i++) {
+                        const uint32_t idx = (bs.pos >= huf_log) ? bs.peek_at(bs.pos - huf_log, huf_log)
+                                                                 : (bs.peek_at(0, bs.pos > 0 ? bs.pos : 0) << (huf_log - (bs.pos > 0 ? bs.pos : 0)));
+                        const uint32_t e = zl->huf[idx];
+                        bs.pos -= int(e >> 8);
+                        out[o_off + i] = uint8_t(e);
+                    }
+                    if (bs.pos != 0) bad = true;
+                }
+            }
+        }
+        if (__ballot(bad)) return kErr;
+        // ------------------------------------------------------------ step 1c/1d: sequence tables, then the sequences themselves
+        if (mine && nseq > 0) {
+            uint32_t* const logs = zl->rank + 12;                      // table logs of LL / OF / ML (rank[] is free after the Huffman build)
+            logs[0] = logs[1] = logs[2] = 0;
+            int pos = spos;
+            for (int t = 0; t < 3 && !bad; t++) {
+                int mode = int((modes >> (6 - 2 * t)) & 3);
+                if (mode != 3) { const int lg = build_seq_table_lane(zl, bp, bend, pos, t, mode); if (lg < 0) bad = true; else logs[t] = uint32_t(lg); continue; }
+                // repeat: the most recent earlier block with sequences defines it (possibly itself by repeating)
+                int j = lane - 1; bool found = false;
+                for (; j >= 0 && !bad; j--) {
+                    if (I->type[j] != 2 || I->nseq[j] == 0) continue;
+                    const uint8_t* bj = src + I->off[j]; const int be = int(I->size[j]);
+                    LitHdr hj; int pj, nj; uint32_t mj;
+                    if (!parse_lit_hdr(bj, be, hj)) { bad = true; break; }
+                    pj = int(hj.lh + hj.lcsize);
+                    if (!parse_seq_hdr(bj, be, pj, nj, mj)) { bad = true; break; }
+                    const int mt = int((mj >> (6 - 2 * t)) & 3);
+                    if (mt == 3) continue;
+                    for (int u = 0; u < t && !bad; u++) if (!skip_seq_table(zl, bj, be, pj, u, int((mj >> (6 - 2 * u)) & 3))) bad = true;
+                    if (!bad) { const int lg = build_seq_table_lane(zl, bj, be, pj, t, mt); if (lg < 0) bad = true; else logs[t] = uint32_t(lg); }
+                    found = true;
+                    break;
+                }
+                if (!found) bad = true;
+            }
+            if (!bad) {
+                const int ll_log = int(logs[0]), of_log = int(logs[1]), ml_log = int(logs[2]);
+                for (int u = 0; u < (1 << ll_log); u++) { const uint32_t c = zl->ll[u] & 0xff; zl->llv[u] = z->llb[c] | (uint32_t(z->llx[c]) << 20); }
+                for (int u = 0; u < (1 << ml_log); u++) { const uint32_t c = zl->ml[u] & 0xff; zl->mlv[u] = z->mlb[c] | (uint32_t(z->mlx[c]) << 20); }
+                BitsBack bs;
+                if (!bs.init(bp + pos, bend - pos)) bad = true;
+                else {
+                    uint32_t sl = bs.read(ll_log), so = bs.read(of_log), sm = bs.read(ml_log);
+                    uint32_t* out = seqarea + size_t(soff) * 3;
+                    for (int n = 0; n < nseq; n++) {
+                        const uint32_t el = zl->ll[sl], eo = zl->of[so], em = zl->ml[sm];
+                        const uint32_t lv = zl->llv[sl], mv = zl->mlv[sm];
+                        const uint32_t ocode = eo & 0xff;
+                        if (ocode > 31) { bad = true; break; }
+                        const uint32_t ov = (1u << ocode) + bs.read(int(ocode));                 // Offset_Value: 1..3 repeat codes, else offset + 3
+                        const uint32_t mlen = (mv & 0xFFFFF) + bs.read(int(mv >> 20));
+                        const uint32_t llen = (lv & 0xFFFFF) + bs.read(int(lv >> 20));
+                        sl = (el >> 16) + bs.read(int((el >> 8) & 0xff));
+                        sm = (em >> 16) + bs.read(int((em >> 8) & 0xff));
+                        so = (eo >> 16) + bs.read(int((eo >> 8) & 0xff));
+                        out[3 * n] = llen; out[3 * n + 1] = mlen; out[3 * n + 2] = ov;
+                    }
+                    if (bs.pos > 0) bad = true;                        // bits left over: corruption
+                }
+            }
+        }
+        if (__ballot(bad)) return kErr;
+    }
+    // ---------------------------------------------------------------- step 2: execute the blocks in order
+    int op = 0;
+    uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
+    uint32_t pv = 0; int p_base = 0, p_n = 0;
+    for (int b = 0; b < nblk; b++) {
+        const int btype = I->type[b];
+        const uint32_t bsize = I->size[b];
+        if (btype == 0) {
+            if (bsize > uint32_t(cap - op)) return kErr;
+            wave_copy(dst + op, src + I->off[b], int(bsize), lane);
+            op += int(bsize);
+            continue;
+        }
+        if (btype == 1) {
+            if (bsize > uint32_t(cap - op)) return kErr;
+            const uint8_t v = src[I->off[b]];
+            for (uint32_t k = lane; k < bsize; k += 64) dst[op + k] = v;
+            op += int(bsize);
+            continue;
+        }
+        Lits lits; lits.pos = 0; lits.size = I->lit_size[b]; lits.is_rle = I->lit_kind[b] == 1; lits.rle = I->lit_rle[b];
+        lits.p = I->lit_kind[b] == 2 ? litarea + I->lit_off[b] : src + I->lit_off[b];
+        const int nsq = int(I->nseq[b]);
+        const uint32_t* sq = seqarea + size_t(I->seq_off[b]) * 3;
+        int n = 0;
+        bool have_c = false; uint32_t c_ll = 0, c_ml = 0, c_off = 0;
+        while (n < nsq || have_c) {
+            // ---- gather up to 64 sequences (one coalesced load), resolve their repeat codes in order
+            uint32_t my_ll = 0, my_ml = 0, my_off = 0, T = 0, Lsum = 0;
+            int cnt = 0;
+            const int take = min(64, nsq - n);
+            uint32_t r_ll = 0, r_ml = 0, r_ov = 0;
+            if (lane < take) { r_ll = sq[3 * (n + lane)]; r_ml = sq[3 * (n + lane) + 1]; r_ov = sq[3 * (n + lane) + 2]; }
+            int used = 0;
+            for (;;) {
+                uint32_t llen, mlen, offset;
+                if (have_c) { llen = c_ll; mlen = c_ml; offset = c_off; have_c = false; }
+                else if (used < take) {
+                    llen = uint32_t(__builtin_amdgcn_readlane(int(r_ll), used)); mlen = uint32_t(__builtin_amdgcn_readlane(int(r_ml), used));
+                    const uint32_t ov = uint32_t(__builtin_amdgcn_readlane(int(r_ov), used));
+                    used++;
+                    if (ov > 3) { offset = ov - 3; rep2 = rep1; rep1 = rep0; rep0 = offset; }
+                    else {
+                        const uint32_t idx = ov - 1 + (llen == 0 ? 1u : 0u);
+                        if (idx == 0) offset = rep0;
+                        else {
+                            uint32_t t = idx == 1 ? rep1 : (idx == 2 ? rep2 : rep0 - 1);
+                            t += !t;
+                            if (idx != 1) rep2 = rep1;
+                            rep1 = rep0; rep0 = offset = t;
+                        }
+                    }
+                } else break;
+                if (cnt == 64 || T + llen + mlen > uint32_t(kOwnBytes)) { have_c = true; c_ll = llen; c_ml = mlen; c_off = offset; break; }
+                if (lane == cnt) { my_ll = llen; my_ml = mlen; my_off = offset; }
+                cnt++; T += llen + mlen; Lsum += llen;
+            }
+            n += used;
+            if (cnt > 0 && Lsum <= lits.size - lits.pos && uint32_t(op) + T + 64 <= uint32_t(cap)) {
+                const uint32_t sz = my_ll + my_ml;
+                const uint32_t ostart = scan_add(sz) - sz, lstart = scan_add(my_ll) - my_ll;
+                const bool badq = lane < cnt && my_off > uint32_t(op) + ostart + my_ll;
+                if (__ballot(badq)) return kErr;
+                for (uint32_t k = 4u * lane; k < T; k += 256) *reinterpret_cast<uint32_t*>(z->own + k) = 0;
+                if (lane < cnt) z->own[ostart] = uint8_t(lane + 1);
+                const uint8_t* const lbase = lits.is_rle ? dst : lits.p + lits.pos;
+                uint32_t carry = 0;
+                if (p_n == 0) p_base = op;
+                for (uint32_t c0 = 0; c0 < T; c0 += 64) {
+                    const uint32_t o = c0 + lane;
+                    const bool live = o < T;
+                    uint32_t m = live ? uint32_t(z->own[o]) : 0u;
+                    m = max(scan_max(m), carry);
+                    carry = uint32_t(__builtin_amdgcn_readlane(int(m), 63));
+                    const int tl = (int(m) - 1) & 63;
+                    const uint32_t os = __shfl(ostart, tl), lt = __shfl(my_ll, tl), offt = __shfl(my_off, tl), ls = __shfl(lstart, tl);
+                    const uint32_t rel = o - os;
+                    const bool is_lit = live && rel < lt;
+                    const int sp = op + int(o) - int(offt);
+                    const int cs = op + int(c0);
+                    const bool is_match = live && !is_lit;
+                    const bool from_mem = is_match && sp < cs - p_n;
+                    const bool in_pend = is_match && sp >= cs - p_n && sp < cs;
+                    const uint8_t* const addr = (is_lit && !lits.is_rle) ? lbase + ls + rel : dst + (from_mem ? sp : 0);
+                    const uint32_t ld = *addr;
+                    dst[p_base + lane] = uint8_t(pv);
+                    const uint32_t fw = __shfl(pv, (sp - p_base) & 63);
+                    uint32_t v = ld;
+                    if (is_lit && lits.is_rle) v = lits.rle;
+                    if (in_pend) v = fw;
+                    bool done = !is_match || from_mem || in_pend;
+                    int dep = sp - cs;
+                    while (__ballot(!done)) {
+                        const int d = dep & 63;
+                        const uint32_t v2 = __shfl(v, d);
+                        const int dn = __shfl(int(done), d);
+                        const int dd = __shfl(dep, d);
+                        if (!done) { if (dn) { v = v2; done = true; } else dep = dd; }
+                    }
+                    pv = v; p_base = cs; p_n = min(64, int(T - c0));
+                }
+                op += int(T); lits.pos += Lsum;
+            } else {
+                if (lane < p_n) dst[p_base + lane] = uint8_t(pv);
+                p_n = 0;
+                for (int k = 0; k < cnt + (have_c && cnt == 0 ? 1 : 0); k++) {
+                    uint32_t llen, mlen, offset;
+                    if (k < cnt) { llen = uint32_t(__builtin_amdgcn_readlane(int(my_ll), k)); mlen = uint32_t(__builtin_amdgcn_readlane(int(my_ml), k)); offset = uint32_t(__builtin_amdgcn_readlane(int(my_off), k)); }
+                    else { llen = c_ll; mlen = c_ml; offset = c_off; have_c = false; }
+                    if (llen > lits.size - lits.pos) return kErr;
+                    if (llen + mlen > uint32_t(cap - op)) return kErr;
+                    copy_lits(dst + op, lits, llen, lane);
+                    lits.pos += llen; op += int(llen);
+                    if (offset > uint32_t(op)) return kErr;
+                    copy_match(dst, op, int(offset), int(mlen), lane);
+                    op += int(mlen);
+                }
+            }
+        }
+        if (lane < p_n) dst[p_base + lane] = uint8_t(pv);
+        p_n = 0;
+        {
+            const uint32_t rest = lits.size - lits.pos;
+            if (rest > uint32_t(cap - op)) return kErr;
+            copy_lits(dst + op, lits, rest, lane);
+            op += int(rest);
+        }
+    }
+    if (fcs != ~0ull && uint64_t(op) != fcs) return kErr;
+    return op;
+}
+
 // container_mode as in lz4_decode.hip (BADSUM skip, stored copy, negative -> CORRUPT)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
 void zstd_decode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks,
@@ -693,24 +1089,27 @@ void zstd_decode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
     const fourmc_block blk = blocks[b];
     const uint8_t* src = src_base + blk.src_off;
     uint8_t* dst = dst_base + blk.dst_off;
-    uint8_t* litbuf = scratch + size_t(b) * (kBlockMax + 64);
+    uint8_t* const work = scratch + size_t(b) * kV2Bytes;
+    uint8_t* litbuf = work + kV2Bytes - (kBlockMax + 64);              // the serial path's literal buffer: the tail of the slot
     int r;
     if (container_mode) {
         if (blk.result == FOURMC_BLK_BADSUM) return;
         if (blk.src_len == blk.dst_cap) { wave_copy(dst, src, int(blk.src_len), threadIdx.x); r = int(blk.src_len); }
         else {
-            r = zstd_decode_frames(src, int(blk.src_len), dst, int(blk.dst_cap), litbuf, &zs, threadIdx.x);
+            r = zstd_decode_frame_v2(src, int(blk.src_len), dst, int(blk.dst_cap), work, &zs, threadIdx.x);
+            if (r == kDecline) r = zstd_decode_frames(src, int(blk.src_len), dst, int(blk.dst_cap), litbuf, &zs, threadIdx.x);
             if (r < 0) r = FOURMC_BLK_CORRUPT;
         }
     } else {
-        r = zstd_decode_frames(src, int(blk.src_len), dst, int(blk.dst_cap), litbuf, &zs, threadIdx.x);
+        r = zstd_decode_frame_v2(src, int(blk.src_len), dst, int(blk.dst_cap), work, &zs, threadIdx.x);
+        if (r == kDecline) r = zstd_decode_frames(src, int(blk.src_len), dst, int(blk.dst_cap), litbuf, &zs, threadIdx.x);
     }
     if (threadIdx.x == 0) blocks[b].result = r;
 }
 
 } // namespace
 
-extern "C" size_t fourmc_zstd_scratch_bytes(uint32_t n) { return size_t(n) * (kBlockMax + 64); }
+extern "C" size_t fourmc_zstd_scratch_bytes(uint32_t n) { return size_t(n) * kV2Bytes; }
 
 extern "C" hipError_t fourmc_launch_zstd_decode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                                 void* d_scratch, int container_mode, hipStream_t stream)
