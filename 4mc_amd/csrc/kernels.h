@@ -29,6 +29,7 @@ hipError_t fourmc_launch_lz4hc_encode(const void* d_src, void* d_dst, fourmc_blo
 hipError_t fourmc_launch_lz4mc_encode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                       void* d_work, int container_mode, hipStream_t stream);
 size_t     fourmc_zstd_scratch_bytes(uint32_t n);
+size_t     fourmc_zstd_dec_counter_offset(void);
 hipError_t fourmc_launch_zstd_decode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                      void* d_scratch, int container_mode, hipStream_t stream);
 size_t     fourmc_zstd_enc_work_bytes(uint32_t n, int level);

@@ -790,6 +790,7 @@ __device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csiz
     ZState* const zl = reinterpret_cast<ZState*>(work + size_t(lane) * kV2State);
     uint8_t* const litarea = work + kMaxInner * kV2State;
     uint32_t* const seqarea = reinterpret_cast<uint32_t*>(litarea + kV2Lit);
+    uint64_t t_lit = 0, t_hdr = 0, t_seq = 0, t_exec = 0, t0 = __builtin_readcyclecounter(), t1;   // phase cycle counters (profiling aid)
     // ---------------------------------------------------------------- step 0: frame header + block headers (wave-uniform)
     if (csize < 9) return kDecline;
     const uint32_t magic = uint32_t(src[0]) | (uint32_t(src[1]) << 8) | (uint32_t(src[2]) << 16) | (uint32_t(src[3]) << 24);
@@ -845,6 +846,7 @@ __device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csiz
             I->lit_off[lane] = lh.ltype >= 2 ? loff : I->off[lane] + lh.lh;
             I->lit_rle[lane] = (mine && lh.ltype == 1) ? bp[lh.lh] : uint8_t(0);
         }
+        ZPH(t_hdr);
         // ------------------------------------------------------------ step 1b: Huffman literals (table of this block or of the block it repeats)
         if (mine && lh.ltype >= 2) {
             int huf_log = 0, used = 0;
@@ -892,6 +894,7 @@ __device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csiz
             }
         }
         if (__ballot(bad)) return kErr;
+        ZPH(t_lit);
         // ------------------------------------------------------------ step 1c/1d: sequence tables, then the sequences themselves
         if (mine && nseq > 0) {
             uint32_t* const logs = zl->rank + 12;                      // table logs of LL / OF / ML (rank[] is free after the Huffman build)
@@ -946,6 +949,7 @@ __device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csiz
         }
         if (__ballot(bad)) return kErr;
     }
+    ZPH(t_seq);
     // ---------------------------------------------------------------- step 2: execute the blocks in order
     int op = 0;
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
@@ -1075,6 +1079,8 @@ __device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csiz
         }
     }
     if (fcs != ~0ull && uint64_t(op) != fcs) return kErr;
+    ZPH(t_exec);
+    if (lane == 0) { uint64_t* c = reinterpret_cast<uint64_t*>(work + kV2Bytes - 64); c[0] = t_lit; c[1] = t_hdr; c[2] = t_seq; c[3] = t_exec; }
     return op;
 }
 
@@ -1110,6 +1116,7 @@ void zstd_decode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
 } // namespace
 
 extern "C" size_t fourmc_zstd_scratch_bytes(uint32_t n) { return size_t(n) * kV2Bytes; }
+extern "C" size_t fourmc_zstd_dec_counter_offset(void) { return kV2Bytes - 64; }   // phase counters of block 0 (profiling aid)
 
 extern "C" hipError_t fourmc_launch_zstd_decode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                                 void* d_scratch, int container_mode, hipStream_t stream)

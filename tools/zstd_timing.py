@@ -32,7 +32,9 @@ def run(src, nb, tag):
     out = torch.empty(nb * B + 64, dtype=torch.uint8, device="cuda")
     ec = counters(ENC_WORK, ENC_CTR, ("match", "literals", "sequences", "frame")) if nb == 1 else ""
     td = t(lambda: p.decode_blocks(stage, out, dec, codec=p.CODEC_ZSTD))
-    dc = "(lane-parallel path: no phase counters)"
+    import ctypes as C
+    p.lib().fourmc_zstd_dec_counter_offset.restype = C.c_size_t
+    dc = counters(0, p.lib().fourmc_zstd_dec_counter_offset(), ("literals", "headers", "sequences", "execute")) if nb == 1 else ""
     ok = torch.equal(out[: nb * B], src[: nb * B])
     cs = int(r["result"].astype(np.int64).sum())
     print(f"{tag:12s} blocks {nb:5d} ratio {nb * B / cs:6.3f}  enc {te:9.2f} ms ({nb * B / te / 1e6:7.2f} GB/s)  dec {td:9.2f} ms ({nb * B / td / 1e6:7.2f} GB/s) roundtrip {'ok' if ok else 'BAD'}", flush=True)
