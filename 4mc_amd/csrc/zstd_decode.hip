@@ -975,40 +975,51 @@ __device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csiz
         const int nsq = int(I->nseq[b]);
         const uint32_t* sq = seqarea + size_t(I->seq_off[b]) * 3;
         int n = 0;
-        bool have_c = false; uint32_t c_ll = 0, c_ml = 0, c_off = 0;
-        while (n < nsq || have_c) {
-            // ---- gather up to 64 sequences (one coalesced load), resolve their repeat codes in order
-            uint32_t my_ll = 0, my_ml = 0, my_off = 0, T = 0, Lsum = 0;
-            int cnt = 0;
+        while (n < nsq) {
+            // ---- 64 sequences per coalesced load.  How many fit one batch follows from the lengths alone (prefix sum);
+            // repeat offsets are the only serial part and cost work only where a repeat code actually occurs: runs of
+            // real offsets between two repeat codes just shift the history.
             const int take = min(64, nsq - n);
-            uint32_t r_ll = 0, r_ml = 0, r_ov = 0;
-            if (lane < take) { r_ll = sq[3 * (n + lane)]; r_ml = sq[3 * (n + lane) + 1]; r_ov = sq[3 * (n + lane) + 2]; }
-            int used = 0;
-            for (;;) {
-                uint32_t llen, mlen, offset;
-                if (have_c) { llen = c_ll; mlen = c_ml; offset = c_off; have_c = false; }
-                else if (used < take) {
-                    llen = uint32_t(__builtin_amdgcn_readlane(int(r_ll), used)); mlen = uint32_t(__builtin_amdgcn_readlane(int(r_ml), used));
-                    const uint32_t ov = uint32_t(__builtin_amdgcn_readlane(int(r_ov), used));
-                    used++;
-                    if (ov > 3) { offset = ov - 3; rep2 = rep1; rep1 = rep0; rep0 = offset; }
+            uint32_t my_ll = 0, my_ml = 0, r_ov = 4;
+            if (lane < take) { my_ll = sq[3 * (n + lane)]; my_ml = sq[3 * (n + lane) + 1]; r_ov = sq[3 * (n + lane) + 2]; }
+            const uint32_t incl = scan_add(my_ll + my_ml);
+            const unsigned long long over = __ballot(lane < take && incl > uint32_t(kOwnBytes));
+            int cnt = over ? __builtin_ctzll(over) : take;
+            const bool single = cnt == 0;                              // one sequence larger than a whole batch: executed alone below
+            if (single) cnt = 1;
+            if (lane >= cnt) { my_ll = 0; my_ml = 0; }
+            const uint32_t T = uint32_t(__builtin_amdgcn_readlane(int(incl), cnt - 1));
+            const uint32_t Lsum = uint32_t(__builtin_amdgcn_readlane(int(scan_add(my_ll)), 63));
+            uint32_t my_off = r_ov - 3;                                // real offsets; repeat codes are patched below
+            {
+                const unsigned long long rmask = __ballot(lane < cnt && r_ov <= 3);
+                int prev = -1;                                         // last position whose effect is folded into rep0..2
+                auto advance = [&](int upto) {                         // fold the real offsets of positions (prev, upto) into the history
+                    const int g = upto - 1 - prev;
+                    if (g >= 3) { rep0 = uint32_t(__builtin_amdgcn_readlane(int(my_off), upto - 1)); rep1 = uint32_t(__builtin_amdgcn_readlane(int(my_off), upto - 2)); rep2 = uint32_t(__builtin_amdgcn_readlane(int(my_off), upto - 3)); }
+                    else if (g == 2) { rep2 = rep0; rep0 = uint32_t(__builtin_amdgcn_readlane(int(my_off), upto - 1)); rep1 = uint32_t(__builtin_amdgcn_readlane(int(my_off), upto - 2)); }
+                    else if (g == 1) { rep2 = rep1; rep1 = rep0; rep0 = uint32_t(__builtin_amdgcn_readlane(int(my_off), upto - 1)); }
+                };
+                for (unsigned long long todo = rmask; todo; todo &= todo - 1) {
+                    const int k = __builtin_ctzll(todo);
+                    advance(k);
+                    const uint32_t ov = uint32_t(__builtin_amdgcn_readlane(int(r_ov), k));
+                    const uint32_t idx = ov - 1 + (uint32_t(__builtin_amdgcn_readlane(int(my_ll), k)) == 0 ? 1u : 0u);
+                    uint32_t offset;
+                    if (idx == 0) offset = rep0;
                     else {
-                        const uint32_t idx = ov - 1 + (llen == 0 ? 1u : 0u);
-                        if (idx == 0) offset = rep0;
-                        else {
-                            uint32_t t = idx == 1 ? rep1 : (idx == 2 ? rep2 : rep0 - 1);
-                            t += !t;
-                            if (idx != 1) rep2 = rep1;
-                            rep1 = rep0; rep0 = offset = t;
-                        }
+                        uint32_t t = idx == 1 ? rep1 : (idx == 2 ? rep2 : rep0 - 1);
+                        t += !t;
+                        if (idx != 1) rep2 = rep1;
+                        rep1 = rep0; rep0 = offset = t;
                     }
-                } else break;
-                if (cnt == 64 || T + llen + mlen > uint32_t(kOwnBytes)) { have_c = true; c_ll = llen; c_ml = mlen; c_off = offset; break; }
-                if (lane == cnt) { my_ll = llen; my_ml = mlen; my_off = offset; }
-                cnt++; T += llen + mlen; Lsum += llen;
+                    if (lane == k) my_off = offset;
+                    prev = k;
+                }
+                advance(cnt);
             }
-            n += used;
-            if (cnt > 0 && Lsum <= lits.size - lits.pos && uint32_t(op) + T + 64 <= uint32_t(cap)) {
+            n += cnt;
+            if (!single && Lsum <= lits.size - lits.pos && uint32_t(op) + T + 64 <= uint32_t(cap)) {
                 const uint32_t sz = my_ll + my_ml;
                 const uint32_t ostart = scan_add(sz) - sz, lstart = scan_add(my_ll) - my_ll;
                 const bool badq = lane < cnt && my_off > uint32_t(op) + ostart + my_ll;
@@ -1055,10 +1066,9 @@ __device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csiz
             } else {
                 if (lane < p_n) dst[p_base + lane] = uint8_t(pv);
                 p_n = 0;
-                for (int k = 0; k < cnt + (have_c && cnt == 0 ? 1 : 0); k++) {
-                    uint32_t llen, mlen, offset;
-                    if (k < cnt) { llen = uint32_t(__builtin_amdgcn_readlane(int(my_ll), k)); mlen = uint32_t(__builtin_amdgcn_readlane(int(my_ml), k)); offset = uint32_t(__builtin_amdgcn_readlane(int(my_off), k)); }
-                    else { llen = c_ll; mlen = c_ml; offset = c_off; have_c = false; }
+                for (int k = 0; k < cnt; k++) {
+                    const uint32_t llen = uint32_t(__builtin_amdgcn_readlane(int(my_ll), k)), mlen = uint32_t(__builtin_amdgcn_readlane(int(my_ml), k));
+                    const uint32_t offset = uint32_t(__builtin_amdgcn_readlane(int(my_off), k));
                     if (llen > lits.size - lits.pos) return kErr;
                     if (llen + mlen > uint32_t(cap - op)) return kErr;
                     copy_lits(dst + op, lits, llen, lane);
