@@ -848,11 +848,23 @@ __device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csiz
         }
         ZPH(t_hdr);
         // ------------------------------------------------------------ step 1b: Huffman literals (table of this block or of the block it repeats)
-        if (mine && lh.ltype >= 2) {
+        // With <= 32 inner blocks the upper half-wave would idle: lane L works on block L & 31 and decodes the stream
+        // pair L >> 5 of its four Huffman streams (each half builds its own copy of the table in its own slot).
+        // Only when the launch leaves the CUs under-filled: at 8 waves per CU the extra table builds cost more than they save.
+        const bool split = nblk <= 32 && gridDim.x < 1024u;
+        const int hb = split ? (lane & 31) : lane, half = split ? (lane >> 5) : 0;
+        LitHdr hh = lh; const uint8_t* hbp = bp; uint32_t hloff = loff; bool hmine = mine;
+        if (split && lane >= 32) {
+            hmine = hb < nblk && I->type[hb < nblk ? hb : 0] == 2;
+            hbp = src + (hb < nblk ? I->off[hb] : 0u);
+            hh.ltype = 0;
+            if (hmine) { parse_lit_hdr(hbp, int(I->size[hb]), hh); hloff = I->lit_off[hb]; }      // already validated by lane hb
+        }
+        if (hmine && hh.ltype >= 2) {
             int huf_log = 0, used = 0;
-            if (lh.ltype == 2) used = read_huf_table(zl, bp + lh.lh, int(lh.lcsize), &huf_log);
+            if (hh.ltype == 2) used = read_huf_table(zl, hbp + hh.lh, int(hh.lcsize), &huf_log);
             else {
-                int j = lane - 1, ok = 0;
+                int j = hb - 1, ok = 0;
                 for (; j >= 0; j--) {
                     if (I->type[j] != 2) continue;
                     LitHdr hj;
@@ -864,22 +876,23 @@ __device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csiz
             }
             if (used < 0) bad = true;
             else {
-                const uint8_t* hp8 = bp + lh.lh + used;
-                const int hlen = int(lh.lcsize) - used;
-                uint8_t* const out = litarea + loff;
-                int nstreams = 1, l1 = 0, l2 = 0, l3 = 0, seg = int(lh.lsize);
-                if (!lh.one) {
-                    if (hlen < 10 || lh.lsize < 6) bad = true;
+                const uint8_t* hp8 = hbp + hh.lh + used;
+                const int hlen = int(hh.lcsize) - used;
+                uint8_t* const out = litarea + hloff;
+                int nstreams = 1, l1 = 0, l2 = 0, l3 = 0, seg = int(hh.lsize);
+                if (!hh.one) {
+                    if (hlen < 10 || hh.lsize < 6) bad = true;
                     else {
                         l1 = hp8[0] | (hp8[1] << 8); l2 = hp8[2] | (hp8[3] << 8); l3 = hp8[4] | (hp8[5] << 8);
-                        seg = (int(lh.lsize) + 3) / 4; nstreams = 4;
-                        if (hlen - 6 - l1 - l2 - l3 < 1 || 3 * seg > int(lh.lsize)) bad = true;
+                        seg = (int(hh.lsize) + 3) / 4; nstreams = 4;
+                        if (hlen - 6 - l1 - l2 - l3 < 1 || 3 * seg > int(hh.lsize)) bad = true;
                     }
                 }
-                for (int j = 0; j < nstreams && !bad; j++) {
+                const int j0 = split ? (nstreams == 4 ? 2 * half : 0) : 0, j1 = split ? (nstreams == 4 ? 2 * half + 2 : (half == 0 ? 1 : 0)) : nstreams;
+                for (int j = j0; j < j1 && !bad; j++) {
                     const int s_off = nstreams == 1 ? 0 : 6 + (j > 0 ? l1 : 0) + (j > 1 ? l2 : 0) + (j > 2 ? l3 : 0);
                     const int s_len = nstreams == 1 ? hlen : (j == 0 ? l1 : (j == 1 ? l2 : (j == 2 ? l3 : hlen - 6 - l1 - l2 - l3)));
-                    const int o_off = nstreams == 1 ? 0 : seg * j, o_len = nstreams == 1 ? int(lh.lsize) : ((j == 3) ? int(lh.lsize) - 3 * seg : seg);
+                    const int o_off = nstreams == 1 ? 0 : seg * j, o_len = nstreams == 1 ? int(hh.lsize) : ((j == 3) ? int(hh.lsize) - 3 * seg : seg);
                     BitsBack bs;
                     if (!bs.init(hp8 + s_off, s_len)) { bad = true; break; }
                     for (int i = 0; i < o_len; i++) {
