@@ -58,6 +58,17 @@ __device__ __forceinline__ Q16 ld16(const uint8_t* p) { const U16B t = *reinterp
 __device__ __forceinline__ uint64_t u64(uint32_t lo, uint32_t hi) { return (uint64_t(hi) << 32) | lo; }
 __device__ __forceinline__ uint32_t rl(uint32_t v, int l) { return uint32_t(__builtin_amdgcn_readlane(int(v), l)); }
 
+// wave64 inclusive prefix sum on the DPP network (row shifts, then row broadcasts)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v)
+{ return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, ROWMASK, 0xf, false)); }
+__device__ __forceinline__ uint32_t scan_add(uint32_t v)
+{
+    v += dpp0<0x111, 0xf>(v); v += dpp0<0x112, 0xf>(v); v += dpp0<0x114, 0xf>(v); v += dpp0<0x118, 0xf>(v);
+    v += dpp0<0x142, 0xa>(v); v += dpp0<0x143, 0xc>(v);
+    return v;
+}
+
 template <bool U32TAB> __device__ __forceinline__ uint32_t hash_of(uint64_t v)
 {
     if (U32TAB) return uint32_t(((v << 24) * 889523592379ULL) >> (64 - kHashLog));
@@ -70,10 +81,12 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
 {
     uint16_t* tab16 = reinterpret_cast<uint16_t*>(tab32);
 #ifdef K2_PROF   // one-off phase profile (tools/k2_phases.py builds a side library with -DK2_PROF): cycles per phase
-    uint64_t pt_search = 0, pt_ext = 0, pt_match = 0, pt0 = __builtin_readcyclecounter(), pt1;
-#define K2PH(acc) do { pt1 = __builtin_readcyclecounter(); acc += pt1 - pt0; pt0 = pt1; } while (0)
+    uint64_t pt_search = 0, pt_ext = 0, pt_match = 0, pt_cur = 0, pt_tab = 0, pt_gather = 0, pt_emit = 0, pt_nwin = 0, pt_nseq = 0, pt_nslow = 0, pt0 = __builtin_readcyclecounter(), pt1;
+#define K2PH(acc) do { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); pt1 = __builtin_readcyclecounter(); acc += pt1 - pt0; pt0 = pt1; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define K2CNT(c) do { c++; } while (0)
 #else
 #define K2PH(acc) do { } while (0)
+#define K2CNT(c) do { } while (0)
 #endif
     const bool limited = cap < n + n / 255 + 16;                       // lz4.c:1352
     uint32_t op = 0, anchor = 0;
@@ -81,208 +94,372 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
     for (int i = lane; i < (1 << kHashLog); i += 64) tab32[i] = 0;     // LZ4_initStream
     for (int i = lane; i < kScore; i += 64) score[i] = 0xFFFFFFFFu;
 
+    // A 32-bit table entry is position << cbits | check, the check being cbits hash bits of the 4 bytes at that
+    // position: a probe whose check differs cannot be a 4-byte match and skips the (random, cache-line wide) read
+    // of its candidate.  Entries with position 0 (empty slots read as position 0, lz4.c:1348) are always read.
+    const int cbits = U32TAB ? __builtin_clz(uint32_t(n - 1) | 1u) : 0;
+    const uint32_t cmask = (1u << cbits) - 1;
+    auto chk_of = [&](uint32_t w) -> uint32_t { return U32TAB ? (w * 2654435761u) >> (32 - cbits) : 0u; };
+    auto enc = [&](uint32_t pos, uint32_t ck) -> uint32_t { return U32TAB ? (pos << cbits) | ck : pos; };
     auto tab_get = [&](uint32_t h) -> uint32_t { return U32TAB ? tab32[h] : uint32_t(tab16[h]); };
-    auto tab_put = [&](uint32_t h, uint32_t v) { if (U32TAB) tab32[h] = v; else tab16[h] = uint16_t(v); };
+    auto tab_put = [&](uint32_t h, uint32_t pos, uint32_t ck) { if (U32TAB) tab32[h] = enc(pos, ck); else tab16[h] = uint16_t(pos); };
 
     if (n >= kMinLen) {
         const uint32_t un = uint32_t(n);
         const uint32_t lim = un - kMfLimit + 1;                        // mflimitPlusOne
         const uint32_t matchlimit = un - kLastLit;
-        if (lane == 0) tab_put(hash_at<U32TAB>(src), 0);
-        uint32_t sp = 1;                                               // first probe of the search
-        // Cursor window: lane l keeps the 16 bytes [wsp+l-4, wsp+l+12) of the input.  Loaded once per ~50
-        // bytes of progress, it feeds (through lane permutes / readlane, no memory round trip) the probe
-        // words of the following searches, the extension bytes around a hit, short literal runs and the
-        // ip-2 / ip refill after a match.
-        Q16 W = {0, 0, 0, 0}; uint32_t wsp = 0; bool wvalid = false;
-        // After a match the reference refills ip-2, re-tests ip at once (lz4.c:1207-1259) and only then starts the
-        // next search at ip+1.  Here that re-test is lane 0 of the next search's first batch (`retest`): same table
-        // order (ip-2, then ip, then ip+1 ...), one candidate round trip instead of two.
-        bool retest = false;
+        if (lane == 0) tab_put(hash_at<U32TAB>(src), 0, chk_of(ld4(src)));
+
+        // One sequence (lz4.c:1080-1200): catch-up, literals, offset, match length.  `ip`/`cand` are the hit; `back`
+        // (0..4) bytes before them and `fwd` bytes after ip+4 are already known equal, `*_more` says the comparison
+        // has to go on in memory.  Literals at [wsp, wsp+64) come from `wbyte` (lane l holds src[wsp+l]).
+        // Returns 0 and the end of the match in ip_out, 1 = go to the last literals, 2 = output full.
+        auto sequence = [&](uint32_t ip, uint32_t cand, const bool rt_hit, const uint32_t back, const bool back_more,
+                            uint32_t fwd, const bool fwd_more, const uint32_t wsp, const uint32_t wbyte, uint32_t& ip_out) -> int {
+            uint32_t token_pos, tok;
+            if (rt_hit) { token_pos = op++; tok = 0; }                 // lz4.c:1250-1256: zero literals, straight to _next_match
+            else {
+                const uint32_t maxback = min(ip - anchor, cand);
+                uint32_t b = min(back, maxback);
+                if (back_more && maxback > back) {
+                    for (;;) {
+                        const uint32_t j = b + uint32_t(lane) + 1;
+                        const bool ok = (j <= maxback) && src[ip - j] == src[cand - j];
+                        const unsigned long long bad = ~__ballot(ok);
+                        const int t = bad ? __builtin_ctzll(bad) : 64;
+                        b += t;
+                        if (t < 64) break;
+                    }
+                }
+                b = U(b);
+                ip = U(ip - b); cand = U(cand - b);
+                fwd += b;                                              // everything in [new ip, old ip + 4 + fwd) is equal
+                const uint32_t lit = ip - anchor;                      // literals (lz4.c:1083-1107)
+                token_pos = op++;
+                if (limited && op + lit + (2 + 1 + kLastLit) + lit / 255 > uint32_t(cap)) return 2;
+                if (lit >= 15) { tok = 0xF0; op += emit_len(dst + op, lit - 15, lane); }
+                else tok = lit << 4;
+                if (wsp != 0xFFFFFFFFu && ip > wsp && ip <= wsp + 64) {
+                    if (anchor < wsp) copy_bytes(dst + op, src + anchor, wsp - anchor, lane);
+                    const uint32_t q = wsp + lane;
+                    if (q >= anchor && q < ip) dst[op + (q - anchor)] = uint8_t(wbyte);
+                } else copy_bytes(dst + op, src + anchor, lit, lane);
+                op += lit;
+            }
+            // _next_match (lz4.c:1109-1200)
+            const uint32_t off = ip - cand, off_pos = op;
+            op += 2;
+            uint32_t mcode = fwd;
+            if (fwd_more) {
+                uint32_t a = ip + 4 + mcode, b = cand + 4 + mcode;
+                for (;;) {
+                    if (a + 1024 <= matchlimit && mcode >= 64) {
+                        const U16B x = *reinterpret_cast<const U16B*>(src + a + 16 * lane);
+                        const U16B y = *reinterpret_cast<const U16B*>(src + b + 16 * lane);
+                        const uint64_t d0 = x.a ^ y.a, d1 = x.b ^ y.b;
+                        const uint32_t eq = d0 ? uint32_t(__builtin_ctzll(d0) >> 3)
+                                               : (d1 ? 8u + uint32_t(__builtin_ctzll(d1) >> 3) : 16u);
+                        const unsigned long long bad = __ballot(eq < 16);
+                        if (bad) {
+                            const int l = __builtin_ctzll(bad);
+                            mcode += 16 * l + __builtin_amdgcn_readlane(eq, l);
+                            break;
+                        }
+                        mcode += 1024; a += 1024; b += 1024;
+                    } else {
+                        const uint32_t i = a + lane;
+                        const bool same = (i < matchlimit) && src[i] == src[b + lane];
+                        const unsigned long long bad = ~__ballot(same);
+                        if (bad) { mcode += __builtin_ctzll(bad); break; }
+                        mcode += 64; a += 64; b += 64;
+                    }
+                }
+            }
+            mcode = U(mcode);
+            ip = U(ip + mcode + 4);
+            if (limited && op + (1 + kLastLit) + (mcode + 240) / 255 > uint32_t(cap)) return 2;
+            uint32_t tok_add;
+            if (mcode >= 15) { tok_add = 15; op += emit_len(dst + op, mcode - 15, lane); }
+            else tok_add = mcode;
+            if (lane < 3) {                                            // token, offset low, offset high: one store
+                const uint32_t at = lane == 0 ? token_pos : off_pos + uint32_t(lane) - 1;
+                const uint32_t v  = lane == 0 ? tok + tok_add : (lane == 1 ? off : off >> 8);
+                dst[at] = uint8_t(v);
+            }
+            anchor = ip; op = U(op);
+            ip_out = ip;
+            return ip >= lim ? 1 : 0;
+        };
+
+        // Parser state: `sp` is the next position to act on.  With `retest` it is the position right after a match,
+        // whose ip-2 refill and immediate re-test (lz4.c:1207-1259) are still owed and whose search starts at sp+1;
+        // otherwise it is probe number k0 of the running search.
+        uint32_t sp = 1, k0 = 0; bool retest = false;
+        uint32_t pw_sp = 0xFFFFFFFFu, pwbyte = 0;                      // previous dense window: start, and the byte each lane held
         for (;;) {
-            // ------------------------------------------------------------ search (lz4.c:1014-1076)
-            uint32_t ip, cand;
-            bool rt_hit = false;
-            uint64_t e_ipx = 0, e_cx = 0; uint32_t e_ipb = 0, e_cb = 0; bool e_regs = false;   // extension data of the hit
-            // Probe width: candidate checks are random 64 KiB-window gathers (one cache line each), the
-            // real cost of a batch.  In compressible data a match turns up within a few probes, so a
-            // search starts 16 lanes wide and doubles after every batch that found nothing.
-            uint32_t width = 16;
-            for (uint32_t k0 = 0;; ) {
-                const bool act = uint32_t(lane) < width;
+            if (sp >= 4 && sp + 100 <= un && k0 <= 32) {
+                // ------------------------------------------------------------ dense window
+                // Probes 0..65 of a search are one byte apart, so around a fresh search the parse walks consecutive
+                // positions.  Lane l takes position sp+l, whatever role the parse will give it (probe, re-test,
+                // refill, or inside a match), and prepares everything against the table as it stands: candidate,
+                // 4-byte test, up to 4 equal bytes backwards and 24 forwards.  A scalar loop of ballots and
+                // readlanes then only CHOOSES the sequences of the window (which hit lanes the greedy walk lands
+                // on); sizes, output positions and all bytes of the chosen sequences are produced afterwards by all
+                // lanes at once.  A lane whose table slot is also touched by an earlier lane of the window
+                // ("dirty") cannot trust its candidate: when the walk reaches it as a probe the window ends there.
+                const uint32_t sp0 = sp;
+                const uint32_t pos = sp0 + uint32_t(lane);
+                const Q16 q0 = ld16(src + pos - 4), q1 = ld16(src + pos + 12);          // [pos-4, pos+28)
+                K2PH(pt_cur); K2CNT(pt_nwin);
+                const uint64_t v8 = u64(q0.d1, q0.d2);
+                const uint32_t h = hash_of<U32TAB>(v8);
+                uint32_t h2 = 0xFFFFFFFFu;                              // slot of the owed refill of sp-2
+                const uint32_t ck = chk_of(q0.d1);
+                uint32_t ck2 = 0;
+                if (retest) {
+                    const uint32_t w2 = __builtin_amdgcn_alignbit(q0.d1, q0.d0, 16);
+                    h2 = rl(hash_of<U32TAB>(u64(w2, __builtin_amdgcn_alignbit(q0.d2, q0.d1, 16))), 0);
+                    ck2 = rl(chk_of(w2), 0);
+                }
+                uint32_t ent = tab_get(h);
+                if (h == h2) ent = enc(sp0 - 2, ck2);
+                const uint32_t c = U32TAB ? ent >> cbits : ent;
+                const bool pass = !U32TAB || (c + kMaxDist >= pos && (c == 0 || (ent & cmask) == ck));
+                uint32_t* sc = &score[h & (kScore - 1)];
+                atomicMin(sc, uint32_t(lane));
+                const bool dirty = (*sc != uint32_t(lane));
+                *sc = 0xFFFFFFFFu;
+                if (retest && lane == 0) tab_put(h2, sp0 - 2, ck2);
+                K2PH(pt_tab);
+                // info: lane of the match end | back bytes << 8 (5: four and possibly more) | raw back << 12 |
+                // back_more << 15 | fwd_more << 16
+                uint32_t info;
+                bool hit = false, slow = false;
+                if (!pass) info = uint32_t(lane) + 4;
+                else if (c >= 4) {
+                    const Q16 c0 = ld16(src + c - 4), c1 = ld16(src + c + 12);
+                    hit = c0.d1 == q0.d1;
+                    const uint32_t xb = q0.d0 ^ c0.d0;                  // byte 3 (MSB) is position -1
+                    const uint32_t bk = xb ? uint32_t(__builtin_clz(xb) >> 3) : 4u;
+                    const uint64_t x0 = u64(q0.d2, q0.d3) ^ u64(c0.d2, c0.d3), x1 = u64(q1.d0, q1.d1) ^ u64(c1.d0, c1.d1),
+                                   x2 = u64(q1.d2, q1.d3) ^ u64(c1.d2, c1.d3);
+                    const uint32_t fw = x0 ? uint32_t(__builtin_ctzll(x0) >> 3) : (x1 ? 8u + uint32_t(__builtin_ctzll(x1) >> 3)
+                                           : (x2 ? 16u + uint32_t(__builtin_ctzll(x2) >> 3) : 24u));
+                    slow = fw == 24;
+                    info = (uint32_t(lane) + 4 + fw) | ((bk == 4 && c > 4 ? 5u : bk) << 8) | (bk << 12) | (uint32_t(bk == 4) << 15) | (uint32_t(fw == 24) << 16);
+                } else {
+                    hit = ld4(src + c) == q0.d1;
+                    slow = true;                                        // nothing known: compare in memory
+                    info = (uint32_t(lane) + 4) | (1u << 15) | (1u << 16);
+                }
+                const unsigned long long m_hit = __ballot(hit), m_dirty = __ballot(dirty), m_slow = __ballot(hit && slow);
+                const uint32_t wbyte = q0.d1;
+                K2PH(pt_gather);
+                // The first sequence may own literals of the previous window: they are still in registers if that was
+                // a dense window too (pw_sp); anything older goes through the general path.  Near the end of the
+                // output buffer every sequence does, for its exact capacity checks.
+                const uint32_t pw_lo = (pw_sp != 0xFFFFFFFFu && pw_sp + 64 >= sp0) ? pw_sp : sp0;
+                const bool capok = !limited || op + 320 <= uint32_t(cap);
+                const unsigned long long stop2 = m_dirty | m_slow | (capok ? 0ull : m_hit);
+                unsigned long long stop1 = stop2;
+                const int scut = (!retest && k0 > 1) ? 65 - int(k0) : 64;   // first lane that is not one byte on from its predecessor
+                if (scut < 64) stop1 |= 1ull << scut;
+                if (anchor < pw_lo) stop1 |= m_hit & (0ull - m_hit);
+                const unsigned long long hd2 = m_hit | stop2;
+                unsigned long long hd = m_hit | stop1, stp = stop1;
+                unsigned long long selw = 0, xint = 0;                  // chosen hit lanes; lanes inside directly emitted matches
+                int cur = 0, anc = int(anchor - sp0);                   // lane of the next action; anchor as a lane number
+                bool any = retest, fresh = true;                        // a search has begun in this window; no sequence yet
+                int stoplane = 64, status = 0;
+                uint32_t anc_v = 0;
+                for (;;) {
+                    unsigned long long sel = 0;
+                    int reason = 0, e = 0;                              // 0: no event left, 1: stop lane, 2: match leaves the window
+                    for (;;) {
+                        const unsigned long long ev = hd & (~0ull << cur);
+                        if (!ev) break;
+                        e = __builtin_ctzll(ev);
+                        if ((stp >> e) & 1) { reason = 1; break; }
+                        const uint32_t inf = rl(info, e);
+                        if (min(int((inf >> 8) & 7), e - anc) == 5) { reason = 1; break; }   // the catch-up has to go on in memory
+                        if (lane == e) anc_v = uint32_t(anc);
+                        sel |= 1ull << e;
+                        K2CNT(pt_nseq);
+                        anc = cur = int(inf & 255);
+                        hd = hd2; stp = stop2;
+                        if (cur >= 64) { reason = 2; break; }
+                    }
+                    K2PH(pt_ext);
+                    if (sel) {
+                        // sizes, positions and bytes of the chosen sequences, all at once (lz4.c:1080-1200)
+                        const bool mine = (sel >> lane) & 1;
+                        const int myanc = int(anc_v);
+                        const uint32_t b = uint32_t(min(int((info >> 8) & 7), lane - myanc));
+                        const uint32_t lit = uint32_t(lane - myanc) - b, mc = (info & 255) - uint32_t(lane) - 4 + b;
+                        const uint32_t xl = lit >= 15 ? 1u : 0u;
+                        const uint32_t size = mine ? 3 + lit + xl + (mc >= 15 ? 1u : 0u) : 0u;
+                        const uint32_t incl = scan_add(size);
+                        const uint32_t opb = op + incl - size;
+                        const uint32_t pk = uint32_t(myanc + 128) | (b << 9) | (xl << 12);
+                        // a literal lane belongs to the next chosen hit lane E at or after it, if it lies in that
+                        // sequence's [anchor, ip)
+                        const unsigned long long ahead = sel >> lane;
+                        const int E = lane + (ahead ? __builtin_ctzll(ahead) : 0);
+                        const uint32_t opbE = __shfl(opb, E), pkE = __shfl(pk, E);
+                        const int aE = int(pkE & 511) - 128, ipnE = E - int((pkE >> 9) & 7);
+                        if (ahead && lane >= aE && lane < ipnE) dst[opbE + 1 + ((pkE >> 12) & 1) + uint32_t(lane - aE)] = uint8_t(wbyte);
+                        const int E1 = __builtin_ctzll(sel);
+                        const int a1 = int(rl(pk, E1) & 511) - 128;
+                        if (a1 < 0) {                                   // literals still held by the previous window's lanes
+                            const uint32_t pk1 = rl(pk, E1), opb1 = rl(opb, E1);
+                            const int pl = int(pw_sp - sp0) + lane, ipn1 = E1 - int((pk1 >> 9) & 7);
+                            if (pl >= a1 && pl < min(0, ipn1)) dst[opb1 + 1 + ((pk1 >> 12) & 1) + uint32_t(pl - a1)] = uint8_t(pwbyte);
+                        }
+                        if (mine) {
+                            const uint32_t off = pos - c;
+                            uint32_t o = opb;
+                            dst[o++] = uint8_t((min(lit, 15u) << 4) | min(mc, 15u));
+                            if (xl) dst[o++] = uint8_t(lit - 15);
+                            o += lit;
+                            dst[o] = uint8_t(off); dst[o + 1] = uint8_t(off >> 8);
+                            if (mc >= 15) dst[o + 2] = uint8_t(mc - 15);
+                        }
+                        op = U(op + rl(incl, 63));
+                        anchor = sp0 + uint32_t(anc);
+                        selw |= sel; any = true; fresh = false;
+                    }
+                    K2PH(pt_emit);
+                    if (reason == 0) {                                  // every remaining lane was a probe
+                        const int s = any ? cur + 1 : -int(k0);
+                        k0 = uint32_t(64 - s); sp = sp0 + 64; retest = false;
+                        break;
+                    }
+                    if (reason == 2) {
+                        const uint32_t ip = sp0 + uint32_t(cur);
+                        if (ip >= lim) { status = 1; break; }
+                        sp = ip; k0 = 0; retest = true;                 // the next window pays the refill
+                        break;
+                    }
+                    if (((m_dirty >> e) & 1) || (fresh && e == scut)) { // the window ends in front of lane e
+                        stoplane = e;
+                        if (any && e == cur) { k0 = 0; retest = true; }
+                        else { k0 = uint32_t(e - (any ? cur + 1 : -int(k0))); retest = false; }
+                        sp = sp0 + uint32_t(e);
+                        break;
+                    }
+                    {   // a hit that needs the general path
+                        K2CNT(pt_nslow);
+                        const uint32_t inf = rl(info, e);
+                        uint32_t ip;
+                        status = sequence(sp0 + uint32_t(e), rl(c, e), any && e == cur, (inf >> 12) & 7, (inf >> 15) & 1,
+                                          (inf & 255) - uint32_t(e) - 4, (inf >> 16) & 1, sp0, wbyte, ip);
+                        if (status) break;
+                        any = true; fresh = false;
+                        if (ip - sp0 >= 64) {
+                            xint |= ~1ull << e;
+                            sp = ip; k0 = 0; retest = true;
+                            break;
+                        }
+                        cur = anc = int(ip - sp0);
+                        xint |= (~1ull << e) & ~(~0ull << cur) & ~(1ull << (cur - 2));
+                        hd = hd2; stp = stop2;
+                    }
+                }
+                if (status == 2) return 0;
+                if (status == 1) goto last_literals;
+                // commit: every lane the walk passed as a probe, re-test or refill enters the table; the latest
+                // position of a slot wins (a refill lane may share its slot with an earlier probe)
+                {
+                    const unsigned long long below = selw & ~(~0ull << lane);
+                    const int P = below ? 63 - __builtin_clzll(below) : 0;
+                    const int endP = int(__shfl(info, P) & 255);
+                    const bool inside = (below && lane < endP && lane != endP - 2) || ((xint >> lane) & 1);
+                    if (lane < stoplane && !inside) {
+                        if (U32TAB) atomicMax(&tab32[h], enc(pos, ck));
+                        else for (;;) { tab16[h] = uint16_t(pos); asm volatile("" ::: "memory"); if (uint32_t(tab16[h]) >= pos) break; }
+                    }
+                }
+                pw_sp = sp0; pwbyte = wbyte;
+                sp = U(sp); k0 = U(k0);
+                K2PH(pt_match);
+                continue;
+            }
+            // ---------------------------------------------------------------- sparse batch (lz4.c:1014-1076)
+            // 64 probes of the running search at their strided positions: start and end of a block, and searches
+            // that found nothing for a while.  The first lane (serial order) that hits or reaches the end limit ends
+            // the batch; it is cut at the first lane that shares a table slot with an earlier one.
+            {
+                const bool rt = retest;                                 // lane 0 is the re-test of sp, the search starts at sp+1
+                pw_sp = 0xFFFFFFFFu;
                 uint32_t pos, next;
-                if (k0 == 0) { pos = sp + lane; next = pos + 1; }       // the first 65 probes of a search are 1 apart
-                else { pos = sp + probe_offset(k0 + lane); next = sp + probe_offset(k0 + lane + 1); }
+                if (k0 == 0) { pos = sp + lane; next = pos + 1; }
+                else { pos = sp + probe_offset(k0 + lane) - probe_offset(k0); next = sp + probe_offset(k0 + lane + 1) - probe_offset(k0); }
                 const bool in_range = next <= lim;                     // else: this probe ends the block
-                // One 16-byte load per lane covers everything needed on the cursor side: [pos-4, pos) for the
-                // backward extension, [pos, pos+8) for the hash, [pos+4, pos+12) for the forward extension
-                // (in_range lanes have pos+12 <= n; the first few positions of a block take the plain path).
                 const bool wide = sp >= 4;
                 const uint32_t rp = in_range ? pos : (wide ? 4u : 0u);   // keep speculative reads in bounds
                 uint64_t v8, ipx = 0; uint32_t ipb = 0;
-                if (wide && k0 == 0) {
-                    // probes of a search's first (stride-1) batch: from the cursor window when they are
-                    // inside it, else re-centre the window on this search
-                    if (!(wvalid && sp >= wsp && sp + width <= wsp + 64 && wsp + 64 + 12 <= un)) {
-                        W = ld16(src + rp - 4); wsp = sp; wvalid = (sp + 64 + 12 <= un);
-                    }
-                    Q16 q = W;
-                    if (wvalid && sp != wsp) {
-                        const int sl = (lane + int(sp - wsp)) & 63;
-                        q.d0 = __shfl(W.d0, sl); q.d1 = __shfl(W.d1, sl); q.d2 = __shfl(W.d2, sl); q.d3 = __shfl(W.d3, sl);
-                    }
-                    ipb = q.d0; v8 = u64(q.d1, q.d2); ipx = u64(q.d2, q.d3);
-                } else if (wide) {
-                    const Q16 q = ld16(src + rp - 4);
-                    ipb = q.d0; v8 = u64(q.d1, q.d2); ipx = u64(q.d2, q.d3);
-                } else v8 = ld8(src + rp);
+                if (wide) { const Q16 q = ld16(src + rp - 4); ipb = q.d0; v8 = u64(q.d1, q.d2); ipx = u64(q.d2, q.d3); }
+                else v8 = ld8(src + rp);
                 const uint32_t h = hash_of<U32TAB>(v8);
-                // re-test batch: position sp-2 enters the table first; its 8 bytes are bytes 2..9 of lane 0's 16
-                const bool rt = retest && k0 == 0;
                 uint32_t h2 = 0xFFFFFFFFu;
-                if (rt) h2 = rl(hash_of<U32TAB>(u64(__builtin_amdgcn_alignbit(uint32_t(v8), ipb, 16), __builtin_amdgcn_alignbit(uint32_t(v8 >> 32), uint32_t(v8), 16))), 0);
-                uint32_t c = 0, cw = 0; uint64_t cx = 0; uint32_t cb = 0; bool shared = false, cregs = false;
-                if (act) {
-                    c = tab_get(h);
-                    if (h == h2) c = sp - 2;                           // the refill of ip-2 comes before every probe of this batch
-                    // scoreboard: does an earlier lane of this batch touch the same (folded) slot?
-                    uint32_t* sc = &score[h & (kScore - 1)];
-                    atomicMin(sc, uint32_t(lane));
-                    shared = (*sc != uint32_t(lane));
-                    *sc = 0xFFFFFFFFu;
-                    // candidate side, same shape: [c-4, c+12) in one load (c + 12 <= n always holds)
-                    if (wide && c >= 4) { const Q16 q = ld16(src + c - 4); cb = q.d0; cw = q.d1; cx = u64(q.d2, q.d3); cregs = true; }
-                    else cw = ld4(src + c);
+                const uint32_t ck = chk_of(uint32_t(v8));
+                uint32_t ck2 = 0;
+                if (rt) {
+                    const uint32_t w2 = __builtin_amdgcn_alignbit(uint32_t(v8), ipb, 16);
+                    h2 = rl(hash_of<U32TAB>(u64(w2, __builtin_amdgcn_alignbit(uint32_t(v8 >> 32), uint32_t(v8), 16))), 0);
+                    ck2 = rl(chk_of(w2), 0);
                 }
-                const bool hit = act && in_range && (!U32TAB || c + kMaxDist >= pos) && cw == uint32_t(v8);
+                uint32_t ent = tab_get(h);
+                if (h == h2) ent = enc(sp - 2, ck2);                   // the refill of ip-2 comes before every probe of this batch
+                const uint32_t c = U32TAB ? ent >> cbits : ent;
+                const bool pass = in_range && (!U32TAB || (c + kMaxDist >= pos && (c == 0 || (ent & cmask) == ck)));
+                uint32_t* sc = &score[h & (kScore - 1)];
+                atomicMin(sc, uint32_t(lane));
+                const bool shared = (*sc != uint32_t(lane));
+                *sc = 0xFFFFFFFFu;
+                uint32_t cw = 0, cb = 0; uint64_t cx = 0; bool cregs = false;
+                if (!pass) { }
+                else if (wide && c >= 4) { const Q16 q = ld16(src + c - 4); cb = q.d0; cw = q.d1; cx = u64(q.d2, q.d3); cregs = true; }
+                else cw = ld4(src + c);
+                const bool hit = pass && cw == uint32_t(v8);
                 const unsigned long long m_cut  = __ballot(shared);
-                const unsigned long long m_term = __ballot(act && !in_range);
+                const unsigned long long m_term = __ballot(!in_range);
                 const unsigned long long m_hit  = __ballot(hit);
-                const int cut = m_cut ? __builtin_ctzll(m_cut) : int(width);
-                // first lane (serial order) that ends this batch
+                const int cut = m_cut ? __builtin_ctzll(m_cut) : 64;
                 const unsigned long long ev = (m_term | m_hit) & ((cut >= 64) ? ~0ull : ((1ull << cut) - 1));
                 const int e = ev ? __builtin_ctzll(ev) : cut;
                 const bool e_is_hit = ev && ((m_hit >> e) & 1) && !((m_term >> e) & 1);
-                // commit table writes of the probes that really happen (after the ip-2 refill of a re-test batch)
-                if (rt && lane == 0) tab_put(h2, sp - 2);
-                if (lane < e || (lane == e && e_is_hit)) tab_put(h, pos);
+                if (rt && lane == 0) tab_put(h2, sp - 2, ck2);
+                if (lane < e || (lane == e && e_is_hit)) tab_put(h, pos, ck);
+                K2PH(pt_search);
                 if (ev) {
                     if (!e_is_hit) goto last_literals;
-                    ip   = __builtin_amdgcn_readlane(pos, e);
-                    cand = __builtin_amdgcn_readlane(c, e);
+                    const uint32_t ip = rl(pos, e), cand = rl(c, e);
+                    uint32_t back = 0, fwd = 0; bool back_more = true, fwd_more = true;
                     if (rl(uint32_t(cregs), e)) {
-                        e_regs = true;
-                        e_ipx = u64(rl(uint32_t(ipx), e), rl(uint32_t(ipx >> 32), e));
-                        e_cx  = u64(rl(uint32_t(cx), e), rl(uint32_t(cx >> 32), e));
-                        e_ipb = rl(ipb, e); e_cb = rl(cb, e);
+                        const uint32_t xb = rl(ipb, e) ^ rl(cb, e);
+                        back = xb ? uint32_t(__builtin_clz(xb) >> 3) : 4u;
+                        back_more = back == 4;
+                        const uint64_t x = u64(rl(uint32_t(ipx), e), rl(uint32_t(ipx >> 32), e)) ^ u64(rl(uint32_t(cx), e), rl(uint32_t(cx >> 32), e));
+                        const uint32_t eq = x ? uint32_t(__builtin_ctzll(x) >> 3) : 8u;
+                        const uint32_t room = matchlimit - (ip + 4);   // ip < lim  =>  room >= 3
+                        fwd = min(eq, room);
+                        fwd_more = !((eq < 8) || (room <= 8));
                     }
-                    rt_hit = rt && e == 0;                            // the immediate re-test hit: no literals, no catch-up
-                    break;
+                    uint32_t ipn;
+                    const int status = sequence(ip, cand, rt && e == 0, back, back_more, fwd, fwd_more, 0xFFFFFFFFu, 0, ipn);
+                    if (status == 2) return 0;
+                    if (status == 1) goto last_literals;
+                    sp = U(ipn); k0 = 0; retest = true;
+                    K2PH(pt_search);
+                    continue;
                 }
-                k0 = U(k0 + e);
-                if (rt) { sp = U(sp + 1); k0 = U(k0 - 1); retest = false; }   // the search proper starts one past the re-test
-                if (e == int(width) && width < 64) width *= 2;
+                // nobody hit: lanes [0, e) were probes (lane 0 possibly the re-test)
+                sp = U(sp + (k0 == 0 ? uint32_t(e) : probe_offset(k0 + uint32_t(e)) - probe_offset(k0)));
+                k0 = U(k0 + uint32_t(e) - (rt ? 1u : 0u));
+                retest = false;
+                K2PH(pt_search);
             }
-            retest = false;
-            K2PH(pt_search);
-            // ------------------------------------------------------------ catch up (lz4.c:1080)
-            {
-                // forward bytes already known from the hit registers (relative to the ORIGINAL ip)
-                uint32_t fwd_known = 0; bool fwd_done = false;
-                if (e_regs) {
-                    const uint64_t x = e_ipx ^ e_cx;
-                    const uint32_t eq = x ? uint32_t(__builtin_ctzll(x) >> 3) : 8u;
-                    const uint32_t room = matchlimit - (ip + 4);       // ip < lim  =>  room >= 3
-                    fwd_known = min(eq, room);
-                    fwd_done = (eq < 8) || (room <= 8);
-                }
-                uint32_t token_pos, tok;      // the token byte is written once both nibbles are known
-                if (rt_hit) { token_pos = op++; tok = 0; }             // lz4.c:1250-1256: zero literals, straight to _next_match
-                else {
-                const uint32_t maxback = min(ip - anchor, cand);
-                uint32_t back = 0; bool more = maxback > 0;
-                if (e_regs && more && cand >= 4) {                     // first 4 bytes from registers
-                    const uint32_t x = e_ipb ^ e_cb;                   // byte 3 (MSB) is position -1
-                    const uint32_t eq = x ? uint32_t(__builtin_clz(x) >> 3) : 4u;
-                    back = min(eq, maxback);
-                    more = (eq == 4 && maxback > 4);
-                }
-                while (more) {
-                    const uint32_t j = back + uint32_t(lane) + 1;
-                    const bool ok = (j <= maxback) && src[ip - j] == src[cand - j];
-                    const unsigned long long bad = ~__ballot(ok);
-                    const int b = bad ? __builtin_ctzll(bad) : 64;
-                    back += b;
-                    if (b < 64) break;
-                }
-                back = U(back);
-                ip = U(ip - back); cand = U(cand - back);
-                // everything in [new ip, old ip + 4 + fwd_known) is equal: the forward count restarts from
-                // the new ip+4, so the `back` bytes just walked over are already part of it
-                if (e_regs) fwd_known += back;
-                // ---------------------------------------------------------- literals (lz4.c:1083-1107)
-                {
-                    const uint32_t lit = ip - anchor;
-                    token_pos = op++;
-                    if (limited && op + lit + (2 + 1 + kLastLit) + lit / 255 > uint32_t(cap)) return 0;
-                    if (lit >= 15) { tok = 0xF0; op += emit_len(dst + op, lit - 15, lane); }
-                    else tok = lit << 4;
-                    if (wvalid && anchor + 1 >= wsp && ip <= wsp + 64) {
-                        // the run lies inside the cursor window: lane l owns position wsp+l (byte 4 of its
-                        // 16), lane 0 also owns wsp-1 (byte 3)
-                        const uint32_t q = wsp + lane;
-                        if (q >= anchor && q < ip) dst[op + (q - anchor)] = uint8_t(W.d1);
-                        if (lane == 0 && anchor + 1 == wsp && lit) dst[op] = uint8_t(W.d0 >> 24);
-                    } else copy_bytes(dst + op, src + anchor, lit, lane);
-                    op += lit;
-                }
-                }
-                K2PH(pt_ext);
-                {   // _next_match (lz4.c:1109-1200)
-                    const uint32_t off = ip - cand;
-                    if (lane == 0) { dst[op] = uint8_t(off); dst[op + 1] = uint8_t(off >> 8); }
-                    op += 2;
-                    // forward extension: bytes equal from ip+4 / cand+4, bounded by matchlimit
-                    uint32_t mcode = fwd_known;
-                    if (!fwd_done) {
-                        uint32_t a = ip + 4 + mcode, b = cand + 4 + mcode;
-                        for (;;) {
-                            if (a + 1024 <= matchlimit && mcode >= 64) {
-                                const U16B x = *reinterpret_cast<const U16B*>(src + a + 16 * lane);
-                                const U16B y = *reinterpret_cast<const U16B*>(src + b + 16 * lane);
-                                const uint64_t d0 = x.a ^ y.a, d1 = x.b ^ y.b;
-                                const uint32_t eq = d0 ? uint32_t(__builtin_ctzll(d0) >> 3)
-                                                       : (d1 ? 8u + uint32_t(__builtin_ctzll(d1) >> 3) : 16u);
-                                const unsigned long long bad = __ballot(eq < 16);
-                                if (bad) {
-                                    const int l = __builtin_ctzll(bad);
-                                    mcode += 16 * l + __builtin_amdgcn_readlane(eq, l);
-                                    break;
-                                }
-                                mcode += 1024; a += 1024; b += 1024;
-                            } else {
-                                const uint32_t i = a + lane;
-                                const bool same = (i < matchlimit) && src[i] == src[b + lane];
-                                const unsigned long long bad = ~__ballot(same);
-                                if (bad) { mcode += __builtin_ctzll(bad); break; }
-                                mcode += 64; a += 64; b += 64;
-                            }
-                        }
-                    }
-                    mcode = U(mcode);
-                    ip = U(ip + mcode + 4);
-                    if (limited && op + (1 + kLastLit) + (mcode + 240) / 255 > uint32_t(cap)) return 0;
-                    uint32_t tok_add;
-                    if (mcode >= 15) { tok_add = 15; op += emit_len(dst + op, mcode - 15, lane); }
-                    else tok_add = mcode;
-                    if (lane == 0) dst[token_pos] = uint8_t(tok + tok_add);
-                    anchor = ip; op = U(op);
-                    if (ip >= lim) goto last_literals;
-                    // the refill of ip-2 and the immediate re-test of ip (lz4.c:1207-1259) ride on the next batch
-                }
-            }
-            sp = U(ip); retest = true; anchor = U(anchor); op = U(op);
-            K2PH(pt_match);
         }
     }
 last_literals:
@@ -301,7 +478,7 @@ last_literals:
         op += run;
     }
 #ifdef K2_PROF
-    if (lane == 0 && n == (4 << 20)) { uint64_t* c = reinterpret_cast<uint64_t*>(dst + n - 32); c[0] = pt_search; c[1] = pt_ext; c[2] = pt_match; }
+    if (lane == 0 && n == (4 << 20)) { uint64_t* c = reinterpret_cast<uint64_t*>(dst + n - 32); c[0] = pt_search; c[1] = pt_ext; c[2] = pt_match; uint64_t* d = reinterpret_cast<uint64_t*>(dst + n - 128); d[0] = pt_cur; d[1] = pt_tab; d[2] = pt_gather; d[3] = pt_emit; d[4] = pt_nwin; d[5] = pt_nseq; d[6] = pt_nslow; }
 #endif
     return int(op);
 }
