@@ -6,11 +6,12 @@
 //
 // XXH32 is four independent multiply-rotate chains over 16-byte stripes; a chain step depends on
 // the previous one and the round function is not associative, so there is no intra-block
-// parallel prefix.  Parallelism is ACROSS blocks: one wavefront per block, lanes 0..3 carry the
-// four accumulators; the other lanes only stream.  The payload is read once with coalesced
-// 16 B/lane loads (one 1 KiB granule in flight ahead of use) into a 4 KiB LDS ring, from which
-// the accumulator lanes pick their 4-byte words (payloads start at arbitrary byte offsets inside a
-// .4mc file, so words are re-aligned with v_alignbyte).  Bound: HBM read, `len` bytes per block.
+// parallel prefix, and its two 32-bit multiplies run at quarter rate whatever the number of active
+// lanes.  So lanes are not spent on streaming: four lanes are the four accumulators of one block and
+// a wavefront carries G blocks side by side (G = 1..16, chosen at launch so that every SIMD still
+// has a wave).  Each lane reads its own 4-byte words straight from memory (unaligned dword loads, the
+// next 64 rounds in flight while 64 are consumed); the four lanes of a block cover 16 contiguous bytes per round, 128 bytes - one
+// cache line - per unrolled iteration.  Bound: the multiply chain, then HBM read of `len` bytes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "fourmc_gpu.h"
@@ -19,99 +20,82 @@
 namespace {
 
 constexpr uint32_t P1 = 2654435761u, P2 = 2246822519u, P3 = 3266489917u, P4 = 668265263u, P5 = 374761393u;
-constexpr int kRing = 4096, kChunk = 1024;
 
+struct __attribute__((packed, aligned(1))) W4 { uint32_t v; };
+__device__ __forceinline__ uint32_t ldw(const uint8_t* p) { return reinterpret_cast<const W4*>(p)->v; }
 __device__ __forceinline__ uint32_t rotl(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__device__ __forceinline__ uint32_t round1(uint32_t acc, uint32_t x) { return rotl(acc + x * P2, 13) * P1; }
 
-__device__ uint32_t xxh32_block(const uint8_t* p, uint32_t len, uint32_t seed, uint8_t* ring, int lane)
+// lanes 4g..4g+3 hash block g of this wave; returns the digest in every lane of the group
+__device__ uint32_t xxh32_group(const uint8_t* p, uint32_t len, uint32_t seed, int lane)
 {
-    const uint32_t delta = uint32_t(reinterpret_cast<uintptr_t>(p) & 15);
-    const uint8_t* abase = p - delta;          // pointer arithmetic keeps the global address space (no flat_load)
-    const uint32_t qend = delta + len;                 // end in aligned coordinates
+    const int chain = lane & 3;
     const uint32_t nstripes = len >> 4;
-    const uint32_t sh = delta & 3;
-
-    auto fetch = [&](uint32_t q) {
-        const uint32_t g = q + 16u * lane;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (g < qend) v = *reinterpret_cast<const uint4*>(abase + g);
-        return v;
-    };
-    uint32_t fill_hi = 0;                              // ring holds aligned positions [.., fill_hi)
-    uint4 pend = fetch(0);
-    uint32_t acc = (lane == 0) ? seed + P1 + P2 : (lane == 1) ? seed + P2 : (lane == 2) ? seed : seed - P1;
-
-    uint32_t s = 0;                                    // next stripe
-    while (s < nstripes) {
-        // stage one more granule, then consume every stripe that is now complete in the ring
-        *reinterpret_cast<uint4*>(ring + ((fill_hi + 16u * lane) & (kRing - 1))) = pend;
-        fill_hi += kChunk;
-        pend = fetch(fill_hi);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        uint32_t s_hi = (fill_hi >= delta + 16) ? (fill_hi - delta) >> 4 : 0;   // stripes fully staged
-        if (s_hi > nstripes) s_hi = nstripes;
-        if (lane < 4) {
-            uint32_t q = delta + 16u * s + 4u * lane;  // aligned-space byte position of my word
-            const uint32_t* r32 = reinterpret_cast<const uint32_t*>(ring);
-            for (; s + 4 <= s_hi; s += 4, q += 64) {
-                uint32_t lo[4], hi[4];
+    uint32_t acc = (chain == 0) ? seed + P1 + P2 : (chain == 1) ? seed + P2 : (chain == 2) ? seed : seed - P1;
+    const uint8_t* q = p + 4 * chain;
+    uint32_t s = 0;
+    // xxhash.c:352-389.  A round is ~40 clocks of dependent arithmetic, a read from HBM ~2000: the words of the next
+    // 32 rounds are read while the current 32 are consumed (two register banks, ping-pong).
+    constexpr int kB = 64;
+    if (nstripes >= uint32_t(kB)) {
+        uint32_t xa[kB], xb[kB];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t w = (q + 16u * u) >> 2;
-                    lo[u] = r32[w & (kRing / 4 - 1)];
-                    hi[u] = r32[(w + 1) & (kRing / 4 - 1)];
-                }
+        for (int u = 0; u < kB; u++) xa[u] = ldw(q + 16 * u);
+        q += 16 * kB; s = kB;                                           // s = stripes whose words are loaded
+        for (;;) {
+            const bool more_b = s + kB <= nstripes;
+            if (more_b) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t x = (sh == 0) ? lo[u] : __builtin_amdgcn_alignbyte(hi[u], lo[u], sh);
-                    acc = rotl(acc + x * P2, 13) * P1;
-                }
+                for (int u = 0; u < kB; u++) xb[u] = ldw(q + 16 * u);
+                q += 16 * kB; s += kB;
             }
-            for (; s < s_hi; s++, q += 16) {
-                const uint32_t w = q >> 2;
-                const uint32_t lo = r32[w & (kRing / 4 - 1)], hi = r32[(w + 1) & (kRing / 4 - 1)];
-                const uint32_t x = (sh == 0) ? lo : __builtin_amdgcn_alignbyte(hi, lo, sh);
-                acc = rotl(acc + x * P2, 13) * P1;
+#pragma unroll
+            for (int u = 0; u < kB; u++) acc = round1(acc, xa[u]);
+            if (!more_b) break;
+            const bool more_a = s + kB <= nstripes;
+            if (more_a) {
+#pragma unroll
+                for (int u = 0; u < kB; u++) xa[u] = ldw(q + 16 * u);
+                q += 16 * kB; s += kB;
             }
+#pragma unroll
+            for (int u = 0; u < kB; u++) acc = round1(acc, xb[u]);
+            if (!more_a) break;
         }
-        s = s_hi;
     }
+    for (; s < nstripes; s++, q += 16) acc = round1(acc, ldw(q));
     uint32_t h;
     if (len >= 16) {
-        const uint32_t a0 = __builtin_amdgcn_readlane(acc, 0), a1 = __builtin_amdgcn_readlane(acc, 1);
-        const uint32_t a2 = __builtin_amdgcn_readlane(acc, 2), a3 = __builtin_amdgcn_readlane(acc, 3);
+        const int g0 = lane & ~3;
+        const uint32_t a0 = __shfl(acc, g0), a1 = __shfl(acc, g0 + 1), a2 = __shfl(acc, g0 + 2), a3 = __shfl(acc, g0 + 3);
         h = rotl(a0, 1) + rotl(a1, 7) + rotl(a2, 12) + rotl(a3, 18);
     } else {
         h = seed + P5;
     }
     h += len;
-    // tail (< 16 bytes): lane j reads byte j of the tail straight from memory
+    const uint8_t* t = p + (len & ~15u);               // tail, < 16 bytes (xxhash.c:291-345)
     const uint32_t tail = len & 15;
-    const uint32_t tb = (uint32_t(lane) < tail) ? p[(len & ~15u) + lane] : 0u;
     uint32_t i = 0;
-    for (; i + 4 <= tail; i += 4) {
-        const uint32_t w = uint32_t(__builtin_amdgcn_readlane(tb, i)) | (uint32_t(__builtin_amdgcn_readlane(tb, i + 1)) << 8) |
-                           (uint32_t(__builtin_amdgcn_readlane(tb, i + 2)) << 16) | (uint32_t(__builtin_amdgcn_readlane(tb, i + 3)) << 24);
-        h = rotl(h + w * P3, 17) * P4;
-    }
-    for (; i < tail; i++) h = rotl(h + uint32_t(__builtin_amdgcn_readlane(tb, i)) * P5, 11) * P1;
+    for (; i + 4 <= tail; i += 4) h = rotl(h + ldw(t + i) * P3, 17) * P4;
+    for (; i < tail; i++) h = rotl(h + uint32_t(t[i]) * P5, 11) * P1;
     h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
     return h;
 }
 
 __global__ __launch_bounds__(64)
 void xxh32_kernel(const uint8_t* __restrict__ base, fourmc_block* blocks, uint32_t nblocks,
-                  uint32_t seed, int mode)
+                  uint32_t seed, int mode, uint32_t groups)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
-    const uint32_t b = blockIdx.x;
-    if (b >= nblocks) return;
+    const int lane = threadIdx.x;
+    const uint32_t g = uint32_t(lane) >> 2;
+    const uint32_t b = blockIdx.x * groups + g;
+    if (g >= groups || b >= nblocks) return;
     const fourmc_block blk = blocks[b];
     uint64_t off; uint32_t len;
     if (mode == FOURMC_HASH_DST_RESULT) { off = blk.dst_off; len = blk.result > 0 ? uint32_t(blk.result) : 0u; }
     else                                { off = blk.src_off; len = blk.src_len; }
-    const uint32_t h = xxh32_block(base + off, len, seed, ring, threadIdx.x);
-    if (threadIdx.x == 0) {
+    const uint32_t h = xxh32_group(base + off, len, seed, lane);
+    if ((lane & 3) == 0) {
         if (mode == FOURMC_VERIFY_SRC) blocks[b].result = (h == blk.xxh32) ? 0 : FOURMC_BLK_BADSUM;
         else blocks[b].xxh32 = h;
     }
@@ -123,7 +107,9 @@ extern "C" hipError_t fourmc_launch_xxh32(const void* d_base, fourmc_block* d_bl
                                           uint32_t seed, int mode, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(xxh32_kernel, dim3(n), dim3(64), 0, stream,
-                       static_cast<const uint8_t*>(d_base), d_blocks, n, seed, mode);
+    uint32_t groups = 1;                               // blocks per wavefront: keep about one wave per SIMD (256 CUs x 4)
+    while (groups < 16 && n / groups > 1024) groups *= 2;
+    hipLaunchKernelGGL(xxh32_kernel, dim3((n + groups - 1) / groups), dim3(64), 0, stream,
+                       static_cast<const uint8_t*>(d_base), d_blocks, n, seed, mode, groups);
     return hipGetLastError();
 }
