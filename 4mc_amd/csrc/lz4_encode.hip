@@ -271,29 +271,53 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                 int cur = 0, anc = int(anchor - sp0);                   // lane of the next action; anchor as a lane number
                 bool any = retest, fresh = true;                        // a search has begun in this window; no sequence yet
                 int stoplane = 64, status = 0;
-                uint32_t anc_v = 0;
+                // Where the walk goes from lane l when a search starts there with nothing pending (anchor == l), for
+                // every l at once: the end of the first hit at or after l (| that hit lane << 8), or 0x8000 | the lane
+                // it has to stop at (64: none).  The scalar walk below is then one readlane per sequence.
+                uint32_t nxt;
+                {
+                    const unsigned long long shm = (m_hit | stop2) >> lane;
+                    const int E = lane + (shm ? __builtin_ctzll(shm) : 0);
+                    const uint32_t infE = __shfl(info | (uint32_t((stop2 >> lane) & 1) << 17), E);
+                    const bool term = !shm || ((infE >> 17) & 1) || (((infE >> 8) & 7) == 5 && E - lane >= 5);
+                    nxt = term ? (0x8000u | (shm ? uint32_t(E) : 64u)) : ((infE & 255) | (uint32_t(E) << 8));
+                }
                 for (;;) {
                     unsigned long long sel = 0;
-                    int reason = 0, e = 0;                              // 0: no event left, 1: stop lane, 2: match leaves the window
-                    for (;;) {
+                    int reason = -1, e = 0;                             // 0: no event left, 1: stop at lane e, 2: match leaves the window
+                    const int anc0 = anc;
+                    if (anc != cur || hd != hd2) {
+                        // the running search began before this window, or first-sequence stops apply: one general step
                         const unsigned long long ev = hd & (~0ull << cur);
-                        if (!ev) break;
-                        e = __builtin_ctzll(ev);
-                        if ((stp >> e) & 1) { reason = 1; break; }
-                        const uint32_t inf = rl(info, e);
-                        if (min(int((inf >> 8) & 7), e - anc) == 5) { reason = 1; break; }   // the catch-up has to go on in memory
-                        if (lane == e) anc_v = uint32_t(anc);
-                        sel |= 1ull << e;
-                        K2CNT(pt_nseq);
-                        anc = cur = int(inf & 255);
-                        hd = hd2; stp = stop2;
-                        if (cur >= 64) { reason = 2; break; }
+                        if (!ev) reason = 0;
+                        else {
+                            e = __builtin_ctzll(ev);
+                            const uint32_t inf = rl(info, e);
+                            if (((stp >> e) & 1) || min(int((inf >> 8) & 7), e - anc) == 5) reason = 1;   // 5: the catch-up goes on in memory
+                            else {
+                                sel = 1ull << e;
+                                anc = cur = int(inf & 255);
+                                hd = hd2; stp = stop2;
+                                if (cur >= 64) reason = 2;
+                            }
+                        }
                     }
+                    while (reason < 0) {
+                        const uint32_t t = rl(nxt, cur);
+                        if (t & 0x8000u) { e = int(t & 127); reason = e == 64 ? 0 : 1; break; }
+                        sel |= 1ull << ((t >> 8) & 63);
+                        cur = int(t & 255);
+                        if (cur >= 64) reason = 2;
+                    }
+                    anc = cur;
                     K2PH(pt_ext);
                     if (sel) {
                         // sizes, positions and bytes of the chosen sequences, all at once (lz4.c:1080-1200)
                         const bool mine = (sel >> lane) & 1;
-                        const int myanc = int(anc_v);
+                        const unsigned long long below = sel & ~(~0ull << lane);
+                        const int P = below ? 63 - __builtin_clzll(below) : 0;
+                        const int endP = int(__shfl(info, P) & 255);
+                        const int myanc = below ? endP : anc0;           // my anchor: the end of the sequence chosen before me
                         const uint32_t b = uint32_t(min(int((info >> 8) & 7), lane - myanc));
                         const uint32_t lit = uint32_t(lane - myanc) - b, mc = (info & 255) - uint32_t(lane) - 4 + b;
                         const uint32_t xl = lit >= 15 ? 1u : 0u;
