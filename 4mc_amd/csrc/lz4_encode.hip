@@ -81,7 +81,7 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
 {
     uint16_t* tab16 = reinterpret_cast<uint16_t*>(tab32);
 #ifdef K2_PROF   // one-off phase profile (tools/k2_phases.py builds a side library with -DK2_PROF): cycles per phase
-    uint64_t pt_search = 0, pt_ext = 0, pt_match = 0, pt_cur = 0, pt_tab = 0, pt_gather = 0, pt_emit = 0, pt_nwin = 0, pt_nseq = 0, pt_nslow = 0, pt0 = __builtin_readcyclecounter(), pt1;
+    uint64_t pt_search = 0, pt_ext = 0, pt_match = 0, pt_cur = 0, pt_tab = 0, pt_gather = 0, pt_emit = 0, pt_nwin = 0, pt_nseq = 0, pt_nslow = 0, pt_none = 0, pt_cross = 0, pt_dcut = 0, pt_scut = 0, pt0 = __builtin_readcyclecounter(), pt1;
 #define K2PH(acc) do { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); pt1 = __builtin_readcyclecounter(); acc += pt1 - pt0; pt0 = pt1; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define K2CNT(c) do { c++; } while (0)
 #else
@@ -97,9 +97,11 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
     // A 32-bit table entry is position << cbits | check, the check being cbits hash bits of the 4 bytes at that
     // position: a probe whose check differs cannot be a 4-byte match and skips the (random, cache-line wide) read
     // of its candidate.  Entries with position 0 (empty slots read as position 0, lz4.c:1348) are always read.
-    const int cbits = U32TAB ? __builtin_clz(uint32_t(n - 1) | 1u) : 0;
+    // Entries stay below 2^31: values above that are lane tags, written for a moment while a dense window finds out
+    // which of its lanes share a slot.
+    const int cbits = U32TAB ? max(__builtin_clz(uint32_t(n - 1) | 1u) - 1, 0) : 0;
     const uint32_t cmask = (1u << cbits) - 1;
-    auto chk_of = [&](uint32_t w) -> uint32_t { return U32TAB ? (w * 2654435761u) >> (32 - cbits) : 0u; };
+    auto chk_of = [&](uint32_t w) -> uint32_t { return (U32TAB && cbits) ? (w * 2654435761u) >> (32 - cbits) : 0u; };
     auto enc = [&](uint32_t pos, uint32_t ck) -> uint32_t { return U32TAB ? (pos << cbits) | ck : pos; };
     auto tab_get = [&](uint32_t h) -> uint32_t { return U32TAB ? tab32[h] : uint32_t(tab16[h]); };
     auto tab_put = [&](uint32_t h, uint32_t pos, uint32_t ck) { if (U32TAB) tab32[h] = enc(pos, ck); else tab16[h] = uint16_t(pos); };
@@ -221,15 +223,34 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                     h2 = rl(hash_of<U32TAB>(u64(w2, __builtin_amdgcn_alignbit(q0.d2, q0.d1, 16))), 0);
                     ck2 = rl(chk_of(w2), 0);
                 }
-                uint32_t ent = tab_get(h);
-                if (h == h2) ent = enc(sp0 - 2, ck2);
+                if (retest && lane == 0) tab_put(h2, sp0 - 2, ck2);    // the owed refill, ahead of every read of this window
+                const uint32_t ent = tab_get(h);
                 const uint32_t c = U32TAB ? ent >> cbits : ent;
                 const bool pass = !U32TAB || (c + kMaxDist >= pos && (c == 0 || (ent & cmask) == ck));
-                uint32_t* sc = &score[h & (kScore - 1)];
-                atomicMin(sc, uint32_t(lane));
-                const bool dirty = (*sc != uint32_t(lane));
-                *sc = 0xFFFFFFFFu;
-                if (retest && lane == 0) tab_put(h2, sp0 - 2, ck2);
+                // Lanes that share a table slot.  32-bit table: the slot itself is the scoreboard - every lane tags it
+                // (atomic max of a value above any entry: the lowest lane wins), the losers tag once more among
+                // themselves, the winner puts the entry back.  That gives, exactly: the first lane of a slot (clean),
+                // the second (its only predecessor in the window is `pred`), and later ones ("dirty": the window ends
+                // in front of one the walk reaches as a probe).  16-bit table: a folded min-scoreboard, first lane
+                // clean, all others dirty.
+                bool dirty, second = false; int pred = 0;
+                if (U32TAB) {
+                    atomicMax(&tab32[h], 0x80000000u | uint32_t(63 - lane));
+                    pred = 63 - int(tab32[h] & 63);
+                    const bool first = pred == lane;
+                    dirty = false;
+                    if (__ballot(!first)) {
+                        if (!first) atomicMax(&tab32[h], 0x80000040u | uint32_t(63 - lane));
+                        second = !first && 63 - int(tab32[h] & 63) == lane;
+                        dirty = !first && !second;
+                    }
+                    if (first) tab32[h] = ent;
+                } else {
+                    uint32_t* sc = &score[h & (kScore - 1)];
+                    atomicMin(sc, uint32_t(lane));
+                    dirty = (*sc != uint32_t(lane));
+                    *sc = 0xFFFFFFFFu;
+                }
                 K2PH(pt_tab);
                 // info: lane of the match end | back bytes << 8 (5: four and possibly more) | raw back << 12 |
                 // back_more << 15 | fwd_more << 16
@@ -252,7 +273,12 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                     slow = true;                                        // nothing known: compare in memory
                     info = (uint32_t(lane) + 4) | (1u << 15) | (1u << 16);
                 }
-                const unsigned long long m_hit = __ballot(hit), m_dirty = __ballot(dirty), m_slow = __ballot(hit && slow);
+                // A second lane of a slot sees its predecessor's position instead of the table entry if the walk made the
+                // predecessor a probe.  Hit on neither: an ordinary probe.  Otherwise it is decided when the walk gets there.
+                const uint32_t wpred = __shfl(q0.d1, pred);              // (every lane takes part: the source lane must be active)
+                const bool hitA = second && wpred == q0.d1;
+                const unsigned long long m_cond = __ballot(second && (hitA || hit));
+                const unsigned long long m_hit = __ballot(hit) & ~m_cond, m_dirty = __ballot(dirty), m_slow = __ballot(hit && slow);
                 const uint32_t wbyte = q0.d1;
                 K2PH(pt_gather);
                 // The first sequence may own literals of the previous window: they are still in registers if that was
@@ -260,7 +286,7 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                 // output buffer every sequence does, for its exact capacity checks.
                 const uint32_t pw_lo = (pw_sp != 0xFFFFFFFFu && pw_sp + 64 >= sp0) ? pw_sp : sp0;
                 const bool capok = !limited || op + 320 <= uint32_t(cap);
-                const unsigned long long stop2 = m_dirty | m_slow | (capok ? 0ull : m_hit);
+                const unsigned long long stop2 = m_dirty | m_slow | m_cond | (capok ? 0ull : m_hit);
                 unsigned long long stop1 = stop2;
                 const int scut = (!retest && k0 > 1) ? 65 - int(k0) : 64;   // first lane that is not one byte on from its predecessor
                 if (scut < 64) stop1 |= 1ull << scut;
@@ -306,10 +332,9 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                         const uint32_t t = rl(nxt, cur);
                         if (t & 0x8000u) { e = int(t & 127); reason = e == 64 ? 0 : 1; break; }
                         sel |= 1ull << ((t >> 8) & 63);
-                        cur = int(t & 255);
+                        cur = anc = int(t & 255);
                         if (cur >= 64) reason = 2;
                     }
-                    anc = cur;
                     K2PH(pt_ext);
                     if (sel) {
                         // sizes, positions and bytes of the chosen sequences, all at once (lz4.c:1080-1200)
@@ -354,7 +379,8 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                     }
                     K2PH(pt_emit);
                     if (reason == 0) {                                  // every remaining lane was a probe
-                        const int s = any ? cur + 1 : -int(k0);
+                        K2CNT(pt_none);
+                        const int s = any ? anc + 1 : -int(k0);
                         k0 = uint32_t(64 - s); sp = sp0 + 64; retest = false;
                         break;
                     }
@@ -362,20 +388,41 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                         const uint32_t ip = sp0 + uint32_t(cur);
                         if (ip >= lim) { status = 1; break; }
                         sp = ip; k0 = 0; retest = true;                 // the next window pays the refill
+                        K2CNT(pt_cross);
                         break;
                     }
                     if (((m_dirty >> e) & 1) || (fresh && e == scut)) { // the window ends in front of lane e
                         stoplane = e;
-                        if (any && e == cur) { k0 = 0; retest = true; }
-                        else { k0 = uint32_t(e - (any ? cur + 1 : -int(k0))); retest = false; }
+                        if ((m_dirty >> e) & 1) K2CNT(pt_dcut); else K2CNT(pt_scut);
+                        if (any && e == anc) { k0 = 0; retest = true; }
+                        else { k0 = uint32_t(e - (any ? anc + 1 : -int(k0))); retest = false; }
                         sp = sp0 + uint32_t(e);
                         break;
                     }
+                    uint32_t s_cand = rl(c, e), s_inf = rl(info, e);
+                    if ((m_cond >> e) & 1) {
+                        // second lane of its slot: did the walk put its predecessor j into the table?  Yes if j is a probe
+                        // of the running search (j >= anchor lane) or lies outside every match chosen so far.
+                        const int j = int(rl(uint32_t(pred), e));
+                        const unsigned long long below = selw & ~(~0ull << lane);
+                        const int P = below ? 63 - __builtin_clzll(below) : 0;
+                        const int endP = int(__shfl(info, P) & 255);
+                        const bool inside = (below && lane < endP && lane != endP - 2) || ((xint >> lane) & 1);
+                        const bool visited = j >= anc || !rl(uint32_t(inside), j);
+                        const bool use = visited ? rl(uint32_t(hitA), e) : rl(uint32_t(hit), e);
+                        if (!use) {                                     // an ordinary probe after all: the search goes on behind it
+                            cur = e + 1;
+                            if (cur < 64) continue;
+                            k0 = uint32_t(64 - (any ? anc + 1 : -int(k0))); sp = sp0 + 64; retest = false;
+                            break;
+                        }
+                        if (visited) { s_cand = sp0 + uint32_t(j); s_inf = (uint32_t(e) + 4) | (1u << 15) | (1u << 16); }
+                    }
                     {   // a hit that needs the general path
                         K2CNT(pt_nslow);
-                        const uint32_t inf = rl(info, e);
+                        const uint32_t inf = s_inf;
                         uint32_t ip;
-                        status = sequence(sp0 + uint32_t(e), rl(c, e), any && e == cur, (inf >> 12) & 7, (inf >> 15) & 1,
+                        status = sequence(sp0 + uint32_t(e), s_cand, any && e == anc, (inf >> 12) & 7, (inf >> 15) & 1,
                                           (inf & 255) - uint32_t(e) - 4, (inf >> 16) & 1, sp0, wbyte, ip);
                         if (status) break;
                         any = true; fresh = false;
@@ -502,7 +549,7 @@ last_literals:
         op += run;
     }
 #ifdef K2_PROF
-    if (lane == 0 && n == (4 << 20)) { uint64_t* c = reinterpret_cast<uint64_t*>(dst + n - 32); c[0] = pt_search; c[1] = pt_ext; c[2] = pt_match; uint64_t* d = reinterpret_cast<uint64_t*>(dst + n - 128); d[0] = pt_cur; d[1] = pt_tab; d[2] = pt_gather; d[3] = pt_emit; d[4] = pt_nwin; d[5] = pt_nseq; d[6] = pt_nslow; }
+    if (lane == 0 && n == (4 << 20)) { uint64_t* c = reinterpret_cast<uint64_t*>(dst + n - 32); c[0] = pt_search; c[1] = pt_ext; c[2] = pt_match; uint64_t* d = reinterpret_cast<uint64_t*>(dst + n - 128); d[0] = pt_cur; d[1] = pt_tab; d[2] = pt_gather; d[3] = pt_emit; d[4] = pt_nwin; d[5] = pt_nseq; d[6] = pt_nslow; uint64_t* f = reinterpret_cast<uint64_t*>(dst + n - 192); f[0] = pt_none; f[1] = pt_cross; f[2] = pt_dcut; f[3] = pt_scut; }
 #endif
     return int(op);
 }

@@ -22,6 +22,7 @@ for b in range(12):
     r = int(enc.download()["result"][0])
     c = stage[B - 32: B - 8].cpu().numpy().view(np.uint64) if r < B - 256 else np.zeros(3, np.uint64)
     d = stage[B - 128: B - 72].cpu().numpy().view(np.uint64) if r < B - 256 else np.zeros(7, np.uint64)
+    f = stage[B - 192: B - 160].cpu().numpy().view(np.uint64) if r < B - 256 else np.zeros(4, np.uint64)
     tot = float(c.sum() + d[:4].sum()) or 1.0
     dec = p.DeviceBatch(p.make_blocks([0], [0], [r], [B], enc.download()["xxh32"]))
     out = torch.zeros(B + 64, dtype=torch.uint8, device="cuda")
@@ -31,4 +32,4 @@ for b in range(12):
     k = out[B: B + 56].cpu().numpy().view(np.uint64)               # the side build leaves K1's phase cycles behind the output
     kt = float(k[:4].sum()) or 1.0
     print(f"        K1 dec {ds.elapsed_time(de):7.2f} ms  parse {100*k[0]/kt:4.1f}% map {100*k[1]/kt:4.1f}% copy {100*k[2]/kt:4.1f}% general {100*k[3]/kt:4.1f}%  batches {int(k[4])} steps {int(k[5])} general-seqs {int(k[6])}")
-    print(f"{names[b]:7s} csize {r:8d} enc {s.elapsed_time(e):8.2f} ms   dense: cursor {100*d[0]/tot:4.1f}% table {100*d[1]/tot:4.1f}% gather {100*d[2]/tot:4.1f}% parse {100*c[1]/tot:4.1f}% emit {100*d[3]/tot:4.1f}% commit {100*c[2]/tot:4.1f}% | sparse {100*c[0]/tot:4.1f}%  windows {int(d[4])} seq {int(d[5])} slow-seq {int(d[6])}")
+    print(f"{names[b]:7s} csize {r:8d} enc {s.elapsed_time(e):8.2f} ms   dense: cursor {100*d[0]/tot:4.1f}% table {100*d[1]/tot:4.1f}% gather {100*d[2]/tot:4.1f}% parse {100*c[1]/tot:4.1f}% emit {100*d[3]/tot:4.1f}% commit {100*c[2]/tot:4.1f}% | sparse {100*c[0]/tot:4.1f}%  windows {int(d[4])} seq {int(d[5])} slow-seq {int(d[6])} | window ends: none {int(f[0])} cross {int(f[1])} dirty-cut {int(f[2])} stride-cut {int(f[3])}")
