@@ -286,7 +286,7 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                 // output buffer every sequence does, for its exact capacity checks.
                 const uint32_t pw_lo = (pw_sp != 0xFFFFFFFFu && pw_sp + 64 >= sp0) ? pw_sp : sp0;
                 const bool capok = !limited || op + 320 <= uint32_t(cap);
-                const unsigned long long stop2 = m_dirty | m_slow | m_cond | (capok ? 0ull : m_hit);
+                unsigned long long stop2 = m_dirty | m_slow | m_cond | (capok ? 0ull : m_hit);
                 unsigned long long stop1 = stop2;
                 const int scut = (!retest && k0 > 1) ? 65 - int(k0) : 64;   // first lane that is not one byte on from its predecessor
                 if (scut < 64) stop1 |= 1ull << scut;
@@ -296,6 +296,7 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                 unsigned long long selw = 0, xint = 0;                  // chosen hit lanes; lanes inside directly emitted matches
                 int cur = 0, anc = int(anchor - sp0);                   // lane of the next action; anchor as a lane number
                 bool any = retest, fresh = true;                        // a search has begun in this window; no sequence yet
+                bool gen = false;                                       // take one general step next (a resolved second lane)
                 int stoplane = 64, status = 0;
                 // Where the walk goes from lane l when a search starts there with nothing pending (anchor == l), for
                 // every l at once: the end of the first hit at or after l (| that hit lane << 8), or 0x8000 | the lane
@@ -312,7 +313,8 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                     unsigned long long sel = 0;
                     int reason = -1, e = 0;                             // 0: no event left, 1: stop at lane e, 2: match leaves the window
                     const int anc0 = anc;
-                    if (anc != cur || hd != hd2) {
+                    if (gen || anc != cur || hd != hd2) {
+                        gen = false;
                         // the running search began before this window, or first-sequence stops apply: one general step
                         const unsigned long long ev = hd & (~0ull << cur);
                         if (!ev) reason = 0;
@@ -417,6 +419,10 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                             break;
                         }
                         if (visited) { s_cand = sp0 + uint32_t(j); s_inf = (uint32_t(e) + 4) | (1u << 15) | (1u << 16); }
+                        else if (capok && !((m_slow >> e) & 1) && min(int((s_inf >> 8) & 7), e - anc) != 5) {   // a plain hit on its table entry: back to the walk, which takes it as such
+                            stop2 &= ~(1ull << e); stp &= ~(1ull << e); gen = true;
+                            continue;
+                        }
                     }
                     {   // a hit that needs the general path
                         K2CNT(pt_nslow);
