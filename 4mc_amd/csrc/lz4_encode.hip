@@ -199,12 +199,12 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
         uint32_t sp = 1, k0 = 0; bool retest = false;
         uint32_t pw_sp = 0xFFFFFFFFu, pwbyte = 0;                      // previous dense window: start, and the byte each lane held
         for (;;) {
-            if (sp >= 4 && sp + 100 <= un && k0 <= 32) {
+            if (sp >= 4 && sp + 132 <= un && k0 <= 32) {
                 // ------------------------------------------------------------ dense window
                 // Probes 0..65 of a search are one byte apart, so around a fresh search the parse walks consecutive
                 // positions.  Lane l takes position sp+l, whatever role the parse will give it (probe, re-test,
                 // refill, or inside a match), and prepares everything against the table as it stands: candidate,
-                // 4-byte test, up to 4 equal bytes backwards and 24 forwards.  A scalar loop of ballots and
+                // 4-byte test, up to 4 equal bytes backwards and 24 (56 for the lanes that need it) forwards.  A scalar loop of ballots and
                 // readlanes then only CHOOSES the sequences of the window (which hit lanes the greedy walk lands
                 // on); sizes, output positions and all bytes of the chosen sequences are produced afterwards by all
                 // lanes at once.  A lane whose table slot is also touched by an earlier lane of the window
@@ -256,18 +256,32 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                 // back_more << 15 | fwd_more << 16
                 uint32_t info;
                 bool hit = false, slow = false;
-                if (!pass) info = uint32_t(lane) + 4;
-                else if (c >= 4) {
+                uint32_t fw = 0, bk = 0;
+                if (pass && c >= 4) {
                     const Q16 c0 = ld16(src + c - 4), c1 = ld16(src + c + 12);
                     hit = c0.d1 == q0.d1;
                     const uint32_t xb = q0.d0 ^ c0.d0;                  // byte 3 (MSB) is position -1
-                    const uint32_t bk = xb ? uint32_t(__builtin_clz(xb) >> 3) : 4u;
+                    bk = xb ? uint32_t(__builtin_clz(xb) >> 3) : 4u;
                     const uint64_t x0 = u64(q0.d2, q0.d3) ^ u64(c0.d2, c0.d3), x1 = u64(q1.d0, q1.d1) ^ u64(c1.d0, c1.d1),
                                    x2 = u64(q1.d2, q1.d3) ^ u64(c1.d2, c1.d3);
-                    const uint32_t fw = x0 ? uint32_t(__builtin_ctzll(x0) >> 3) : (x1 ? 8u + uint32_t(__builtin_ctzll(x1) >> 3)
+                    fw = x0 ? uint32_t(__builtin_ctzll(x0) >> 3) : (x1 ? 8u + uint32_t(__builtin_ctzll(x1) >> 3)
                                            : (x2 ? 16u + uint32_t(__builtin_ctzll(x2) >> 3) : 24u));
-                    slow = fw == 24;
-                    info = (uint32_t(lane) + 4 + fw) | ((bk == 4 && c > 4 ? 5u : bk) << 8) | (bk << 12) | (uint32_t(bk == 4) << 15) | (uint32_t(fw == 24) << 16);
+                }
+                // matches that run past the 28 bytes held: those lanes (only) read 32 more of both sides
+                const bool sat = hit && fw == 24;
+                if (__ballot(sat)) {
+                    if (sat) {
+                        const Q16 q2 = ld16(src + pos + 28), q3 = ld16(src + pos + 44), c2 = ld16(src + c + 28), c3 = ld16(src + c + 44);
+                        const uint64_t x3 = u64(q2.d0, q2.d1) ^ u64(c2.d0, c2.d1), x4 = u64(q2.d2, q2.d3) ^ u64(c2.d2, c2.d3),
+                                       x5 = u64(q3.d0, q3.d1) ^ u64(c3.d0, c3.d1), x6 = u64(q3.d2, q3.d3) ^ u64(c3.d2, c3.d3);
+                        fw = x3 ? 24u + uint32_t(__builtin_ctzll(x3) >> 3) : (x4 ? 32u + uint32_t(__builtin_ctzll(x4) >> 3)
+                                : (x5 ? 40u + uint32_t(__builtin_ctzll(x5) >> 3) : (x6 ? 48u + uint32_t(__builtin_ctzll(x6) >> 3) : 56u)));
+                    }
+                }
+                if (!pass) info = uint32_t(lane) + 4;
+                else if (c >= 4) {
+                    slow = fw == 56;
+                    info = (uint32_t(lane) + 4 + fw) | ((bk == 4 && c > 4 ? 5u : bk) << 8) | (bk << 12) | (uint32_t(bk == 4) << 15) | (uint32_t(fw == 56) << 16);
                 } else {
                     hit = ld4(src + c) == q0.d1;
                     slow = true;                                        // nothing known: compare in memory
