@@ -692,10 +692,11 @@ __device__ __forceinline__ int zstd_decode_frames(const uint8_t* src, int csize,
 // serial path above decides.
 constexpr int      kDecline  = -1000000007;
 constexpr int      kMaxInner = 64;
-constexpr uint32_t kSeqArea  = 512 * 1024;                    // sequences of one 4mc block held at once
+constexpr uint32_t kSeqArea  = 1024 * 1024;                   // sequences of one 4mc block held at once, 8 bytes each:
+                                                              // ll (18 bits) | ml low 14 << 18, Offset_Value (28 bits) | ml high 4 << 28
 constexpr size_t   kV2State  = (sizeof(ZState) + 255) & ~size_t(255);
 constexpr size_t   kV2Lit    = (size_t(4) << 20) + kMaxInner * 64 + 256;
-constexpr size_t   kV2Bytes  = kMaxInner * kV2State + kV2Lit + size_t(kSeqArea) * 12 + (kBlockMax + 64);
+constexpr size_t   kV2Bytes  = kMaxInner * kV2State + kV2Lit + size_t(kSeqArea) * 8 + (kBlockMax + 64);
 
 struct V2Info {                                               // LDS, aliases ZState::huf (unused on this path)
     uint32_t off[kMaxInner], size[kMaxInner];                // block content offset / size in the payload
@@ -942,7 +943,7 @@ __device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csiz
                 if (!bs.init(bp + pos, bend - pos)) bad = true;
                 else {
                     uint32_t sl = bs.read(ll_log), so = bs.read(of_log), sm = bs.read(ml_log);
-                    uint32_t* out = seqarea + size_t(soff) * 3;
+                    uint32_t* out = seqarea + size_t(soff) * 2;
                     for (int n = 0; n < nseq; n++) {
                         const uint32_t el = zl->ll[sl], eo = zl->of[so], em = zl->ml[sm];
                         const uint32_t lv = zl->llv[sl], mv = zl->mlv[sm];
@@ -954,7 +955,8 @@ __device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csiz
                         sl = (el >> 16) + bs.read(int((el >> 8) & 0xff));
                         sm = (em >> 16) + bs.read(int((em >> 8) & 0xff));
                         so = (eo >> 16) + bs.read(int((eo >> 8) & 0xff));
-                        out[3 * n] = llen; out[3 * n + 1] = mlen; out[3 * n + 2] = ov;
+                        if (ov >> 28) { bad = true; break; }                                   // no such distance inside one 4mc block
+                        out[2 * n] = llen | (mlen << 18); out[2 * n + 1] = ov | ((mlen >> 14) << 28);
                     }
                     if (bs.pos > 0) bad = true;                        // bits left over: corruption
                 }
@@ -986,7 +988,7 @@ __device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csiz
         Lits lits; lits.pos = 0; lits.size = I->lit_size[b]; lits.is_rle = I->lit_kind[b] == 1; lits.rle = I->lit_rle[b];
         lits.p = I->lit_kind[b] == 2 ? litarea + I->lit_off[b] : src + I->lit_off[b];
         const int nsq = int(I->nseq[b]);
-        const uint32_t* sq = seqarea + size_t(I->seq_off[b]) * 3;
+        const uint32_t* sq = seqarea + size_t(I->seq_off[b]) * 2;
         int n = 0;
         while (n < nsq) {
             // ---- 64 sequences per coalesced load.  How many fit one batch follows from the lengths alone (prefix sum);
@@ -994,7 +996,10 @@ __device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csiz
             // real offsets between two repeat codes just shift the history.
             const int take = min(64, nsq - n);
             uint32_t my_ll = 0, my_ml = 0, r_ov = 4;
-            if (lane < take) { my_ll = sq[3 * (n + lane)]; my_ml = sq[3 * (n + lane) + 1]; r_ov = sq[3 * (n + lane) + 2]; }
+            if (lane < take) {
+                const uint32_t w0 = sq[2 * (n + lane)], w1 = sq[2 * (n + lane) + 1];
+                my_ll = w0 & 0x3FFFF; my_ml = (w0 >> 18) | ((w1 >> 28) << 14); r_ov = w1 & 0x0FFFFFFF;
+            }
             const uint32_t incl = scan_add(my_ll + my_ml);
             const unsigned long long over = __ballot(lane < take && incl > uint32_t(kOwnBytes));
             int cnt = over ? __builtin_ctzll(over) : take;
