@@ -407,7 +407,11 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                         K2CNT(pt_cross);
                         break;
                     }
-                    if (((m_dirty >> e) & 1) || (fresh && e == scut)) { // the window ends in front of lane e
+                    // A dirty lane that is the re-test right after a match, and whose slot the refill two bytes back has
+                    // just written (byte runs: same five bytes): its candidate is that refill, nothing else can have
+                    // written the slot since.
+                    const bool run_rt = ((m_dirty >> e) & 1) && any && e == anc && e >= 2 && rl(h, e - 2) == rl(h, e);
+                    if (!run_rt && (((m_dirty >> e) & 1) || (fresh && e == scut))) { // the window ends in front of lane e
                         stoplane = e;
                         if ((m_dirty >> e) & 1) K2CNT(pt_dcut); else K2CNT(pt_scut);
                         if (any && e == anc) { k0 = 0; retest = true; }
@@ -416,7 +420,15 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                         break;
                     }
                     uint32_t s_cand = rl(c, e), s_inf = rl(info, e);
-                    if ((m_cond >> e) & 1) {
+                    if (run_rt) {
+                        if (rl(q0.d1, e - 2) != rl(q0.d1, e)) {         // no match: the search goes on behind the re-test
+                            cur = e + 1;
+                            if (cur < 64) continue;
+                            k0 = uint32_t(64 - (anc + 1)); sp = sp0 + 64; retest = false;
+                            break;
+                        }
+                        s_cand = sp0 + uint32_t(e) - 2; s_inf = (uint32_t(e) + 4) | (1u << 15) | (1u << 16);
+                    } else if ((m_cond >> e) & 1) {
                         // second lane of its slot: did the walk put its predecessor j into the table?  Yes if j is a probe
                         // of the running search (j >= anchor lane) or lies outside every match chosen so far.
                         const int j = int(rl(uint32_t(pred), e));
