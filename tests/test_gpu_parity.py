@@ -160,6 +160,39 @@ def test_lz4_encode_bytes_identical_edge_inputs(gpu):
             assert np.array_equal(o, want), (mode, k)
 
 
+def test_lz4_encode_capacity_sweep(gpu):
+    """limitedOutput (lz4.c:1083-1107,1184-1196,1266-1293): the same input at capacities around its compressed size
+    and at tiny ones - return value (0 = does not fit) and every byte must equal the reference's."""
+    inputs = helpers.edge_inputs()
+    rng = np.random.default_rng(11)
+    for name in ("text_300k", "two_symbols", "far_repeat", "random_100k", "period37", "zeros_64k_limit"):
+        s = inputs[name]
+        full, _ = helpers.orc_compress(s, helpers.oracle().orc_lz4_compress_bound(len(s)))
+        caps = sorted(set([0, 1, 5, 13, 64, 200, 1000] + list(range(max(full - 40, 1), full + 6)) +
+                          [int(c) for c in rng.integers(1, full + 300, 24)] + [full - 300, full - 1000, len(s) - 1, len(s)]))
+        caps = [c for c in caps if c >= 0]
+        res, outs = _encode_batch(gpu, [s] * len(caps), caps)
+        for cap, r, o in zip(caps, res, outs):
+            want_r, want = helpers.orc_compress(s, cap)
+            assert r == want_r, (name, cap, r, want_r)
+            assert np.array_equal(o, want), (name, cap)
+
+
+def test_lz4_encode_sizes_around_the_dense_window_limits(gpu):
+    """Block lengths around the byU16/byU32 switch and around every length at which the dense window hands over to the
+    strided batch near the end of a block (a few bytes more or less of tail change which path takes the last sequences)."""
+    text = helpers.corpus(B)[:140000]
+    sizes = list(range(13, 40)) + list(range(120, 150)) + list(range(65530, 65560)) + list(range(70000, 70140, 7)) + [139999, 140000]
+    srcs = [text[:n] for n in sizes] + [np.tile(text[1000:1064], 40)[:n] for n in range(130, 400, 9)]
+    caps = [helpers.oracle().orc_lz4_compress_bound(len(s)) for s in srcs]
+    for mode, cc in (("bound", caps), ("n-1", [len(s) - 1 for s in srcs])):
+        res, outs = _encode_batch(gpu, srcs, cc)
+        for s, cap, r, o in zip(srcs, cc, res, outs):
+            want_r, want = helpers.orc_compress(s, cap)
+            assert r == want_r, (mode, len(s), r, want_r)
+            assert np.array_equal(o, want), (mode, len(s))
+
+
 def test_lz4_encode_bytes_identical_corpus(gpu):
     data = helpers.corpus(12 * B + 123457)       # 12 full blocks + a ragged tail block
     srcs = [data[b * B:(b + 1) * B] for b in range(13)]
