@@ -938,12 +938,50 @@ __device__ __forceinline__ uint32_t count_fwd(const uint8_t* s, uint32_t a, uint
     }
 }
 
+// ZSTD_storeSeq (zstd_compress_internal.h:643-686).  Only the lengths are recorded while parsing: the literal bytes are
+// gathered once per block (gather_literals), off the parser's chain of dependent memory round trips.
 __device__ __forceinline__ void store_seq(SeqStore& S, const uint8_t* s, uint32_t anchor, uint32_t ll, uint32_t off_base, uint32_t ml, int lane)
 {
-    copy_bytes(S.lit + S.nlit, s + anchor, ll, lane);
+    (void)s; (void)anchor;
     S.nlit += ll;
     if (lane == 0) { S.ll[S.nseq] = ll; S.ml[S.nseq] = ml - 3; S.off[S.nseq] = off_base; }
     S.nseq++;
+}
+
+struct __attribute__((packed, aligned(1))) LP8 { uint64_t v; };
+struct __attribute__((packed, aligned(1))) LP4 { uint32_t v; };
+struct __attribute__((packed, aligned(1))) LP2 { uint16_t v; };
+__device__ __forceinline__ void lane_copy32(uint8_t* b, const uint8_t* a, uint32_t n)   // exact length, n <= 32, one lane
+{
+    if (n & 32) { const U16B x = *reinterpret_cast<const U16B*>(a), y = *reinterpret_cast<const U16B*>(a + 16);
+                  *reinterpret_cast<U16B*>(b) = x; *reinterpret_cast<U16B*>(b + 16) = y; return; }
+    if (n & 16) { const U16B x = *reinterpret_cast<const U16B*>(a); *reinterpret_cast<U16B*>(b) = x; a += 16; b += 16; }
+    if (n & 8) { const LP8 x = *reinterpret_cast<const LP8*>(a); *reinterpret_cast<LP8*>(b) = x; a += 8; b += 8; }
+    if (n & 4) { const LP4 x = *reinterpret_cast<const LP4*>(a); *reinterpret_cast<LP4*>(b) = x; a += 4; b += 4; }
+    if (n & 2) { const LP2 x = *reinterpret_cast<const LP2*>(a); *reinterpret_cast<LP2*>(b) = x; a += 2; b += 2; }
+    if (n & 1) *b = *a;
+}
+
+// the literal runs of the block's sequences, in order, into S.lit: 64 sequences per step, positions by prefix sums of
+// the recorded lengths; short runs lane by lane, long ones with the whole wave
+__device__ __forceinline__ void gather_literals(const SeqStore& S, const uint8_t* s, uint32_t start, int lane)
+{
+    uint32_t srcpos = start, dstpos = 0;
+    for (uint32_t base = 0; base < S.nseq; base += 64) {
+        const uint32_t i = base + lane;
+        const bool on = i < S.nseq;
+        const uint32_t ll = on ? S.ll[i] : 0u, tot = on ? ll + S.ml[i] + 3 : 0u;
+        const uint32_t il = scan_add(ll), it = scan_add(tot);
+        const uint32_t my_src = srcpos + it - tot, my_dst = dstpos + il - ll;
+        if (ll && ll <= 32) lane_copy32(S.lit + my_dst, s + my_src, ll);
+        unsigned long long big = __ballot(ll > 32);
+        while (big) {
+            const int l = __builtin_ctzll(big);
+            copy_bytes(S.lit + rl(my_dst, l), s + rl(my_src, l), rl(ll, l), lane);
+            big &= big - 1;
+        }
+        srcpos += rl(it, 63); dstpos += rl(il, 63);
+    }
 }
 
 // after a match ending at ip0: table refills and the repcode-2 loop (zstd_fast.c:263-281)
@@ -951,12 +989,17 @@ __device__ __forceinline__ void after_match(SeqStore& S, uint32_t* tab, const Pa
                                             uint32_t cur0_idx, uint32_t& rep1, uint32_t& rep2, uint32_t end, int64_t ilimit, int lane)
 {
     if (int64_t(ip0) > ilimit) return;
+    // the four reads of this step in one round trip, ahead of the table stores
+    const uint64_t w_a = ld8(s + cur0_idx), w_b = ld8(s + ip0 - 2);
+    uint32_t r_cur = ld4(s + ip0), r_rep = ld4(s + ip0 - rep2);         // (rep2 == 0 reads ip0 itself: not used then)
     {
-        const uint32_t h_a = zhash(ld8(s + cur0_idx), P.hlog, P.mml), h_b = zhash(ld8(s + ip0 - 2), P.hlog, P.mml);
+        const uint32_t h_a = zhash(w_a, P.hlog, P.mml), h_b = zhash(w_b, P.hlog, P.mml);
         if (lane == 0) { tab[h_a] = cur0_idx + 2; tab[h_b] = ip0; }
     }
     if (rep2 > 0)
-        while (int64_t(ip0) <= ilimit && ld4(s + ip0) == ld4(s + ip0 - rep2)) {
+        for (bool first = true; int64_t(ip0) <= ilimit; first = false) {
+            if (!first) { r_cur = ld4(s + ip0); r_rep = ld4(s + ip0 - rep2); }
+            if (r_cur != r_rep) break;
             const uint32_t rlen = count_fwd(s, ip0 + 4, ip0 + 4 - rep2, end, lane) + 4;
             const uint32_t t = rep2; rep2 = rep1; rep1 = t;
             const uint32_t h = zhash(ld8(s + ip0), P.hlog, P.mml);
@@ -1598,6 +1641,7 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
             if (P.strat >= 4) tail = lazy_block(L, S, Z, P, ne.rep, src, pos, pos + len, n, lane);
             else tail = P.strat == 2 ? dfast_block(L, S, tab, tab_s, P, ne.rep, src, pos, pos + len, lane)
                                      : fast_block(L, S, tab, P, ne.rep, src, pos, pos + len, n, serial, lane);
+            gather_literals(S, src, pos, lane);
             copy_bytes(S.lit + S.nlit, src + pos + len - tail, tail, lane);
             S.nlit += tail;
             ZPH(t_mf);
