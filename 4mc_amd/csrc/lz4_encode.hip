@@ -6,21 +6,27 @@
 //
 // The reference parse is a serial greedy walk whose bytes depend on the exact order of hash
 // table reads and overwrites (lz4.c:1059,1207,1247), on the probe stride schedule
-// (`step = searchMatchNb++ >> 6`, :1017-1027) and on backward extension (:1080).  It is
-// reproduced exactly, but 64 probes at a time:
+// (`step = searchMatchNb++ >> 6`, :1017-1027), on backward extension (:1080), the ip-2 refill and
+// the immediate re-test (:1207-1259).  It is reproduced exactly, 64 positions at a time:
 //   * one wavefront owns one block; its hash table (4096 x u32, or 8192 x u16 for blocks
-//     < 65547 B, lz4.c:1353) lives in LDS and is zeroed per block like LZ4_initStream (:1348);
-//   * lane l speculatively executes probe k0+l of the current search (its position follows from
-//     the closed form of the stride schedule), reads its candidate from the LDS table and tests
-//     the 4-byte match; a ballot finds the FIRST lane (serial order) that hits, or that runs
-//     into the end-of-block limit; only lanes before it commit their table writes;
-//   * two probes of one batch that fall into the same table slot would see each other's write in
-//     the serial order, so the batch is cut at the first lane that shares a (folded) slot with an
-//     earlier lane - detected with an LDS atomic-min scoreboard; the cut lane simply becomes
-//     lane 0 of the next batch.  False sharing of the scoreboard only shortens a batch;
-//   * match extension (backwards and forwards) and literal / length emission are wave-wide
-//     compares + ballots and wave-wide byte copies.
-// Per block HBM traffic: n bytes read (+ candidate re-reads that hit L2/MALL), csize written.
+//     < 65547 B, lz4.c:1353) lives in LDS and is zeroed per block like LZ4_initStream (:1348).
+//     20 KiB of LDS per block (table + scoreboard) also is what spreads a 2048-block launch evenly,
+//     8 blocks on each of the 256 CUs: with 16 KiB the dispatcher packs 10 per CU and the launch
+//     takes 11 % longer (measured);
+//   * "dense window": lane l takes position sp+l whatever role the walk will give it, prepares
+//     candidate / 4-byte test / match extents against the table as it stands; lanes sharing a
+//     slot are found on the table itself (lane tags, atomic max); a scalar walk of one readlane
+//     per sequence chooses the hit lanes; sizes, positions and all bytes of the chosen sequences
+//     are then written by all lanes at once, and the visited lanes enter the table (latest
+//     position of a slot wins);
+//   * "sparse batch": lane l speculatively executes probe k0+l of the running search at its
+//     strided position (block start / end, long searches); a ballot finds the FIRST lane (serial
+//     order) that hits or runs into the end-of-block limit, only lanes before it commit their
+//     table writes, and the batch is cut at the first lane that shares a (folded) slot with an
+//     earlier one - an LDS atomic-min scoreboard; the cut lane becomes lane 0 of the next batch;
+//   * whatever the registers do not hold (long matches, long catch-up, output nearly full) goes
+//     through one general sequence routine with wave-wide compares and copies.
+// Per block HBM traffic: n bytes read (+ candidate re-reads that hit L1/L2), csize written.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "fourmc_gpu.h"
