@@ -10,9 +10,9 @@
 // the immediate re-test (:1207-1259).  It is reproduced exactly, 64 positions at a time:
 //   * one wavefront owns one block; its hash table (4096 x u32, or 8192 x u16 for blocks
 //     < 65547 B, lz4.c:1353) lives in LDS and is zeroed per block like LZ4_initStream (:1348).
-//     20 KiB of LDS per block (table + scoreboard) also is what spreads a 2048-block launch evenly,
-//     8 blocks on each of the 256 CUs: with 16 KiB the dispatcher packs 10 per CU and the launch
-//     takes 11 % longer (measured);
+//     20 KiB of LDS per block (table + the sparse batch's scoreboard): 8 blocks per CU, which is what a
+//     2048-block launch needs (a 16 KiB variant that tagged the table in the sparse batch too
+//     measured 11 % slower and was not kept);
 //   * "dense window": lane l takes position sp+l whatever role the walk will give it, prepares
 //     candidate / 4-byte test / match extents against the table as it stands; lanes sharing a
 //     slot are found on the table itself (lane tags, atomic max); a scalar walk of one readlane
