@@ -63,7 +63,17 @@ struct HC {
     uint32_t  wbase;       // first position of the window, 0xFFFFFFFF: none
     uint32_t  n, matchlimit, mflimit;
     int       lane;
+#ifdef K2_PROF   // side build (make prof): cycles in window build / searches / emission, call counts
+    uint64_t  pt_build, pt_search, pt_emit, pt0; uint32_t n_build, n_search, n_emit, n_mem;
+#endif
 };
+#ifdef K2_PROF
+#define K3PH(c, acc) do { const uint64_t t_ = __builtin_readcyclecounter(); (c).acc += t_ - (c).pt0; (c).pt0 = t_; } while (0)
+#define K3CNT(c, f) do { (c).f++; } while (0)
+#else
+#define K3PH(c, acc) do { } while (0)
+#define K3CNT(c, f) do { } while (0)
+#endif
 
 // LZ4HC_Insert (lz4hc.c:120-141): positions [ntu, upto) enter the tables in order.
 __device__ __forceinline__ void hc_insert(HC& c, uint32_t upto)
@@ -202,7 +212,9 @@ __device__ __forceinline__ int hc_wider(HC& c, uint32_t ip, uint32_t low, uint32
 {
     const uint8_t* s = c.src;
     const int lane = c.lane;
-    if (c.wbase == 0xFFFFFFFFu || ip - c.wbase >= 64u) hc_build_window(c, ip, attempts);
+    K3PH(c, pt_emit);
+    if (c.wbase == 0xFFFFFFFFu || ip - c.wbase >= 64u) { hc_build_window(c, ip, attempts); K3CNT(c, n_build); K3PH(c, pt_build); }
+    K3CNT(c, n_search);
     const uint32_t j = ip - c.wbase;
     const uint32_t ip_idx = ip + kIdx0;
     const uint32_t lowest = (kIdx0 + 65536 > ip_idx) ? kIdx0 : ip_idx - kMaxDist;
@@ -210,7 +222,7 @@ __device__ __forceinline__ int hc_wider(HC& c, uint32_t ip, uint32_t low, uint32
     const uint32_t pattern = ld4(s + ip);
     int nc = int(c.win->nc[j]);
     uint32_t mi = c.win->next[j];
-    if (nc == 0) return longest;                                      // empty chain (the common case in incompressible data)
+    if (nc == 0) { K3PH(c, pt_search); return longest; }               // empty chain (the common case in incompressible data)
     attempts -= nc;
     bool from_window = true;
     for (;;) {
@@ -231,6 +243,7 @@ __device__ __forceinline__ int hc_wider(HC& c, uint32_t ip, uint32_t low, uint32
                 const int l = __builtin_ctzll(todo);
                 const uint32_t mm = uint32_t(__builtin_amdgcn_readlane(int(m), l));
                 const uint32_t extra = wave_count_fwd(s, ip + kMinMatch + 32, mm + kMinMatch + 32, high, lane);
+                K3CNT(c, n_mem);
                 if (lane == l) fl += extra;
             }
             for (unsigned long long todo = __ballot(more_b); todo; todo &= todo - 1) {
@@ -298,6 +311,7 @@ __device__ __forceinline__ int hc_wider(HC& c, uint32_t ip, uint32_t low, uint32
         from_window = false;
         if (!(mi != 0 && mi >= lowest && attempts > 0)) break;
     }
+    K3PH(c, pt_search);
     return longest;
 }
 
@@ -331,6 +345,9 @@ __device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int c
 {
     if (uint32_t(n) > 0x7E000000u) return 0;
     HC c; c.src = src; c.lane = lane; c.ntu = 0; c.score = score; c.win = win; c.wbase = 0xFFFFFFFFu;
+#ifdef K2_PROF
+    c.pt_build = c.pt_search = c.pt_emit = 0; c.n_build = c.n_search = c.n_emit = c.n_mem = 0; c.pt0 = __builtin_readcyclecounter();
+#endif
     c.n = uint32_t(n); c.matchlimit = n > kLastLit ? uint32_t(n) - kLastLit : 0u; c.mflimit = n > kMfLimit ? uint32_t(n) - kMfLimit : 0u;
     c.heads = reinterpret_cast<uint32_t*>(work);
     c.chain = reinterpret_cast<uint16_t*>(work + (size_t(4) << kHashLog));
@@ -426,6 +443,12 @@ __device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int c
         copy_bytes(dst + op, src + anchor, run, lane);
         op += run;
     }
+#ifdef K2_PROF
+    if (lane == 0 && n == (4 << 20) && op + 256 < uint32_t(n)) {
+        uint64_t* o = reinterpret_cast<uint64_t*>(dst + n - 128);
+        o[0] = c.pt_build; o[1] = c.pt_search; o[2] = c.pt_emit; o[3] = c.n_build; o[4] = c.n_search; o[5] = c.n_mem;
+    }
+#endif
     return int(op);
 }
 
