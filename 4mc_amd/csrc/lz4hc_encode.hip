@@ -75,26 +75,41 @@ struct HC {
 #define K3CNT(c, f) do { } while (0)
 #endif
 
-// LZ4HC_Insert (lz4hc.c:120-141): positions [ntu, upto) enter the tables in order.
+// LZ4HC_Insert (lz4hc.c:120-141): positions [ntu, upto) enter the tables in order, 64 per step.  Inside one step the
+// serial order only matters between positions with the same hash: each of those chains to its nearest predecessor in
+// the step (a lane distance), only the first of a hash needs the old head from memory and only the last one becomes
+// the new head - so a step is one read round trip however many lanes share a hash (byte runs put dozens into one).
+// Lanes that share are found with the folded LDS scoreboard, their exact predecessor with one ballot per distinct hash.
 __device__ __forceinline__ void hc_insert(HC& c, uint32_t upto)
 {
     while (c.ntu < upto) {
         const uint32_t pos = c.ntu + c.lane;
-        bool pending = pos < upto;
-        const uint32_t h = pending ? hc_hash(ld4(c.src + pos)) : 0u;
+        const bool on = pos < upto;
+        const uint32_t h = on ? hc_hash(ld4(c.src + pos)) : 0xFFFFFFFFu;
         const uint32_t idx = pos + kIdx0;
-        uint32_t* sc = &c.score[h & (kScore - 1)];
-        while (__ballot(pending)) {
-            if (pending) atomicMin(sc, uint32_t(c.lane));
-            const bool win = pending && (*sc == uint32_t(c.lane));     // lowest pending lane of its bucket
-            if (win) {
-                uint32_t delta = idx - c.heads[h];
-                if (delta > kMaxDist) delta = kMaxDist;
-                c.chain[idx & kChainMask] = uint16_t(delta);
-                c.heads[h] = idx;
-                *sc = 0xFFFFFFFFu;
-                pending = false;
+        int prev = -1; bool last = on;
+        if (on) {
+            uint32_t* sc = &c.score[h & (kScore - 1)];
+            atomicMin(sc, uint32_t(c.lane));
+        }
+        const bool lost = on && c.score[h & (kScore - 1)] != uint32_t(c.lane);      // an earlier lane sits in my bucket
+        if (on) c.score[h & (kScore - 1)] = 0xFFFFFFFFu;
+        for (unsigned long long rem = __ballot(lost); rem; ) {
+            const uint32_t hv = uint32_t(__builtin_amdgcn_readlane(int(h), __builtin_ctzll(rem)));
+            const unsigned long long m = __ballot(h == hv);
+            if (h == hv) {
+                const unsigned long long lower = m & ~(~0ull << c.lane), upper = m & (~1ull << c.lane);
+                if (lower) prev = 63 - __builtin_clzll(lower);
+                last = upper == 0;
             }
+            rem &= ~m;
+        }
+        if (on) {
+            uint32_t delta;
+            if (prev >= 0) delta = uint32_t(c.lane - prev);
+            else { delta = idx - c.heads[h]; if (delta > kMaxDist) delta = kMaxDist; }
+            c.chain[idx & kChainMask] = uint16_t(delta);
+            if (last) c.heads[h] = idx;
         }
         c.ntu = min(upto, c.ntu + 64u);
     }
@@ -182,16 +197,21 @@ __device__ __forceinline__ void hc_build_window(HC& c, uint32_t wb, int attempts
         if (go) {
             const uint32_t m = mi - kIdx0;
             const uint32_t d = c.chain[mi & kChainMask];
+            // everything this candidate can be asked for is read at once, whether or not its first four bytes match:
+            // one round trip per chain step instead of up to three dependent ones
+            const bool wf = wide_f, wb2 = wide_b && m >= 16;
             const uint32_t c4 = ld4(s + m);
+            U16B g0 = {0, 0}, g1 = {0, 0}, h0 = {0, 0};
+            if (wf) { g0 = *reinterpret_cast<const U16B*>(s + m + 4); g1 = *reinterpret_cast<const U16B*>(s + m + 20); }
+            if (wb2) h0 = *reinterpret_cast<const U16B*>(s + m - 16);
             uint32_t fl = 0xFF, bl = 0;
             if (c4 == pat) {
-                if (wide_f) {
-                    const U16B g0 = *reinterpret_cast<const U16B*>(s + m + 4);
+                if (wf) {
                     uint32_t e = eq16_fwd(f0, g0);
-                    if (e == 16) { const U16B g1 = *reinterpret_cast<const U16B*>(s + m + 20); e += eq16_fwd(f1, g1); }
+                    if (e == 16) e += eq16_fwd(f1, g1);
                     fl = min(e, fcap);
                 } else { fl = 0; while (fl < fcap && s[q + 4 + fl] == s[m + 4 + fl]) fl++; }
-                if (wide_b && m >= 16) bl = eq16_back(b0, *reinterpret_cast<const U16B*>(s + m - 16));
+                if (wb2) bl = eq16_back(b0, h0);
                 else { const uint32_t bc = min(16u, min(q, m)); while (bl < bc && s[q - 1 - bl] == s[m - 1 - bl]) bl++; }
             }
             c.win->cand[lane * kWinK + k] = mi; c.win->fl[lane * kWinK + k] = uint8_t(fl); c.win->bl[lane * kWinK + k] = uint8_t(bl);
