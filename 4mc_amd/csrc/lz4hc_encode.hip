@@ -51,6 +51,8 @@ struct HCWin {
     uint32_t next[64];           // chain continuation after the cached candidates (0: chain ended)
     uint8_t  nc[64];             // cached candidates of the position
     uint8_t  live[64];           // 0: no candidate of the position can give a match (none shares its first 4 bytes, chain ended)
+    uint8_t  fm[64];             // the search that opens a sequence at this position (nothing to look back at, longest = 3),
+    uint32_t fr[64];             // answered ahead: match length (0: none, 0xFF: ask hc_wider) and the candidate's table index
 };
 
 struct HC {
@@ -63,6 +65,7 @@ struct HC {
     uint32_t  wbase;       // first position of the window, 0xFFFFFFFF: none
     uint32_t  n, matchlimit, mflimit;
     int       lane;
+    uint32_t  pl_byte, pl_dst, pl_n;   // literal run of the last sequence: read, not yet written (see hc_emit)
 #ifdef K2_PROF   // side build (make prof): cycles in window build / searches / emission, call counts
     uint64_t  pt_build, pt_search, pt_emit, pt0; uint32_t n_build, n_search, n_emit, n_mem;
 #endif
@@ -191,6 +194,7 @@ __device__ __forceinline__ void hc_build_window(HC& c, uint32_t wb, int attempts
         if (go && d == kMaxDist) go = hc_hash(ld4(s + (mi - kIdx0))) == hc_hash(pat);
     }
     uint32_t cnt = 0; bool any = false;
+    uint32_t best = 0, best_mi = 0; bool ask = attempts > kWinK;      // running "ml > longest" in chain order: the earliest of the longest
     const int K = attempts < kWinK ? attempts : kWinK;
     for (int k = 0; k < K; k++) {
         if (!__ballot(go)) break;
@@ -216,11 +220,16 @@ __device__ __forceinline__ void hc_build_window(HC& c, uint32_t wb, int attempts
             }
             c.win->cand[lane * kWinK + k] = mi; c.win->fl[lane * kWinK + k] = uint8_t(fl); c.win->bl[lane * kWinK + k] = uint8_t(bl);
             cnt++; any |= fl != 0xFF;
+            if (fl != 0xFF) {
+                if (fl == 32 && q + kMinMatch + 32 < c.matchlimit) ask = true;      // longer than what was read
+                if (kMinMatch + fl > best) { best = kMinMatch + fl; best_mi = mi; }
+            }
             mi -= d;
             go = mi >= lowest;
         }
     }
     c.win->nc[lane] = uint8_t(cnt);
+    c.win->fm[lane] = uint8_t(ask ? 0xFF : best); c.win->fr[lane] = best_mi;
     c.win->next[lane] = go ? mi : 0u;
     c.win->live[lane] = uint8_t((any ? 1 : 0) | ((go && attempts > K) ? 2 : 0));
     c.wbase = wb;
@@ -336,7 +345,7 @@ __device__ __forceinline__ int hc_wider(HC& c, uint32_t ip, uint32_t low, uint32
 }
 
 // LZ4HC_encodeSequence (lz4hc.c:467-548): returns true when `limited` and the output would overflow
-__device__ __forceinline__ bool hc_emit(const uint8_t* src, uint8_t* dst, uint32_t& ip, uint32_t& op, uint32_t& anchor,
+__device__ __forceinline__ bool hc_emit(HC& c, const uint8_t* src, uint8_t* dst, uint32_t& ip, uint32_t& op, uint32_t& anchor,
                                         int ml, uint32_t match, bool limited, uint32_t cap, int lane)
 {
     const uint32_t lit = ip - anchor;
@@ -345,7 +354,16 @@ __device__ __forceinline__ bool hc_emit(const uint8_t* src, uint8_t* dst, uint32
     uint32_t tok;
     if (lit >= 15) { tok = 0xF0; op += emit_len(dst + op, lit - 15, lane); }
     else tok = lit << 4;
-    copy_bytes(dst + op, src + anchor, lit, lane);
+    // a short literal run is read now and written at the NEXT emit: the parser never waits for the read to come back
+    if (lit <= 64) {
+        const uint32_t v = uint32_t(lane) < lit ? uint32_t(src[anchor + lane]) : 0u;
+        if (uint32_t(lane) < c.pl_n) dst[c.pl_dst + lane] = uint8_t(c.pl_byte);
+        c.pl_byte = v; c.pl_dst = op; c.pl_n = lit;
+    } else {
+        if (uint32_t(lane) < c.pl_n) dst[c.pl_dst + lane] = uint8_t(c.pl_byte);
+        c.pl_n = 0;
+        copy_bytes(dst + op, src + anchor, lit, lane);
+    }
     op += lit;
     const uint32_t off = ip - match;
     if (lane == 0) { dst[op] = uint8_t(off); dst[op + 1] = uint8_t(off >> 8); }
@@ -365,6 +383,7 @@ __device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int c
 {
     if (uint32_t(n) > 0x7E000000u) return 0;
     HC c; c.src = src; c.lane = lane; c.ntu = 0; c.score = score; c.win = win; c.wbase = 0xFFFFFFFFu;
+    c.pl_byte = 0; c.pl_dst = 0; c.pl_n = 0;
 #ifdef K2_PROF
     c.pt_build = c.pt_search = c.pt_emit = 0; c.n_build = c.n_search = c.n_emit = c.n_mem = 0; c.pt0 = __builtin_readcyclecounter();
 #endif
@@ -386,7 +405,13 @@ __device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int c
         int ml, ml2, ml3, ml0;
         uint32_t ref = 0, start2 = 0, ref2 = 0, start3 = 0, ref3 = 0, start0, ref0, dummy = 0;
         while (ip <= mflimit) {
-            ml = hc_wider(c, ip, ip, matchlimit, kMinMatch - 1, ref, dummy, attempts);
+            // the search that opens a sequence looks back at nothing: its answer was prepared with the window
+            if (c.wbase == 0xFFFFFFFFu || ip - c.wbase >= 64u) { K3PH(c, pt_emit); hc_build_window(c, ip, attempts); K3CNT(c, n_build); K3PH(c, pt_build); }
+            {
+                const uint32_t f = c.win->fm[ip - c.wbase];
+                if (f != 0xFF) { ml = f ? int(f) : kMinMatch - 1; ref = c.win->fr[ip - c.wbase] - kIdx0; }
+                else ml = hc_wider(c, ip, ip, matchlimit, kMinMatch - 1, ref, dummy, attempts);
+            }
             if (ml < kMinMatch) {
                 // no match here: go straight to the next window position that has a candidate sharing its first four
                 // bytes - a search anywhere in between returns "none" without side effects (tables are filled ahead)
@@ -404,7 +429,7 @@ __device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int c
             if (ip + ml <= mflimit) ml2 = hc_wider(c, ip + ml - 2, ip, matchlimit, ml, ref2, start2, attempts);
             else ml2 = ml;
             if (ml2 == ml) {
-                if (hc_emit(src, dst, ip, op, anchor, ml, ref, limited, ucap, lane)) return 0;
+                if (hc_emit(c, src, dst, ip, op, anchor, ml, ref, limited, ucap, lane)) return 0;
                 continue;
             }
             if (start0 < ip && start2 < ip + ml0) { ip = start0; ref = ref0; ml = ml0; }
@@ -421,9 +446,9 @@ __device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int c
             else ml3 = ml2;
             if (ml3 == ml2) {
                 if (start2 < ip + ml) ml = int(start2 - ip);
-                if (hc_emit(src, dst, ip, op, anchor, ml, ref, limited, ucap, lane)) return 0;
+                if (hc_emit(c, src, dst, ip, op, anchor, ml, ref, limited, ucap, lane)) return 0;
                 ip = start2;
-                if (hc_emit(src, dst, ip, op, anchor, ml2, ref2, limited, ucap, lane)) return 0;
+                if (hc_emit(c, src, dst, ip, op, anchor, ml2, ref2, limited, ucap, lane)) return 0;
                 continue;
             }
             if (start3 < ip + ml + 3) {
@@ -433,7 +458,7 @@ __device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int c
                         start2 += correction; ref2 += correction; ml2 -= correction;
                         if (ml2 < kMinMatch) { start2 = start3; ref2 = ref3; ml2 = ml3; }
                     }
-                    if (hc_emit(src, dst, ip, op, anchor, ml, ref, limited, ucap, lane)) return 0;
+                    if (hc_emit(c, src, dst, ip, op, anchor, ml, ref, limited, ucap, lane)) return 0;
                     ip = start3; ref = ref3; ml = ml3;
                     start0 = start2; ref0 = ref2; ml0 = ml2;
                     goto search2;
@@ -449,12 +474,13 @@ __device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int c
                     if (correction > 0) { start2 += correction; ref2 += correction; ml2 -= correction; }
                 } else ml = int(start2 - ip);
             }
-            if (hc_emit(src, dst, ip, op, anchor, ml, ref, limited, ucap, lane)) return 0;
+            if (hc_emit(c, src, dst, ip, op, anchor, ml, ref, limited, ucap, lane)) return 0;
             ip = start2; ref = ref2; ml = ml2;
             start2 = start3; ref2 = ref3; ml2 = ml3;
             goto search3;
         }
     }
+    if (uint32_t(lane) < c.pl_n) dst[c.pl_dst + lane] = uint8_t(c.pl_byte);
     {   // last literals (lz4hc.c:735-762)
         const uint32_t run = uint32_t(n) - anchor, add = (run + 255 - 15) / 255;
         if (limited && op + 1 + add + run > ucap) return 0;
