@@ -7,21 +7,22 @@
 // search LZ4HC_InsertAndGetWiderMatch :239-447 (patternAnalysis off for <= 128 attempts :565,
 // chainSwap off :461,:603,:648), tables LZ4HC_Insert :120-141.
 //
-// One wavefront owns one block.  The 256 KiB of match-finder state (32768 x u32 hash heads +
-// 65536 x u16 chain deltas) exceeds LDS, so it lives in a per-block HBM workspace slot (L2/MALL
-// resident while the block is in flight).  What is parallel:
-//   * inserting positions: 64 positions per step; lanes that fall into one hash bucket are
-//     serialised in position order with an LDS atomic-min scoreboard (rounds), everything else is
-//     one gather + two scatters;
-//   * evaluating a chain: the chain is walked once (serial pointer chase through the chain table),
-//     then up to 64 candidates are measured at once, one per lane - pattern check, forward length
-//     (8 bytes per step; candidates still equal after 32 bytes are finished by the whole
-//     wavefront, 1 KiB per step) and backward length.  The reference's running
-//     "if (ml > longest)" over candidates in chain order equals max-length with earliest-wins
-//     ties, which is what the wave reduction computes (its 2-byte pre-filter at `longest` can
-//     never reject a winner, so it does not change results);
-//   * the lazy three-match arbitration (lz4hc.c:592-732) is scalar code, mirrored statement by
-//     statement; sequence emission is wave-wide copies.
+// TWO wavefronts own one block.  LZ4HC_Insert puts every position into the tables, in order, whatever the
+// parse does, so tables and candidate chains are a function of the input alone:
+//   * the BUILDER wave inserts positions (64 per step, one read round trip per step: positions that
+//     share a hash chain to each other by lane distance) and builds a look-ahead window for every
+//     aligned group of 64 positions: the chains of the 64 positions walked at once, one per lane,
+//     every candidate measured on the way (4-byte check, 32 bytes forward, 16 backward, all read in one
+//     round trip per chain step), and the answer of the search that opens a sequence there;
+//   * the PARSER wave runs the lazy three-match arbitration (lz4hc.c:592-732, mirrored statement by
+//     statement) out of those windows in LDS - a ring of 3, the builder stays at most 2 ahead - and
+//     emits the sequences.  Its searches only apply the limits that depend on the parse (how far it
+//     may look back, the running `longest`); matches longer than the cached 32 / 16 bytes, and the
+//     attempts beyond 8 of levels 5-8, touch memory again.
+// The 384 KiB of match-finder state (32768 x u32 hash heads + 131072 x u16 chain deltas, twice the
+// reference's chain so that inserting ahead of the parser overwrites nothing it needs) live in a
+// per-block HBM workspace slot.  The reference's running "if (ml > longest)" over candidates in chain
+// order equals max-length with earliest-wins ties, which is what the reductions compute.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "fourmc_gpu.h"
@@ -55,12 +56,26 @@ struct HCWin {
     uint32_t fr[64];             // answered ahead: match length (0: none, 0xFF: ask hc_wider) and the candidate's table index
 };
 
+// Two wavefronts own one block.  The table state and the look-ahead windows depend on the input alone, so a BUILDER
+// wave inserts positions and builds the windows of the aligned 64-position groups in order, a few ahead, while the
+// PARSER wave runs the serial lazy parse out of them.  A ring of kRing windows in LDS; `built` = windows finished,
+// `keep` = oldest window the parser may still open (it can step back one window at most without rebuilding).
+constexpr int kRing = 3;
+struct HCSync { uint32_t built, keep, done; };
+__device__ __forceinline__ uint32_t ld_acq(uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st_rel(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+constexpr uint32_t kSpinLimit = 1u << 24;    // a wait that long means the other wave is gone: give up instead of hanging
+
 struct HC {
     const uint8_t* src;
     uint32_t* heads;       // [32768]
     uint16_t* chain;       // [131072]
     uint32_t* score;       // LDS [kScore], all 0xFFFFFFFF between uses
-    HCWin*    win;         // LDS
+    HCWin*    win;         // LDS: the window in use (parser) / being built (builder)
+    HCWin*    wins;        // LDS: kRing shared windows + one private to the parser
+    HCSync*   sync;        // LDS
+    uint32_t  wmax;        // parser: highest window opened so far
+    bool      failed;
     uint32_t  ntu;         // next position to insert (runs AHEAD of the search position)
     uint32_t  wbase;       // first position of the window, 0xFFFFFFFF: none
     uint32_t  n, matchlimit, mflimit;
@@ -170,11 +185,11 @@ __device__ __forceinline__ uint32_t eq16_back(const U16B& x, const U16B& y)     
 // recorded when q itself was inserted.  That lets the wave walk the chains of 64 consecutive positions AT ONCE (one
 // per lane, kWinK dependent steps for all of them together) and measure every candidate on the way, instead of one
 // dependent chain step per memory round trip.  The serial parser below then reads its searches out of LDS.
-__device__ __forceinline__ void hc_build_window(HC& c, uint32_t wb, int attempts)
+__device__ __forceinline__ void hc_build_window(HC& c, uint32_t wb, int attempts, bool insert)
 {
     const uint8_t* s = c.src;
     const int lane = c.lane;
-    hc_insert(c, min(wb + 64u, c.n - 3u));
+    if (insert) hc_insert(c, min(wb + 64u, c.n - 3u));
     const uint32_t q = wb + lane;
     const bool act = q <= c.mflimit;                                  // no search starts beyond mflimit
     const uint32_t qi = q + kIdx0, lowest = (kIdx0 + 65536 > qi) ? kIdx0 : qi - kMaxDist;
@@ -186,7 +201,7 @@ __device__ __forceinline__ void hc_build_window(HC& c, uint32_t wb, int attempts
     const uint32_t fcap = act ? min(32u, c.matchlimit - (q + 4)) : 0u;
     uint32_t mi = 0; bool go = false;
     if (act) {
-        const uint32_t d = c.chain[qi & kChainMask];
+        const uint32_t d = insert ? uint32_t(c.chain[qi & kChainMask]) : uint32_t(__hip_atomic_load(&c.chain[qi & kChainMask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         mi = qi - d;
         go = mi >= lowest;
         // a delta of 65535 is either that distance or "further" (capped at insertion): it is the former iff the
@@ -200,7 +215,7 @@ __device__ __forceinline__ void hc_build_window(HC& c, uint32_t wb, int attempts
         if (!__ballot(go)) break;
         if (go) {
             const uint32_t m = mi - kIdx0;
-            const uint32_t d = c.chain[mi & kChainMask];
+            const uint32_t d = insert ? uint32_t(c.chain[mi & kChainMask]) : uint32_t(__hip_atomic_load(&c.chain[mi & kChainMask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             // everything this candidate can be asked for is read at once, whether or not its first four bytes match:
             // one round trip per chain step instead of up to three dependent ones
             const bool wf = wide_f, wb2 = wide_b && m >= 16;
@@ -235,6 +250,20 @@ __device__ __forceinline__ void hc_build_window(HC& c, uint32_t wb, int attempts
     c.wbase = wb;
 }
 
+// parser: make the window of position ip current
+__device__ __forceinline__ void hc_acquire(HC& c, uint32_t ip, int attempts)
+{
+    const uint32_t w = ip >> 6;
+    if (w > c.wmax) { c.wmax = w; if (c.lane == 0) st_rel(&c.sync->keep, w - 1); }
+    for (uint32_t spins = 0; ld_acq(&c.sync->built) <= w; ) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kSpinLimit) { c.failed = true; break; }
+    }
+    if (w + 1 >= c.wmax) c.win = c.wins + (w % kRing);       // still in the ring (the builder never overwrites >= keep)
+    else { c.win = c.wins + kRing; hc_build_window(c, w << 6, attempts, false); }   // stepped further back: rebuild it privately (tables are already ahead)
+    c.wbase = w << 6;
+}
+
 // LZ4HC_InsertAndGetWiderMatch (lz4hc.c:239-447), no dictionary, no pattern analysis, no chain swap.
 __device__ __forceinline__ int hc_wider(HC& c, uint32_t ip, uint32_t low, uint32_t high, int longest,
                                         uint32_t& mpos, uint32_t& spos, int attempts)
@@ -242,7 +271,7 @@ __device__ __forceinline__ int hc_wider(HC& c, uint32_t ip, uint32_t low, uint32
     const uint8_t* s = c.src;
     const int lane = c.lane;
     K3PH(c, pt_emit);
-    if (c.wbase == 0xFFFFFFFFu || ip - c.wbase >= 64u) { hc_build_window(c, ip, attempts); K3CNT(c, n_build); K3PH(c, pt_build); }
+    if (c.wbase == 0xFFFFFFFFu || ip - c.wbase >= 64u) { hc_acquire(c, ip, attempts); K3CNT(c, n_build); K3PH(c, pt_build); }
     K3CNT(c, n_search);
     const uint32_t j = ip - c.wbase;
     const uint32_t ip_idx = ip + kIdx0;
@@ -287,7 +316,7 @@ __device__ __forceinline__ int hc_wider(HC& c, uint32_t ip, uint32_t low, uint32
             while (mi >= lowest && attempts > 0 && nc < 64) {
                 if (lane == nc) cand = mi;
                 nc++; attempts--;
-                mi -= uint32_t(uni(int(c.chain[mi & kChainMask])));
+                mi -= uint32_t(uni(int(__hip_atomic_load(&c.chain[mi & kChainMask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));   // (the builder wave is writing this table: not through a stale L1 line)
             }
             m = cand - kIdx0;
             live = lane < nc && ld4(s + (lane < nc ? m : 0u)) == pattern;
@@ -378,15 +407,11 @@ __device__ __forceinline__ bool hc_emit(HC& c, const uint8_t* src, uint8_t* dst,
     return false;
 }
 
-__device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int cap, int attempts,
-                                  uint8_t* work, uint32_t* score, HCWin* win, int lane)
+// builder wave: clear the tables, then positions and windows in order, at most kRing - 1 windows ahead of the parser
+__device__ void lz4hc_build_block(const uint8_t* src, int n, int attempts, uint8_t* work, uint32_t* score, HCWin* wins, HCSync* sync, int lane)
 {
-    if (uint32_t(n) > 0x7E000000u) return 0;
-    HC c; c.src = src; c.lane = lane; c.ntu = 0; c.score = score; c.win = win; c.wbase = 0xFFFFFFFFu;
-    c.pl_byte = 0; c.pl_dst = 0; c.pl_n = 0;
-#ifdef K2_PROF
-    c.pt_build = c.pt_search = c.pt_emit = 0; c.n_build = c.n_search = c.n_emit = c.n_mem = 0; c.pt0 = __builtin_readcyclecounter();
-#endif
+    HC c; c.src = src; c.lane = lane; c.ntu = 0; c.score = score; c.wins = wins; c.sync = sync; c.win = wins; c.wbase = 0xFFFFFFFFu;
+    c.wmax = 0; c.failed = false; c.pl_byte = 0; c.pl_dst = 0; c.pl_n = 0;
     c.n = uint32_t(n); c.matchlimit = n > kLastLit ? uint32_t(n) - kLastLit : 0u; c.mflimit = n > kMfLimit ? uint32_t(n) - kMfLimit : 0u;
     c.heads = reinterpret_cast<uint32_t*>(work);
     c.chain = reinterpret_cast<uint16_t*>(work + (size_t(4) << kHashLog));
@@ -396,6 +421,37 @@ __device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int c
         for (uint32_t i = lane; i < nt; i += 64) w[i] = i < nh ? make_uint4(0, 0, 0, 0) : make_uint4(~0u, ~0u, ~0u, ~0u);
         for (int i = lane; i < kScore; i += 64) score[i] = 0xFFFFFFFFu;
     }
+    if (n < kMfLimit + 1) return;
+    const uint32_t nwin = (c.mflimit >> 6) + 1;
+    for (uint32_t v = 0; v < nwin; v++) {
+        uint32_t keep;
+        for (uint32_t spins = 0; v >= (keep = ld_acq(&sync->keep)) + kRing; ) {
+            if (ld_acq(&sync->done)) return;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit) return;
+        }
+        if (ld_acq(&sync->done)) return;
+        c.win = wins + (v % kRing);
+        if (v + 1 < keep) hc_insert(c, min((v << 6) + 64u, c.n - 3u));          // the parser is past it: tables only
+        else hc_build_window(c, v << 6, attempts, true);
+        if (lane == 0) st_rel(&sync->built, v + 1);
+    }
+}
+
+// parser wave
+__device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int cap, int attempts,
+                                  uint8_t* work, HCWin* wins, HCSync* sync, int lane)
+{
+    if (uint32_t(n) > 0x7E000000u) return 0;
+    HC c; c.src = src; c.lane = lane; c.ntu = 0; c.score = nullptr; c.wins = wins; c.sync = sync; c.win = wins; c.wbase = 0xFFFFFFFFu;
+    c.wmax = 0; c.failed = false;
+    c.pl_byte = 0; c.pl_dst = 0; c.pl_n = 0;
+#ifdef K2_PROF
+    c.pt_build = c.pt_search = c.pt_emit = 0; c.n_build = c.n_search = c.n_emit = c.n_mem = 0; c.pt0 = __builtin_readcyclecounter();
+#endif
+    c.n = uint32_t(n); c.matchlimit = n > kLastLit ? uint32_t(n) - kLastLit : 0u; c.mflimit = n > kMfLimit ? uint32_t(n) - kMfLimit : 0u;
+    c.heads = reinterpret_cast<uint32_t*>(work);
+    c.chain = reinterpret_cast<uint16_t*>(work + (size_t(4) << kHashLog));
     const bool limited = cap < n + n / 255 + 16;
     const uint32_t ucap = uint32_t(cap);
     uint32_t ip = 0, anchor = 0, op = 0;
@@ -406,7 +462,8 @@ __device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int c
         uint32_t ref = 0, start2 = 0, ref2 = 0, start3 = 0, ref3 = 0, start0, ref0, dummy = 0;
         while (ip <= mflimit) {
             // the search that opens a sequence looks back at nothing: its answer was prepared with the window
-            if (c.wbase == 0xFFFFFFFFu || ip - c.wbase >= 64u) { K3PH(c, pt_emit); hc_build_window(c, ip, attempts); K3CNT(c, n_build); K3PH(c, pt_build); }
+            if (c.wbase == 0xFFFFFFFFu || ip - c.wbase >= 64u) { K3PH(c, pt_emit); hc_acquire(c, ip, attempts); K3CNT(c, n_build); K3PH(c, pt_build); }
+            if (c.failed) return 0;
             {
                 const uint32_t f = c.win->fm[ip - c.wbase];
                 if (f != 0xFF) { ml = f ? int(f) : kMinMatch - 1; ref = c.win->fr[ip - c.wbase] - kIdx0; }
@@ -498,22 +555,32 @@ __device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int c
     return int(op);
 }
 
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(128)
 void lz4hc_encode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks,
                          uint32_t nblocks, uint8_t* work_base, int attempts, int container_mode)
 {
     __shared__ uint32_t score[kScore];
-    __shared__ HCWin win;
+    __shared__ HCWin wins[kRing + 1];
+    __shared__ HCSync sync;
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
+    if (threadIdx.x == 0) { sync.built = 0; sync.keep = 0; sync.done = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
     const fourmc_block blk = blocks[b];
     const uint8_t* src = src_base + blk.src_off;
-    uint8_t* dst = dst_base + blk.dst_off;
     const int n = int(blk.src_len);
+    uint8_t* work = work_base + size_t(b) * kWorkBytes;
+    if (threadIdx.x >= 64) {
+        if (uint32_t(n) <= 0x7E000000u) lz4hc_build_block(src, n, attempts, work, score, wins, &sync, lane);
+        return;
+    }
+    uint8_t* dst = dst_base + blk.dst_off;
     const int cap = container_mode ? n - 1 : int(blk.dst_cap);
-    int r = lz4hc_encode_block(src, dst, n, cap, attempts, work_base + size_t(b) * kWorkBytes, score, &win, threadIdx.x);
-    if (container_mode && r <= 0) { copy_bytes(dst, src, uint32_t(n), threadIdx.x); r = n; }
-    if (threadIdx.x == 0) blocks[b].result = r;
+    int r = lz4hc_encode_block(src, dst, n, cap, attempts, work, wins, &sync, lane);
+    if (lane == 0) st_rel(&sync.done, 1u);
+    if (container_mode && r <= 0) { copy_bytes(dst, src, uint32_t(n), lane); r = n; }
+    if (lane == 0) blocks[b].result = r;
 }
 
 } // namespace
@@ -526,7 +593,7 @@ extern "C" hipError_t fourmc_launch_lz4hc_encode(const void* d_src, void* d_dst,
     if (n == 0) return hipSuccess;
     static const int searches[9] = {2, 2, 2, 4, 8, 16, 32, 64, 128};       // lz4hc.c:817-827, levels 0..8
     if (level < 1 || level > 8) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(lz4hc_encode_kernel, dim3(n), dim3(64), 0, stream,
+    hipLaunchKernelGGL(lz4hc_encode_kernel, dim3(n), dim3(128), 0, stream,
                        static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n,
                        static_cast<uint8_t*>(d_work), searches[level], container_mode);
     return hipGetLastError();
