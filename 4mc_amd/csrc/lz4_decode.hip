@@ -261,25 +261,39 @@ __device__ __forceinline__ uint32_t scan_max(uint32_t v, int)      // values are
     return v;
 }
 
-__device__ __forceinline__ int lz4_decode_block_fast(const uint8_t* src, int csize, uint8_t* dst, int cap,
-                                     uint8_t* lds, uint8_t* own, int lane)
+// The fast path runs on TWO wavefronts per block: what the tokens say (lengths, offsets, where each sequence's output
+// starts) depends on the compressed stream alone, so a PARSER wave walks the stream and hands finished batches to a
+// COPIER wave through a ring of records in LDS; the copier produces the output.  Neither waits for the other's memory.
+constexpr int kRec = 8;
+enum : uint32_t { kRecBatch = 1, kRecGeneral = 2, kRecEnd = 3, kRecRetry = 4 };
+struct Rec {
+    uint32_t type;
+    uint32_t T;              // batch: output bytes; general: match length (0: the block's last, literal-only sequence)
+    uint32_t op;             // output position where the record starts (end: the decoded size)
+    uint32_t lit, lit_ip, off;      // general sequence
+    unsigned long long tokmask;     // batch: lanes (window slots) that are tokens
+    uint32_t pack[64];       // batch, per token lane: output start in the batch | literals << 13 | (token header - 1) << 19
+    uint32_t offb[64];       // batch: match offset | this slot's stream byte << 16
+};
+struct DSync { uint32_t produced, consumed; };
+__device__ __forceinline__ uint32_t ld_acq(uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st_rel(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+constexpr uint32_t kSpinLimit = 1u << 24;    // a wait that long means the other wave is gone: give up (-> retry kernel) instead of hanging
+
+// PARSER wave: same acceptance rules as before, no output access at all
+__device__ void lz4_fast_parse(const uint8_t* src, int csize, int cap, uint8_t* lds, Rec* recs, DSync* sy, int lane)
 {
-    if (cap < 64 || csize < 1) return kRetry;
+    uint32_t k = 0;                                                     // records published
+    auto slot = [&]() -> Rec* {                                         // next record, once the copier has freed it
+        for (uint32_t spins = 0; k >= ld_acq(&sy->consumed) + kRec; ) { __builtin_amdgcn_s_sleep(1); if (++spins > kSpinLimit) return nullptr; }
+        return recs + (k % kRec);
+    };
+    auto publish = [&]() { if (lane == 0) st_rel(&sy->produced, k + 1); k++; };
+    auto finish = [&](uint32_t type, int value) { Rec* r = slot(); if (!r) return; if (lane == 0) { r->type = type; r->op = uint32_t(value); } publish(); };
+    if (cap < 64 || csize < 1) { finish(kRecRetry, 0); return; }
     Stream s; s.init(src, csize, lds, lane);
     const int iend = csize, oend = cap;
     int ip = 0, op = 0;
-    // One 64-byte step of output is kept PENDING in registers: it is stored only after the next
-    // step's loads have been issued, so a step waits for its own loads (vmcnt leaves the younger
-    // store outstanding) and never for a store acknowledgement.  Sources that fall into the
-    // pending step are forwarded from its registers.
-    uint32_t pv = 0; int p_base = 0, p_n = 0;
-#ifdef K2_PROF   // one-off phase profile of the batch decoder (side build, make prof): cycles per phase, printed by block 0
-    uint64_t pt_parse = 0, pt_map = 0, pt_copy = 0, pt_gen = 0, pt0 = __builtin_readcyclecounter(), pt1; uint32_t n_batch = 0, n_step = 0, n_gen = 0;
-#define K1PH(acc) do { pt1 = __builtin_readcyclecounter(); acc += pt1 - pt0; pt0 = pt1; } while (0)
-#else
-#define K1PH(acc) do { } while (0)
-#endif
-
     for (;;) {
         // ---------------------------------------------------------------- batch of sequences inside one window
         if (ip + 64 + 16 <= iend && op + kOwnBytes + 64 + 16 <= oend) {
@@ -306,7 +320,6 @@ __device__ __forceinline__ int lz4_decode_block_fast(const uint8_t* src, int csi
                 tokmask |= 1ull << pos;
                 pos = uint32_t(__builtin_amdgcn_readlane(int(nxt), int(pos)));
             }
-            K1PH(pt_parse);
             if (tokmask) {
                 bool is_tok = (tokmask >> lane) & 1;
                 uint32_t sz = is_tok ? L + ml : 0;
@@ -323,115 +336,154 @@ __device__ __forceinline__ int lz4_decode_block_fast(const uint8_t* src, int csi
                 const uint32_t ostart = incl - sz;
                 const uint32_t off = wo & 0xffff;
                 const bool bad = is_tok && (off == 0 || off > uint32_t(op) + ostart + L);
-                if (__ballot(bad)) return kRetry;
-                const uint32_t pack = ostart | (L << 13) | ((lhdr - 1) << 19);
-                // owner map: own[o] = token lane + 1 at the first output byte of each sequence
-                for (uint32_t k = 4u * lane; k < T; k += 256) *reinterpret_cast<uint32_t*>(own + k) = 0;
-                if (is_tok) own[ostart] = uint8_t(lane + 1);
-                uint32_t carry = 0;
-                if (p_n == 0) p_base = op;
-                K1PH(pt_map);
-                for (uint32_t c0 = 0; c0 < T; c0 += 64) {
-                    const uint32_t o = c0 + lane;
-                    const bool live = o < T;
-                    uint32_t m = live ? uint32_t(own[o]) : 0u;
-                    m = max(scan_max(m, lane), carry);
-                    carry = uint32_t(__builtin_amdgcn_readlane(int(m), 63));
-                    const int tl = int(m) - 1;                                  // owning token lane
-                    const uint32_t P = __shfl(pack, tl & 63);
-                    const uint32_t offt = __shfl(off, tl & 63);
-                    const uint32_t rel = o - (P & 0x1FFF);
-                    const uint32_t Lt = (P >> 13) & 63, hdr = 1 + ((P >> 19) & 1);
-                    const bool is_lit = rel < Lt;
-                    uint32_t v = __shfl(b, (tl + int(hdr) + int(rel)) & 63);    // literal byte from the window
-                    const int sp = op + int(o) - int(offt);                     // absolute source of a match byte
-                    const int cs = op + int(c0);                                // == p_base + p_n while a step is pending
-                    const bool is_match = live && !is_lit;
-                    const bool from_mem = is_match && sp < cs - p_n;
-                    const bool in_pend = is_match && sp >= cs - p_n && sp < cs;
-                    const uint32_t ld = dst[from_mem ? sp : 0];                 // issue this step's loads (branch-free) ...
-                    // ... then store the previous step.  All 64 lanes store (no branch, so the load above
-                    // and this store sit in one basic block and the wait below becomes vmcnt(1)): lanes
-                    // >= p_n hit [cs, cs+64-p_n), bytes this very step re-writes later and that nothing
-                    // reads from memory before then (they are served from the pending registers).
-                    dst[p_base + lane] = uint8_t(pv);
-                    const uint32_t fw = __shfl(pv, (sp - p_base) & 63);
-                    if (in_pend) v = fw;
-                    if (from_mem) v = ld;
-                    bool done = !is_match || from_mem || in_pend;
-                    int dep = sp - cs;                                          // lane that produces my byte
-                    while (__ballot(!done)) {                                   // pointer jumping, <= 6 rounds
-                        const int d = dep & 63;
-                        const uint32_t v2 = __shfl(v, d);
-                        const int dn = __shfl(int(done), d);
-                        const int dd = __shfl(dep, d);
-                        if (!done) { if (dn) { v = v2; done = true; } else dep = dd; }
-                    }
-                    pv = v; p_base = cs; p_n = min(64, int(T - c0));
-                }
+                if (__ballot(bad)) { finish(kRecRetry, 0); return; }
+                Rec* r = slot();
+                if (!r) return;
+                r->pack[lane] = ostart | (L << 13) | ((lhdr - 1) << 19);
+                r->offb[lane] = off | (b << 16);
+                if (lane == 0) { r->type = kRecBatch; r->T = T; r->op = uint32_t(op); r->tokmask = tokmask; }
+                publish();
                 op += int(T);
                 ip += int(pos);
-#ifdef K2_PROF
-                n_batch++; n_step += (T + 63) / 64;
-#endif
-                K1PH(pt_copy);
                 continue;
             }
         }
         // ---------------------------------------------------------------- one general sequence (strict rules)
-        if (lane < p_n) dst[p_base + lane] = uint8_t(pv);
-        p_n = 0; p_base = 0;
-        if (ip >= iend) return kRetry;
+        if (ip >= iend) { finish(kRecRetry, 0); return; }
         if (ip < s.la_pos || ip + 24 > s.la_pos + 64) s.reload(ip);
-#ifdef K2_PROF
-        n_gen++;
-        if (ip + 64 >= iend && lane == 0) {      // tools/k2_phases.py leaves 64 spare bytes behind the output
-            uint64_t* c = reinterpret_cast<uint64_t*>(dst + cap);
-            c[0] = pt_parse; c[1] = pt_map; c[2] = pt_copy; c[3] = pt_gen; c[4] = n_batch; c[5] = n_step; c[6] = n_gen;
-        }
-#endif
         const uint32_t token = s.get(ip); ip++;
         int lit = int(token >> 4), mlen = int(token & 15);
-        if (lit == 15) { if (!more_len(s, ip, iend - 15, true, lit)) return kRetry; }
+        if (lit == 15) { if (!more_len(s, ip, iend - 15, true, lit)) { finish(kRecRetry, 0); return; } }
         if (op + lit > oend - 12 || ip + lit > iend - 8) {
-            if (ip + lit != iend || op + lit > oend) return kRetry;
-            copy_literals(s, src, dst, ip, op, lit);
-            return op + lit;
+            if (ip + lit != iend || op + lit > oend) { finish(kRecRetry, 0); return; }
+            Rec* r = slot();
+            if (!r) return;
+            if (lane == 0) { r->type = kRecGeneral; r->T = 0; r->op = uint32_t(op); r->lit = uint32_t(lit); r->lit_ip = uint32_t(ip); r->off = 0; }
+            publish();
+            finish(kRecEnd, op + lit);
+            return;
         }
-        copy_literals(s, src, dst, ip, op, lit);
-        ip += lit; op += lit;
+        const int lit_ip = ip;
+        ip += lit;
+        const int op2 = op + lit;
         const int off = int(s.get(ip)) | (int(s.get(ip + 1)) << 8);
         ip += 2;
-        if (mlen == 15) { if (!more_len(s, ip, iend - 4, false, mlen)) return kRetry; }
+        if (mlen == 15) { if (!more_len(s, ip, iend - 4, false, mlen)) { finish(kRecRetry, 0); return; } }
         mlen += 4;
-        if (off == 0 || off > op || op + mlen > oend - 5) return kRetry;
-        copy_match(dst, op, off, mlen, lane);
-        op += mlen;
-        K1PH(pt_gen);
+        if (off == 0 || off > op2 || op2 + mlen > oend - 5) { finish(kRecRetry, 0); return; }
+        Rec* r = slot();
+        if (!r) return;
+        if (lane == 0) { r->type = kRecGeneral; r->T = uint32_t(mlen); r->op = uint32_t(op); r->lit = uint32_t(lit); r->lit_ip = uint32_t(lit_ip); r->off = uint32_t(off); }
+        publish();
+        op = op2 + mlen;
+    }
+}
+
+// COPIER wave: executes the records in order
+__device__ int lz4_fast_copy(const uint8_t* src, uint8_t* dst, Rec* recs, DSync* sy, uint8_t* own, int lane)
+{
+    // One 64-byte step of output is kept PENDING in registers: it is stored only after the next
+    // step's loads have been issued, so a step waits for its own loads (vmcnt leaves the younger
+    // store outstanding) and never for a store acknowledgement.  Sources that fall into the
+    // pending step are forwarded from its registers.
+    uint32_t pv = 0; int p_base = 0, p_n = 0;
+    for (uint32_t k = 0;; k++) {
+        for (uint32_t spins = 0; ld_acq(&sy->produced) <= k; ) { __builtin_amdgcn_s_sleep(1); if (++spins > kSpinLimit) return kRetry; }
+        Rec* r = recs + (k % kRec);
+        const uint32_t type = r->type, T = r->T;
+        const int op = int(r->op);
+        if (type == kRecBatch) {
+            const unsigned long long tokmask = r->tokmask;
+            const uint32_t pack = r->pack[lane], ob = r->offb[lane];
+            if (lane == 0) st_rel(&sy->consumed, k + 1);                 // everything of the record is in registers now
+            const uint32_t off = ob & 0xffff, b = ob >> 16;
+            const bool is_tok = (tokmask >> lane) & 1;
+            // owner map: own[o] = token lane + 1 at the first output byte of each sequence
+            for (uint32_t i = 4u * lane; i < T; i += 256) *reinterpret_cast<uint32_t*>(own + i) = 0;
+            if (is_tok) own[pack & 0x1FFF] = uint8_t(lane + 1);
+            uint32_t carry = 0;
+            if (p_n == 0) p_base = op;
+            for (uint32_t c0 = 0; c0 < T; c0 += 64) {
+                const uint32_t o = c0 + lane;
+                const bool live = o < T;
+                uint32_t m = live ? uint32_t(own[o]) : 0u;
+                m = max(scan_max(m, lane), carry);
+                carry = uint32_t(__builtin_amdgcn_readlane(int(m), 63));
+                const int tl = int(m) - 1;                                  // owning token lane
+                const uint32_t P = __shfl(pack, tl & 63);
+                const uint32_t offt = __shfl(off, tl & 63);
+                const uint32_t rel = o - (P & 0x1FFF);
+                const uint32_t Lt = (P >> 13) & 63, hdr = 1 + ((P >> 19) & 1);
+                const bool is_lit = rel < Lt;
+                uint32_t v = __shfl(b, (tl + int(hdr) + int(rel)) & 63);    // literal byte from the window
+                const int sp = op + int(o) - int(offt);                     // absolute source of a match byte
+                const int cs = op + int(c0);                                // == p_base + p_n while a step is pending
+                const bool is_match = live && !is_lit;
+                const bool from_mem = is_match && sp < cs - p_n;
+                const bool in_pend = is_match && sp >= cs - p_n && sp < cs;
+                const uint32_t ld = dst[from_mem ? sp : 0];                 // issue this step's loads (branch-free) ...
+                // ... then store the previous step.  All 64 lanes store (no branch, so the load above
+                // and this store sit in one basic block and the wait below becomes vmcnt(1)): lanes
+                // >= p_n hit [cs, cs+64-p_n), bytes this very step re-writes later and that nothing
+                // reads from memory before then (they are served from the pending registers).
+                dst[p_base + lane] = uint8_t(pv);
+                const uint32_t fw = __shfl(pv, (sp - p_base) & 63);
+                if (in_pend) v = fw;
+                if (from_mem) v = ld;
+                bool done = !is_match || from_mem || in_pend;
+                int dep = sp - cs;                                          // lane that produces my byte
+                while (__ballot(!done)) {                                   // pointer jumping, <= 6 rounds
+                    const int d = dep & 63;
+                    const uint32_t v2 = __shfl(v, d);
+                    const int dn = __shfl(int(done), d);
+                    const int dd = __shfl(dep, d);
+                    if (!done) { if (dn) { v = v2; done = true; } else dep = dd; }
+                }
+                pv = v; p_base = cs; p_n = min(64, int(T - c0));
+            }
+            continue;
+        }
+        const uint32_t lit = r->lit, lit_ip = r->lit_ip, off = r->off;
+        if (lane == 0) st_rel(&sy->consumed, k + 1);
+        if (type == kRecGeneral) {
+            if (lane < p_n) dst[p_base + lane] = uint8_t(pv);
+            p_n = 0; p_base = 0;
+            wave_copy(dst + op, src + lit_ip, int(lit), lane);
+            if (T) copy_match(dst, op + int(lit), int(off), int(T), lane);
+            continue;
+        }
+        if (lane < p_n) dst[p_base + lane] = uint8_t(pv);
+        return type == kRecEnd ? op : kRetry;
     }
 }
 
 // retry_only = 0: fast path for every block (container rules as in the exact kernel);
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(128)
 void lz4_decode_fast_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
                             fourmc_block* blocks, uint32_t nblocks, int container_mode)
 {
     __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
     __shared__ __attribute__((aligned(16))) uint8_t own[kOwnBytes];
+    __shared__ Rec recs[kRec];
+    __shared__ DSync sy;
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
     const fourmc_block blk = blocks[b];
+    if (container_mode && blk.result == FOURMC_BLK_BADSUM) return;
+    if (threadIdx.x == 0) { sy.produced = 0; sy.consumed = 0; }
+    __syncthreads();
     const uint8_t* src = src_base + blk.src_off;
     uint8_t* dst = dst_base + blk.dst_off;
-    int r;
-    if (container_mode) {
-        if (blk.result == FOURMC_BLK_BADSUM) return;
-        if (blk.src_len == blk.dst_cap) { wave_copy(dst, src, int(blk.src_len), threadIdx.x); r = int(blk.src_len); }
-        else r = lz4_decode_block_fast(src, int(blk.src_len), dst, int(blk.dst_cap), ring, own, threadIdx.x);
-    } else {
-        r = lz4_decode_block_fast(src, int(blk.src_len), dst, int(blk.dst_cap), ring, own, threadIdx.x);
+    const int lane = threadIdx.x & 63;
+    const bool stored = container_mode && blk.src_len == blk.dst_cap;
+    if (threadIdx.x >= 64) {
+        if (!stored) lz4_fast_parse(src, int(blk.src_len), int(blk.dst_cap), ring, recs, &sy, lane);
+        return;
     }
-    if (threadIdx.x == 0) blocks[b].result = r;
+    int r;
+    if (stored) { wave_copy(dst, src, int(blk.src_len), lane); r = int(blk.src_len); }
+    else r = lz4_fast_copy(src, dst, recs, &sy, own, lane);
+    if (lane == 0) blocks[b].result = r;
 }
 
 // second pass: blocks the fast path handed back (result == kRetry) are decoded by the exact walker
@@ -463,7 +515,7 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
         hipLaunchKernelGGL(lz4_decode_exact_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(lz4_decode_fast_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
+    hipLaunchKernelGGL(lz4_decode_fast_kernel, dim3(n), dim3(128), 0, stream, s8, d8, d_blocks, n, container_mode);
     hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
     return hipGetLastError();
 }

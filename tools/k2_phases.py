@@ -29,7 +29,5 @@ for b in range(12):
     ds = torch.cuda.Event(enable_timing=True); de = torch.cuda.Event(enable_timing=True)
     p.decode_blocks(stage, out, dec); torch.cuda.synchronize()
     ds.record(); p.decode_blocks(stage, out, dec); de.record(); torch.cuda.synchronize()
-    k = out[B: B + 56].cpu().numpy().view(np.uint64)               # the side build leaves K1's phase cycles behind the output
-    kt = float(k[:4].sum()) or 1.0
-    print(f"        K1 dec {ds.elapsed_time(de):7.2f} ms  parse {100*k[0]/kt:4.1f}% map {100*k[1]/kt:4.1f}% copy {100*k[2]/kt:4.1f}% general {100*k[3]/kt:4.1f}%  batches {int(k[4])} steps {int(k[5])} general-seqs {int(k[6])}")
+    print(f"        K1 dec {ds.elapsed_time(de):7.2f} ms")
     print(f"{names[b]:7s} csize {r:8d} enc {s.elapsed_time(e):8.2f} ms   dense: cursor {100*d[0]/tot:4.1f}% table {100*d[1]/tot:4.1f}% gather {100*d[2]/tot:4.1f}% parse {100*c[1]/tot:4.1f}% emit {100*d[3]/tot:4.1f}% commit {100*c[2]/tot:4.1f}% | sparse {100*c[0]/tot:4.1f}%  windows {int(d[4])} seq {int(d[5])} slow-seq {int(d[6])} | window ends: none {int(f[0])} cross {int(f[1])} dirty-cut {int(f[2])} stride-cut {int(f[3])}")
