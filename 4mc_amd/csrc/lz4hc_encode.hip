@@ -41,6 +41,17 @@ constexpr uint32_t kChainMask = 0x1FFFF;     // chain deltas of the last 128 Ki 
 constexpr int      kWinK = 8;                // candidates cached per position of the look-ahead window
 constexpr size_t   kWorkBytes = (size_t(4) << kHashLog) + 2 * (size_t(kChainMask) + 1);     // per block: heads + chain
 
+// maximum over the wavefront on the DPP network (row shifts, then row broadcasts: the total lands in lane 63)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v)
+{ return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, ROWMASK, 0xf, false)); }
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)            // values >= 0, identity 0
+{
+    v = max(v, dpp0<0x111, 0xf>(v)); v = max(v, dpp0<0x112, 0xf>(v)); v = max(v, dpp0<0x114, 0xf>(v)); v = max(v, dpp0<0x118, 0xf>(v));
+    v = max(v, dpp0<0x142, 0xa>(v)); v = max(v, dpp0<0x143, 0xc>(v));
+    return uint32_t(__builtin_amdgcn_readlane(int(v), 63));
+}
+
 __device__ __forceinline__ uint32_t hc_hash(uint32_t v) { return (v * 2654435761u) >> (32 - kHashLog); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -357,9 +368,7 @@ __device__ __forceinline__ int hc_wider(HC& c, uint32_t ip, uint32_t low, uint32
         // ---- running "ml > longest" in chain order == max length, earliest candidate wins ties
         const uint32_t ml = live ? kMinMatch + fl + bk : 0u;
         uint32_t key = (live && int(ml) > longest) ? ((ml << 6) | uint32_t(63 - lane)) : 0u;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) key = max(key, uint32_t(__shfl_xor(int(key), d)));
-        key = uint32_t(uni(int(key)));
+        key = wave_max(key);
         if (key) {
             const int l = 63 - int(key & 63);
             longest = int(key >> 6);
