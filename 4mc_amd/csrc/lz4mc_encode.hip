@@ -113,9 +113,10 @@ __device__ int lz4mc_encode_block(const uint8_t* src, uint8_t* dst, int n, int c
             if (lane == l) fl += extra;
         }
         uint32_t key = live ? (((4 + fl) << 6) | uint32_t(63 - lane)) : 0u;
-#pragma unroll
-        for (int d = 2; d >= 1; d >>= 1) key = max(key, uint32_t(__shfl_xor(int(key), d)));   // lanes 0..3 hold the candidates
-        key = uni(key);
+        // lanes 0..3 hold the candidates: maximum by two DPP row shifts, read from lane 3
+        key = max(key, uint32_t(__builtin_amdgcn_update_dpp(0, int(key), 0x111, 0xf, 0xf, false)));
+        key = max(key, uint32_t(__builtin_amdgcn_update_dpp(0, int(key), 0x112, 0xf, 0xf, false)));
+        key = uint32_t(__builtin_amdgcn_readlane(int(key), 3));
         if (!key) { ip += step; step = tries++ >> 6; continue; }
         const uint32_t ml = key >> 6;
         const uint32_t best = uint32_t(__builtin_amdgcn_readlane(cand, 63 - int(key & 63)));

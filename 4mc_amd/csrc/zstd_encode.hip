@@ -58,15 +58,15 @@ __device__ __forceinline__ void st4(uint8_t* p, uint32_t v) { reinterpret_cast<S
 __device__ __forceinline__ uint32_t U(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
 __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t l) { return uint32_t(__builtin_amdgcn_readlane(int(v), int(l))); }
 __device__ __forceinline__ int hibit(uint32_t v) { return 31 - __clz(v); }
-__device__ __forceinline__ uint32_t wave_max(uint32_t v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, uint32_t(__shfl_xor(int(v), d)));
-    return v;
-}
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ uint32_t dpp0(uint32_t v)
 { return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, ROWMASK, 0xf, false)); }
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)          // wave64 maximum (values >= 0) on the DPP network, uniform result
+{
+    v = max(v, dpp0<0x111, 0xf>(v)); v = max(v, dpp0<0x112, 0xf>(v)); v = max(v, dpp0<0x114, 0xf>(v)); v = max(v, dpp0<0x118, 0xf>(v));
+    v = max(v, dpp0<0x142, 0xa>(v)); v = max(v, dpp0<0x143, 0xc>(v));
+    return uint32_t(__builtin_amdgcn_readlane(int(v), 63));
+}
 __device__ __forceinline__ uint32_t scan_add(uint32_t v)          // wave64 inclusive prefix sum
 {
     v += dpp0<0x111, 0xf>(v); v += dpp0<0x112, 0xf>(v); v += dpp0<0x114, 0xf>(v); v += dpp0<0x118, 0xf>(v);
@@ -612,8 +612,7 @@ __device__ __forceinline__ int huf_compress(ZLds& L, uint32_t* table, uint8_t* d
     // bit estimates before the weight coder borrows L.count
     uint32_t old_bits = 0, new_bits = 0;
     for (uint32_t s = lane; s <= max_sym; s += 64) { old_bits += (table[s] >> 16) * L.count[s]; new_bits += (L.fresh[s] >> 16) * L.count[s]; }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { old_bits += uint32_t(__shfl_xor(int(old_bits), d)); new_bits += uint32_t(__shfl_xor(int(new_bits), d)); }
+    old_bits = rl(scan_add(old_bits), 63); new_bits = rl(scan_add(new_bits), 63);
     const int h = huf_write_table(L, dst, cap, max_sym, log, lane);
     if (h < 0) return h;
     if (repeat != kRepNone) {
@@ -734,8 +733,7 @@ __device__ __forceinline__ uint32_t fse_bit_cost(ZLds& L, const FseCt* prev, uin
         if (c) { if (bits >= badc) bad = true; cost += c * bits; }
     }
     if (__ballot(bad)) return kCostErr;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) cost += uint32_t(__shfl_xor(int(cost), d));
+    cost = rl(scan_add(cost), 63);
     return cost >> 8;
 }
 
@@ -758,8 +756,7 @@ __device__ __forceinline__ int select_type(ZLds& L, int& repeat, int which, uint
                 const int dn = default_norm(which, sy);
                 c += L.count[sy] * kInvLog.v[uint32_t(dn != -1 ? dn : 1) << (8 - def_log)];
             }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) c += uint32_t(__shfl_xor(int(c), d));
+            c = rl(scan_add(c), 63);
             basic = c >> 8;
         }
         if (repeat != kRepNone) rep = fse_bit_cost(L, prev, max, lane);
@@ -774,8 +771,7 @@ __device__ __forceinline__ int select_type(ZLds& L, int& repeat, int which, uint
                 if (cnt && !q) q = 1;
                 c += cnt * kInvLog.v[q];
             }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) c += uint32_t(__shfl_xor(int(c), d));
+            c = rl(scan_add(c), 63);
             comp = (uint32_t(nc) << 3) + (c >> 8);
         }
         if (basic <= rep && basic <= comp) { repeat = kRepNone; return 0; }
