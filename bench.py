@@ -211,6 +211,7 @@ def main():
         compressed batch is decoded back and compared.  Reported beside the headline, never part of `value`."""
         out = {}
         def timed(fn):
+            fn()                                       # untimed first call: workspace allocation happens here
             a, b = ev(), ev()
             torch.cuda.synchronize(); a.record(); fn(); b.record(); torch.cuda.synchronize()
             return a.elapsed_time(b)
