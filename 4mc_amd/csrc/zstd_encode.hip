@@ -1128,11 +1128,12 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
                 width = min(64u, width * 2);
             }
             if (ev_kind == 4) break;                             // _cleanup
+            uint32_t room;
             if (ev_kind == 1) {
                 cur0 = ev_b + 2;
                 ip0 = ev_b + ev_s; match0 = ip0 - rep1;
-                mlen = (s[ip0 - 1] == s[match0 - 1]) ? 1 : 0;
-                ip0 -= mlen; match0 -= mlen; off_base = 1; mlen += 4;
+                off_base = 1;
+                room = 1;                                        // mLength = ip0[-1] == match0[-1] (zstd_fast.c:236)
             } else {
                 if (ev_kind == 3) {
                     ip0 = ev_b + 1;
@@ -1140,21 +1141,47 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
                 } else ip0 = ev_b;
                 cur0 = ip0 + 2;
                 match0 = ev_idx - 2;
-                rep2 = rep1; rep1 = ip0 - match0; off_base = rep1 + 3; mlen = 4;
-                // backward extension, 64 bytes per step
-                for (;;) {
-                    const uint32_t room = min(ip0 - anchor, match0 - prefix);
-                    const bool same = uint32_t(lane) < room && s[ip0 - 1 - lane] == s[match0 - 1 - lane];
-                    const unsigned long long bad = ~__ballot(same);
-                    const uint32_t k = bad ? uint32_t(__builtin_ctzll(bad)) : 64u;
-                    ip0 -= k; match0 -= k; mlen += k;
-                    if (k < 64) break;
+                rep2 = rep1; rep1 = ip0 - match0; off_base = rep1 + 3;
+                room = min(ip0 - anchor, match0 - prefix);
+            }
+            {
+                // backward and forward extension in ONE round trip: where the forward count starts does not depend on
+                // how far the match reaches back (it is the 4 bytes behind the event position either way)
+                const uint32_t fa = ip0 + 4, fb = match0 + 4;
+                const bool wide = fa + 1024 <= end;
+                const bool bl = uint32_t(lane) < room;
+                const uint32_t b_i = bl ? uint32_t(s[ip0 - 1 - lane]) : 0u, b_m = bl ? uint32_t(s[match0 - 1 - lane]) : 1u;
+                U16B x = {0, 0}, y = {0, 0}; uint32_t f_i = 0, f_m = 1;
+                if (wide) { x = *reinterpret_cast<const U16B*>(s + fa + 16 * lane); y = *reinterpret_cast<const U16B*>(s + fb + 16 * lane); }
+                else if (fa + lane < end) { f_i = s[fa + lane]; f_m = s[fb + lane]; }
+                {
+                    const unsigned long long bad = ~__ballot(bl && b_i == b_m);
+                    uint32_t k = bad ? uint32_t(__builtin_ctzll(bad)) : 64u;
+                    ip0 -= k; match0 -= k; mlen = 4 + k;
+                    while (k == 64) {                            // (only hash hits can get here: room is 1 for a repcode)
+                        const uint32_t room2 = min(ip0 - anchor, match0 - prefix);
+                        const bool same = uint32_t(lane) < room2 && s[ip0 - 1 - lane] == s[match0 - 1 - lane];
+                        const unsigned long long bad2 = ~__ballot(same);
+                        k = bad2 ? uint32_t(__builtin_ctzll(bad2)) : 64u;
+                        ip0 -= k; match0 -= k; mlen += k;
+                    }
+                }
+                if (wide) {
+                    const uint64_t d0 = x.a ^ y.a, d1 = x.b ^ y.b;
+                    const uint32_t eq = d0 ? uint32_t(__builtin_ctzll(d0) >> 3) : (d1 ? 8u + uint32_t(__builtin_ctzll(d1) >> 3) : 16u);
+                    const unsigned long long bad = __ballot(eq < 16);
+                    if (bad) { const int l = __builtin_ctzll(bad); mlen += 16 * l + rl(eq, l); }
+                    else mlen += 1024 + count_fwd(s, fa + 1024, fb + 1024, end, lane);
+                } else {
+                    const unsigned long long bad = ~__ballot(fa + lane < end && f_i == f_m);
+                    if (bad) mlen += uint32_t(__builtin_ctzll(bad));
+                    else mlen += 64 + count_fwd(s, fa + 64, fb + 64, end, lane);
                 }
             }
             found = true;
         }
         if (!found) break;
-        mlen += count_fwd(s, ip0 + mlen, match0 + mlen, end, lane);
+        if (serial) mlen += count_fwd(s, ip0 + mlen, match0 + mlen, end, lane);
         store_seq(S, s, anchor, ip0 - anchor, off_base, mlen, lane);
         ip0 += mlen; anchor = ip0;
         after_match(S, tab, P, s, ip0, anchor, cur0, rep1, rep2, end, ilimit, lane);
