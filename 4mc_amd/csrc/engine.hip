@@ -5,6 +5,7 @@
 // fails with FOURMC_ENODEV (the product must fail loudly rather than fall back).
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <condition_variable>
 #include <vector>
 #include <stdio.h>
 #include <stdlib.h>
@@ -281,8 +282,23 @@ int fourmc_gpu_4mc_pack_image(const void* d_staging, void* d_image, const fourmc
 // ------------------------------------------------------------------------ host-buffer API
 int fourmc_LZ4_compressBound(int n) { return (unsigned)n > 0x7E000000u ? 0 : n + n / 255 + 16; }
 
-static int host_roundtrip(const void* src, size_t src_bytes, void* dst, size_t dst_bytes,
-                          fourmc_block* blocks, uint32_t n, int op, int codec, int level)
+static int launch_host_op(int op, int codec, int level, uint32_t n, hipStream_t s)
+{
+    switch (op) {
+        case 0: return fourmc_gpu_4mc_encode_blocks(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, codec, level, s);
+        case 1: return fourmc_gpu_4mc_decode_blocks(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, codec, s);
+        case 2: return fourmc_gpu_lz4_compress_fast(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s);
+        case 3: return fourmc_gpu_lz4_decompress(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s);
+        case 5: return fourmc_gpu_zstd_decompress(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s);
+        case 8: return fourmc_gpu_zstd_compress(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, level, s);
+        case 7: return fourmc_gpu_lz4_compress_mc(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s);
+        case 6: return fourmc_gpu_lz4_compress_hc(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, level, s);
+        default: return fourmc_gpu_xxh32(g_arena.d_src, g_arena.d_blk, n, (uint32_t)level, s);
+    }
+}
+
+static int host_roundtrip_many(const void* src, size_t src_bytes, void* dst, size_t dst_bytes,
+                               fourmc_block* blocks, uint32_t n, int op, int codec, int level)
 {
     if (int r = ensure_device()) return r;
     std::lock_guard<std::mutex> lk(g_mu);
@@ -290,19 +306,7 @@ static int host_roundtrip(const void* src, size_t src_bytes, void* dst, size_t d
     hipStream_t s = g_arena.stream;
     HIP_TRY(hipMemcpyAsync(g_arena.d_src, src, src_bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(g_arena.d_blk, blocks, n * sizeof(fourmc_block), hipMemcpyHostToDevice, s));
-    int r;
-    switch (op) {
-        case 0: r = fourmc_gpu_4mc_encode_blocks(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, codec, level, s); break;
-        case 1: r = fourmc_gpu_4mc_decode_blocks(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, codec, s); break;
-        case 2: r = fourmc_gpu_lz4_compress_fast(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
-        case 3: r = fourmc_gpu_lz4_decompress(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
-        case 5: r = fourmc_gpu_zstd_decompress(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
-        case 8: r = fourmc_gpu_zstd_compress(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, level, s); break;
-        case 7: r = fourmc_gpu_lz4_compress_mc(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s); break;
-        case 6: r = fourmc_gpu_lz4_compress_hc(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, level, s); break;
-        default: r = fourmc_gpu_xxh32(g_arena.d_src, g_arena.d_blk, n, (uint32_t)level, s); break;
-    }
-    if (r) return r;
+    if (int r = launch_host_op(op, codec, level, n, s)) return r;
     HIP_TRY(hipMemcpyAsync(blocks, g_arena.d_blk, n * sizeof(fourmc_block), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (op != 4) {
@@ -316,6 +320,98 @@ static int host_roundtrip(const void* src, size_t src_bytes, void* dst, size_t d
         HIP_TRY(hipStreamSynchronize(s));
     }
     return FOURMC_OK;
+}
+
+// ---- one-block calls (the JNI methods, the LZ4_* / ZSTD_* twins).  One call is one block and returns synchronously, so
+// a lone caller cannot be batched - but Hadoop runs many compressor objects on many threads.  Calls that arrive while a
+// launch is in flight queue up; the caller that finds nobody serving becomes the server and takes everything queued for
+// the same operation into ONE staging copy and ONE launch.  No timer: a lone caller pays nothing, concurrency batches itself.
+struct OneReq {
+    const void* src; size_t src_bytes; void* dst; size_t dst_bytes; fourmc_block* blk;
+    int op, codec, level, rc; bool done; OneReq* next;
+};
+static std::mutex g_qmu;
+static std::condition_variable g_qcv;
+static OneReq* g_qhead = nullptr; static OneReq* g_qtail = nullptr;
+static bool g_qserving = false;
+static unsigned long long g_one_calls = 0, g_one_launches = 0;
+
+static int serve_group(std::vector<OneReq*>& g)
+{
+    if (int r = ensure_device()) return r;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const uint32_t n = (uint32_t)g.size();
+    std::vector<fourmc_block> blocks(n);
+    size_t so = 0, dof = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        blocks[i] = *g[i]->blk;
+        blocks[i].src_off = so; blocks[i].dst_off = dof;
+        so += (g[i]->src_bytes + 63) & ~size_t(63); dof += (g[i]->dst_bytes + 63) & ~size_t(63);
+    }
+    if (int r = arena_reserve(so, dof, n)) return r;
+    hipStream_t s = g_arena.stream;
+    for (uint32_t i = 0; i < n; i++)
+        if (g[i]->src_bytes) HIP_TRY(hipMemcpyAsync(static_cast<char*>(g_arena.d_src) + blocks[i].src_off, g[i]->src, g[i]->src_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(g_arena.d_blk, blocks.data(), n * sizeof(fourmc_block), hipMemcpyHostToDevice, s));
+    if (int r = launch_host_op(g[0]->op, g[0]->codec, g[0]->level, n, s)) return r;
+    HIP_TRY(hipMemcpyAsync(blocks.data(), g_arena.d_blk, n * sizeof(fourmc_block), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (uint32_t i = 0; i < n; i++) {
+        g[i]->blk->result = blocks[i].result; g[i]->blk->xxh32 = blocks[i].xxh32;
+        if (g[i]->op != 4 && blocks[i].result > 0)
+            HIP_TRY(hipMemcpyAsync(g[i]->dst, static_cast<char*>(g_arena.d_dst) + blocks[i].dst_off, (size_t)blocks[i].result, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return FOURMC_OK;
+}
+
+static int host_one(const void* src, size_t src_bytes, void* dst, size_t dst_bytes, fourmc_block* blk, int op, int codec, int level)
+{
+    OneReq me = {src, src_bytes, dst, dst_bytes, blk, op, codec, level, FOURMC_OK, false, nullptr};
+    std::unique_lock<std::mutex> lk(g_qmu);
+    g_one_calls++;
+    if (g_qtail) g_qtail->next = &me; else g_qhead = &me;
+    g_qtail = &me;
+    if (g_qserving) {                                   // somebody is serving: it will not leave before the queue is empty
+        g_qcv.wait(lk, [&] { return me.done; });
+        return me.rc;
+    }
+    g_qserving = true;
+    while (g_qhead) {
+        // everything queued for the same operation as the oldest request, in arrival order
+        std::vector<OneReq*> grp;
+        OneReq* keep_head = nullptr; OneReq* keep_tail = nullptr;
+        const OneReq* first = g_qhead;
+        for (OneReq* r = g_qhead; r; ) {
+            OneReq* nx = r->next; r->next = nullptr;
+            if (r->op == first->op && r->codec == first->codec && r->level == first->level && grp.size() < 4096) grp.push_back(r);
+            else { if (keep_tail) keep_tail->next = r; else keep_head = r; keep_tail = r; }
+            r = nx;
+        }
+        g_qhead = keep_head; g_qtail = keep_tail;
+        g_one_launches++;
+        lk.unlock();
+        const int rc = serve_group(grp);
+        lk.lock();
+        for (OneReq* r : grp) { r->rc = rc; r->done = true; }
+        g_qcv.notify_all();
+    }
+    g_qserving = false;
+    return me.rc;
+}
+
+static int host_roundtrip(const void* src, size_t src_bytes, void* dst, size_t dst_bytes,
+                          fourmc_block* blocks, uint32_t n, int op, int codec, int level)
+{
+    if (n == 1 && op >= 2) return host_one(src, src_bytes, dst, dst_bytes, blocks, op, codec, level);
+    return host_roundtrip_many(src, src_bytes, dst, dst_bytes, blocks, n, op, codec, level);
+}
+
+void fourmc_debug_one_block_counters(unsigned long long* calls, unsigned long long* launches)
+{
+    std::lock_guard<std::mutex> lk(g_qmu);
+    if (calls) *calls = g_one_calls;
+    if (launches) *launches = g_one_launches;
 }
 
 int fourmc_host_4mc_encode(const void* src, size_t src_bytes, void* dst, size_t dst_bytes,

@@ -79,6 +79,8 @@ int fourmc_gpu_lz4_compress_mc(const void* d_src, void* d_dst, fourmc_block* d_b
 /* Profiling aid (not part of the reference boundary): copy a range of the engine's per-block device
  * workspace to the host; the zstd kernels leave per-phase cycle counters there (tools/zstd_timing.py). */
 int fourmc_gpu_debug_read_workspace(void* host, size_t offset, size_t bytes);
+/* one-block host calls (LZ4_* / ZSTD_* twins, JNI) made so far, and the launches that served them (concurrent calls share one) */
+void fourmc_debug_one_block_counters(unsigned long long* calls, unsigned long long* launches);
 
 /* result = ZSTD_compress(dst + dst_off, dst_cap, src + src_off, src_len, level) as int: frame bytes, or
  * -(ZSTD error number), e.g. -70 = dstSize_tooSmall        native/zstd/compress/zstd_compress.c:4806

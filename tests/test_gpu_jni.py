@@ -49,3 +49,56 @@ def test_jni_entry_points_through_mock_env(gpu, tmp_path):
     for codec, fn in (("Lz4", "LZ4_decompress_safe"), ("Zstd", "LZ4_decompress_safe")):   # zstd reuses the text (jniZstdDecompressor.c:96)
         d, rest = out[codec + "_decompress_garbage"]
         assert d < 0 and ("java/lang/InternalError: %s returned: %d" % (fn, d)) in rest, (codec, d, rest)
+
+
+def test_concurrent_one_block_calls_share_launches(gpu):
+    """One JNI call is one block; calls from concurrent threads are combined inside the library into
+    shared launches.  Results must equal the oracle's for every call, whatever was batched with what."""
+    import ctypes as C, threading
+    import numpy as np
+    import helpers
+    L = gpu.binding.lib()
+    data = helpers.corpus(helpers.B)
+    rng = np.random.default_rng(5)
+    jobs = []
+    for i in range(96):
+        n = int(rng.integers(1000, 300000)); o = int(rng.integers(0, helpers.B - n))
+        jobs.append((i, np.ascontiguousarray(data[o:o + n]), ("fast", "hc", "zstd", "dec")[i % 4]))
+    c0, l0 = C.c_ulonglong(), C.c_ulonglong()
+    L.fourmc_debug_one_block_counters(C.byref(c0), C.byref(l0))
+    results = {}
+    def work(job):
+        i, s, kind = job
+        bound = helpers.oracle().orc_lz4_compress_bound(len(s))
+        if kind == "fast":
+            dst = np.empty(bound, np.uint8)
+            r = L.fourmc_LZ4_compress_default(s.ctypes.data, dst.ctypes.data, len(s), bound)
+            results[i] = (r, dst[:max(r, 0)].copy())
+        elif kind == "hc":
+            dst = np.empty(bound, np.uint8)
+            r = L.fourmc_LZ4_compress_HC(s.ctypes.data, dst.ctypes.data, len(s), bound, 4)
+            results[i] = (r, dst[:max(r, 0)].copy())
+        elif kind == "zstd":
+            cap = helpers.zstd_bound(len(s)); dst = np.empty(cap, np.uint8)
+            r = L.fourmc_ZSTD_compress(dst.ctypes.data, cap, s.ctypes.data, len(s), 1)
+            results[i] = (int(r), dst[:max(int(r), 0)].copy())
+        else:
+            wr, wb = helpers.orc_compress(s, bound)
+            out = np.empty(len(s), np.uint8)
+            r = L.fourmc_LZ4_decompress_safe(wb.ctypes.data, out.ctypes.data, wr, len(s))
+            results[i] = (r, out[:max(r, 0)].copy())
+    threads = [threading.Thread(target=lambda part=jobs[t::12]: [work(j) for j in part]) for t in range(12)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    for i, s, kind in jobs:
+        r, out = results[i]
+        if kind == "fast": wr, wb = helpers.orc_compress(s, helpers.oracle().orc_lz4_compress_bound(len(s)))
+        elif kind == "hc": wr, wb = helpers.orc_compress_hc(s, 4)
+        elif kind == "zstd": wr, wb = helpers.orc_zstd_compress(s, 1, helpers.zstd_bound(len(s)))
+        else: wr, wb = len(s), s
+        assert r == wr, (i, kind, r, wr)
+        assert np.array_equal(out, wb), (i, kind)
+    c1, l1 = C.c_ulonglong(), C.c_ulonglong()
+    L.fourmc_debug_one_block_counters(C.byref(c1), C.byref(l1))
+    assert c1.value - c0.value == len(jobs)
+    assert l1.value - l0.value < len(jobs), "no two concurrent calls ever shared a launch"
