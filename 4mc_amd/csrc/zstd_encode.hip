@@ -1399,6 +1399,45 @@ __device__ __forceinline__ uint32_t row_search(ZLds& L, LazyState& Z, const Para
     const uint32_t curr = ip + 2, low = lz_low(Z, P, curr);
     const uint32_t rowlog = min(max(P.slog, 4u), 6u), entries = 1u << rowlog, mask = entries - 1, mls = min(max(P.mml, 4u), 6u);
     const uint32_t attempts = 1u << min(P.slog, rowlog);
+    if (curr - Z.ntu <= 1) {
+        // The usual step of the lazy walk: nothing, or exactly one position (the previous one), is still to be inserted.
+        // Its row and the row of this search are read in ONE round trip - cursor words first, then both heads, the tags and the
+        // entries (unrotated: lane j takes entry j, which is the ((j - head) & mask)-th newest) - instead of five
+        // dependent ones; if both are the same row the insertion is applied to the registers.
+        const bool ins = curr - Z.ntu == 1;
+        const uint32_t idx0 = ins ? Z.ntu : curr, hbits = P.hlog - rowlog + 8;          // (no insertion: the same reads, nothing written)
+        const uint64_t wA = ld8(s + idx0 - 2), wS = ld8(s + ip);
+        const uint32_t hA = zhash(wA, hbits, mls), hS = zhash(wS, hbits, mls);
+        const uint32_t relA = (hA >> 8) << rowlog, relS = (hS >> 8) << rowlog, tag = hS & 255;
+        uint8_t* const rowA = Z.tags + 2 * size_t(relA);
+        uint8_t* const rowS = Z.tags + 2 * size_t(relS);
+        const bool in_row = uint32_t(lane) < entries;
+        const uint32_t headA = rowA[0];
+        uint32_t head_byte = rowS[0];
+        uint32_t tg = in_row ? uint32_t(rowS[16 + lane]) : 0u, e = in_row ? Z.tab[relS + lane] : 0u;
+        const uint32_t posA = (headA - 1u) & mask;
+        if (ins && lane == 0) { rowA[0] = uint8_t(posA); rowA[16 + posA] = uint8_t(hA); Z.tab[relA + posA] = idx0; }
+        if (ins && relA == relS) { head_byte = posA; if (uint32_t(lane) == posA) { tg = hA & 255; e = idx0; } }
+        const uint32_t head = head_byte & mask;
+        const uint32_t ord = (uint32_t(lane) - head) & mask;
+        const bool valid = in_row && tg == tag;
+        const unsigned long long emask = entries == 64 ? ~0ull : ((1ull << entries) - 1);
+        auto rot = [&](unsigned long long m) -> unsigned long long {       // bit i of the result: entry (head + i) & mask
+            m &= emask;
+            return head ? ((m >> head) | (m << (entries - head))) & emask : m;
+        };
+        unsigned long long vm = rot(__ballot(valid));
+        const unsigned long long stop = rot(__ballot(valid && e < low));
+        if (stop) vm &= (1ull << __builtin_ctzll(stop)) - 1;
+        const uint32_t rank = uint32_t(__builtin_popcountll(vm & ((1ull << ord) - 1)));
+        const bool has = in_row && ((vm >> ord) & 1) && rank < attempts;
+        if (lane == 0) {                                               // the current position goes in as well (:1229-1234)
+            const uint32_t p0 = (head_byte - 1u) & mask;
+            rowS[0] = uint8_t(p0); rowS[16 + p0] = uint8_t(tag); Z.tab[relS + p0] = curr;
+        }
+        Z.ntu = curr + 1;
+        return best_candidate(s, ip, end, n_total, e, has, rank, curr, ofb, lane);
+    }
     {   // ZSTD_row_update_internal: catch up to curr (skipping the middle of long gaps)
         uint32_t idx = Z.ntu;
         if (curr - idx > 384) { row_insert_range(L, Z, P, s, idx, idx + 96, lane); idx = curr - 32; }
