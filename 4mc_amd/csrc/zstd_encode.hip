@@ -1283,15 +1283,38 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
             const uint32_t ip1 = ev_ip + ev_s;
             uint32_t match = ev_idx - 2, base_len = ev_kind == 4 ? 4u : 8u;
             ip = ev_kind == 3 ? ip1 : ev_ip;
-            mlen = count_fwd(s, ip + base_len, match + base_len, end, lane) + base_len;
             const uint32_t offset = ip - match;
-            for (;;) {                                           // catch up, 64 bytes per step
+            {
+                // forward count and catch-up in ONE round trip (neither depends on the other's result)
+                const uint32_t fa = ip + base_len, fb = match + base_len;
+                const bool wide = fa + 1024 <= end;
                 const uint32_t room = min(ip - anchor, match - prefix);
-                const bool same = uint32_t(lane) < room && s[ip - 1 - lane] == s[match - 1 - lane];
-                const unsigned long long bad = ~__ballot(same);
-                const uint32_t k = bad ? uint32_t(__builtin_ctzll(bad)) : 64u;
+                const bool bl = uint32_t(lane) < room;
+                const uint32_t b_i = bl ? uint32_t(s[ip - 1 - lane]) : 0u, b_m = bl ? uint32_t(s[match - 1 - lane]) : 1u;
+                U16B x = {0, 0}, y = {0, 0}; uint32_t f_i = 0, f_m = 1;
+                if (wide) { x = *reinterpret_cast<const U16B*>(s + fa + 16 * lane); y = *reinterpret_cast<const U16B*>(s + fb + 16 * lane); }
+                else if (fa + lane < end) { f_i = s[fa + lane]; f_m = s[fb + lane]; }
+                if (wide) {
+                    const uint64_t d0 = x.a ^ y.a, d1 = x.b ^ y.b;
+                    const uint32_t eq = d0 ? uint32_t(__builtin_ctzll(d0) >> 3) : (d1 ? 8u + uint32_t(__builtin_ctzll(d1) >> 3) : 16u);
+                    const unsigned long long bad = __ballot(eq < 16);
+                    if (bad) { const int l = __builtin_ctzll(bad); mlen = base_len + 16 * l + rl(eq, l); }
+                    else mlen = base_len + 1024 + count_fwd(s, fa + 1024, fb + 1024, end, lane);
+                } else {
+                    const unsigned long long bad = ~__ballot(fa + lane < end && f_i == f_m);
+                    if (bad) mlen = base_len + uint32_t(__builtin_ctzll(bad));
+                    else mlen = base_len + 64 + count_fwd(s, fa + 64, fb + 64, end, lane);
+                }
+                const unsigned long long badb = ~__ballot(bl && b_i == b_m);
+                uint32_t k = badb ? uint32_t(__builtin_ctzll(badb)) : 64u;
                 ip -= k; match -= k; mlen += k;
-                if (k < 64) break;
+                while (k == 64) {                                // catch up further, 64 bytes per step
+                    const uint32_t room2 = min(ip - anchor, match - prefix);
+                    const bool same = uint32_t(lane) < room2 && s[ip - 1 - lane] == s[match - 1 - lane];
+                    const unsigned long long bad2 = ~__ballot(same);
+                    k = bad2 ? uint32_t(__builtin_ctzll(bad2)) : 64u;
+                    ip -= k; match -= k; mlen += k;
+                }
             }
             rep2 = rep1; rep1 = offset; off_base = offset + 3;
             if (ev_s < 4 && lane == 0) tl[ev_hl1] = ip1 + 2;
@@ -1300,11 +1323,14 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
         ip += mlen; anchor = ip;
         if (int64_t(ip) <= ilimit) {
             const uint64_t wa = ld8(s + cur0), wb = ld8(s + ip - 2), wc = ld8(s + ip - 1);
+            uint32_t r_cur = ld4(s + ip), r_rep = ld4(s + ip - rep2);     // (the reads of this step in one round trip; rep2 == 0: not used)
             if (lane == 0) {
                 tl[HL(wa)] = cur0 + 2; tl[HL(wb)] = ip;
                 ts[zhash(wa, hs_log, mls)] = cur0 + 2; ts[zhash(wc, hs_log, mls)] = ip + 1;
             }
-            while (int64_t(ip) <= ilimit && ((rep2 > 0) & (ld4(s + ip) == ld4(s + ip - rep2)))) {
+            for (bool first = true; int64_t(ip) <= ilimit && rep2 > 0; first = false) {
+                if (!first) { r_cur = ld4(s + ip); r_rep = ld4(s + ip - rep2); }
+                if (r_cur != r_rep) break;
                 const uint32_t rlen = count_fwd(s, ip + 4, ip + 4 - rep2, end, lane) + 4;
                 const uint32_t t = rep2; rep2 = rep1; rep1 = t;
                 const uint64_t wi = ld8(s + ip);
