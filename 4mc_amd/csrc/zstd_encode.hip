@@ -1354,7 +1354,11 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
 // insertions left them); the wave parallelises inside a search: a row's 16-64 tags are compared in one step, all
 // candidates are measured at once (one per lane), skipped positions enter their rows in conflict-free rounds.
 // The reference's 8-entry hash cache only prefetches: the cached value always equals the hash of its position.
-struct LazyState { uint32_t* tab; uint32_t* chain; uint8_t* tags; uint32_t ntu, low_limit, dict_limit; };
+struct LazyState {
+    uint32_t* tab; uint32_t* chain; uint8_t* tags; uint32_t ntu, low_limit, dict_limit;
+    // row of the NEXT position, read ahead while this position's candidates are compared (row_search)
+    uint32_t pf_ip, pf_hash, pf_head, pf_tg, pf_e;
+};
 
 __device__ __forceinline__ uint32_t lz_low(const LazyState& Z, const Params& P, uint32_t curr)
 { const uint32_t md = 1u << P.wlog; return curr - Z.low_limit > md ? curr - md : Z.low_limit; }
@@ -1432,18 +1436,33 @@ __device__ __forceinline__ uint32_t row_search(ZLds& L, LazyState& Z, const Para
         // dependent ones; if both are the same row the insertion is applied to the registers.
         const bool ins = curr - Z.ntu == 1;
         const uint32_t idx0 = ins ? Z.ntu : curr, hbits = P.hlog - rowlog + 8;          // (no insertion: the same reads, nothing written)
-        const uint64_t wA = ld8(s + idx0 - 2), wS = ld8(s + ip);
-        const uint32_t hA = zhash(wA, hbits, mls), hS = zhash(wS, hbits, mls);
-        const uint32_t relA = (hA >> 8) << rowlog, relS = (hS >> 8) << rowlog, tag = hS & 255;
-        uint8_t* const rowA = Z.tags + 2 * size_t(relA);
-        uint8_t* const rowS = Z.tags + 2 * size_t(relS);
         const bool in_row = uint32_t(lane) < entries;
-        const uint32_t headA = rowA[0];
-        uint32_t head_byte = rowS[0];
-        uint32_t tg = in_row ? uint32_t(rowS[16 + lane]) : 0u, e = in_row ? Z.tab[relS + lane] : 0u;
-        const uint32_t posA = (headA - 1u) & mask;
-        if (ins && lane == 0) { rowA[0] = uint8_t(posA); rowA[16 + posA] = uint8_t(hA); Z.tab[relA + posA] = idx0; }
-        if (ins && relA == relS) { head_byte = posA; if (uint32_t(lane) == posA) { tg = hA & 255; e = idx0; } }
+        const bool from_pf = !ins && Z.pf_ip == ip;                      // this row was read ahead by the previous search
+        const uint64_t wN = ld8(s + ip + 1);                             // next position: its row is read ahead below
+        uint32_t hS, head_byte, tg, e;
+        uint32_t hA = 0, relA = 0, posA = 0;
+        if (from_pf) { hS = Z.pf_hash; head_byte = Z.pf_head; tg = Z.pf_tg; e = Z.pf_e; }
+        else {
+            const uint64_t wA = ld8(s + idx0 - 2), wS = ld8(s + ip);
+            hA = zhash(wA, hbits, mls); hS = zhash(wS, hbits, mls);
+            relA = (hA >> 8) << rowlog;
+            const uint32_t relS0 = (hS >> 8) << rowlog;
+            uint8_t* const rowA = Z.tags + 2 * size_t(relA);
+            uint8_t* const rowS0 = Z.tags + 2 * size_t(relS0);
+            const uint32_t headA = rowA[0];
+            head_byte = rowS0[0];
+            tg = in_row ? uint32_t(rowS0[16 + lane]) : 0u; e = in_row ? Z.tab[relS0 + lane] : 0u;
+            posA = (headA - 1u) & mask;
+            if (ins && lane == 0) { rowA[0] = uint8_t(posA); rowA[16 + posA] = uint8_t(hA); Z.tab[relA + posA] = idx0; }
+            if (ins && relA == relS0) { head_byte = posA; if (uint32_t(lane) == posA) { tg = hA & 255; e = idx0; } }
+        }
+        const uint32_t relS = (hS >> 8) << rowlog, tag = hS & 255;
+        uint8_t* const rowS = Z.tags + 2 * size_t(relS);
+        // read ahead: the row of ip+1 as it stands now (this search's own insertion is applied to it below)
+        const uint32_t hN = zhash(wN, hbits, mls), relN = (hN >> 8) << rowlog;
+        uint8_t* const rowN = Z.tags + 2 * size_t(relN);
+        uint32_t n_head = rowN[0], n_tg = in_row ? uint32_t(rowN[16 + lane]) : 0u, n_e = in_row ? Z.tab[relN + lane] : 0u;
+        if (!from_pf && ins && relA == relN) { n_head = posA; if (uint32_t(lane) == posA) { n_tg = hA & 255; n_e = idx0; } }   // (read before that store landed)
         const uint32_t head = head_byte & mask;
         const uint32_t ord = (uint32_t(lane) - head) & mask;
         const bool valid = in_row && tg == tag;
@@ -1461,9 +1480,15 @@ __device__ __forceinline__ uint32_t row_search(ZLds& L, LazyState& Z, const Para
             const uint32_t p0 = (head_byte - 1u) & mask;
             rowS[0] = uint8_t(p0); rowS[16 + p0] = uint8_t(tag); Z.tab[relS + p0] = curr;
         }
+        {
+            const uint32_t p0 = (head_byte - 1u) & mask;
+            if (relN == relS) { n_head = p0; if (uint32_t(lane) == p0) { n_tg = tag; n_e = curr; } }
+            Z.pf_ip = ip + 1; Z.pf_hash = hN; Z.pf_head = n_head; Z.pf_tg = n_tg; Z.pf_e = n_e;
+        }
         Z.ntu = curr + 1;
         return best_candidate(s, ip, end, n_total, e, has, rank, curr, ofb, lane);
     }
+    Z.pf_ip = 0xFFFFFFFFu;                                             // the general path writes rows: nothing read ahead survives it
     {   // ZSTD_row_update_internal: catch up to curr (skipping the middle of long gaps)
         uint32_t idx = Z.ntu;
         if (curr - idx > 384) { row_insert_range(L, Z, P, s, idx, idx + 96, lane); idx = curr - 32; }
@@ -1658,6 +1683,7 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
     uint8_t* const tmp = work + kOffTmp;
     LazyState Z;
     Z.tab = tab; Z.ntu = 2; Z.low_limit = 2; Z.dict_limit = 2;
+    Z.pf_ip = 0xFFFFFFFFu; Z.pf_hash = Z.pf_head = Z.pf_tg = Z.pf_e = 0;
     Z.tags = reinterpret_cast<uint8_t*>(tab) + (size_t(4) << P.hlog);                                   // rows: tag table behind the entries
     Z.chain = tab + (size_t(1) << P.hlog);                                                              // hash chains: chain table there
     uint32_t o = 0;
