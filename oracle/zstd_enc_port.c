@@ -4,8 +4,9 @@
  * (native/4mc.c:467: ZSTD_compress(out+12, n-1, in, n, level)).  TEST INFRASTRUCTURE, NOT PRODUCT.
  *
  * Covered: ZSTD_fast (4mz "fast" = zstd level 1), ZSTD_dfast ("medium" = level 3), ZSTD_lazy / lazy2 with the row-hash
- * and hash-chain match finders ("high" = level 6: every size class; "ultra" = level 12: inputs > 256 KiB only - its
- * smaller size classes use btlazy2 / btopt, which are not restated).  Anything else returns ORC_ZSTD_UNSUPPORTED.
+ * and hash-chain match finders ("high" = level 6: every size class; "ultra" = level 12: lazy2 for inputs > 256 KiB) and
+ * ZSTD_btlazy2 (the binary-tree finder of level 12 between 16 KiB + 1 and 256 KiB).  Level 12 at 16 KiB and below uses
+ * btopt, which is not restated: that, and any other level, returns ORC_ZSTD_UNSUPPORTED.
  *
  *   parameters   ZSTD_getCParams_internal        compress/zstd_compress.c:6465-6488, clevels.h:25-130,
  *                ZSTD_adjustCParams_internal     compress/zstd_compress.c:1335-1399
@@ -1096,14 +1097,111 @@ static size_t hc_search(zmatch* m, const uint8_t* s, size_t ip, size_t end, uint
     return ml;
 }
 
-static size_t lazy_block(zmatch* m, uint32_t rep[3], const uint8_t* s, size_t start, size_t end, int depth, int use_row)
+/* Binary-tree match finder of btlazy2 (compress/zstd_lazy.c:20-58 ZSTD_updateDUBT, :64-150 ZSTD_insertDUBT1, :231-379
+ * ZSTD_DUBT_findBestMatch, :383-392 ZSTD_BtFindBestMatch; noDict).  m->small is the tree: two links per index. */
+#define DUBT_UNSORTED 1u
+static void bt_insert1(zmatch* m, const uint8_t* s, uint32_t curr, size_t end, uint32_t nb_compares, uint32_t bt_low)
 {
+    uint32_t* const bt = m->small;
+    const uint32_t bt_mask = (1u << (m->p.clog - 1)) - 1, max_dist = 1u << m->p.wlog;
+    const uint32_t window_low = curr - m->low_limit > max_dist ? curr - max_dist : m->low_limit;
+    const size_t ip = curr - 2;
+    size_t common_smaller = 0, common_larger = 0;
+    uint32_t dummy, *smaller = bt + 2 * (curr & bt_mask), *larger = smaller + 1, mi = *smaller;
+    for (; nb_compares && mi > window_low; --nb_compares) {
+        uint32_t* const next = bt + 2 * (mi & bt_mask);
+        const size_t match = mi - 2;
+        size_t ml = common_smaller < common_larger ? common_smaller : common_larger;
+        ml += count_eq(s, ip + ml, match + ml, end);
+        if (ip + ml == end) break;                                    /* equal: no way to know if smaller or larger */
+        if (s[match + ml] < s[ip + ml]) {
+            *smaller = mi; common_smaller = ml;
+            if (mi <= bt_low) { smaller = &dummy; break; }
+            smaller = next + 1; mi = next[1];
+        } else {
+            *larger = mi; common_larger = ml;
+            if (mi <= bt_low) { larger = &dummy; break; }
+            larger = next; mi = next[0];
+        }
+    }
+    *smaller = *larger = 0;
+}
+
+static size_t bt_search(zmatch* m, const uint8_t* s, size_t ip, size_t end, uint32_t* ofb)
+{
+    uint32_t* const bt = m->small;
+    const uint32_t curr = (uint32_t)ip + 2, mls = lz_mls(m), bt_mask = (1u << (m->p.clog - 1)) - 1;
+    uint32_t idx, h, mi, nb_compares, nb_candidates, previous = 0, *next_cand, *unsorted;
+    uint32_t window_low, bt_low, unsort_limit;
+    if (curr < m->next_to_update) return 0;                           /* skipped area */
+    for (idx = m->next_to_update; idx < curr; idx++) {                /* ZSTD_updateDUBT: chain the new positions in, unsorted */
+        const uint32_t hh = zhash(s + idx - 2, m->p.hlog, mls);
+        bt[2 * (idx & bt_mask)] = m->table[hh];
+        bt[2 * (idx & bt_mask) + 1] = DUBT_UNSORTED;
+        m->table[hh] = idx;
+    }
+    m->next_to_update = curr;
+    h = zhash(s + ip, m->p.hlog, mls);
+    mi = m->table[h];
+    window_low = lz_low_limit(m, curr);
+    bt_low = bt_mask >= curr ? 0 : curr - bt_mask;
+    unsort_limit = bt_low > window_low ? bt_low : window_low;
+    next_cand = bt + 2 * (mi & bt_mask); unsorted = next_cand + 1;
+    nb_compares = 1u << m->p.slog; nb_candidates = nb_compares;
+    while (mi > unsort_limit && *unsorted == DUBT_UNSORTED && nb_candidates > 1) {      /* reach the end of the unsorted candidates */
+        *unsorted = previous; previous = mi;
+        mi = *next_cand;
+        next_cand = bt + 2 * (mi & bt_mask); unsorted = next_cand + 1;
+        nb_candidates--;
+    }
+    if (mi > unsort_limit && *unsorted == DUBT_UNSORTED) *next_cand = *unsorted = 0;   /* nullify the last one if still unsorted */
+    mi = previous;
+    while (mi) {                                                      /* batch sort the stacked candidates */
+        uint32_t* const nip = bt + 2 * (mi & bt_mask) + 1;
+        const uint32_t nxt = *nip;
+        bt_insert1(m, s, mi, end, nb_candidates, unsort_limit);
+        mi = nxt; nb_candidates++;
+    }
+    {   /* find the longest match, inserting curr into the tree */
+        size_t common_smaller = 0, common_larger = 0, best = 0;
+        uint32_t dummy, *smaller = bt + 2 * (curr & bt_mask), *larger = smaller + 1, match_end_idx = curr + 8 + 1;
+        mi = m->table[h];
+        m->table[h] = curr;
+        for (; nb_compares && mi > window_low; --nb_compares) {
+            uint32_t* const next = bt + 2 * (mi & bt_mask);
+            const size_t match = mi - 2;
+            size_t ml = common_smaller < common_larger ? common_smaller : common_larger;
+            ml += count_eq(s, ip + ml, match + ml, end);
+            if (ml > best) {
+                if (ml > match_end_idx - mi) match_end_idx = mi + (uint32_t)ml;
+                if (4 * (int)(ml - best) > (int)(hibit(curr - mi + 1) - hibit(*ofb))) { best = ml; *ofb = curr - mi + 3; }
+                if (ip + ml == end) break;                            /* equal: drop, to keep the tree consistent */
+            }
+            if (s[match + ml] < s[ip + ml]) {
+                *smaller = mi; common_smaller = ml;
+                if (mi <= bt_low) { smaller = &dummy; break; }
+                smaller = next + 1; mi = next[1];
+            } else {
+                *larger = mi; common_larger = ml;
+                if (mi <= bt_low) { larger = &dummy; break; }
+                larger = next; mi = next[0];
+            }
+        }
+        *smaller = *larger = 0;
+        m->next_to_update = match_end_idx - 8;                        /* skip repetitive patterns */
+        return best;
+    }
+}
+
+static size_t lazy_block(zmatch* m, uint32_t rep[3], const uint8_t* s, size_t start, size_t end, int depth, int method /* 0 hash chains, 1 rows, 2 binary tree */)
+{
+    const int use_row = method == 1;
     const int64_t ilimit = (int64_t)end - 8 - (use_row ? 8 : 0);
     const uint32_t prefix_idx = m->dict_limit;
     const size_t prefix = prefix_idx - 2;
     size_t ip = start, anchor = start;
     uint32_t rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0;
-#define SEARCH(pos_, ofb_) (use_row ? row_search(m, s, (pos_), end, (ofb_)) : hc_search(m, s, (pos_), end, (ofb_)))
+#define SEARCH(pos_, ofb_) (method == 1 ? row_search(m, s, (pos_), end, (ofb_)) : method == 2 ? bt_search(m, s, (pos_), end, (ofb_)) : hc_search(m, s, (pos_), end, (ofb_)))
     ip += (ip == prefix);
     {
         const uint32_t c = (uint32_t)ip + 2, max_dist = 1u << m->p.wlog;
@@ -1180,19 +1278,19 @@ static size_t lazy_block(zmatch* m, uint32_t rep[3], const uint8_t* s, size_t st
 }
 
 /* ------------------------------------------------------------------------------------------------ frame */
-/* clevels.h rows of the levels 4mz uses; strat: 1 fast, 2 dfast, 4 lazy, 5 lazy2, 0 = a strategy this port does not restate */
+/* clevels.h rows of the levels 4mz uses; strat: 1 fast, 2 dfast, 4 lazy, 5 lazy2, 6 btlazy2, 0 = a strategy this port does not restate */
 static zparams level_params(int level, size_t n)
 {
     static const zparams rows[4][4] = {            /* tables for > 256 KB, <= 256 KB, <= 128 KB, <= 16 KB */
         {{19, 13, 14, 1, 7, 0, 1}, {18, 13, 14, 1, 6, 0, 1}, {17, 12, 13, 1, 6, 0, 1}, {14, 14, 15, 1, 5, 0, 1}},     /* level 1  */
         {{21, 16, 17, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {17, 15, 16, 2, 5, 0, 2}, {14, 14, 15, 2, 4, 0, 2}},     /* level 3  */
         {{21, 18, 19, 3, 5, 4, 4}, {18, 18, 19, 3, 5, 4, 4}, {17, 16, 17, 3, 4, 4, 4}, {14, 14, 14, 4, 4, 8, 5}},     /* level 6  */
-        {{22, 22, 23, 6, 5, 32, 5}, {18, 19, 19, 7, 4, 12, 0}, {17, 18, 17, 7, 4, 12, 0}, {14, 15, 14, 4, 3, 24, 0}}};/* level 12: btlazy2 / btopt below 256 KB */
+        {{22, 22, 23, 6, 5, 32, 5}, {18, 19, 19, 7, 4, 12, 6}, {17, 18, 17, 7, 4, 12, 6}, {14, 15, 14, 4, 3, 24, 0}}};/* level 12: btlazy2 below 256 KB, btopt (not restated) below 16 KB */
     zparams p = rows[level == 3 ? 1 : level == 6 ? 2 : level == 12 ? 3 : 0][(n <= 256 * 1024) + (n <= 128 * 1024) + (n <= 16 * 1024)];
     const uint32_t src_log = n < 64 ? 6 : (uint32_t)hibit((uint32_t)(n - 1)) + 1;
     if (p.wlog > src_log) p.wlog = src_log;
     if (p.hlog > p.wlog + 1) p.hlog = p.wlog + 1;
-    if (p.clog > p.wlog) p.clog = p.wlog;
+    if (p.clog - (p.strat >= 6) > p.wlog) p.clog = p.wlog + (p.strat >= 6);     /* ZSTD_cycleLog: a binary tree has half as many nodes */
     if (p.wlog < 10) p.wlog = 10;
     return p;
 }
@@ -1271,7 +1369,7 @@ int64_t orc_zstd_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap
                 const uint32_t curr = (uint32_t)pos + 2;
                 if (curr > m.next_to_update + 384) { const uint32_t gap = curr - m.next_to_update - 384; m.next_to_update = curr - (gap < 192 ? gap : 192); }
             }
-            if (p.strat >= 4) tail = lazy_block(&m, next->rep, src, pos, pos + len, p.strat == 5 ? 2 : 1, p.wlog > 14);
+            if (p.strat >= 4) tail = lazy_block(&m, next->rep, src, pos, pos + len, p.strat >= 5 ? 2 : 1, p.strat == 6 ? 2 : p.wlog > 14);
             else tail = p.strat == 2 ? dfast_block(&m, next->rep, src, pos, pos + len) : fast_block(&m, next->rep, src, pos, pos + len);
             memcpy(m.lit + m.nlit, src + pos + len - tail, tail); m.nlit += tail;
             lsz = compress_literals(prev, next, out, bcap, m.lit, m.nlit, m.nseq == 0 || m.nlit / m.nseq >= 20, p.strat);

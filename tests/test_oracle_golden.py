@@ -241,8 +241,8 @@ def test_zstd_enc_port_golden_manifest(level, key):
             continue                                   # level 12 runs at ~25 MB/s on one host core: sample
         blk = data[b * B: b * B + u]
         r, comp = helpers.orc_zstd_compress(blk, level, u - 1)
-        if level == 12 and u <= 256 * 1024:
-            assert r == -1000                          # btlazy2 size class: refused, not guessed
+        if level == 12 and u <= 16 * 1024:
+            assert r == -1000                          # btopt size class: refused, not guessed
             continue
         payload = comp if r > 0 else blk
         assert (len(payload), helpers.orc_xxh32(payload)) == (c, x), b
@@ -251,12 +251,42 @@ def test_zstd_enc_port_golden_manifest(level, key):
 
 
 @pytest.mark.skipif(helpers.ref() is None, reason="oracle/_ref not built (needs /root/reference)")
-def test_zstd_enc_port_level12_small_inputs_are_refused():
-    """Level 12 below 256 KiB uses btlazy2 / btopt, which the port does not restate: it must say so, not guess."""
-    r, _ = helpers.orc_zstd_compress(helpers.corpus(200000), 12)
+def test_zstd_enc_port_level12_size_classes():
+    """Level 12: lazy2 above 256 KiB, btlazy2 (binary tree) down to 16 KiB + 1 - both pinned to the reference's own
+    ZSTD_compress here; at 16 KiB and below the reference uses btopt, which the port does not restate: it must say
+    so, not guess."""
+    import ctypes as C
+    ref = helpers.ref()
+    ref.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]; ref.ZSTD_compress.restype = C.c_size_t
+    r, _ = helpers.orc_zstd_compress(helpers.corpus(16384), 12)
     assert r == -1000
     r, _ = helpers.orc_zstd_compress(helpers.corpus(300000), 12)
     assert r > 0
+
+    def check(d, cap, tag):
+        d = np.array(d, dtype=np.uint8, copy=True)
+        out = np.zeros(max(cap, 1) + 64, np.uint8)
+        rr = ref.ZSTD_compress(out.ctypes.data, cap, d.ctypes.data, len(d), 12)
+        rr = rr if rr < (1 << 62) else rr - (1 << 64)
+        r, comp = helpers.orc_zstd_compress(d, 12, cap)
+        assert r == rr and np.array_equal(comp, out[:max(rr, 0)]), (tag, len(d), cap, r, rr)
+        return rr
+
+    rng = np.random.default_rng(12)
+    src = helpers.corpus(3 * B, first_block=2)
+    for n in (16385, 16390, 32768, 65535, 65536, 65537, 100000, 131071, 131072, 131073, 200000, 262143, 262144):
+        off = int(rng.integers(0, 2 * B))
+        check(src[off:off + n], helpers.zstd_bound(n), "size")
+        check(src[off:off + n], n - 1, "size n-1")
+    for name, d in helpers.edge_inputs().items():
+        if len(d) > 16384:
+            d = d[:262144]
+            for cap in {len(d) - 1, helpers.zstd_bound(len(d)), len(d) // 3}:
+                check(d, cap, name)
+    d = src[5000: 5000 + 70000]
+    c = check(d, helpers.zstd_bound(len(d)), "bound")
+    for cap in range(max(0, c - 16), c + 6):
+        check(d, cap, "tight")
 
 
 @pytest.mark.skipif(helpers.ref() is None, reason="oracle/_ref not built (needs /root/reference)")
