@@ -177,8 +177,8 @@ int fourmc_gpu_zstd_decompress(const void* d_src, void* d_dst, fourmc_block* d_b
     return FOURMC_OK;
 }
 
-// zstd level 12 is on the device for inputs > 256 KiB only (below that the reference switches to btlazy2 / btopt):
-// refuse the whole batch rather than emit anything the reference would not
+// zstd level 12 is on the device for inputs > 16 KiB (lazy2 above 256 KiB, btlazy2 below; at 16 KiB and less the
+// reference switches to btopt): refuse the whole batch rather than emit anything the reference would not
 static int zstd_level_ok(const fourmc_block* d_blocks, uint32_t n, int level, hipStream_t s)
 {
     if (level == 1 || level == 3 || level == 6) return FOURMC_OK;
@@ -187,8 +187,8 @@ static int zstd_level_ok(const fourmc_block* d_blocks, uint32_t n, int level, hi
     HIP_TRY(hipMemcpyAsync(h.data(), d_blocks, n * sizeof(fourmc_block), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     for (uint32_t b = 0; b < n; b++)
-        if (h[b].src_len <= 256u * 1024u) {
-            snprintf(g_err, sizeof g_err, "ZSTD level 12 not on the device for inputs <= 256 KiB (block %u has %u bytes; the reference uses btlazy2/btopt there)", b, h[b].src_len);
+        if (h[b].src_len <= 16u * 1024u) {
+            snprintf(g_err, sizeof g_err, "ZSTD level 12 not on the device for inputs <= 16 KiB (block %u has %u bytes; the reference uses btopt there)", b, h[b].src_len);
             return FOURMC_EUNSUP;
         }
     return FOURMC_OK;

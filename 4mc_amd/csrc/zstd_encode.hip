@@ -49,7 +49,7 @@ constexpr size_t   kOffTmp    = kOffPrev + 4736;                     // 512 B: F
 constexpr size_t   kStoreBytes = kOffTmp + 512 + 192;
 static_assert(kStoreBytes % 64 == 0, "tables start 64-byte aligned");
 // tables by level: 1 -> hash table (<= 2^15 x u32); 3 -> long 2^17 + short 2^16; 6 -> rows 2^19 x u32 + tags 2^19 x u16;
-// 12 (inputs > 256 KiB only) -> rows 2^23 x u32 + tags 2^23 x u16
+// 12 -> rows 2^23 x u32 + tags 2^23 x u16 (inputs > 256 KiB), hash 2^19 x u32 + binary tree 2^19 x u32 (btlazy2, smaller inputs)
 __host__ __device__ constexpr size_t table_bytes(int level)
 { return level == 12 ? (size_t(4) << 23) + (size_t(2) << 23) : level == 6 ? (size_t(4) << 19) + (size_t(2) << 19) : level == 3 ? (size_t(4) << 17) + (size_t(4) << 16) : (size_t(4) << 15); }
 
@@ -1538,16 +1538,114 @@ __device__ __forceinline__ uint32_t hc_search(LazyState& Z, const Params& P, con
     return best_candidate(s, ip, end, n_total, cand, uint32_t(lane) < n, uint32_t(lane), curr, ofb, lane);
 }
 
+// Binary-tree match finder of ZSTD_btlazy2 (compress/zstd_lazy.c:20-58 ZSTD_updateDUBT, :64-150 ZSTD_insertDUBT1, :231-379
+// ZSTD_DUBT_findBestMatch, :383-392 ZSTD_BtFindBestMatch; noDict): zstd level 12 for blocks of 16 KiB + 1 .. 256 KiB, i.e. only
+// the short last block of a file.  A tree descent is one dependent step after the other, so this is the reference's code
+// run by the whole wave in lockstep (lane 0 writes; byte comparisons use all lanes).  Z.chain is the tree: two links per index.
+__device__ __forceinline__ void bt_insert1(LazyState& Z, const Params& P, const uint8_t* s, uint32_t curr, uint32_t end,
+                                           uint32_t nb_compares, uint32_t bt_low, int lane)
+{
+    uint32_t* const bt = Z.chain;
+    const uint32_t bt_mask = (1u << (P.clog - 1)) - 1, max_dist = 1u << P.wlog;
+    const uint32_t window_low = curr - Z.low_limit > max_dist ? curr - max_dist : Z.low_limit;
+    const uint32_t ip = curr - 2;
+    uint32_t common_smaller = 0, common_larger = 0;
+    uint32_t smaller = 2 * (curr & bt_mask), larger = smaller + 1;          // tree slots to fill; 0xFFFFFFFF: the dummy
+    uint32_t mi = bt[smaller];
+    for (; nb_compares && mi > window_low; --nb_compares) {
+        const uint32_t next = 2 * (mi & bt_mask), match = mi - 2;
+        uint32_t ml = min(common_smaller, common_larger);
+        ml += count_fwd(s, ip + ml, match + ml, end, lane);
+        if (ip + ml == end) break;                                           // equal: no way to know if smaller or larger
+        if (s[match + ml] < s[ip + ml]) {
+            if (lane == 0 && smaller != 0xFFFFFFFFu) bt[smaller] = mi;
+            common_smaller = ml;
+            if (mi <= bt_low) { smaller = 0xFFFFFFFFu; break; }
+            smaller = next + 1; mi = bt[next + 1];
+        } else {
+            if (lane == 0 && larger != 0xFFFFFFFFu) bt[larger] = mi;
+            common_larger = ml;
+            if (mi <= bt_low) { larger = 0xFFFFFFFFu; break; }
+            larger = next; mi = bt[next];
+        }
+    }
+    if (lane == 0) { if (smaller != 0xFFFFFFFFu) bt[smaller] = 0; if (larger != 0xFFFFFFFFu) bt[larger] = 0; }
+}
+
+__device__ __forceinline__ uint32_t bt_search(LazyState& Z, const Params& P, const uint8_t* s, uint32_t ip, uint32_t end, uint32_t& ofb, int lane)
+{
+    uint32_t* const bt = Z.chain;
+    const uint32_t curr = ip + 2, mls = min(max(P.mml, 4u), 6u), bt_mask = (1u << (P.clog - 1)) - 1;
+    if (curr < Z.ntu) return 0;                                              // skipped area
+    for (uint32_t idx = Z.ntu; idx < curr; idx++) {                          // ZSTD_updateDUBT: chain the new positions in, unsorted
+        const uint32_t hh = zhash(ld8(s + idx - 2), P.hlog, mls);
+        const uint32_t old = Z.tab[hh];
+        if (lane == 0) { bt[2 * (idx & bt_mask)] = old; bt[2 * (idx & bt_mask) + 1] = 1u; Z.tab[hh] = idx; }
+    }
+    Z.ntu = curr;
+    const uint32_t h = zhash(ld8(s + ip), P.hlog, mls);
+    uint32_t mi = Z.tab[h];
+    const uint32_t window_low = lz_low(Z, P, curr);
+    const uint32_t bt_low = bt_mask >= curr ? 0u : curr - bt_mask;
+    const uint32_t unsort_limit = max(bt_low, window_low);
+    uint32_t nb_compares = 1u << P.slog, nb_candidates = nb_compares, previous = 0;
+    while (mi > unsort_limit && bt[2 * (mi & bt_mask) + 1] == 1u && nb_candidates > 1) {   // reach the end of the unsorted candidates
+        const uint32_t nxt = bt[2 * (mi & bt_mask)];
+        if (lane == 0) bt[2 * (mi & bt_mask) + 1] = previous;
+        previous = mi; mi = nxt;
+        nb_candidates--;
+    }
+    if (mi > unsort_limit && bt[2 * (mi & bt_mask) + 1] == 1u) {             // nullify the last one if still unsorted
+        if (lane == 0) { bt[2 * (mi & bt_mask)] = 0; bt[2 * (mi & bt_mask) + 1] = 0; }
+    }
+    mi = previous;
+    while (mi) {                                                             // batch sort the stacked candidates
+        const uint32_t nxt = bt[2 * (mi & bt_mask) + 1];
+        bt_insert1(Z, P, s, mi, end, nb_candidates, unsort_limit, lane);
+        mi = nxt; nb_candidates++;
+    }
+    // find the longest match, inserting curr into the tree
+    uint32_t common_smaller = 0, common_larger = 0, best = 0;
+    uint32_t smaller = 2 * (curr & bt_mask), larger = smaller + 1, match_end_idx = curr + 8 + 1;
+    mi = Z.tab[h];
+    if (lane == 0) Z.tab[h] = curr;
+    for (; nb_compares && mi > window_low; --nb_compares) {
+        const uint32_t next = 2 * (mi & bt_mask), match = mi - 2;
+        uint32_t ml = min(common_smaller, common_larger);
+        ml += count_fwd(s, ip + ml, match + ml, end, lane);
+        if (ml > best) {
+            if (ml > match_end_idx - mi) match_end_idx = mi + ml;
+            if (4 * int(ml - best) > int(hibit(curr - mi + 1) - hibit(ofb))) { best = ml; ofb = curr - mi + 3; }
+            if (ip + ml == end) break;                                       // equal: drop, to keep the tree consistent
+        }
+        if (s[match + ml] < s[ip + ml]) {
+            if (lane == 0 && smaller != 0xFFFFFFFFu) bt[smaller] = mi;
+            common_smaller = ml;
+            if (mi <= bt_low) { smaller = 0xFFFFFFFFu; break; }
+            smaller = next + 1; mi = bt[next + 1];
+        } else {
+            if (lane == 0 && larger != 0xFFFFFFFFu) bt[larger] = mi;
+            common_larger = ml;
+            if (mi <= bt_low) { larger = 0xFFFFFFFFu; break; }
+            larger = next; mi = bt[next];
+        }
+    }
+    if (lane == 0) { if (smaller != 0xFFFFFFFFu) bt[smaller] = 0; if (larger != 0xFFFFFFFFu) bt[larger] = 0; }
+    Z.ntu = match_end_idx - 8;                                               // skip repetitive patterns
+    return best;
+}
+
 __device__ __forceinline__ uint32_t lazy_block(ZLds& L, SeqStore& S, LazyState& Z, const Params& P, uint32_t rep[3],
                                                const uint8_t* s, uint32_t start, uint32_t end, uint32_t n_total, int lane)
 {
-    const bool use_row = P.wlog > 14;
-    const uint32_t depth = P.strat == 5 ? 2u : 1u;
+    const bool use_row = P.strat != 6 && P.wlog > 14;
+    const uint32_t depth = P.strat >= 5 ? 2u : 1u;
     const int64_t ilimit = int64_t(end) - 8 - (use_row ? 8 : 0);
     const uint32_t prefix_idx = Z.dict_limit, prefix = prefix_idx - 2;
     uint32_t ip = start, anchor = start;
     uint32_t rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0;
     auto search = [&](uint32_t at, uint32_t& ofb) -> uint32_t {
+        if (P.strat == 6) return bt_search(Z, P, s, at, end, ofb, lane);
         return use_row ? row_search(L, Z, P, s, at, end, n_total, ofb, lane) : hc_search(Z, P, s, at, end, n_total, ofb, lane);
     };
     ip += (ip == prefix) ? 1 : 0;
@@ -1631,8 +1729,10 @@ __device__ __forceinline__ Params level_params(uint32_t n, int level)
     Params p;
     uint32_t wlog, hlog, clog;
     p.slog = 1;
-    if (level == 12) {                                  // clevels.h level 12, > 256 KB row only (ZSTD_lazy2); smaller inputs use btlazy2 / btopt
-        wlog = 22; clog = 22; hlog = 23; p.slog = 6; p.mml = 5; p.strat = 5;
+    if (level == 12) {                                  // clevels.h level 12: ZSTD_lazy2 above 256 KB, ZSTD_btlazy2 (strat 6) below; <= 16 KB is btopt (refused by the engine)
+        if (n <= 128 * 1024) { wlog = 17; clog = 18; hlog = 17; p.slog = 7; p.mml = 4; p.strat = 6; }
+        else if (n <= 256 * 1024) { wlog = 18; clog = 19; hlog = 19; p.slog = 7; p.mml = 4; p.strat = 6; }
+        else { wlog = 22; clog = 22; hlog = 23; p.slog = 6; p.mml = 5; p.strat = 5; }
     } else if (level == 6) {                                   // clevels.h rows of level 6 (ZSTD_lazy; lazy2 for <= 16 KB)
         if (n <= 16 * 1024) { wlog = 14; clog = 14; hlog = 14; p.slog = 4; p.mml = 4; p.strat = 5; }
         else if (n <= 128 * 1024) { wlog = 17; clog = 16; hlog = 17; p.slog = 3; p.mml = 4; p.strat = 4; }
@@ -1654,7 +1754,7 @@ __device__ __forceinline__ Params level_params(uint32_t n, int level)
     const uint32_t src_log = n < 64 ? 6u : uint32_t(hibit(n - 1)) + 1;
     if (wlog > src_log) wlog = src_log;
     if (hlog > wlog + 1) hlog = wlog + 1;
-    if (clog > wlog) clog = wlog;
+    if (clog - (p.strat >= 6 ? 1u : 0u) > wlog) clog = wlog + (p.strat >= 6 ? 1u : 0u);   // ZSTD_cycleLog: a binary tree has half as many nodes
     if (wlog < 10) wlog = 10;
     p.wlog = wlog; p.hlog = hlog; p.clog = clog; p.tlen = 0;
     return p;
@@ -1671,7 +1771,7 @@ __device__ __forceinline__ bool is_rle(const uint8_t* s, uint32_t n, int lane)
 // ZSTD_compress(dst, cap, src, n, 1); returns the frame size or a negative ZSTD error number
 __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* work, int level, bool serial, int lane)
 {
-    if (level == 12 && n <= 256 * 1024) return kErrGeneric;      // refused by the engine before launch; never silently stored
+    if (level == 12 && n <= 16 * 1024) return kErrGeneric;       // btopt: refused by the engine before launch; never silently stored
     const Params P = level_params(n, level);
     uint32_t* const tab = reinterpret_cast<uint32_t*>(work + kStoreBytes);
     uint32_t* const tab_s = reinterpret_cast<uint32_t*>(work + kStoreBytes + (size_t(4) << 17));      // level 3: short-hash table
@@ -1717,7 +1817,7 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
         }
         if (P.strat >= 4) {                                    // tag table (2 bytes per entry) or chain table (4 bytes per entry)
             uint4* s4 = reinterpret_cast<uint4*>(Z.tags);
-            const uint32_t m16 = P.wlog > 14 ? (2u << P.hlog) / 16 : (4u << P.clog) / 16;
+            const uint32_t m16 = (P.strat != 6 && P.wlog > 14) ? (2u << P.hlog) / 16 : (4u << P.clog) / 16;
             for (uint32_t i = lane; i < m16; i += 64) s4[i] = make_uint4(0, 0, 0, 0);
         }
         for (int i = lane; i < 1024; i += 64) L.score[i] = 0xFFFFFFFFu;

@@ -58,9 +58,12 @@ def _run(gpu, srcs, caps, launch):
     return res, [out[d:d + max(r, 0)] for d, r in zip(dsts, res)], d_out, dsts
 
 
-@pytest.mark.parametrize("codec", ["lz4_fast", "lz4_mc", "lz4_hc4", "zstd1", "zstd3", "zstd6"])
+@pytest.mark.parametrize("codec", ["lz4_fast", "lz4_mc", "lz4_hc4", "zstd1", "zstd3", "zstd6", "zstd12"])
 def test_fuzz_encoders_equal_oracle(gpu, codec):
-    srcs = _inputs({"lz4_fast": 1, "lz4_mc": 2, "lz4_hc4": 3, "zstd1": 4, "zstd3": 5, "zstd6": 6}[codec], 160 if codec != "lz4_hc4" else 60)
+    srcs = _inputs({"lz4_fast": 1, "lz4_mc": 2, "lz4_hc4": 3, "zstd1": 4, "zstd3": 5, "zstd6": 6, "zstd12": 7}[codec],
+                   60 if codec == "lz4_hc4" else 240 if codec == "zstd12" else 160)
+    if codec == "zstd12":                                 # btlazy2 (16 KiB + 1 .. 256 KiB) and lazy2 above; btopt sizes are refused
+        srcs = [s for s in srcs if len(s) > 16384]
     lz4_bound = [helpers.oracle().orc_lz4_compress_bound(len(s)) for s in srcs]
     rng = np.random.default_rng(99)
     # a mix of capacities: bound, n-1 (container), and something smaller
@@ -76,6 +79,7 @@ def test_fuzz_encoders_equal_oracle(gpu, codec):
         "zstd1": lambda a, b, c: gpu.zstd_compress(a, b, c, 1),
         "zstd3": lambda a, b, c: gpu.zstd_compress(a, b, c, 3),
         "zstd6": lambda a, b, c: gpu.zstd_compress(a, b, c, 6),
+        "zstd12": lambda a, b, c: gpu.zstd_compress(a, b, c, 12),
     }[codec]
     oracle = {
         "lz4_fast": lambda s, cap: helpers.orc_compress(s, cap),
@@ -84,6 +88,7 @@ def test_fuzz_encoders_equal_oracle(gpu, codec):
         "zstd1": lambda s, cap: helpers.orc_zstd_compress(s, 1, cap),
         "zstd3": lambda s, cap: helpers.orc_zstd_compress(s, 3, cap),
         "zstd6": lambda s, cap: helpers.orc_zstd_compress(s, 6, cap),
+        "zstd12": lambda s, cap: helpers.orc_zstd_compress(s, 12, cap),
     }[codec]
     res, outs, d_out, dsts = _run(gpu, srcs, caps, launch)
     for i, (s, cap, r, o) in enumerate(zip(srcs, caps, res, outs)):

@@ -128,8 +128,6 @@ def test_cli_4mz_file_equals_reference(gpu, tmp_path, flag, key):
     back = tmp_path / "back.bin"
     assert subprocess.run([gpu.cli_path(), "-d", "-z", "-f", str(out), str(back)], capture_output=True).returncode == 0
     assert back.read_bytes() == data.tobytes()
-    r = subprocess.run([gpu.cli_path(), "-z", "-4", "-f", str(src), str(tmp_path / "c2.4mz")], capture_output=True)
-    assert r.returncode != 0 and b"not on the device" in r.stderr          # the corpus ends in a 123457-byte block
 
 
 def test_host_zstd_compress_entry_point(gpu):
@@ -155,9 +153,10 @@ def test_host_zstd_compress_entry_point(gpu):
         assert r == want_r and np.array_equal(out[:r], want), lvl
 
 
-def test_zstd12_full_blocks_golden_manifest_and_small_inputs_refused(gpu, tmp_path):
-    """4mz Ultra (zstd level 12, lazy2 + 64-entry rows) is on the device for inputs > 256 KiB: the 12 full corpus
-    blocks equal the reference CLI's manifest; smaller inputs (btlazy2 / btopt in the reference) are refused loudly."""
+def test_zstd12_golden_manifest_size_classes_and_tiny_inputs_refused(gpu, tmp_path):
+    """4mz Ultra (zstd level 12) on the device: lazy2 + 64-entry rows above 256 KiB, the binary-tree finder (btlazy2)
+    from 16 KiB + 1 to 256 KiB.  The 12 full corpus blocks AND the 123457-byte tail equal the reference CLI's manifest;
+    inputs of 16 KiB and less (btopt in the reference) are refused loudly."""
     import subprocess
     m = json.load(open(os.path.join(G, "corpus_manifest.json")))
     nb = 12
@@ -176,17 +175,31 @@ def test_zstd12_full_blocks_golden_manifest_and_small_inputs_refused(gpu, tmp_pa
     sizes = [262145, 300001, 1000003, 2 * 1024 * 1024 + 5]
     _check(gpu, ["n=%d" % n for n in sizes], [src[n: 2 * n].copy() for n in sizes], [n - 1 for n in sizes], "n-1", 12)
     _check(gpu, ["n=%d" % n for n in sizes], [src[n: 2 * n].copy() for n in sizes], [n // 4 for n in sizes], "n/4", 12)
-    # small input: refused (never a silently different payload)
-    small = gpu.DeviceBatch(gpu.make_blocks([0], [0], [200000], [200000]))
+    # btlazy2 size classes (<= 128 KiB, <= 256 KiB), window / table clamps for small inputs, capacities that fail
+    sizes = [16385, 20000, 65536, 65537, 100000, 131072, 131073, 200000, 262144]
+    _check(gpu, ["n=%d" % n for n in sizes], [src[n: 2 * n].copy() for n in sizes], [helpers.zstd_bound(n) for n in sizes], "bound", 12)
+    _check(gpu, ["n=%d" % n for n in sizes], [src[n: 2 * n].copy() for n in sizes], [n - 1 for n in sizes], "n-1", 12)
+    _check(gpu, ["n=%d" % n for n in sizes], [src[n: 2 * n].copy() for n in sizes], [n // 4 for n in sizes], "n/4", 12)
+    edge = {k: v[:262144] for k, v in helpers.edge_inputs().items() if len(v) > 16384}
+    _check(gpu, list(edge), [v.copy() for v in edge.values()], [len(v) - 1 for v in edge.values()], "edge n-1", 12)
+    # tiny input: refused (never a silently different payload)
+    small = gpu.DeviceBatch(gpu.make_blocks([0], [0], [16384], [16384]))
     with pytest.raises(gpu.EngineError, match="not on the device"):
         gpu.zstd_compress(d_src, d_dst, small, 12)
-    # CLI: a file of whole blocks compresses and round-trips; the full corpus (123457-byte tail) is refused up front
+    # CLI: the full corpus file (12 blocks + a 123457-byte tail) equals the reference CLI's; a file with a tiny tail is refused up front
+    full = tmp_path / "full.bin"; full.write_bytes(helpers.corpus(m["corpus"]["bytes"]).tobytes())
+    fo = tmp_path / "full.4mz"
+    assert subprocess.run([gpu.cli_path(), "-z", "-4", "-f", str(full), str(fo)], capture_output=True).returncode == 0
+    img = fo.read_bytes()
+    assert len(img) == m["levels"]["4mz-4"]["file_bytes"]
+    import hashlib
+    assert hashlib.sha256(img).hexdigest() == m["levels"]["4mz-4"]["sha256"], "file differs from the reference CLI's"
     f = tmp_path / "whole.bin"; f.write_bytes(data[: 3 * B].tobytes())
     out = tmp_path / "whole.4mz"
     assert subprocess.run([gpu.cli_path(), "-z", "-4", "-f", str(f), str(out)], capture_output=True).returncode == 0
     back = tmp_path / "whole.back"
     assert subprocess.run([gpu.cli_path(), "-d", "-z", "-f", str(out), str(back)], capture_output=True).returncode == 0
     assert back.read_bytes() == data[: 3 * B].tobytes()
-    g = tmp_path / "tail.bin"; g.write_bytes(helpers.corpus(B + 123457).tobytes())
+    g = tmp_path / "tail.bin"; g.write_bytes(helpers.corpus(B + 12345).tobytes())
     r = subprocess.run([gpu.cli_path(), "-z", "-4", "-f", str(g), str(tmp_path / "tail.4mz")], capture_output=True)
     assert r.returncode == 1 and b"not on the device" in r.stderr and not (tmp_path / "tail.4mz").exists()
