@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "fourmc_gpu.h"
 #include "kernels.h"
 #include "devcopy.h"
@@ -261,9 +262,14 @@ __device__ __forceinline__ uint32_t scan_max(uint32_t v, int)      // values are
     return v;
 }
 
-// The fast path runs on TWO wavefronts per block: what the tokens say (lengths, offsets, where each sequence's output
-// starts) depends on the compressed stream alone, so a PARSER wave walks the stream and hands finished batches to a
-// COPIER wave through a ring of records in LDS; the copier produces the output.  Neither waits for the other's memory.
+// The fast path runs on 1 + kCopiers wavefronts per block: what the tokens say (lengths, offsets, where each sequence's
+// output starts) depends on the compressed stream alone, so a PARSER wave walks the stream and hands finished records
+// (a batch of sequences, or one general sequence) to COPIER waves through a ring in LDS; record k belongs to copier
+// k % kCopiers.  The output ranges of records are disjoint, so copiers only meet where a match reads what a record still
+// in flight on another copier produces: the parser works out, per record, the youngest earlier record its sources touch
+// (`need`), and a copier starts record k once every record <= need is complete (done[] counters, release / acquire at
+// workgroup scope; the waves of a workgroup share the CU's L1, so completed stores are visible to plain loads).
+constexpr int kCopiers = 2;
 constexpr int kRec = 8;
 enum : uint32_t { kRecBatch = 1, kRecGeneral = 2, kRecEnd = 3, kRecRetry = 4 };
 struct Rec {
@@ -271,25 +277,50 @@ struct Rec {
     uint32_t T;              // batch: output bytes; general: match length (0: the block's last, literal-only sequence)
     uint32_t op;             // output position where the record starts (end: the decoded size)
     uint32_t lit, lit_ip, off;      // general sequence
+    int      need;           // every record with an index <= need has to be complete before this one reads the output
     unsigned long long tokmask;     // batch: lanes (window slots) that are tokens
     uint32_t pack[64];       // batch, per token lane: output start in the batch | literals << 13 | (token header - 1) << 19
     uint32_t offb[64];       // batch: match offset | this slot's stream byte << 16
 };
-struct DSync { uint32_t produced, consumed; };
+struct DSync {
+    uint32_t produced;               // records published
+    uint32_t total;                  // number of records of the block, once the parser has stopped (else 0xFFFFFFFF)
+    uint32_t consumed[kCopiers];     // copier w has taken every record of its own below this index into registers
+    int      done[kCopiers];         // copier w has completed every record of its own below this index
+    uint32_t failed;                 // someone gave up: the retry kernel decides
+    int      end_value;              // the End record's decoded size
+};
 __device__ __forceinline__ uint32_t ld_acq(uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int ld_acq(int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void st_rel(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st_rel(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 constexpr uint32_t kSpinLimit = 1u << 24;    // a wait that long means the other wave is gone: give up (-> retry kernel) instead of hanging
 
 // PARSER wave: same acceptance rules as before, no output access at all
 __device__ void lz4_fast_parse(const uint8_t* src, int csize, int cap, uint8_t* lds, Rec* recs, DSync* sy, int lane)
 {
     uint32_t k = 0;                                                     // records published
-    auto slot = [&]() -> Rec* {                                         // next record, once the copier has freed it
-        for (uint32_t spins = 0; k >= ld_acq(&sy->consumed) + kRec; ) { __builtin_amdgcn_s_sleep(1); if (++spins > kSpinLimit) return nullptr; }
+    uint32_t op_km1 = 0, op_km2 = 0;                                    // where the two previous records start
+    auto stop = [&](bool failed) { if (lane == 0) { if (failed) sy->failed = 1; st_rel(&sy->total, k); } };
+    auto slot = [&]() -> Rec* {                                         // next record, once its copier has freed it
+        if (k >= uint32_t(kRec)) {
+            uint32_t* c = &sy->consumed[(k - kRec) % kCopiers];
+            for (uint32_t spins = 0; ld_acq(c) <= k - kRec; ) { __builtin_amdgcn_s_sleep(1); if (++spins > kSpinLimit) { stop(true); return nullptr; } }
+        }
         return recs + (k % kRec);
     };
-    auto publish = [&]() { if (lane == 0) st_rel(&sy->produced, k + 1); k++; };
-    auto finish = [&](uint32_t type, int value) { Rec* r = slot(); if (!r) return; if (lane == 0) { r->type = type; r->op = uint32_t(value); } publish(); };
+    auto publish = [&](uint32_t at) { if (lane == 0) st_rel(&sy->produced, k + 1); k++; op_km2 = op_km1; op_km1 = at; };
+    // the youngest earlier record whose output [its start, this record's start) a source range ending at `reach` touches
+    auto need_of = [&](uint32_t reach) -> int {
+        if (reach > op_km1) return int(k) - 1;
+        if (kCopiers >= 3 && reach > op_km2) return int(k) - 2;
+        return int(k) - kCopiers;
+    };
+    auto finish = [&](uint32_t type, int value) {
+        Rec* r = slot(); if (!r) return;
+        if (lane == 0) { r->type = type; r->op = uint32_t(value); r->need = int(k) - kCopiers; }
+        publish(uint32_t(value)); stop(false);
+    };
     if (cap < 64 || csize < 1) { finish(kRecRetry, 0); return; }
     Stream s; s.init(src, csize, lds, lane);
     const int iend = csize, oend = cap;
@@ -335,14 +366,18 @@ __device__ void lz4_fast_parse(const uint8_t* src, int csize, int cap, uint8_t* 
                 }
                 const uint32_t ostart = incl - sz;
                 const uint32_t off = wo & 0xffff;
-                const bool bad = is_tok && (off == 0 || off > uint32_t(op) + ostart + L);
+                const uint32_t mstart = uint32_t(op) + ostart + L;       // where this sequence's match starts
+                const bool bad = is_tok && (off == 0 || off > mstart);
                 if (__ballot(bad)) { finish(kRecRetry, 0); return; }
+                // how far the sources that lie before this record reach
+                const uint32_t reach1 = (is_tok && mstart - off < uint32_t(op)) ? min(mstart - off + ml, uint32_t(op)) : 0u;
+                const uint32_t reach = uint32_t(__builtin_amdgcn_readlane(int(scan_max(reach1, lane)), 63));
                 Rec* r = slot();
                 if (!r) return;
                 r->pack[lane] = ostart | (L << 13) | ((lhdr - 1) << 19);
                 r->offb[lane] = off | (b << 16);
-                if (lane == 0) { r->type = kRecBatch; r->T = T; r->op = uint32_t(op); r->tokmask = tokmask; }
-                publish();
+                if (lane == 0) { r->type = kRecBatch; r->T = T; r->op = uint32_t(op); r->tokmask = tokmask; r->need = need_of(reach); }
+                publish(uint32_t(op));
                 op += int(T);
                 ip += int(pos);
                 continue;
@@ -358,8 +393,8 @@ __device__ void lz4_fast_parse(const uint8_t* src, int csize, int cap, uint8_t* 
             if (ip + lit != iend || op + lit > oend) { finish(kRecRetry, 0); return; }
             Rec* r = slot();
             if (!r) return;
-            if (lane == 0) { r->type = kRecGeneral; r->T = 0; r->op = uint32_t(op); r->lit = uint32_t(lit); r->lit_ip = uint32_t(ip); r->off = 0; }
-            publish();
+            if (lane == 0) { r->type = kRecGeneral; r->T = 0; r->op = uint32_t(op); r->lit = uint32_t(lit); r->lit_ip = uint32_t(ip); r->off = 0; r->need = int(k) - kCopiers; }
+            publish(uint32_t(op));
             finish(kRecEnd, op + lit);
             return;
         }
@@ -373,37 +408,51 @@ __device__ void lz4_fast_parse(const uint8_t* src, int csize, int cap, uint8_t* 
         if (off == 0 || off > op2 || op2 + mlen > oend - 5) { finish(kRecRetry, 0); return; }
         Rec* r = slot();
         if (!r) return;
-        if (lane == 0) { r->type = kRecGeneral; r->T = uint32_t(mlen); r->op = uint32_t(op); r->lit = uint32_t(lit); r->lit_ip = uint32_t(lit_ip); r->off = uint32_t(off); }
-        publish();
+        const uint32_t reach = (op2 - off < op) ? uint32_t(min(op2 - off + mlen, op)) : 0u;
+        if (lane == 0) { r->type = kRecGeneral; r->T = uint32_t(mlen); r->op = uint32_t(op); r->lit = uint32_t(lit); r->lit_ip = uint32_t(lit_ip); r->off = uint32_t(off); r->need = need_of(reach); }
+        publish(uint32_t(op));
         op = op2 + mlen;
     }
 }
 
-// COPIER wave: executes the records in order
-__device__ int lz4_fast_copy(const uint8_t* src, uint8_t* dst, Rec* recs, DSync* sy, uint8_t* own, int lane)
+// COPIER wave w: executes records w, w + kCopiers, ... in order
+__device__ void lz4_fast_copy(const uint8_t* src, uint8_t* dst, Rec* recs, DSync* sy, uint8_t* own, int w, int lane)
 {
-    // One 64-byte step of output is kept PENDING in registers: it is stored only after the next
-    // step's loads have been issued, so a step waits for its own loads (vmcnt leaves the younger
-    // store outstanding) and never for a store acknowledgement.  Sources that fall into the
-    // pending step are forwarded from its registers.
-    uint32_t pv = 0; int p_base = 0, p_n = 0;
-    for (uint32_t k = 0;; k++) {
-        for (uint32_t spins = 0; ld_acq(&sy->produced) <= k; ) { __builtin_amdgcn_s_sleep(1); if (++spins > kSpinLimit) return kRetry; }
+    auto leave = [&](bool failed) {                                      // nobody may wait for this wave any more
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) { if (failed) sy->failed = 1; st_rel(&sy->done[w], 0x7FFFFFFF); st_rel(&sy->consumed[w], 0xFFFFFFFFu); }
+    };
+    for (uint32_t k = uint32_t(w);; k += kCopiers) {
+        for (uint32_t spins = 0; ld_acq(&sy->produced) <= k; ) {
+            if (ld_acq(&sy->total) <= k) { leave(false); return; }
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit) { leave(true); return; }
+        }
         Rec* r = recs + (k % kRec);
         const uint32_t type = r->type, T = r->T;
-        const int op = int(r->op);
+        const int op = int(r->op), need = r->need;
+        const unsigned long long tokmask = r->tokmask;
+        const uint32_t pack = r->pack[lane], ob = r->offb[lane];
+        const uint32_t lit = r->lit, lit_ip = r->lit_ip, goff = r->off;
+        if (lane == 0) st_rel(&sy->consumed[w], k + 1);                 // everything of the record is in registers now
+        if (type == kRecEnd) { if (lane == 0) sy->end_value = op; leave(false); return; }
+        if (type != kRecBatch && type != kRecGeneral) { leave(true); return; }
+        // the records this one reads from have to be complete
+        for (int o = 0; o < kCopiers; o++) {
+            if (o == w) continue;
+            for (uint32_t spins = 0; ld_acq(&sy->done[o]) <= need; ) { __builtin_amdgcn_s_sleep(1); if (++spins > kSpinLimit) { leave(true); return; } }
+        }
         if (type == kRecBatch) {
-            const unsigned long long tokmask = r->tokmask;
-            const uint32_t pack = r->pack[lane], ob = r->offb[lane];
-            if (lane == 0) st_rel(&sy->consumed, k + 1);                 // everything of the record is in registers now
             const uint32_t off = ob & 0xffff, b = ob >> 16;
             const bool is_tok = (tokmask >> lane) & 1;
             // owner map: own[o] = token lane + 1 at the first output byte of each sequence
             for (uint32_t i = 4u * lane; i < T; i += 256) *reinterpret_cast<uint32_t*>(own + i) = 0;
             if (is_tok) own[pack & 0x1FFF] = uint8_t(lane + 1);
-            uint32_t carry = 0;
-            if (p_n == 0) p_base = op;
-            for (uint32_t c0 = 0; c0 < T; c0 += 64) {
+            // One 64-byte step of output is kept PENDING in registers: it is stored only after the next step's loads
+            // have been issued, so a step waits for its own loads (vmcnt leaves the younger store outstanding) and never
+            // for a store acknowledgement.  Sources that fall into the pending step are forwarded from its registers.
+            uint32_t carry = 0, pv = 0;
+            auto step = [&](uint32_t c0, auto first) {
                 const uint32_t o = c0 + lane;
                 const bool live = o < T;
                 uint32_t m = live ? uint32_t(own[o]) : 0u;
@@ -417,18 +466,17 @@ __device__ int lz4_fast_copy(const uint8_t* src, uint8_t* dst, Rec* recs, DSync*
                 const bool is_lit = rel < Lt;
                 uint32_t v = __shfl(b, (tl + int(hdr) + int(rel)) & 63);    // literal byte from the window
                 const int sp = op + int(o) - int(offt);                     // absolute source of a match byte
-                const int cs = op + int(c0);                                // == p_base + p_n while a step is pending
+                const int cs = op + int(c0);
+                const int pn = decltype(first)::value ? 0 : 64;             // bytes pending (the previous step was a full one)
                 const bool is_match = live && !is_lit;
-                const bool from_mem = is_match && sp < cs - p_n;
-                const bool in_pend = is_match && sp >= cs - p_n && sp < cs;
+                const bool from_mem = is_match && sp < cs - pn;
+                const bool in_pend = is_match && sp >= cs - pn && sp < cs;
                 const uint32_t ld = dst[from_mem ? sp : 0];                 // issue this step's loads (branch-free) ...
-                // ... then store the previous step.  All 64 lanes store (no branch, so the load above
-                // and this store sit in one basic block and the wait below becomes vmcnt(1)): lanes
-                // >= p_n hit [cs, cs+64-p_n), bytes this very step re-writes later and that nothing
-                // reads from memory before then (they are served from the pending registers).
-                dst[p_base + lane] = uint8_t(pv);
-                const uint32_t fw = __shfl(pv, (sp - p_base) & 63);
-                if (in_pend) v = fw;
+                if constexpr (!decltype(first)::value) {
+                    dst[cs - 64 + lane] = uint8_t(pv);                      // ... then store the previous step
+                    const uint32_t fw = __shfl(pv, (sp - (cs - 64)) & 63);
+                    if (in_pend) v = fw;
+                }
                 if (from_mem) v = ld;
                 bool done = !is_match || from_mem || in_pend;
                 int dep = sp - cs;                                          // lane that produces my byte
@@ -439,51 +487,51 @@ __device__ int lz4_fast_copy(const uint8_t* src, uint8_t* dst, Rec* recs, DSync*
                     const int dd = __shfl(dep, d);
                     if (!done) { if (dn) { v = v2; done = true; } else dep = dd; }
                 }
-                pv = v; p_base = cs; p_n = min(64, int(T - c0));
-            }
-            continue;
-        }
-        const uint32_t lit = r->lit, lit_ip = r->lit_ip, off = r->off;
-        if (lane == 0) st_rel(&sy->consumed, k + 1);
-        if (type == kRecGeneral) {
-            if (lane < p_n) dst[p_base + lane] = uint8_t(pv);
-            p_n = 0; p_base = 0;
+                pv = v;
+            };
+            step(0u, std::true_type{});
+            uint32_t c0 = 64;
+            for (; c0 < T; c0 += 64) step(c0, std::false_type{});
+            if (uint32_t(lane) < T - (c0 - 64)) dst[op + int(c0 - 64) + lane] = uint8_t(pv);
+        } else {
             wave_copy(dst + op, src + lit_ip, int(lit), lane);
-            if (T) copy_match(dst, op + int(lit), int(off), int(T), lane);
-            continue;
+            if (T) copy_match(dst, op + int(lit), int(goff), int(T), lane);
         }
-        if (lane < p_n) dst[p_base + lane] = uint8_t(pv);
-        return type == kRecEnd ? op : kRetry;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) st_rel(&sy->done[w], int(k) + kCopiers);
     }
 }
 
 // retry_only = 0: fast path for every block (container rules as in the exact kernel);
-__global__ __launch_bounds__(128)
+__global__ __launch_bounds__(64 * (kCopiers + 1))
 void lz4_decode_fast_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
                             fourmc_block* blocks, uint32_t nblocks, int container_mode)
 {
     __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
-    __shared__ __attribute__((aligned(16))) uint8_t own[kOwnBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t own[kCopiers][kOwnBytes];
     __shared__ Rec recs[kRec];
     __shared__ DSync sy;
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
     const fourmc_block blk = blocks[b];
     if (container_mode && blk.result == FOURMC_BLK_BADSUM) return;
-    if (threadIdx.x == 0) { sy.produced = 0; sy.consumed = 0; }
+    if (threadIdx.x == 0) {
+        sy.produced = 0; sy.total = 0xFFFFFFFFu; sy.failed = 0; sy.end_value = kRetry;
+        for (int w = 0; w < kCopiers; w++) { sy.consumed[w] = 0; sy.done[w] = w; }
+    }
     __syncthreads();
     const uint8_t* src = src_base + blk.src_off;
     uint8_t* dst = dst_base + blk.dst_off;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
     const bool stored = container_mode && blk.src_len == blk.dst_cap;
-    if (threadIdx.x >= 64) {
-        if (!stored) lz4_fast_parse(src, int(blk.src_len), int(blk.dst_cap), ring, recs, &sy, lane);
+    if (stored) {
+        if (wave == 0) { wave_copy(dst, src, int(blk.src_len), lane); if (lane == 0) blocks[b].result = int(blk.src_len); }
         return;
     }
-    int r;
-    if (stored) { wave_copy(dst, src, int(blk.src_len), lane); r = int(blk.src_len); }
-    else r = lz4_fast_copy(src, dst, recs, &sy, own, lane);
-    if (lane == 0) blocks[b].result = r;
+    if (wave == kCopiers) lz4_fast_parse(src, int(blk.src_len), int(blk.dst_cap), ring, recs, &sy, lane);
+    else lz4_fast_copy(src, dst, recs, &sy, own[wave], wave, lane);
+    __syncthreads();
+    if (threadIdx.x == 0) blocks[b].result = sy.failed ? kRetry : sy.end_value;
 }
 
 // second pass: blocks the fast path handed back (result == kRetry) are decoded by the exact walker
@@ -515,7 +563,7 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
         hipLaunchKernelGGL(lz4_decode_exact_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(lz4_decode_fast_kernel, dim3(n), dim3(128), 0, stream, s8, d8, d_blocks, n, container_mode);
+    hipLaunchKernelGGL(lz4_decode_fast_kernel, dim3(n), dim3(64 * (kCopiers + 1)), 0, stream, s8, d8, d_blocks, n, container_mode);
     hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
     return hipGetLastError();
 }
