@@ -326,6 +326,9 @@ __device__ void lz4_fast_parse(const uint8_t* src, int csize, int cap, uint8_t* 
     const int iend = csize, oend = cap;
     int ip = 0, op = 0;
     for (;;) {
+        ip = __builtin_amdgcn_readfirstlane(ip); op = __builtin_amdgcn_readfirstlane(op); k = uint32_t(__builtin_amdgcn_readfirstlane(int(k)));
+        op_km1 = uint32_t(__builtin_amdgcn_readfirstlane(int(op_km1))); op_km2 = uint32_t(__builtin_amdgcn_readfirstlane(int(op_km2)));
+        s.fill_hi = __builtin_amdgcn_readfirstlane(s.fill_hi); s.la_pos = __builtin_amdgcn_readfirstlane(s.la_pos);
         // ---------------------------------------------------------------- batch of sequences inside one window
         if (ip + 64 + 16 <= iend && op + kOwnBytes + 64 + 16 <= oend) {
             // w: 4 consecutive stream bytes per lane (lane j = bytes ip+j .. ip+j+3)
@@ -344,13 +347,14 @@ __device__ void lz4_fast_parse(const uint8_t* src, int csize, int cap, uint8_t* 
             const uint32_t ml = (M0 == 15) ? 19 + e1 : M0 + 4;
             const uint32_t nxt = offpos + 2 + (M0 == 15 ? 1 : 0);
             const bool ok = (L0 != 15 || b1 != 255) && (M0 != 15 || e1 != 255) && nxt <= 64;
-            const unsigned long long okmask = __ballot(ok);
+            const uint32_t jump = ok ? nxt : 128u + uint32_t(lane);
             unsigned long long tokmask = 0;
             uint32_t pos = 0;
-            while (pos < 64 && ((okmask >> pos) & 1)) {
+            do {
                 tokmask |= 1ull << pos;
-                pos = uint32_t(__builtin_amdgcn_readlane(int(nxt), int(pos)));
-            }
+                pos = uint32_t(__builtin_amdgcn_readlane(int(jump), int(pos)));
+            } while (pos < 64);
+            if (pos >= 128) { pos -= 128; tokmask &= ~(1ull << pos); }
             if (tokmask) {
                 bool is_tok = (tokmask >> lane) & 1;
                 uint32_t sz = is_tok ? L + ml : 0;

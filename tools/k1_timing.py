@@ -32,6 +32,10 @@ if "--classes" in sys.argv:
     for b in range(12):
         run(torch.from_numpy(data[b * B:(b + 1) * B].copy()).cuda(), 1, names[b])
 nb = int(os.environ.get("FOURMC_BENCH_BLOCKS", "2048"))
+if "--class-load" in sys.argv:                      # the whole batch made of one class
+    data = helpers.corpus(12 * B)
+    for b in (0, 1, 3, 5, 10):
+        run(torch.from_numpy(data[b * B:(b + 1) * B].copy()).cuda().repeat(nb), nb, names[b] + " x%d" % nb)
 base = helpers.corpus(48 * B)
 src = torch.from_numpy(base).cuda().repeat(-(-nb // 48))[: nb * B].contiguous()
 run(src, nb, "S-mix")
