@@ -5,8 +5,9 @@
  *
  * Covered: ZSTD_fast (4mz "fast" = zstd level 1), ZSTD_dfast ("medium" = level 3), ZSTD_lazy / lazy2 with the row-hash
  * and hash-chain match finders ("high" = level 6: every size class; "ultra" = level 12: lazy2 for inputs > 256 KiB) and
- * ZSTD_btlazy2 (the binary-tree finder of level 12 between 16 KiB + 1 and 256 KiB).  Level 12 at 16 KiB and below uses
- * btopt, which is not restated: that, and any other level, returns ORC_ZSTD_UNSUPPORTED.
+ * ZSTD_btlazy2 (the binary-tree finder of level 12 between 16 KiB + 1 and 256 KiB) and ZSTD_btopt (the optimal parser of
+ * level 12 at 16 KiB and below: compress/zstd_opt.c, optLevel 0, first-block statistics).  Any other level returns
+ * ORC_ZSTD_UNSUPPORTED.
  *
  *   parameters   ZSTD_getCParams_internal        compress/zstd_compress.c:6465-6488, clevels.h:25-130,
  *                ZSTD_adjustCParams_internal     compress/zstd_compress.c:1335-1399
@@ -991,6 +992,7 @@ cleanup:
  * (ZSTD_RowFindBestMatch :1139-1250, row update :885-946, hash cache :842-883) or the hash-chain one
  * (ZSTD_HcFindBestMatch :649-730).  Which one: ZSTD_resolveRowMatchFinderMode (zstd_compress.c:232-248). */
 static uint32_t lz_mls(const zmatch* m) { return m->p.mml < 4 ? 4 : m->p.mml > 6 ? 6 : m->p.mml; }
+static uint32_t lz_mls3(const zmatch* m) { return m->p.mml < 3 ? 3 : m->p.mml > 6 ? 6 : m->p.mml; }   /* the bt of the optimal parser: 3..6 (zstd_opt.c:862) */
 static uint32_t lz_rowlog(const zmatch* m) { return m->p.slog < 4 ? 4 : m->p.slog > 6 ? 6 : m->p.slog; }
 static uint32_t row_hash(const zmatch* m, const uint8_t* s, uint32_t idx)
 { return zhash(s + idx - 2, m->p.hlog - lz_rowlog(m) + 8, lz_mls(m)); }
@@ -1277,15 +1279,315 @@ static size_t lazy_block(zmatch* m, uint32_t rep[3], const uint8_t* s, size_t st
     return end - anchor;
 }
 
+/* ------------------------------------------------------------------------------------------------ optimal parser */
+/* ZSTD_btopt (compress/zstd_opt.c, optLevel 0): zstd level 12 for inputs of 16 KiB and less (clevels.h:118), which are
+ * one block, so only the first-block statistics (zstd_opt.c:191-226) are restated.  Prices are in 1/256 bit. */
+#define OPT_NUM   4096
+#define OPT_MAXP  (1 << 30)
+#define OPT_BIT   256
+typedef struct { int price; uint32_t off, mlen, litlen, rep[3]; } optnode;
+typedef struct { uint32_t off, len; } optmatch;
+typedef struct {
+    uint32_t lit_freq[256], ll_freq[36], ml_freq[53], of_freq[32];
+    uint32_t lit_sum, ll_sum, ml_sum, of_sum, lit_base, ll_base, ml_base, of_base;
+    int predef;
+    optnode* node; optmatch* match;
+    uint32_t* hash3; uint32_t hlog3, next3;
+} optstate;
+
+static uint32_t opt_weight(uint32_t stat) { return (uint32_t)hibit(stat + 1) * OPT_BIT; }       /* ZSTD_bitWeight :40-43 */
+static void opt_base_prices(optstate* o)                                                         /* :71-78 */
+{ o->lit_base = opt_weight(o->lit_sum); o->ll_base = opt_weight(o->ll_sum); o->ml_base = opt_weight(o->ml_sum); o->of_base = opt_weight(o->of_sum); }
+
+static void opt_first_block_stats(optstate* o, const uint8_t* src, size_t n)                     /* ZSTD_rescaleFreqs :123-240, no dictionary */
+{
+    static const uint8_t of0[11] = {6, 2, 1, 1, 2, 3, 4, 4, 4, 3, 2};
+    unsigned i;
+    o->predef = n <= 1024;
+    memset(o->lit_freq, 0, sizeof o->lit_freq);
+    for (size_t k = 0; k < n; k++) o->lit_freq[src[k]]++;
+    o->lit_sum = 0;
+    for (i = 0; i < 256; i++) { o->lit_freq[i] = 1 + (o->lit_freq[i] >> 8); o->lit_sum += o->lit_freq[i]; }
+    o->ll_sum = 0;
+    for (i = 0; i < 36; i++) { o->ll_freq[i] = i == 0 ? 4 : i == 1 ? 2 : 1; o->ll_sum += o->ll_freq[i]; }
+    for (i = 0; i < 53; i++) o->ml_freq[i] = 1;
+    o->ml_sum = 53;
+    o->of_sum = 0;
+    for (i = 0; i < 32; i++) { o->of_freq[i] = i < 11 ? of0[i] : 1; o->of_sum += o->of_freq[i]; }
+    opt_base_prices(o);
+}
+
+static uint32_t opt_literal_price(const optstate* o, uint8_t b)                                  /* ZSTD_rawLiteralsCost :245-269, one literal */
+{
+    uint32_t w;
+    if (o->predef) return 6 * OPT_BIT;
+    w = opt_weight(o->lit_freq[b]);
+    if (w > o->lit_base - OPT_BIT) w = o->lit_base - OPT_BIT;
+    return o->lit_base - w;
+}
+static uint32_t opt_ll_price(const optstate* o, uint32_t ll)                                     /* ZSTD_litLengthPrice :273-292 */
+{
+    if (o->predef) return opt_weight(ll);
+    if (ll == BLOCK_MAX) return OPT_BIT + opt_ll_price(o, BLOCK_MAX - 1);
+    { const unsigned c = ll_code(ll); return kLLBits[c] * OPT_BIT + o->ll_base - opt_weight(o->ll_freq[c]); }
+}
+static uint32_t opt_match_price(const optstate* o, uint32_t off_base, uint32_t mlen)             /* ZSTD_getMatchPrice :300-328 */
+{
+    const uint32_t ofc = (uint32_t)hibit(off_base), mlb = mlen - 3;
+    uint32_t price;
+    if (o->predef) return opt_weight(mlb) + (16 + ofc) * OPT_BIT;
+    price = ofc * OPT_BIT + (o->of_base - opt_weight(o->of_freq[ofc]));
+    if (ofc >= 20) price += (ofc - 19) * 2 * OPT_BIT;
+    { const unsigned c = ml_code(mlb); price += kMLBits[c] * OPT_BIT + (o->ml_base - opt_weight(o->ml_freq[c])); }
+    return price + OPT_BIT / 5;
+}
+static void opt_count_sequence(optstate* o, uint32_t ll, const uint8_t* lits, uint32_t off_base, uint32_t mlen)   /* ZSTD_updateStats :332-363 */
+{
+    for (uint32_t u = 0; u < ll; u++) o->lit_freq[lits[u]] += 2;
+    o->lit_sum += 2 * ll;
+    o->ll_freq[ll_code(ll)]++; o->ll_sum++;
+    o->of_freq[hibit(off_base)]++; o->of_sum++;
+    o->ml_freq[ml_code(mlen - 3)]++; o->ml_sum++;
+}
+static void opt_new_rep(uint32_t out[3], const uint32_t rep[3], uint32_t off_base, uint32_t ll0)                  /* ZSTD_newRep, zstd_compress_internal.h:676-706 */
+{
+    uint32_t r0 = rep[0], r1 = rep[1], r2 = rep[2];
+    if (off_base > 3) { r2 = r1; r1 = r0; r0 = off_base - 3; }
+    else {
+        const uint32_t code = off_base - 1 + ll0;
+        if (code > 0) { const uint32_t v = code == 3 ? r0 - 1 : code == 1 ? r1 : r2; if (code >= 2) r2 = r1; r1 = r0; r0 = v; }
+    }
+    out[0] = r0; out[1] = r1; out[2] = r2;
+}
+static uint32_t opt_hash3(const uint8_t* p, uint32_t hlog) { return ((rd32(p) << 8) * 506832829u) >> (32 - hlog); }  /* ZSTD_hash3Ptr */
+static uint32_t opt_rd3(const uint8_t* p, uint32_t minmatch) { return minmatch == 3 ? rd32(p) << 8 : rd32(p); }        /* ZSTD_readMINMATCH :369-380 */
+
+/* ZSTD_insertBt1 (:414-530): index curr enters the tree; returns how many positions to move on */
+static uint32_t opt_tree_insert(zmatch* m, const uint8_t* s, uint32_t curr, size_t end, uint32_t target)
+{
+    uint32_t* const bt = m->small;
+    const uint32_t bt_mask = (1u << (m->p.clog - 1)) - 1, bt_low = bt_mask >= curr ? 0 : curr - bt_mask;
+    const uint32_t window_low = lz_low_limit(m, target);
+    const size_t ip = curr - 2;
+    const uint32_t h = zhash(s + ip, m->p.hlog, lz_mls3(m));
+    uint32_t mi = m->table[h], smaller = 2 * (curr & bt_mask), larger = smaller + 1, end_idx = curr + 8 + 1, left = 1u << m->p.slog;
+    size_t common_s = 0, common_l = 0, best = 8;
+    m->table[h] = curr;
+    for (; left && mi >= window_low; --left) {
+        const uint32_t next = 2 * (mi & bt_mask);
+        const size_t match = mi - 2;
+        size_t ml = common_s < common_l ? common_s : common_l;
+        ml += count_eq(s, ip + ml, match + ml, end);
+        if (ml > best) { best = ml; if (ml > end_idx - mi) end_idx = mi + (uint32_t)ml; }
+        if (ip + ml == end) break;
+        if (s[match + ml] < s[ip + ml]) {
+            if (smaller != ~0u) bt[smaller] = mi;
+            common_s = ml;
+            if (mi <= bt_low) { smaller = ~0u; break; }
+            smaller = next + 1; mi = bt[next + 1];
+        } else {
+            if (larger != ~0u) bt[larger] = mi;
+            common_l = ml;
+            if (mi <= bt_low) { larger = ~0u; break; }
+            larger = next; mi = bt[next];
+        }
+    }
+    if (smaller != ~0u) bt[smaller] = 0;
+    if (larger != ~0u) bt[larger] = 0;
+    {   uint32_t positions = 0;
+        if (best > 384) positions = best - 384 < 192 ? (uint32_t)(best - 384) : 192;
+        return positions > end_idx - (curr + 8) ? positions : end_idx - (curr + 8);
+    }
+}
+
+/* ZSTD_btGetAllMatches (:798-816) = ZSTD_updateTree_internal (:533-552) + ZSTD_insertBtAndGetAllMatches (:559-786), noDict:
+ * every match at ip longer than the ones before it, shortest first; ip enters the tree */
+static uint32_t opt_matches(zmatch* m, optstate* o, const uint8_t* s, size_t ip, size_t end, const uint32_t rep[3], uint32_t ll0, uint32_t to_beat)
+{
+    const uint32_t curr = (uint32_t)ip + 2, mls = lz_mls3(m), minmatch = mls == 3 ? 3 : 4;
+    const uint32_t sufficient = m->p.tlen < OPT_NUM - 1 ? m->p.tlen : OPT_NUM - 1;
+    uint32_t* const bt = m->small;
+    optmatch* const out = o->match;
+    uint32_t n = 0;
+    size_t best = to_beat - 1;
+    if (curr < m->next_to_update) return 0;                                      /* skipped area */
+    for (uint32_t idx = m->next_to_update; idx < curr; ) idx += opt_tree_insert(m, s, idx, end, curr);
+    m->next_to_update = curr;
+    {
+        const uint32_t bt_mask = (1u << (m->p.clog - 1)) - 1, bt_low = bt_mask >= curr ? 0 : curr - bt_mask;
+        const uint32_t window_low = lz_low_limit(m, curr), match_low = window_low ? window_low : 1;
+        const uint32_t h = zhash(s + ip, m->p.hlog, mls);
+        uint32_t mi = m->table[h], smaller = 2 * (curr & bt_mask), larger = smaller + 1, end_idx = curr + 8 + 1, left = 1u << m->p.slog;
+        size_t common_s = 0, common_l = 0;
+        /* repeat offsets */
+        for (uint32_t code = ll0; code < 3 + ll0; code++) {
+            const uint32_t off = code == 3 ? rep[0] - 1 : rep[code];
+            uint32_t len = 0;
+            if (off - 1 < curr - m->dict_limit) {                                /* 1 <= off <= distance to the prefix start */
+                if (curr - off >= window_low && opt_rd3(s + ip, minmatch) == opt_rd3(s + ip - off, minmatch))
+                    len = (uint32_t)count_eq(s, ip + minmatch, ip + minmatch - off, end) + minmatch;
+            }
+            if (len > best) {
+                best = len;
+                out[n].off = code - ll0 + 1; out[n].len = len; n++;
+                if (len > sufficient || ip + len == end) return n;
+            }
+        }
+        /* 3-byte matches through their own hash table (:385-404, :659-688) */
+        if (mls == 3 && best < mls) {
+            uint32_t i3;
+            for (uint32_t idx = o->next3; idx < curr; idx++) o->hash3[opt_hash3(s + idx - 2, o->hlog3)] = idx;
+            o->next3 = curr;
+            i3 = o->hash3[opt_hash3(s + ip, o->hlog3)];
+            if (i3 >= match_low && curr - i3 < (1u << 18)) {
+                const size_t len = count_eq(s, ip, i3 - 2, end);
+                if (len >= mls) {
+                    best = len;
+                    out[0].off = curr - i3 + 3; out[0].len = (uint32_t)len; n = 1;
+                    if (len > sufficient || ip + len == end) { m->next_to_update = curr + 1; return 1; }
+                }
+            }
+        }
+        m->table[h] = curr;
+        for (; left && mi >= match_low; --left) {
+            const uint32_t next = 2 * (mi & bt_mask);
+            const size_t match = mi - 2;
+            size_t ml = common_s < common_l ? common_s : common_l;
+            ml += count_eq(s, ip + ml, match + ml, end);
+            if (ml > best) {
+                if (ml > end_idx - mi) end_idx = mi + (uint32_t)ml;
+                best = ml;
+                out[n].off = curr - mi + 3; out[n].len = (uint32_t)ml; n++;
+                if (ml > OPT_NUM || ip + ml == end) break;                       /* equal to the end: no order, keep the tree consistent */
+            }
+            if (s[match + ml] < s[ip + ml]) {
+                if (smaller != ~0u) bt[smaller] = mi;
+                common_s = ml;
+                if (mi <= bt_low) { smaller = ~0u; break; }
+                smaller = next + 1; mi = bt[next + 1];
+            } else {
+                if (larger != ~0u) bt[larger] = mi;
+                common_l = ml;
+                if (mi <= bt_low) { larger = ~0u; break; }
+                larger = next; mi = bt[next];
+            }
+        }
+        if (smaller != ~0u) bt[smaller] = 0;
+        if (larger != ~0u) bt[larger] = 0;
+        m->next_to_update = end_idx - 8;                                         /* skip repetitive patterns */
+    }
+    return n;
+}
+
+/* ZSTD_compressBlock_opt_generic (:1039-1325), optLevel 0, no dictionary, no long-distance matches */
+static size_t opt_block(zmatch* m, optstate* o, uint32_t rep[3], const uint8_t* s, size_t start, size_t end)
+{
+    optnode* const node = o->node;
+    const optmatch* const match = o->match;
+    const int64_t ilimit = (int64_t)end - 8;
+    const uint32_t sufficient = m->p.tlen < OPT_NUM - 1 ? m->p.tlen : OPT_NUM - 1, minmatch = m->p.mml == 3 ? 3 : 4;
+    size_t ip = start, anchor = start;
+    o->next3 = m->next_to_update;
+    opt_first_block_stats(o, s + start, end - start);
+    ip += (uint32_t)ip + 2 == m->dict_limit;
+    while ((int64_t)ip < ilimit) {
+        uint32_t cur, last_pos = 0;
+        optnode last;
+        {   /* the matches at ip open a series */
+            const uint32_t litlen = (uint32_t)(ip - anchor), ll0 = !litlen;
+            const uint32_t nb = opt_matches(m, o, s, ip, end, rep, ll0, minmatch);
+            uint32_t pos, lits_price;
+            if (!nb) { ip++; continue; }
+            memcpy(node[0].rep, rep, sizeof node[0].rep);
+            node[0].mlen = 0; node[0].litlen = litlen; node[0].price = (int)opt_ll_price(o, litlen);
+            if (match[nb - 1].len > sufficient) {                                /* long match: taken at once */
+                last.litlen = litlen; last.mlen = match[nb - 1].len; last.off = match[nb - 1].off; last.price = 0;
+                cur = 0;
+                goto shortest_path;
+            }
+            lits_price = (uint32_t)node[0].price + opt_ll_price(o, 0);
+            for (pos = 1; pos < minmatch; pos++) node[pos].price = OPT_MAXP;
+            for (uint32_t k = 0; k < nb; k++)
+                for (; pos <= match[k].len; pos++) {
+                    node[pos].mlen = pos; node[pos].off = match[k].off; node[pos].litlen = litlen;
+                    node[pos].price = (int)(lits_price + opt_match_price(o, match[k].off, pos));
+                }
+            last_pos = pos - 1;
+        }
+        for (cur = 1; cur <= last_pos; cur++) {
+            const size_t inr = ip + cur;
+            {   /* one more literal, if that is not dearer */
+                const uint32_t litlen = node[cur - 1].mlen == 0 ? node[cur - 1].litlen + 1 : 1;
+                const int price = node[cur - 1].price + (int)opt_literal_price(o, s[inr - 1]) + (int)opt_ll_price(o, litlen) - (int)opt_ll_price(o, litlen - 1);
+                if (price <= node[cur].price) { node[cur].mlen = 0; node[cur].off = 0; node[cur].litlen = litlen; node[cur].price = price; }
+            }
+            if (node[cur].mlen != 0) opt_new_rep(node[cur].rep, node[cur - node[cur].mlen].rep, node[cur].off, node[cur].litlen == 0);
+            else memcpy(node[cur].rep, node[cur - 1].rep, sizeof node[cur].rep);
+            if ((int64_t)inr > ilimit) continue;                                 /* the last match starts at least 8 bytes before the end */
+            if (cur == last_pos) break;
+            if (node[cur + 1].price <= node[cur].price + OPT_BIT / 2) continue;  /* unpromising position */
+            {
+                const uint32_t ll0 = node[cur].mlen != 0, litlen = node[cur].mlen == 0 ? node[cur].litlen : 0;
+                const uint32_t base = (uint32_t)node[cur].price + opt_ll_price(o, 0);
+                const uint32_t nb = opt_matches(m, o, s, inr, end, node[cur].rep, ll0, minmatch);
+                if (!nb) continue;
+                if (match[nb - 1].len > sufficient || cur + match[nb - 1].len >= OPT_NUM) {
+                    last.mlen = match[nb - 1].len; last.off = match[nb - 1].off; last.litlen = litlen; last.price = 0;
+                    cur -= node[cur].mlen == 0 ? node[cur].litlen : 0;           /* may wrap: then it is the first sequence */
+                    if (cur > OPT_NUM) cur = 0;
+                    goto shortest_path;
+                }
+                for (uint32_t k = 0; k < nb; k++) {
+                    const uint32_t first = k ? match[k - 1].len + 1 : minmatch;
+                    for (uint32_t mlen = match[k].len; mlen >= first; mlen--) {  /* downwards */
+                        const uint32_t pos = cur + mlen;
+                        const int price = (int)base + (int)opt_match_price(o, match[k].off, mlen);
+                        if (pos > last_pos || price < node[pos].price) {
+                            while (last_pos < pos) node[++last_pos].price = OPT_MAXP;
+                            node[pos].mlen = mlen; node[pos].off = match[k].off; node[pos].litlen = litlen; node[pos].price = price;
+                        } else break;                                            /* optLevel 0: early abort */
+                    }
+                }
+            }
+        }
+        last = node[last_pos];
+        cur = last_pos > last.litlen + last.mlen ? last_pos - (last.litlen + last.mlen) : 0;
+shortest_path:
+        if (last.mlen != 0) opt_new_rep(rep, node[cur].rep, last.off, last.litlen == 0);
+        else memcpy(rep, node[cur].rep, 3 * sizeof(uint32_t));
+        {   /* walk back through the chosen arrivals, then emit them front to back */
+            const uint32_t store_end = cur + 1;
+            uint32_t store_start = store_end, seq_pos = cur;
+            node[store_end] = last;
+            while (seq_pos > 0) {
+                const uint32_t back = node[seq_pos].litlen + node[seq_pos].mlen;
+                store_start--;
+                node[store_start] = node[seq_pos];
+                seq_pos = seq_pos > back ? seq_pos - back : 0;
+            }
+            for (uint32_t k = store_start; k <= store_end; k++) {
+                const uint32_t llen = node[k].litlen, mlen = node[k].mlen;
+                if (mlen == 0) { ip = anchor + llen; continue; }                 /* trailing literals: the next series starts behind them */
+                opt_count_sequence(o, llen, s + anchor, node[k].off, mlen);
+                store_seq(m, s, anchor, llen, node[k].off, mlen);
+                anchor += llen + mlen;
+                ip = anchor;
+            }
+            opt_base_prices(o);
+        }
+    }
+    return end - anchor;
+}
+
 /* ------------------------------------------------------------------------------------------------ frame */
-/* clevels.h rows of the levels 4mz uses; strat: 1 fast, 2 dfast, 4 lazy, 5 lazy2, 6 btlazy2, 0 = a strategy this port does not restate */
+/* clevels.h rows of the levels 4mz uses; strat: 1 fast, 2 dfast, 4 lazy, 5 lazy2, 6 btlazy2, 7 btopt */
 static zparams level_params(int level, size_t n)
 {
     static const zparams rows[4][4] = {            /* tables for > 256 KB, <= 256 KB, <= 128 KB, <= 16 KB */
         {{19, 13, 14, 1, 7, 0, 1}, {18, 13, 14, 1, 6, 0, 1}, {17, 12, 13, 1, 6, 0, 1}, {14, 14, 15, 1, 5, 0, 1}},     /* level 1  */
         {{21, 16, 17, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {17, 15, 16, 2, 5, 0, 2}, {14, 14, 15, 2, 4, 0, 2}},     /* level 3  */
         {{21, 18, 19, 3, 5, 4, 4}, {18, 18, 19, 3, 5, 4, 4}, {17, 16, 17, 3, 4, 4, 4}, {14, 14, 14, 4, 4, 8, 5}},     /* level 6  */
-        {{22, 22, 23, 6, 5, 32, 5}, {18, 19, 19, 7, 4, 12, 6}, {17, 18, 17, 7, 4, 12, 6}, {14, 15, 14, 4, 3, 24, 0}}};/* level 12: btlazy2 below 256 KB, btopt (not restated) below 16 KB */
+        {{22, 22, 23, 6, 5, 32, 5}, {18, 19, 19, 7, 4, 12, 6}, {17, 18, 17, 7, 4, 12, 6}, {14, 15, 14, 4, 3, 24, 7}}};/* level 12: btlazy2 below 256 KB, btopt at 16 KB and less */
     zparams p = rows[level == 3 ? 1 : level == 6 ? 2 : level == 12 ? 3 : 0][(n <= 256 * 1024) + (n <= 128 * 1024) + (n <= 16 * 1024)];
     const uint32_t src_log = n < 64 ? 6 : (uint32_t)hibit((uint32_t)(n - 1)) + 1;
     if (p.wlog > src_log) p.wlog = src_log;
@@ -1302,6 +1604,7 @@ int64_t orc_zstd_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap
 {
     zparams p;
     zmatch m;
+    optstate opt;
     zentropy ent[2];
     int cur = 0, first = 1;
     size_t o = 0, pos = 0, block;
@@ -1334,6 +1637,12 @@ int64_t orc_zstd_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap
     m.table = (uint32_t*)calloc((size_t)1 << p.hlog, 4);
     m.small = (uint32_t*)calloc((size_t)1 << p.clog, 4);
     m.tags = (uint8_t*)calloc((size_t)2 << p.hlog, 1);
+    memset(&opt, 0, sizeof opt);
+    if (p.strat == 7) {
+        opt.node = (optnode*)malloc((OPT_NUM + 2) * sizeof(optnode)); opt.match = (optmatch*)malloc((OPT_NUM + 2) * sizeof(optmatch));
+        opt.hlog3 = p.mml == 3 ? (p.wlog < 17 ? p.wlog : 17) : 1;       /* ZSTD_reset_matchState: hashLog3 = MIN(ZSTD_HASHLOG3_MAX, windowLog) */
+        opt.hash3 = (uint32_t*)calloc((size_t)1 << opt.hlog3, 4);
+    }
     m.next_to_update = m.low_limit = m.dict_limit = 2;                /* ZSTD_WINDOW_START_INDEX */
     memset(m.hash_cache, 0, sizeof m.hash_cache);
     m.seq = (zseq*)malloc((BLOCK_MAX / 3 + 1) * sizeof(zseq));
@@ -1369,7 +1678,8 @@ int64_t orc_zstd_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap
                 const uint32_t curr = (uint32_t)pos + 2;
                 if (curr > m.next_to_update + 384) { const uint32_t gap = curr - m.next_to_update - 384; m.next_to_update = curr - (gap < 192 ? gap : 192); }
             }
-            if (p.strat >= 4) tail = lazy_block(&m, next->rep, src, pos, pos + len, p.strat >= 5 ? 2 : 1, p.strat == 6 ? 2 : p.wlog > 14);
+            if (p.strat == 7) tail = opt_block(&m, &opt, next->rep, src, pos, pos + len);
+            else if (p.strat >= 4) tail = lazy_block(&m, next->rep, src, pos, pos + len, p.strat >= 5 ? 2 : 1, p.strat == 6 ? 2 : p.wlog > 14);
             else tail = p.strat == 2 ? dfast_block(&m, next->rep, src, pos, pos + len) : fast_block(&m, next->rep, src, pos, pos + len);
             memcpy(m.lit + m.nlit, src + pos + len - tail, tail); m.nlit += tail;
             lsz = compress_literals(prev, next, out, bcap, m.lit, m.nlit, m.nseq == 0 || m.nlit / m.nseq >= 20, p.strat);
@@ -1397,7 +1707,7 @@ int64_t orc_zstd_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap
         }
         pos += len; first = 0;
     }
-    free(m.table); free(m.small); free(m.tags); free(m.seq); free(m.lit); free(llc);
+    free(m.table); free(m.small); free(m.tags); free(m.seq); free(m.lit); free(llc); free(opt.node); free(opt.match); free(opt.hash3);
     return result < 0 ? result : (int64_t)o;
 }
 

@@ -241,9 +241,6 @@ def test_zstd_enc_port_golden_manifest(level, key):
             continue                                   # level 12 runs at ~25 MB/s on one host core: sample
         blk = data[b * B: b * B + u]
         r, comp = helpers.orc_zstd_compress(blk, level, u - 1)
-        if level == 12 and u <= 16 * 1024:
-            assert r == -1000                          # btopt size class: refused, not guessed
-            continue
         payload = comp if r > 0 else blk
         assert (len(payload), helpers.orc_xxh32(payload)) == (c, x), b
         if r > 0 and b % 4 == 0:                       # and the frames decode back with the decoder port
@@ -252,16 +249,13 @@ def test_zstd_enc_port_golden_manifest(level, key):
 
 @pytest.mark.skipif(helpers.ref() is None, reason="oracle/_ref not built (needs /root/reference)")
 def test_zstd_enc_port_level12_size_classes():
-    """Level 12: lazy2 above 256 KiB, btlazy2 (binary tree) down to 16 KiB + 1 - both pinned to the reference's own
-    ZSTD_compress here; at 16 KiB and below the reference uses btopt, which the port does not restate: it must say
-    so, not guess."""
+    """Level 12: lazy2 above 256 KiB, btlazy2 (binary tree) down to 16 KiB + 1, btopt (optimal parser) at 16 KiB and
+    below - all three pinned to the reference's own ZSTD_compress here."""
     import ctypes as C
     ref = helpers.ref()
     ref.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]; ref.ZSTD_compress.restype = C.c_size_t
-    r, _ = helpers.orc_zstd_compress(helpers.corpus(16384), 12)
-    assert r == -1000
-    r, _ = helpers.orc_zstd_compress(helpers.corpus(300000), 12)
-    assert r > 0
+    assert helpers.orc_zstd_compress(helpers.corpus(16384), 12)[0] > 0 and helpers.orc_zstd_compress(helpers.corpus(300000), 12)[0] > 0
+    assert helpers.orc_zstd_compress(helpers.corpus(1000), 9)[0] == -1000          # a level 4mz never uses: refused, not guessed
 
     def check(d, cap, tag):
         d = np.array(d, dtype=np.uint8, copy=True)
@@ -278,11 +272,20 @@ def test_zstd_enc_port_level12_size_classes():
         off = int(rng.integers(0, 2 * B))
         check(src[off:off + n], helpers.zstd_bound(n), "size")
         check(src[off:off + n], n - 1, "size n-1")
+    # btopt: price model switches at 1024 bytes (predefined costs), window / table clamps below
+    for n in (0, 1, 2, 3, 7, 8, 9, 12, 13, 17, 63, 64, 65, 255, 256, 257, 1000, 1023, 1024, 1025, 2048, 4095, 4096, 4097, 8192, 10000, 16383, 16384):
+        for _ in range(2):
+            off = int(rng.integers(0, 2 * B))
+            check(src[off:off + n], helpers.zstd_bound(n), "btopt size")
+            check(src[off:off + n], max(n - 1, 0), "btopt size n-1")
     for name, d in helpers.edge_inputs().items():
-        if len(d) > 16384:
-            d = d[:262144]
-            for cap in {len(d) - 1, helpers.zstd_bound(len(d)), len(d) // 3}:
+        for d in ([d[:262144]] if len(d) > 16384 else []) + [d[:16384], d[:5000], d[:700]]:
+            for cap in {max(len(d) - 1, 0), helpers.zstd_bound(len(d)), len(d) // 3}:
                 check(d, cap, name)
+    import test_gpu_fuzz                                                # the structured fuzz inputs of the GPU suite, cut to btopt sizes
+    for d in test_gpu_fuzz._inputs(77, 120):
+        d = d[: int(rng.integers(0, 16385))] if len(d) > 16384 else d
+        check(d, max(len(d) - 1, 0), "btopt fuzz")
     d = src[5000: 5000 + 70000]
     c = check(d, helpers.zstd_bound(len(d)), "bound")
     for cap in range(max(0, c - 16), c + 6):
