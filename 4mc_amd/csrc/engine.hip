@@ -177,21 +177,13 @@ int fourmc_gpu_zstd_decompress(const void* d_src, void* d_dst, fourmc_block* d_b
     return FOURMC_OK;
 }
 
-// zstd level 12 is on the device for inputs > 16 KiB (lazy2 above 256 KiB, btlazy2 below; at 16 KiB and less the
-// reference switches to btopt): refuse the whole batch rather than emit anything the reference would not
-static int zstd_level_ok(const fourmc_block* d_blocks, uint32_t n, int level, hipStream_t s)
+// zstd levels on the device: 1 (fast), 3 (dfast), 6 (lazy / lazy2), 12 (lazy2, btlazy2, btopt by input size) - the levels 4mz uses;
+// any other level is refused rather than answered with bytes the reference would not emit
+static int zstd_level_ok(const fourmc_block*, uint32_t, int level, hipStream_t)
 {
-    if (level == 1 || level == 3 || level == 6) return FOURMC_OK;
-    if (level != 12) { snprintf(g_err, sizeof g_err, "ZSTD level %d not on the device (levels 1, 3, 6 and 12 are)", level); return FOURMC_EUNSUP; }
-    std::vector<fourmc_block> h(n);
-    HIP_TRY(hipMemcpyAsync(h.data(), d_blocks, n * sizeof(fourmc_block), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    for (uint32_t b = 0; b < n; b++)
-        if (h[b].src_len <= 16u * 1024u) {
-            snprintf(g_err, sizeof g_err, "ZSTD level 12 not on the device for inputs <= 16 KiB (block %u has %u bytes; the reference uses btopt there)", b, h[b].src_len);
-            return FOURMC_EUNSUP;
-        }
-    return FOURMC_OK;
+    if (level == 1 || level == 3 || level == 6 || level == 12) return FOURMC_OK;
+    snprintf(g_err, sizeof g_err, "ZSTD level %d not on the device (levels 1, 3, 6 and 12 are)", level);
+    return FOURMC_EUNSUP;
 }
 
 static int zstd_enc_serial() { const char* e = getenv("FOURMC_ZSTD_SERIAL"); return e && *e == '1'; }

@@ -95,14 +95,6 @@ static int compress_file(int displayLevel, int overwrite, char* in_name, char* o
     } else {                                                          /* native/4mc.c:411-419   */
         codec = FOURMC_CODEC_ZSTD;
         codec_level = level <= 1 ? 1 : level == 2 ? 3 : level == 3 ? 6 : 12;
-        if (codec_level == 12 && strcmp(in_name, FOURMC_STDINMARK)) {
-            /* zstd level 12 runs on the device for blocks > 16 KiB (lazy2, btlazy2; at 16 KiB and less the reference
-             * uses btopt): refuse a file whose last block is that small BEFORE the output is created */
-            struct stat st;
-            long long fsz = (stat(in_name, &st) == 0 && S_ISREG(st.st_mode)) ? (long long)st.st_size : -1;
-            if (fsz > 0 && fsz % BLOCKSIZE != 0 && fsz % BLOCKSIZE <= 16 * 1024)
-                DIE(1, "GPU engine error : 4mz ultra (zstd level 12) is not on the device for a final block of %lld bytes (<= 16 KiB)", fsz % BLOCKSIZE);
-        }
     }
     open_io(displayLevel, overwrite, in_name, out_name, &fin, &fout);
 

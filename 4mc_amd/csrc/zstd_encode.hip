@@ -1558,18 +1558,19 @@ __device__ __forceinline__ void bt_insert1(LazyState& Z, const Params& P, const 
         ml += count_fwd(s, ip + ml, match + ml, end, lane);
         if (ip + ml == end) break;                                           // equal: no way to know if smaller or larger
         if (s[match + ml] < s[ip + ml]) {
-            if (lane == 0 && smaller != 0xFFFFFFFFu) bt[smaller] = mi;
+            if (smaller != 0xFFFFFFFFu) bt[smaller] = mi;
             common_smaller = ml;
             if (mi <= bt_low) { smaller = 0xFFFFFFFFu; break; }
             smaller = next + 1; mi = bt[next + 1];
         } else {
-            if (lane == 0 && larger != 0xFFFFFFFFu) bt[larger] = mi;
+            if (larger != 0xFFFFFFFFu) bt[larger] = mi;
             common_larger = ml;
             if (mi <= bt_low) { larger = 0xFFFFFFFFu; break; }
             larger = next; mi = bt[next];
         }
     }
-    if (lane == 0) { if (smaller != 0xFFFFFFFFu) bt[smaller] = 0; if (larger != 0xFFFFFFFFu) bt[larger] = 0; }
+    if (smaller != 0xFFFFFFFFu) bt[smaller] = 0;
+    if (larger != 0xFFFFFFFFu) bt[larger] = 0;
 }
 
 __device__ __forceinline__ uint32_t bt_search(LazyState& Z, const Params& P, const uint8_t* s, uint32_t ip, uint32_t end, uint32_t& ofb, int lane)
@@ -1580,7 +1581,7 @@ __device__ __forceinline__ uint32_t bt_search(LazyState& Z, const Params& P, con
     for (uint32_t idx = Z.ntu; idx < curr; idx++) {                          // ZSTD_updateDUBT: chain the new positions in, unsorted
         const uint32_t hh = zhash(ld8(s + idx - 2), P.hlog, mls);
         const uint32_t old = Z.tab[hh];
-        if (lane == 0) { bt[2 * (idx & bt_mask)] = old; bt[2 * (idx & bt_mask) + 1] = 1u; Z.tab[hh] = idx; }
+        bt[2 * (idx & bt_mask)] = old; bt[2 * (idx & bt_mask) + 1] = 1u; Z.tab[hh] = idx;
     }
     Z.ntu = curr;
     const uint32_t h = zhash(ld8(s + ip), P.hlog, mls);
@@ -1591,12 +1592,12 @@ __device__ __forceinline__ uint32_t bt_search(LazyState& Z, const Params& P, con
     uint32_t nb_compares = 1u << P.slog, nb_candidates = nb_compares, previous = 0;
     while (mi > unsort_limit && bt[2 * (mi & bt_mask) + 1] == 1u && nb_candidates > 1) {   // reach the end of the unsorted candidates
         const uint32_t nxt = bt[2 * (mi & bt_mask)];
-        if (lane == 0) bt[2 * (mi & bt_mask) + 1] = previous;
+        bt[2 * (mi & bt_mask) + 1] = previous;
         previous = mi; mi = nxt;
         nb_candidates--;
     }
     if (mi > unsort_limit && bt[2 * (mi & bt_mask) + 1] == 1u) {             // nullify the last one if still unsorted
-        if (lane == 0) { bt[2 * (mi & bt_mask)] = 0; bt[2 * (mi & bt_mask) + 1] = 0; }
+        bt[2 * (mi & bt_mask)] = 0; bt[2 * (mi & bt_mask) + 1] = 0;
     }
     mi = previous;
     while (mi) {                                                             // batch sort the stacked candidates
@@ -1608,7 +1609,7 @@ __device__ __forceinline__ uint32_t bt_search(LazyState& Z, const Params& P, con
     uint32_t common_smaller = 0, common_larger = 0, best = 0;
     uint32_t smaller = 2 * (curr & bt_mask), larger = smaller + 1, match_end_idx = curr + 8 + 1;
     mi = Z.tab[h];
-    if (lane == 0) Z.tab[h] = curr;
+    Z.tab[h] = curr;
     for (; nb_compares && mi > window_low; --nb_compares) {
         const uint32_t next = 2 * (mi & bt_mask), match = mi - 2;
         uint32_t ml = min(common_smaller, common_larger);
@@ -1619,34 +1620,36 @@ __device__ __forceinline__ uint32_t bt_search(LazyState& Z, const Params& P, con
             if (ip + ml == end) break;                                       // equal: drop, to keep the tree consistent
         }
         if (s[match + ml] < s[ip + ml]) {
-            if (lane == 0 && smaller != 0xFFFFFFFFu) bt[smaller] = mi;
+            if (smaller != 0xFFFFFFFFu) bt[smaller] = mi;
             common_smaller = ml;
             if (mi <= bt_low) { smaller = 0xFFFFFFFFu; break; }
             smaller = next + 1; mi = bt[next + 1];
         } else {
-            if (lane == 0 && larger != 0xFFFFFFFFu) bt[larger] = mi;
+            if (larger != 0xFFFFFFFFu) bt[larger] = mi;
             common_larger = ml;
             if (mi <= bt_low) { larger = 0xFFFFFFFFu; break; }
             larger = next; mi = bt[next];
         }
     }
-    if (lane == 0) { if (smaller != 0xFFFFFFFFu) bt[smaller] = 0; if (larger != 0xFFFFFFFFu) bt[larger] = 0; }
+    if (smaller != 0xFFFFFFFFu) bt[smaller] = 0;
+    if (larger != 0xFFFFFFFFu) bt[larger] = 0;
     Z.ntu = match_end_idx - 8;                                               // skip repetitive patterns
     return best;
 }
 
+template <bool kTree>
 __device__ __forceinline__ uint32_t lazy_block(ZLds& L, SeqStore& S, LazyState& Z, const Params& P, uint32_t rep[3],
                                                const uint8_t* s, uint32_t start, uint32_t end, uint32_t n_total, int lane)
 {
-    const bool use_row = P.strat != 6 && P.wlog > 14;
+    const bool use_row = !kTree && P.wlog > 14;
     const uint32_t depth = P.strat >= 5 ? 2u : 1u;
     const int64_t ilimit = int64_t(end) - 8 - (use_row ? 8 : 0);
     const uint32_t prefix_idx = Z.dict_limit, prefix = prefix_idx - 2;
     uint32_t ip = start, anchor = start;
     uint32_t rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0;
     auto search = [&](uint32_t at, uint32_t& ofb) -> uint32_t {
-        if (P.strat == 6) return bt_search(Z, P, s, at, end, ofb, lane);
-        return use_row ? row_search(L, Z, P, s, at, end, n_total, ofb, lane) : hc_search(Z, P, s, at, end, n_total, ofb, lane);
+        if constexpr (kTree) return bt_search(Z, P, s, at, end, ofb, lane);
+        else return use_row ? row_search(L, Z, P, s, at, end, n_total, ofb, lane) : hc_search(Z, P, s, at, end, n_total, ofb, lane);
     };
     ip += (ip == prefix) ? 1 : 0;
     {
@@ -1723,14 +1726,318 @@ __device__ __forceinline__ uint32_t lazy_block(ZLds& L, SeqStore& S, LazyState& 
     return end - anchor;
 }
 
+// ------------------------------------------------------------------------------------------------ optimal parser
+// ZSTD_btopt (compress/zstd_opt.c, optLevel 0; restated in oracle/zstd_enc_port.c): zstd level 12 for inputs of 16 KiB and less
+// (clevels.h:118), i.e. a file's short last block.  One block, so only the first-block statistics exist (:191-226).  The
+// forward pass is a chain of dependent price updates: the wave runs it in lockstep (every lane computes and stores the
+// same values, byte comparisons use all lanes).  Everything lives in the block's workspace: hash table, binary tree, 3-byte hash table, price nodes
+// (7 words each), match list, symbol statistics.  Prices are in 1/256 bit.
+constexpr uint32_t kOptNum = 4096, kOptBit = 256;
+constexpr int      kOptMaxPrice = 1 << 30;
+struct OptState {
+    uint32_t *lit_freq, *ll_freq, *ml_freq, *of_freq;             // 256 / 36 / 53 / 32
+    uint32_t lit_sum, ll_sum, ml_sum, of_sum, lit_base, ll_base, ml_base, of_base;
+    bool predef;
+    uint32_t* node;                                               // [kOptNum + 2][7]: price, off, mlen, litlen, rep[3]
+    uint32_t* match;                                              // [kOptNum + 2][2]: off, len
+    uint32_t* hash3; uint32_t hlog3, next3;
+};
+// Every lane stores the same value to the same word: a lane-0-only store followed by a load in the other lanes is a
+// data race in the language's eyes (the compiler may forward the old value to them), a store by all lanes is not.
+#define OPT_W0(lhs, rhs) do { (lhs) = (rhs); } while (0)
+__device__ __forceinline__ uint32_t opt_weight(uint32_t stat) { return uint32_t(hibit(stat + 1)) * kOptBit; }      // ZSTD_bitWeight :40-43
+__device__ __forceinline__ void opt_base_prices(OptState& o)                                                       // :71-78
+{ o.lit_base = opt_weight(o.lit_sum); o.ll_base = opt_weight(o.ll_sum); o.ml_base = opt_weight(o.ml_sum); o.of_base = opt_weight(o.of_sum); }
+__device__ __forceinline__ uint32_t opt_literal_price(const OptState& o, uint32_t b)                               // ZSTD_rawLiteralsCost :245-269, one literal
+{
+    if (o.predef) return 6 * kOptBit;
+    return o.lit_base - min(opt_weight(o.lit_freq[b]), o.lit_base - kOptBit);
+}
+__device__ __forceinline__ uint32_t opt_ll_price(const OptState& o, uint32_t ll)                                   // ZSTD_litLengthPrice :273-292
+{
+    if (o.predef) return opt_weight(ll);
+    const uint32_t c = ll_code(ll);
+    return ll_bits(c) * kOptBit + o.ll_base - opt_weight(o.ll_freq[c]);
+}
+__device__ __forceinline__ uint32_t opt_match_price(const OptState& o, uint32_t off_base, uint32_t mlen)           // ZSTD_getMatchPrice :300-328
+{
+    const uint32_t ofc = uint32_t(hibit(off_base)), mlb = mlen - 3;
+    if (o.predef) return opt_weight(mlb) + (16 + ofc) * kOptBit;
+    uint32_t price = ofc * kOptBit + (o.of_base - opt_weight(o.of_freq[ofc]));
+    if (ofc >= 20) price += (ofc - 19) * 2 * kOptBit;
+    const uint32_t c = ml_code(mlb);
+    price += ml_bits(c) * kOptBit + (o.ml_base - opt_weight(o.ml_freq[c]));
+    return price + kOptBit / 5;
+}
+__device__ __forceinline__ void opt_new_rep(uint32_t out[3], uint32_t r0, uint32_t r1, uint32_t r2, uint32_t off_base, uint32_t ll0)   // ZSTD_newRep
+{
+    if (off_base > 3) { r2 = r1; r1 = r0; r0 = off_base - 3; }
+    else {
+        const uint32_t code = off_base - 1 + ll0;
+        if (code > 0) { const uint32_t v = code == 3 ? r0 - 1 : code == 1 ? r1 : r2; if (code >= 2) r2 = r1; r1 = r0; r0 = v; }
+    }
+    out[0] = r0; out[1] = r1; out[2] = r2;
+}
+__device__ __forceinline__ uint32_t opt_hash3(uint32_t v, uint32_t hlog) { return ((v << 8) * 506832829u) >> (32 - hlog); }            // ZSTD_hash3Ptr
+
+// ZSTD_insertBt1 (:414-530): index curr enters the tree; returns how many positions to move on
+__device__ __forceinline__ uint32_t opt_tree_insert(LazyState& Z, const Params& P, const uint8_t* s, uint32_t curr, uint32_t end, uint32_t target, int lane)
+{
+    uint32_t* const bt = Z.chain;
+    const uint32_t bt_mask = (1u << (P.clog - 1)) - 1, bt_low = bt_mask >= curr ? 0u : curr - bt_mask;
+    const uint32_t window_low = lz_low(Z, P, target), ip = curr - 2;
+    const uint32_t h = zhash(ld4(s + ip), P.hlog, 4);
+    uint32_t mi = Z.tab[h], smaller = 2 * (curr & bt_mask), larger = smaller + 1, end_idx = curr + 8 + 1, left = 1u << P.slog;
+    uint32_t common_s = 0, common_l = 0, best = 8;
+    OPT_W0(Z.tab[h], curr);
+    for (; left && mi >= window_low; --left) {
+        const uint32_t next = 2 * (mi & bt_mask), match = mi - 2;
+        uint32_t ml = min(common_s, common_l);
+        ml += count_fwd(s, ip + ml, match + ml, end, lane);
+        if (ml > best) { best = ml; if (ml > end_idx - mi) end_idx = mi + ml; }
+        if (ip + ml == end) break;
+        if (s[match + ml] < s[ip + ml]) {
+            if (smaller != 0xFFFFFFFFu) OPT_W0(bt[smaller], mi);
+            common_s = ml;
+            if (mi <= bt_low) { smaller = 0xFFFFFFFFu; break; }
+            smaller = next + 1; mi = bt[next + 1];
+        } else {
+            if (larger != 0xFFFFFFFFu) OPT_W0(bt[larger], mi);
+            common_l = ml;
+            if (mi <= bt_low) { larger = 0xFFFFFFFFu; break; }
+            larger = next; mi = bt[next];
+        }
+    }
+    if (smaller != 0xFFFFFFFFu) OPT_W0(bt[smaller], 0u);
+    if (larger != 0xFFFFFFFFu) OPT_W0(bt[larger], 0u);
+    const uint32_t positions = best > 384 ? min(192u, best - 384) : 0u;
+    return max(positions, end_idx - (curr + 8));
+}
+
+// ZSTD_btGetAllMatches (:798-816) = ZSTD_updateTree_internal (:533-552) + ZSTD_insertBtAndGetAllMatches (:559-786), noDict, mls 3:
+// every match at ip longer than the ones before it, shortest first (o.match); ip enters the tree
+__device__ __forceinline__ uint32_t opt_matches(LazyState& Z, const Params& P, OptState& o, const uint8_t* s, uint32_t ip, uint32_t end,
+                                uint32_t r0, uint32_t r1, uint32_t r2, uint32_t ll0, int lane)
+{
+    const uint32_t curr = ip + 2, sufficient = min(P.tlen, kOptNum - 1);
+    uint32_t* const bt = Z.chain;
+    uint32_t* const out = o.match;
+    uint32_t n = 0, best = 2;                                                    // lengthToBeat - 1, minMatch 3
+    if (curr < Z.ntu) return 0;                                                  // skipped area
+    for (uint32_t idx = Z.ntu; idx < curr; ) idx += opt_tree_insert(Z, P, s, idx, end, curr, lane);
+    Z.ntu = curr;
+    const uint32_t bt_mask = (1u << (P.clog - 1)) - 1, bt_low = bt_mask >= curr ? 0u : curr - bt_mask;
+    const uint32_t window_low = lz_low(Z, P, curr), match_low = window_low ? window_low : 1u;
+    const uint32_t word = ld4(s + ip), h = zhash(word, P.hlog, 4);
+    uint32_t mi = Z.tab[h], smaller = 2 * (curr & bt_mask), larger = smaller + 1, end_idx = curr + 8 + 1, left = 1u << P.slog;
+    uint32_t common_s = 0, common_l = 0;
+    for (uint32_t code = ll0; code < 3 + ll0; code++) {                          // repeat offsets
+        const uint32_t off = code == 3 ? r0 - 1 : code == 0 ? r0 : code == 1 ? r1 : r2;
+        uint32_t len = 0;
+        if (off - 1 < curr - Z.dict_limit) {                                     // 1 <= off <= distance to the prefix start
+            if (curr - off >= window_low && (word << 8) == (ld4(s + ip - off) << 8))
+                len = count_fwd(s, ip + 3, ip + 3 - off, end, lane) + 3;
+        }
+        if (len > best) {
+            best = len;
+            OPT_W0(out[2 * n], code - ll0 + 1); OPT_W0(out[2 * n + 1], len); n++;
+            if (len > sufficient || ip + len == end) return n;
+        }
+    }
+    if (best < 3) {                                                              // 3-byte matches through their own hash table (:385-404, :659-688)
+        for (uint32_t idx = o.next3; idx < curr; idx++) o.hash3[opt_hash3(ld4(s + idx - 2), o.hlog3)] = idx;   // in index order
+        o.next3 = curr;
+        const uint32_t i3 = o.hash3[opt_hash3(word, o.hlog3)];
+        if (i3 >= match_low && curr - i3 < (1u << 18)) {
+            const uint32_t len = count_fwd(s, ip, i3 - 2, end, lane);
+            if (len >= 3) {
+                best = len;
+                OPT_W0(out[0], curr - i3 + 3); OPT_W0(out[1], len); n = 1;
+                if (len > sufficient || ip + len == end) { Z.ntu = curr + 1; return 1; }
+            }
+        }
+    }
+    OPT_W0(Z.tab[h], curr);
+    for (; left && mi >= match_low; --left) {
+        const uint32_t next = 2 * (mi & bt_mask), match = mi - 2;
+        uint32_t ml = min(common_s, common_l);
+        ml += count_fwd(s, ip + ml, match + ml, end, lane);
+        if (ml > best) {
+            if (ml > end_idx - mi) end_idx = mi + ml;
+            best = ml;
+            OPT_W0(out[2 * n], curr - mi + 3); OPT_W0(out[2 * n + 1], ml); n++;
+            if (ml > kOptNum || ip + ml == end) break;                           // equal to the end: no order, keep the tree consistent
+        }
+        if (s[match + ml] < s[ip + ml]) {
+            if (smaller != 0xFFFFFFFFu) OPT_W0(bt[smaller], mi);
+            common_s = ml;
+            if (mi <= bt_low) { smaller = 0xFFFFFFFFu; break; }
+            smaller = next + 1; mi = bt[next + 1];
+        } else {
+            if (larger != 0xFFFFFFFFu) OPT_W0(bt[larger], mi);
+            common_l = ml;
+            if (mi <= bt_low) { larger = 0xFFFFFFFFu; break; }
+            larger = next; mi = bt[next];
+        }
+    }
+    if (smaller != 0xFFFFFFFFu) OPT_W0(bt[smaller], 0u);
+    if (larger != 0xFFFFFFFFu) OPT_W0(bt[larger], 0u);
+    Z.ntu = end_idx - 8;                                                         // skip repetitive patterns
+    return n;
+}
+
+// ZSTD_compressBlock_opt_generic (:1039-1325), optLevel 0, no dictionary, no long-distance matches
+__device__ __forceinline__ uint32_t opt_block(ZLds& L, SeqStore& S, LazyState& Z, const Params& P, uint32_t rep[3], uint32_t* area,
+                                                        const uint8_t* s, uint32_t start, uint32_t end, int lane)
+{
+    OptState o;
+    o.hlog3 = min(P.wlog, 17u);                                                  // ZSTD_reset_matchState: hashLog3 = MIN(ZSTD_HASHLOG3_MAX, windowLog)
+    o.hash3 = area; area += size_t(1) << o.hlog3;
+    o.node = area; area += (kOptNum + 2) * 7;
+    o.match = area;
+    o.lit_freq = L.count; o.ll_freq = L.qstack; o.ml_freq = L.qstack + 64; o.of_freq = L.qstack + 128;      // LDS: free until the entropy stage
+    uint32_t* const node = o.node;
+#define ND(i, f) node[(i) * 7 + (f)]                                             /* f: 0 price, 1 off, 2 mlen, 3 litlen, 4..6 rep */
+    {   // ZSTD_rescaleFreqs :123-240, first block, no dictionary
+        const uint32_t n = end - start;
+        o.predef = n <= 1024;
+        for (uint32_t i = lane; i < (1u << o.hlog3); i += 64) o.hash3[i] = 0;
+        { uint32_t largest, max_sym; hist_bytes(L, s + start, n, largest, max_sym, lane); }
+        uint32_t part = 0;
+        for (int i = lane; i < 256; i += 64) { const uint32_t v = 1 + (o.lit_freq[i] >> 8); o.lit_freq[i] = v; part += v; }
+        o.lit_sum = rl(scan_add(part), 63);
+        for (int i = lane; i < 36; i += 64) o.ll_freq[i] = i == 0 ? 4u : i == 1 ? 2u : 1u;
+        for (int i = lane; i < 53; i += 64) o.ml_freq[i] = 1;
+        for (int i = lane; i < 32; i += 64) o.of_freq[i] = i < 11 ? uint32_t((0x23444321126ull >> (4 * i)) & 15) : 1u;   // 6,2,1,1,2,3,4,4,4,3,2
+        o.ll_sum = 4 + 2 + 34; o.ml_sum = 53; o.of_sum = 32 + 21;
+        opt_base_prices(o);
+    }
+    const int64_t ilimit = int64_t(end) - 8;
+    const uint32_t sufficient = min(P.tlen, kOptNum - 1), minmatch = 3;
+    uint32_t ip = start, anchor = start;
+    o.next3 = Z.ntu;
+    ip += (ip + 2 == Z.dict_limit) ? 1u : 0u;
+    while (int64_t(ip) < ilimit) {
+        uint32_t cur, last_pos = 0;
+        uint32_t last_off, last_mlen, last_litlen;
+        bool jump = false;
+        {   // the matches at ip open a series
+            const uint32_t litlen = ip - anchor, ll0 = litlen ? 0u : 1u;
+            const uint32_t nb = opt_matches(Z, P, o, s, ip, end, rep[0], rep[1], rep[2], ll0, lane);
+            if (!nb) { ip++; continue; }
+            const uint32_t price0 = opt_ll_price(o, litlen);
+            OPT_W0(ND(0, 0), price0); OPT_W0(ND(0, 2), 0u); OPT_W0(ND(0, 3), litlen);
+            OPT_W0(ND(0, 4), rep[0]); OPT_W0(ND(0, 5), rep[1]); OPT_W0(ND(0, 6), rep[2]);
+            const uint32_t max_len = o.match[2 * (nb - 1) + 1], max_off = o.match[2 * (nb - 1)];
+            if (max_len > sufficient) {                                          // long match: taken at once
+                last_litlen = litlen; last_mlen = max_len; last_off = max_off; cur = 0; jump = true;
+            } else {
+                const uint32_t lits_price = price0 + opt_ll_price(o, 0);
+                uint32_t pos = 1;
+                for (; pos < minmatch; pos++) OPT_W0(ND(pos, 0), uint32_t(kOptMaxPrice));
+                for (uint32_t k = 0; k < nb; k++) {
+                    const uint32_t off = o.match[2 * k], len = o.match[2 * k + 1];
+                    for (; pos <= len; pos++) {
+                        const uint32_t pr = lits_price + opt_match_price(o, off, pos);
+                        OPT_W0(ND(pos, 0), pr); OPT_W0(ND(pos, 1), off); OPT_W0(ND(pos, 2), pos); OPT_W0(ND(pos, 3), litlen);
+                    }
+                }
+                last_pos = pos - 1;
+            }
+        }
+        if (!jump) {
+            for (cur = 1; cur <= last_pos; cur++) {
+                const uint32_t inr = ip + cur;
+                {   // one more literal, if that is not dearer
+                    const uint32_t pm = ND(cur - 1, 2), litlen = pm == 0 ? ND(cur - 1, 3) + 1 : 1u;
+                    const int price = int(ND(cur - 1, 0)) + int(opt_literal_price(o, s[inr - 1])) + int(opt_ll_price(o, litlen)) - int(opt_ll_price(o, litlen - 1));
+                    if (price <= int(ND(cur, 0))) { OPT_W0(ND(cur, 0), uint32_t(price)); OPT_W0(ND(cur, 1), 0u); OPT_W0(ND(cur, 2), 0u); OPT_W0(ND(cur, 3), litlen); }
+                }
+                const uint32_t c_mlen = ND(cur, 2), c_litlen = ND(cur, 3), c_off = ND(cur, 1);
+                uint32_t cr[3];
+                if (c_mlen != 0) { const uint32_t pv = cur - c_mlen; opt_new_rep(cr, ND(pv, 4), ND(pv, 5), ND(pv, 6), c_off, c_litlen == 0 ? 1u : 0u); }
+                else { cr[0] = ND(cur - 1, 4); cr[1] = ND(cur - 1, 5); cr[2] = ND(cur - 1, 6); }
+                OPT_W0(ND(cur, 4), cr[0]); OPT_W0(ND(cur, 5), cr[1]); OPT_W0(ND(cur, 6), cr[2]);
+                if (int64_t(inr) > ilimit) continue;                             // the last match starts at least 8 bytes before the end
+                if (cur == last_pos) break;
+                const int c_price = int(ND(cur, 0));
+                if (int(ND(cur + 1, 0)) <= c_price + int(kOptBit / 2)) continue; // unpromising position
+                const uint32_t ll0 = c_mlen != 0 ? 1u : 0u, litlen = c_mlen == 0 ? c_litlen : 0u;
+                const uint32_t base = uint32_t(c_price) + opt_ll_price(o, 0);
+                const uint32_t nb = opt_matches(Z, P, o, s, inr, end, cr[0], cr[1], cr[2], ll0, lane);
+                if (!nb) continue;
+                const uint32_t max_len = o.match[2 * (nb - 1) + 1];
+                if (max_len > sufficient || cur + max_len >= kOptNum) {
+                    last_mlen = max_len; last_off = o.match[2 * (nb - 1)]; last_litlen = litlen;
+                    cur -= c_mlen == 0 ? c_litlen : 0u;                          // may wrap: then it is the first sequence
+                    if (cur > kOptNum) cur = 0;
+                    jump = true;
+                    break;
+                }
+                for (uint32_t k = 0; k < nb; k++) {
+                    const uint32_t off = o.match[2 * k], len = o.match[2 * k + 1];
+                    const uint32_t first = k ? o.match[2 * (k - 1) + 1] + 1 : minmatch;
+                    for (uint32_t mlen = len; mlen >= first; mlen--) {           // downwards
+                        const uint32_t pos = cur + mlen;
+                        const int price = int(base) + int(opt_match_price(o, off, mlen));
+                        if (pos > last_pos || price < int(ND(pos, 0))) {
+                            while (last_pos < pos) { last_pos++; OPT_W0(ND(last_pos, 0), uint32_t(kOptMaxPrice)); }
+                            OPT_W0(ND(pos, 0), uint32_t(price)); OPT_W0(ND(pos, 1), off); OPT_W0(ND(pos, 2), mlen); OPT_W0(ND(pos, 3), litlen);
+                        } else break;                                            // optLevel 0: early abort
+                    }
+                }
+            }
+            if (!jump) {
+                last_off = ND(last_pos, 1); last_mlen = ND(last_pos, 2); last_litlen = ND(last_pos, 3);
+                cur = last_pos > last_litlen + last_mlen ? last_pos - (last_litlen + last_mlen) : 0u;
+            }
+        }
+        // shortest path: the next series' repeat offsets, then the chosen arrivals walked back and emitted front to back
+        {
+            const uint32_t a = ND(cur, 4), b = ND(cur, 5), c = ND(cur, 6);
+            if (last_mlen != 0) opt_new_rep(rep, a, b, c, last_off, last_litlen == 0 ? 1u : 0u);
+            else { rep[0] = a; rep[1] = b; rep[2] = c; }
+        }
+        const uint32_t store_end = cur + 1;
+        uint32_t store_start = store_end, seq_pos = cur;
+        OPT_W0(ND(store_end, 1), last_off); OPT_W0(ND(store_end, 2), last_mlen); OPT_W0(ND(store_end, 3), last_litlen);
+        while (seq_pos > 0) {
+            const uint32_t f1 = ND(seq_pos, 1), f2 = ND(seq_pos, 2), f3 = ND(seq_pos, 3);
+            store_start--;
+            OPT_W0(ND(store_start, 1), f1); OPT_W0(ND(store_start, 2), f2); OPT_W0(ND(store_start, 3), f3);
+            const uint32_t back = f3 + f2;
+            seq_pos = seq_pos > back ? seq_pos - back : 0u;
+        }
+        for (uint32_t k = store_start; k <= store_end; k++) {
+            const uint32_t off = ND(k, 1), mlen = ND(k, 2), llen = ND(k, 3);
+            if (mlen == 0) { ip = anchor + llen; continue; }                     // trailing literals: the next series starts behind them
+            {   // ZSTD_updateStats :332-363
+                for (uint32_t u = lane; u < llen; u += 64) atomicAdd(&o.lit_freq[s[anchor + u]], 2u);
+                o.lit_sum += 2 * llen;
+                const uint32_t lc = ll_code(llen), oc = uint32_t(hibit(off)), mc = ml_code(mlen - 3);
+                const uint32_t v0 = o.ll_freq[lc], v1 = o.of_freq[oc], v2 = o.ml_freq[mc];
+                OPT_W0(o.ll_freq[lc], v0 + 1); OPT_W0(o.of_freq[oc], v1 + 1); OPT_W0(o.ml_freq[mc], v2 + 1);
+                o.ll_sum++; o.of_sum++; o.ml_sum++;
+            }
+            store_seq(S, s, anchor, llen, off, mlen, lane);
+            anchor += llen + mlen;
+            ip = anchor;
+        }
+        opt_base_prices(o);
+    }
+#undef ND
+    return end - anchor;
+}
+
 // ------------------------------------------------------------------------------------------------ frame
 __device__ __forceinline__ Params level_params(uint32_t n, int level)
 {
     Params p;
     uint32_t wlog, hlog, clog;
     p.slog = 1;
-    if (level == 12) {                                  // clevels.h level 12: ZSTD_lazy2 above 256 KB, ZSTD_btlazy2 (strat 6) below; <= 16 KB is btopt (refused by the engine)
-        if (n <= 128 * 1024) { wlog = 17; clog = 18; hlog = 17; p.slog = 7; p.mml = 4; p.strat = 6; }
+    if (level == 12) {                                  // clevels.h level 12: ZSTD_lazy2 above 256 KB, ZSTD_btlazy2 (strat 6) below, ZSTD_btopt (strat 7) at 16 KB and less
+        if (n <= 16 * 1024) { wlog = 14; clog = 15; hlog = 14; p.slog = 4; p.mml = 3; p.strat = 7; }
+        else if (n <= 128 * 1024) { wlog = 17; clog = 18; hlog = 17; p.slog = 7; p.mml = 4; p.strat = 6; }
         else if (n <= 256 * 1024) { wlog = 18; clog = 19; hlog = 19; p.slog = 7; p.mml = 4; p.strat = 6; }
         else { wlog = 22; clog = 22; hlog = 23; p.slog = 6; p.mml = 5; p.strat = 5; }
     } else if (level == 6) {                                   // clevels.h rows of level 6 (ZSTD_lazy; lazy2 for <= 16 KB)
@@ -1756,7 +2063,7 @@ __device__ __forceinline__ Params level_params(uint32_t n, int level)
     if (hlog > wlog + 1) hlog = wlog + 1;
     if (clog - (p.strat >= 6 ? 1u : 0u) > wlog) clog = wlog + (p.strat >= 6 ? 1u : 0u);   // ZSTD_cycleLog: a binary tree has half as many nodes
     if (wlog < 10) wlog = 10;
-    p.wlog = wlog; p.hlog = hlog; p.clog = clog; p.tlen = 0;
+    p.wlog = wlog; p.hlog = hlog; p.clog = clog; p.tlen = p.strat == 7 ? 24u : 0u;
     return p;
 }
 
@@ -1769,9 +2076,12 @@ __device__ __forceinline__ bool is_rle(const uint8_t* s, uint32_t n, int lane)
 }
 
 // ZSTD_compress(dst, cap, src, n, 1); returns the frame size or a negative ZSTD error number
+// kTree: the instance for the binary-tree strategies of level 12 (btlazy2 up to 256 KiB, btopt up to 16 KiB: a file's short last
+// block), compiled into a kernel of its own so that their code does not weigh on the register allocation of the fast /
+// dfast / lazy paths every full block takes (with the tree finder inlined next to it, dfast ran 7 % slower)
+template <bool kTree>
 __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* work, int level, bool serial, int lane)
 {
-    if (level == 12 && n <= 16 * 1024) return kErrGeneric;       // btopt: refused by the engine before launch; never silently stored
     const Params P = level_params(n, level);
     uint32_t* const tab = reinterpret_cast<uint32_t*>(work + kStoreBytes);
     uint32_t* const tab_s = reinterpret_cast<uint32_t*>(work + kStoreBytes + (size_t(4) << 17));      // level 3: short-hash table
@@ -1817,7 +2127,7 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
         }
         if (P.strat >= 4) {                                    // tag table (2 bytes per entry) or chain table (4 bytes per entry)
             uint4* s4 = reinterpret_cast<uint4*>(Z.tags);
-            const uint32_t m16 = (P.strat != 6 && P.wlog > 14) ? (2u << P.hlog) / 16 : (4u << P.clog) / 16;
+            const uint32_t m16 = (P.strat < 6 && P.wlog > 14) ? (2u << P.hlog) / 16 : (4u << P.clog) / 16;
             for (uint32_t i = lane; i < m16; i += 64) s4[i] = make_uint4(0, 0, 0, 0);
         }
         for (int i = lane; i < 1024; i += 64) L.score[i] = 0xFFFFFFFFu;
@@ -1852,7 +2162,9 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
             ZPH(t_out);
             if (pos + 2 > Z.ntu + 384) { const uint32_t gap = pos + 2 - Z.ntu - 384; Z.ntu = pos + 2 - min(gap, 192u); }   // ZSTD_buildSeqStore :2890-2896
             uint32_t tail;
-            if (P.strat >= 4) tail = lazy_block(L, S, Z, P, ne.rep, src, pos, pos + len, n, lane);
+            if constexpr (kTree) tail = P.strat == 7 ? opt_block(L, S, Z, P, ne.rep, Z.chain + (size_t(1) << P.clog), src, pos, pos + len, lane)
+                                                     : lazy_block<true>(L, S, Z, P, ne.rep, src, pos, pos + len, n, lane);
+            else if (P.strat >= 4) tail = lazy_block<false>(L, S, Z, P, ne.rep, src, pos, pos + len, n, lane);
             else tail = P.strat == 2 ? dfast_block(L, S, tab, tab_s, P, ne.rep, src, pos, pos + len, lane)
                                      : fast_block(L, S, tab, P, ne.rep, src, pos, pos + len, n, serial, lane);
             gather_literals(S, src, pos, lane);
@@ -1901,22 +2213,41 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
 
 // container_mode 0: ZSTD_compress(dst + dst_off, dst_cap, src + src_off, src_len, 1) -> size or -(error number)
 // container_mode 1: native/4mc.c:467-489 (capacity n-1; an error stores the block raw)
+__device__ __forceinline__ bool tree_sized(int level, uint32_t n) { return level == 12 && n <= 256 * 1024; }   // clevels.h:66,92,118: btlazy2, btopt
+
+template <bool kTree>
+__device__ __forceinline__ void zstd_encode_one(ZLds& L, const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks, uint32_t nblocks,
+                                                uint8_t* work_base, int container_mode, int level, int serial)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    const int lane = threadIdx.x;
+    const fourmc_block blk = blocks[b];
+    const uint32_t n = blk.src_len;
+    if (tree_sized(level, n) != kTree) return;                  // the other kernel's block
+    const uint8_t* src = src_base + blk.src_off;
+    uint8_t* dst = dst_base + blk.dst_off;
+    const uint32_t cap = container_mode ? (n ? n - 1 : 0) : blk.dst_cap;
+    int r = zstd_encode_frame<kTree>(L, src, n, dst, cap, work_base + size_t(b) * (kStoreBytes + table_bytes(level)), level, serial != 0, lane);
+    if (container_mode && r <= 0) { copy_bytes(dst, src, n, lane); r = int(n); }
+    if (lane == 0) blocks[b].result = r;
+}
+
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void zstd_encode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks, uint32_t nblocks,
                         uint8_t* work_base, int container_mode, int level, int serial)
 {
     __shared__ ZLds L;
-    const uint32_t b = blockIdx.x;
-    if (b >= nblocks) return;
-    const int lane = threadIdx.x;
-    const fourmc_block blk = blocks[b];
-    const uint8_t* src = src_base + blk.src_off;
-    uint8_t* dst = dst_base + blk.dst_off;
-    const uint32_t n = blk.src_len;
-    const uint32_t cap = container_mode ? (n ? n - 1 : 0) : blk.dst_cap;
-    int r = zstd_encode_frame(L, src, n, dst, cap, work_base + size_t(b) * (kStoreBytes + table_bytes(level)), level, serial != 0, lane);
-    if (container_mode && r <= 0) { copy_bytes(dst, src, n, lane); r = int(n); }
-    if (lane == 0) blocks[b].result = r;
+    zstd_encode_one<false>(L, src_base, dst_base, blocks, nblocks, work_base, container_mode, level, serial);
+}
+
+// level 12, blocks of 256 KiB and less (a file's short last block): binary-tree finder, optimal parser below 16 KiB
+__global__ __launch_bounds__(64)
+void zstd_encode_tree_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks, uint32_t nblocks,
+                            uint8_t* work_base, int container_mode, int level, int serial)
+{
+    __shared__ ZLds L;
+    zstd_encode_one<true>(L, src_base, dst_base, blocks, nblocks, work_base, container_mode, level, serial);
 }
 
 } // namespace
@@ -1930,5 +2261,9 @@ extern "C" hipError_t fourmc_launch_zstd_encode(const void* d_src, void* d_dst, 
     hipLaunchKernelGGL(zstd_encode_kernel, dim3(n), dim3(64), 0, stream,
                        static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n,
                        static_cast<uint8_t*>(d_work), container_mode, level, serial);
+    if (level == 12)
+        hipLaunchKernelGGL(zstd_encode_tree_kernel, dim3(n), dim3(64), 0, stream,
+                           static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n,
+                           static_cast<uint8_t*>(d_work), container_mode, level, serial);
     return hipGetLastError();
 }

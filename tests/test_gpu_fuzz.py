@@ -62,8 +62,6 @@ def _run(gpu, srcs, caps, launch):
 def test_fuzz_encoders_equal_oracle(gpu, codec):
     srcs = _inputs({"lz4_fast": 1, "lz4_mc": 2, "lz4_hc4": 3, "zstd1": 4, "zstd3": 5, "zstd6": 6, "zstd12": 7}[codec],
                    60 if codec == "lz4_hc4" else 240 if codec == "zstd12" else 160)
-    if codec == "zstd12":                                 # btlazy2 (16 KiB + 1 .. 256 KiB) and lazy2 above; btopt sizes are refused
-        srcs = [s for s in srcs if len(s) > 16384]
     lz4_bound = [helpers.oracle().orc_lz4_compress_bound(len(s)) for s in srcs]
     rng = np.random.default_rng(99)
     # a mix of capacities: bound, n-1 (container), and something smaller

@@ -153,10 +153,10 @@ def test_host_zstd_compress_entry_point(gpu):
         assert r == want_r and np.array_equal(out[:r], want), lvl
 
 
-def test_zstd12_golden_manifest_size_classes_and_tiny_inputs_refused(gpu, tmp_path):
+def test_zstd12_golden_manifest_and_every_size_class(gpu, tmp_path):
     """4mz Ultra (zstd level 12) on the device: lazy2 + 64-entry rows above 256 KiB, the binary-tree finder (btlazy2)
-    from 16 KiB + 1 to 256 KiB.  The 12 full corpus blocks AND the 123457-byte tail equal the reference CLI's manifest;
-    inputs of 16 KiB and less (btopt in the reference) are refused loudly."""
+    from 16 KiB + 1 to 256 KiB, the optimal parser (btopt) at 16 KiB and less.  The 12 full corpus blocks AND the
+    123457-byte tail equal the reference CLI's manifest; a level 4mz never uses is refused loudly."""
     import subprocess
     m = json.load(open(os.path.join(G, "corpus_manifest.json")))
     nb = 12
@@ -182,11 +182,20 @@ def test_zstd12_golden_manifest_size_classes_and_tiny_inputs_refused(gpu, tmp_pa
     _check(gpu, ["n=%d" % n for n in sizes], [src[n: 2 * n].copy() for n in sizes], [n // 4 for n in sizes], "n/4", 12)
     edge = {k: v[:262144] for k, v in helpers.edge_inputs().items() if len(v) > 16384}
     _check(gpu, list(edge), [v.copy() for v in edge.values()], [len(v) - 1 for v in edge.values()], "edge n-1", 12)
-    # tiny input: refused (never a silently different payload)
+    # btopt sizes: predefined prices up to 1024 bytes, statistics above; window / table clamps; capacities that fail
+    sizes = [0, 1, 2, 3, 7, 8, 9, 12, 13, 17, 63, 64, 65, 255, 256, 257, 1000, 1023, 1024, 1025, 2048, 4095, 4096, 4097, 8192, 10000, 16383, 16384]
+    _check(gpu, ["n=%d" % n for n in sizes], [src[3 * n: 4 * n].copy() for n in sizes], [helpers.zstd_bound(n) for n in sizes], "btopt bound", 12)
+    _check(gpu, ["n=%d" % n for n in sizes], [src[5 * n: 6 * n].copy() for n in sizes], [max(n - 1, 0) for n in sizes], "btopt n-1", 12)
+    _check(gpu, ["n=%d" % n for n in sizes], [src[7 * n: 8 * n].copy() for n in sizes], [n // 3 for n in sizes], "btopt n/3", 12)
+    edge = {k: v[:16384] for k, v in helpers.edge_inputs().items()}
+    _check(gpu, list(edge), [v.copy() for v in edge.values()], [max(len(v) - 1, 0) for v in edge.values()], "btopt edge n-1", 12)
+    edge = {k: v[:900] for k, v in helpers.edge_inputs().items()}
+    _check(gpu, list(edge), [v.copy() for v in edge.values()], [helpers.zstd_bound(len(v)) for v in edge.values()], "btopt edge 900", 12)
+    # a level 4mz never uses: refused (never a silently different payload)
     small = gpu.DeviceBatch(gpu.make_blocks([0], [0], [16384], [16384]))
     with pytest.raises(gpu.EngineError, match="not on the device"):
-        gpu.zstd_compress(d_src, d_dst, small, 12)
-    # CLI: the full corpus file (12 blocks + a 123457-byte tail) equals the reference CLI's; a file with a tiny tail is refused up front
+        gpu.zstd_compress(d_src, d_dst, small, 9)
+    # CLI: the full corpus file (12 blocks + a 123457-byte tail) equals the reference CLI's; a file with a tiny (btopt) tail round-trips
     full = tmp_path / "full.bin"; full.write_bytes(helpers.corpus(m["corpus"]["bytes"]).tobytes())
     fo = tmp_path / "full.4mz"
     assert subprocess.run([gpu.cli_path(), "-z", "-4", "-f", str(full), str(fo)], capture_output=True).returncode == 0
@@ -200,6 +209,13 @@ def test_zstd12_golden_manifest_size_classes_and_tiny_inputs_refused(gpu, tmp_pa
     back = tmp_path / "whole.back"
     assert subprocess.run([gpu.cli_path(), "-d", "-z", "-f", str(out), str(back)], capture_output=True).returncode == 0
     assert back.read_bytes() == data[: 3 * B].tobytes()
-    g = tmp_path / "tail.bin"; g.write_bytes(helpers.corpus(B + 12345).tobytes())
-    r = subprocess.run([gpu.cli_path(), "-z", "-4", "-f", str(g), str(tmp_path / "tail.4mz")], capture_output=True)
-    assert r.returncode == 1 and b"not on the device" in r.stderr and not (tmp_path / "tail.4mz").exists()
+    tail = helpers.corpus(B + 12345)
+    g = tmp_path / "tail.bin"; g.write_bytes(tail.tobytes())
+    assert subprocess.run([gpu.cli_path(), "-z", "-4", "-f", str(g), str(tmp_path / "tail.4mz")], capture_output=True).returncode == 0
+    img = np.frombuffer((tmp_path / "tail.4mz").read_bytes(), np.uint8)
+    blocks, _ = gpu.split_container(img, gpu.MAGIC_4MZ)
+    b1 = blocks[1]
+    want_r, want = helpers.orc_zstd_compress(tail[B:], 12, 12345 - 1)              # the tail block is the reference's btopt frame
+    assert int(b1["src_len"]) == want_r and np.array_equal(img[int(b1["src_off"]): int(b1["src_off"]) + want_r], want)
+    assert subprocess.run([gpu.cli_path(), "-d", "-z", "-f", str(tmp_path / "tail.4mz"), str(tmp_path / "tail.back")], capture_output=True).returncode == 0
+    assert (tmp_path / "tail.back").read_bytes() == tail.tobytes()
