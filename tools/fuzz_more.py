@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Extra seeds of tests/test_gpu_fuzz.py for the LZ4 encoders (fast, MC, HC 4/8) - run by hand after kernel changes:
+"""Extra seeds of tests/test_gpu_fuzz.py for the LZ4 encoders (fast, MC, HC 4/8) and the zstd encoder (levels 1, 3, 6, 12;
+half of the level-12 inputs cut to the btopt / btlazy2 size classes) - run by hand after kernel changes:
     python tools/fuzz_more.py [first_seed] [count]"""
 import importlib, sys, os
 import numpy as np, torch
@@ -35,5 +36,25 @@ for seed in range(first, first + count):
             o = int(blocks["dst_off"][k])
             if int(got["result"][k]) != len(srcs[i]) or not np.array_equal(back[o:o + len(srcs[i])], srcs[i]):
                 bad += 1; print("DECODE MISMATCH", name, seed, i)
+    for level in (1, 3, 6, 12):
+        zs = srcs
+        if level == 12:                                   # small last blocks: optimal parser (<= 16 KiB), binary tree (<= 256 KiB)
+            zs = [s[: int(rng.integers(0, 16385))] if k % 2 else s for k, s in enumerate(srcs)]
+        zcaps = [helpers.zstd_bound(len(s)) if p == 0 else max(len(s) - 1, 0) if p == 1 else len(s) // 2 for s, p in zip(zs, pick)]
+        res, outs, d_out, dsts = tf._run(gpu, zs, zcaps, lambda a, b, c: gpu.zstd_compress(a, b, c, level))
+        for i, (s, cap, r, o) in enumerate(zip(zs, zcaps, res, outs)):
+            wr, wb = helpers.orc_zstd_compress(s, level, cap)
+            if r != wr or not np.array_equal(o, wb):
+                bad += 1; print("MISMATCH zstd", level, seed, i, len(s), cap, r, wr)
+        ok = [i for i, r in enumerate(res) if r > 0]
+        blocks = gpu.make_blocks([dsts[i] for i in ok], np.cumsum([0] + [len(zs[i]) + 8 for i in ok[:-1]]).tolist(), [res[i] for i in ok], [len(zs[i]) for i in ok])
+        db = gpu.DeviceBatch(blocks)
+        d_back = torch.zeros(int(sum(len(zs[i]) + 8 for i in ok)) + 64, dtype=torch.uint8, device="cuda")
+        gpu.zstd_decompress(d_out, d_back, db); torch.cuda.synchronize()
+        got = db.download(); back = d_back.cpu().numpy()
+        for k, i in enumerate(ok):
+            o = int(blocks["dst_off"][k])
+            if int(got["result"][k]) != len(zs[i]) or not np.array_equal(back[o:o + len(zs[i])], zs[i]):
+                bad += 1; print("DECODE MISMATCH zstd", level, seed, i)
     print("seed", seed, "done", flush=True)
 print("mismatches:", bad)
