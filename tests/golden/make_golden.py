@@ -76,10 +76,7 @@ for ln in (0, 1, 3, 4, 15, 16, 17, 31, 32, 33, 100, 1000, 4099):
         xx.append({"hex": d.tobytes().hex(), "seed": seed, "xxh32": int(ref.XXH32(d.ctypes.data, ln, seed))})
 
 # zstd frames written by the reference's ZSTD_compress (what a 4mz block payload is), levels 1/3/6/12
-ed = helpers.edge_inputs()
-zin = {"text_30k": ed["text_60k"][:30000], "period37_20k": ed["period37"][:20000], "lit_then_run_30k": ed["lit_then_run"][:30000],
-       "two_symbols_30k": ed["two_symbols"][:30000], "zeros_20k": np.zeros(20000, np.uint8), "random_3k": ed["random_small"][:3000],
-       "hello10": ed["hello10"], "one": ed["one"]}
+zin = helpers.golden_zstd_inputs()
 zf = {}
 for name, d in zin.items():
     d = np.ascontiguousarray(d)

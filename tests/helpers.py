@@ -210,3 +210,15 @@ def orc_zstd_compress(src, level=1, cap=None):
     dst = np.empty(max(cap, 1) + 64, dtype=np.uint8)
     r = L.orc_zstd_compress(src.ctypes.data, len(src), dst.ctypes.data, cap, level)
     return r, dst[:max(r, 0)].copy()
+
+
+def golden_zstd_inputs():
+    """The inputs of tests/golden/zstd_frames.json (frames written by the reference's ZSTD_compress at levels 1/3/6/12);
+    tests/golden/make_golden.py generates the fixture from exactly these."""
+    ed = edge_inputs()
+    return {"text_30k": ed["text_60k"][:30000], "period37_20k": ed["period37"][:20000], "lit_then_run_30k": ed["lit_then_run"][:30000],
+            "two_symbols_30k": ed["two_symbols"][:30000], "zeros_20k": np.zeros(20000, np.uint8), "random_3k": ed["random_small"][:3000],
+            "hello10": ed["hello10"], "one": ed["one"],
+            # level 12 at 16 KiB and less is the optimal parser (btopt): predefined prices up to 1024 bytes, statistics above
+            "text_700": ed["text_60k"][:700], "text_5k": ed["text_60k"][1000:6000], "text_16k": ed["text_60k"][:16384],
+            "period37_9k": ed["period37"][:9000], "two_symbols_12k": ed["two_symbols"][:12000], "lit_then_run_16k": ed["lit_then_run"][:16384]}

@@ -46,6 +46,19 @@ def _check(gpu, names, srcs, caps, tag, level=1):
         assert np.array_equal(o, want), (tag, k, len(s), cap)
 
 
+def test_zstd_golden_frames(gpu):
+    """The device writes the committed frames of the reference's ZSTD_compress (tests/golden/zstd_frames.json) at all four levels."""
+    z = json.load(open(os.path.join(G, "zstd_frames.json")))
+    inputs = helpers.golden_zstd_inputs()
+    names = list(z)
+    for lvl in (1, 3, 6, 12):
+        srcs = [np.ascontiguousarray(inputs[k]) for k in names]
+        res, outs = _encode(gpu, srcs, [len(s) + 1024 for s in srcs], lvl)
+        for k, r, o in zip(names, res, outs):
+            hx = z[k]["frames"][str(lvl)]
+            assert int(r) == len(hx) // 2 and o.tobytes().hex() == hx, (k, lvl)
+
+
 @pytest.mark.parametrize("level", [1, 3, 6])
 def test_zstd_bytes_identical_edge_inputs(gpu, level):
     inputs = helpers.edge_inputs()

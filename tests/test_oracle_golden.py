@@ -231,6 +231,21 @@ def test_lz4mc_port_equals_reference_sources():
 
 
 # ------------------------------------------------------------------------------------------ zstd encoder port (levels 1, 3, 6, 12)
+def test_zstd_enc_port_golden_frames():
+    """The committed frames the reference's ZSTD_compress wrote (tests/golden/zstd_frames.json) - every strategy 4mz reaches:
+    fast, dfast, lazy / lazy2 (rows and chains), btlazy2 (level 12, 16 KiB + 1 .. 256 KiB), btopt (level 12, <= 16 KiB)."""
+    import hashlib
+    z = json.load(open(os.path.join(G, "zstd_frames.json")))
+    inputs = helpers.golden_zstd_inputs()
+    assert set(z) == set(inputs)
+    for name, e in z.items():
+        d = np.ascontiguousarray(inputs[name])
+        assert hashlib.sha256(d.tobytes()).hexdigest() == e["input_sha256"], name
+        for lvl, hx in e["frames"].items():
+            r, comp = helpers.orc_zstd_compress(d, int(lvl), len(d) + 1024)
+            assert r == len(hx) // 2 and comp.tobytes().hex() == hx, (name, lvl)
+
+
 @pytest.mark.parametrize("level,key", [(1, "4mz-1"), (3, "4mz-2"), (6, "4mz-3"), (12, "4mz-4")])
 def test_zstd_enc_port_golden_manifest(level, key):
     """`4mc -z -1` / `-z -2` (ZSTD_compress level 1 / 3, capacity n-1) per-block sizes/checksums written by the reference CLI."""
