@@ -297,7 +297,7 @@ def main():
         }
         if world == 1 and not args.no_extras:
             line["other_configs"] = other_configs()
-        if not args.no_cpu:
+        if world == 1 and not args.no_cpu:             # the host-core baseline is measured at N = 1 only
             line["cpu_baseline"] = cpu_baseline(helpers, base, base_blocks)
         else:
             line["cpu_baseline"] = None
