@@ -51,6 +51,22 @@ def test_xxh32_lengths_and_alignments(gpu):
             assert list(got) == want, (align, seed)
 
 
+@pytest.mark.parametrize("count", [3, 1500, 3000, 6000])
+def test_xxh32_many_blocks_per_wavefront(gpu, count):
+    """Batches above 1024 blocks put 2, 4, 8 blocks on one wavefront (staged kernel up to 4): ragged lengths around the
+    64-stripe bank size, blocks that end while their neighbours go on, a last wavefront that is not full."""
+    rng = np.random.default_rng(count)
+    lens = [int(rng.choice([0, 5, 16, 1023, 1024, 1025, 2047, 2048, 2049, int(rng.integers(0, 9000))])) for _ in range(count)]
+    lens[-1] = 40000; lens[0] = 70001
+    arrays = [rng.integers(0, 256, n, dtype=np.uint8) for n in lens]
+    buf, offs = _pack(arrays, 1)
+    batch = gpu.DeviceBatch(gpu.make_blocks(offs, [0] * count, lens, [0] * count))
+    gpu.xxh32(_dev(buf), batch, 7)
+    got = batch.download()["xxh32"]
+    want = [helpers.orc_xxh32(a, 7) for a in arrays]
+    assert list(got) == want
+
+
 # ------------------------------------------------------------------------------------------ decode
 def _decode_batch(gpu, comps, caps, align=1):
     buf, offs = _pack(comps, align)
