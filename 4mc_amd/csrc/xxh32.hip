@@ -144,35 +144,46 @@ void xxh32_staged_kernel(const uint8_t* __restrict__ base, fourmc_block* blocks,
     const uint8_t* const pl = base + off_l + 4 * j;
     uint32_t acc = (chain == 0) ? seed + P1 + P2 : (chain == 1) ? seed + P2 : (chain == 2) ? seed : seed - P1;
     uint32_t s = 0;
-    uint32_t xa[NI], xb[NI];
-    {
-        const bool on = s + 64 <= nstripes_l;
+    // Three register banks in rotation (the loop body is written out three times so that no loaded value is ever copied:
+    // a copy would make the compiler wait for the youngest load): the words of bank k + 2 are requested while bank k is
+    // consumed, 128 stripes (~5000 clocks) ahead - an HBM read takes about half of that.
+    uint32_t x0[NI], x1[NI], x2[NI];
+    auto fetch = [&](uint32_t (&x)[NI], uint32_t at) {
+        // (branch-free: a lane whose block has no such bank reads the descriptor array instead and its words are never used;
+        // a conditional load would sit in a basic block of its own and the compiler would wait for each before the next)
+        const bool on = at + 64 <= nstripes_l;
+        const uint8_t* const from = on ? pl + 16 * size_t(at) : reinterpret_cast<const uint8_t*>(blocks);
+        const int stride = on ? 4 * W : 0;
 #pragma unroll
-        for (int i = 0; i < NI; i++) xa[i] = on ? ldw(pl + 4 * i * W) : 0u;
-    }
-    while (__ballot(s + 64 <= nstripes_l)) {
-        const bool next_on = s + 128 <= nstripes_l;     // the next bank's words are read while this one is consumed
-#pragma unroll
-        for (int i = 0; i < NI; i++) xb[i] = next_on ? ldw(pl + 16 * size_t(s + 64) + 4 * i * W) : 0u;
+        for (int i = 0; i < NI; i++) x[i] = ldw(from + i * stride);
+    };
+    auto consume = [&](const uint32_t (&x)[NI]) {
 #pragma unroll
         for (int i = 0; i < NI; i++) {                  // word w = i W + j of the bank: stripe w >> 2, accumulator w & 3
             const int w = i * W + j;
-            stage[gl * 256 + (w & 3) * 64 + (w >> 2)] = xa[i] * P2;
+            stage[gl * 256 + (w & 3) * 64 + (w >> 2)] = x[i] * P2;
         }
         if (is_acc && s + 64 <= nstripes) {
             const uint4* const mine = reinterpret_cast<const uint4*>(stage + ga * 256 + chain * 64);
-            uint4 v = mine[0];
+            uint4 v = mine[0], v1 = mine[1];
 #pragma unroll
             for (int r4 = 0; r4 < 16; r4++) {
-                const uint4 vn = mine[r4 < 15 ? r4 + 1 : 15];
+                const uint4 v2 = mine[r4 < 14 ? r4 + 2 : 15];      // two reads ahead of the four stripes being folded in
                 acc = rotl(acc + v.x, 13) * P1; acc = rotl(acc + v.y, 13) * P1;
                 acc = rotl(acc + v.z, 13) * P1; acc = rotl(acc + v.w, 13) * P1;
-                v = vn;
+                v = v1; v1 = v2;
             }
         }
-#pragma unroll
-        for (int i = 0; i < NI; i++) xa[i] = xb[i];
         s += 64;
+    };
+    fetch(x0, 0); fetch(x1, 64);
+    for (;;) {
+        if (!__ballot(s + 64 <= nstripes_l)) break;
+        fetch(x2, s + 128); consume(x0);
+        if (!__ballot(s + 64 <= nstripes_l)) break;
+        fetch(x0, s + 128); consume(x1);
+        if (!__ballot(s + 64 <= nstripes_l)) break;
+        fetch(x1, s + 128); consume(x2);
     }
     if (!have) return;
     const uint32_t h = xxh32_finish(p, len, seed, acc, nstripes & ~63u, lane);
