@@ -347,14 +347,26 @@ __device__ void lz4_fast_parse(const uint8_t* src, int csize, int cap, uint8_t* 
             const uint32_t ml = (M0 == 15) ? 19 + e1 : M0 + 4;
             const uint32_t nxt = offpos + 2 + (M0 == 15 ? 1 : 0);
             const bool ok = (L0 != 15 || b1 != 255) && (M0 != 15 || e1 != 255) && nxt <= 64;
-            const uint32_t jump = ok ? nxt : 128u + uint32_t(lane);
+            // Token chain over a per-lane jump table, without a branch per token: a token never starts in slots 62 / 63 (it needs
+            // three bytes), so slot 63 is an absorbing end state and the walk is a straight run of v_readlane + s_bitset1
+            // pairs, checked for the end every 7 tokens (a window holds at most 21).
+            const uint32_t jump = ok ? nxt : 128u + uint32_t(lane);     // 64: the window ends behind this token; >= 128: no batch token
+            const uint32_t hop = lane == 63 ? 63u : min(jump, 63u);
             unsigned long long tokmask = 0;
             uint32_t pos = 0;
-            do {
-                tokmask |= 1ull << pos;
-                pos = uint32_t(__builtin_amdgcn_readlane(int(jump), int(pos)));
-            } while (pos < 64);
-            if (pos >= 128) { pos -= 128; tokmask &= ~(1ull << pos); }
+            for (int round = 0; round < 3 && pos != 63; round++) {
+#pragma unroll
+                for (int i = 0; i < 7; i++) {
+                    asm volatile("s_bitset1_b64 %0, %1" : "+s"(tokmask) : "s"(pos));
+                    pos = uint32_t(__builtin_amdgcn_readlane(int(hop), int(pos)));
+                }
+            }
+            tokmask &= ~(1ull << 63);
+            {   // where the chain left the window: behind its last token (64), or at a slot that is no batch token (the batch ends before it)
+                const uint32_t last = 63u - uint32_t(__builtin_clzll(tokmask));
+                const uint32_t j = uint32_t(__builtin_amdgcn_readlane(int(jump), int(last)));
+                if (j >= 128) { tokmask &= ~(1ull << last); pos = last; } else pos = j;
+            }
             if (tokmask) {
                 bool is_tok = (tokmask >> lane) & 1;
                 uint32_t sz = is_tok ? L + ml : 0;
