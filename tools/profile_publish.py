@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Turns what tools/profile_round.sh left under gpurun_out/<tag>/ into the files kept under profiles/:
+    python tools/profile_publish.py <tag> <name>     e.g.  r01e6 r01_end3"""
+import json, os, re, sys
+tag, name = sys.argv[1], sys.argv[2]
+o = f"gpurun_out/{tag}/"
+def rows(f, per=5):
+    d = {}
+    for l in open(f):
+        m = re.match(r"\| ([\w<>]+) \| (\w+) \| (\d+) \| (\d+) \| (\d+) \|", l)
+        if m: d.setdefault(m.group(1), {})[m.group(2)] = int(m.group(per))
+    return d
+fe, wr = rows(o + "summary_fetch.md"), rows(o + "summary_write.md")
+xk = [k for k in fe if k.startswith("xxh32")][0]
+t = json.load(open("profiles/r01_traffic.json"))
+t["lz4_encode"] = {"fetch_KiB": fe["lz4_encode_fast_kernel"]["FETCH_SIZE"], "write_KiB": wr["lz4_encode_fast_kernel"]["WRITE_SIZE"]}
+t["lz4_decode"] = {"fetch_KiB": fe["lz4_decode_fast_kernel"]["FETCH_SIZE"] + fe.get("lz4_decode_retry_kernel", {}).get("FETCH_SIZE", 0),
+                   "write_KiB": wr["lz4_decode_fast_kernel"]["WRITE_SIZE"]}
+t["xxh32"] = {"fetch_KiB": fe[xk]["FETCH_SIZE"], "write_KiB": wr[xk]["WRITE_SIZE"]}
+t["pack"] = {"fetch_KiB": fe["pack_image_kernel"]["FETCH_SIZE"], "write_KiB": wr["pack_image_kernel"]["WRITE_SIZE"]}
+json.dump(t, open("profiles/r01_traffic.json", "w"), indent=1)
+open(f"profiles/{name}_kernel_stats.md", "w").write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1   (tools/profile_round.sh)\n\n" + open(o + "summary_stats.md").read())
+open(f"profiles/{name}_hbm_traffic.md", "w").write("# rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) -- python bench.py --blocks 512 --no-extras --no-cpu --steps 2 --warmup 1\n# per-dispatch values are KiB (see the calibration note in r01_traffic.json)\n\n" + open(o + "summary_fetch.md").read() + "\n" + open(o + "summary_write.md").read())
+open(f"profiles/{name}_bench_under_rocprof.json", "w").write(open(o + "bench_stats.json").read())
+open(f"profiles/{name}_bench.json", "w").write(open(o + "bench_stats.json").read())
+a, b = rows(o + "summary_sq.md"), rows(o + "summary_sq2.md")
+out = "# rocprofv3 --pmc <SQ group> -- python bench.py --no-extras --no-cpu --steps 2 --warmup 1   (2048 blocks; two passes, tools/profile_round.sh)\n# per-dispatch sums over all waves; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs\n\n"
+out += "| kernel | waves' time parked (s_waitcnt) | issuing | issue stalls | VALU busy (of 1024 SIMDs) | SALU : VALU instructions | cycles per issued instruction | LDS instr | VMEM rd / wr instr |\n|---|---|---|---|---|---|---|---|---|\n"
+for k in ("lz4_encode_fast_kernel", "lz4_decode_fast_kernel", [k for k in a if k.startswith("xxh32")][0]):
+    x, y = a[k], b[k]; wc = x["SQ_WAVE_CYCLES"]; cyc = y["GRBM_GUI_ACTIVE"] / 8
+    n = x["SQ_INSTS_VALU"] + x["SQ_INSTS_SALU"] + y["SQ_INSTS_LDS"] + y["SQ_INSTS_VMEM_RD"] + y["SQ_INSTS_VMEM_WR"]
+    out += "| %s | %.0f %% | %.0f %% | %.0f %% | %.0f %% | %.2f | %.1f | %.2e | %.2e / %.2e |\n" % (k, 100 * x["SQ_WAIT_ANY"] / wc, 100 * x["SQ_ACTIVE_INST_ANY"] / wc, 100 * x["SQ_WAIT_INST_ANY"] / wc, 100 * 4 * x["SQ_ACTIVE_INST_VALU"] / (1024 * cyc), x["SQ_INSTS_SALU"] / x["SQ_INSTS_VALU"], 4 * x["SQ_ACTIVE_INST_ANY"] / n, y["SQ_INSTS_LDS"], y["SQ_INSTS_VMEM_RD"], y["SQ_INSTS_VMEM_WR"])
+out += "\n" + open(o + "summary_sq.md").read() + "\n" + open(o + "summary_sq2.md").read()
+open(f"profiles/{name}_sq_counters.md", "w").write(out)
+d = json.load(open(o + "bench_stats.json"))
+print(d["value"], d["ms_per_step"], d["kernel_ms"], d["compress_GBps"], d["decompress_GBps"])
