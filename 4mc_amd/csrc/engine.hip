@@ -7,6 +7,8 @@
 #include <mutex>
 #include <condition_variable>
 #include <vector>
+#include <map>
+#include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -17,7 +19,7 @@ namespace {
 
 thread_local char g_err[512] = "";
 std::mutex g_mu;                 // guards device selection and the host-staging arena
-int  g_device = -1;
+std::atomic<int> g_device{-1};
 char g_arch[128] = "";
 
 int fail_hip(hipError_t e, const char* what)
@@ -29,7 +31,7 @@ int fail_hip(hipError_t e, const char* what)
 
 int ensure_device()
 {
-    if (g_device >= 0) return FOURMC_OK;
+    if (g_device.load(std::memory_order_acquire) >= 0) return FOURMC_OK;
     return fourmc_gpu_init(-1);
 }
 
@@ -41,28 +43,44 @@ struct Arena {
     hipStream_t stream = nullptr;
 } g_arena;
 
-// scratch for regenerated zstd literals: one 128 KiB slot per block of the largest batch seen
-void*  g_zscratch = nullptr;
-size_t g_zscratch_cap = 0;
-std::mutex g_zmu;
+// Device workspaces (per-block scratch of the kernels: LZ4 decode records, LZ4 HC/MC tables, zstd literals / sequence
+// areas / encoder tables).  ONE GROWABLE BUFFER PER STREAM: launches on a stream are ordered, so consecutive calls on the
+// same stream can share a buffer, while calls on different streams (the JNI queue's own stream next to a device-API
+// caller's, two device-API callers) never see each other's scratch.  A lease keeps the stream's entry locked from the
+// moment the pointer is handed out until the caller's launches are enqueued; growing synchronizes THAT stream before the
+// old buffer is freed, so no launch can still be using it.
+struct StreamWs { std::mutex mu; void* p = nullptr; size_t cap = 0; };
+std::mutex g_wsmu;
+std::map<hipStream_t, StreamWs*> g_ws;
+StreamWs* g_ws_last = nullptr;          // for fourmc_gpu_debug_read_workspace
 
-int zstd_scratch_bytes(size_t need, void** out);
-int zstd_scratch(uint32_t n, void** out) { return zstd_scratch_bytes(fourmc_zstd_scratch_bytes(n), out); }
-
-// one growable device workspace shared by the kernels that need per-block scratch
-// (zstd literals: 128 KiB / block, LZ4 HC tables: 256 KiB / block); calls are stream-ordered
-// on the caller's stream, so one buffer serves consecutive launches.
-int zstd_scratch_bytes(size_t need, void** out)
-{
-    std::lock_guard<std::mutex> lk(g_zmu);
-    if (need > g_zscratch_cap) {
-        if (g_zscratch) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g_zscratch)); g_zscratch = nullptr; g_zscratch_cap = 0; }
-        HIP_TRY(hipMalloc(&g_zscratch, need));
-        g_zscratch_cap = need;
+class WsLease {
+    StreamWs* w_ = nullptr;
+public:
+    WsLease() {}
+    WsLease(const WsLease&) = delete;
+    ~WsLease() { if (w_) w_->mu.unlock(); }
+    int get(hipStream_t s, size_t need, void** out)
+    {
+        if (!w_) {
+            {
+                std::lock_guard<std::mutex> lk(g_wsmu);
+                auto it = g_ws.find(s);
+                if (it == g_ws.end()) it = g_ws.emplace(s, new StreamWs()).first;
+                w_ = it->second; g_ws_last = w_;
+            }
+            w_->mu.lock();          // entries are never removed; the registry lock is not held while waiting here
+        }
+        if (need > w_->cap) {
+            if (w_->p) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(w_->p)); w_->p = nullptr; w_->cap = 0; }
+            const size_t want = need + need / 16 + 4096;
+            HIP_TRY(hipMalloc(&w_->p, want));
+            w_->cap = want;
+        }
+        *out = w_->p;
+        return FOURMC_OK;
     }
-    *out = g_zscratch;
-    return FOURMC_OK;
-}
+};
 
 int arena_reserve(size_t src_bytes, size_t dst_bytes, size_t nblk)
 {
@@ -119,7 +137,7 @@ int fourmc_gpu_init(int device)
         snprintf(g_err, sizeof g_err, "device %d is %s; this build carries gfx950 code only", device, prop.gcnArchName);
         return FOURMC_ENODEV;
     }
-    g_device = device;
+    g_device.store(device, std::memory_order_release);
     return FOURMC_OK;
 }
 
@@ -127,7 +145,10 @@ int fourmc_gpu_init(int device)
 int fourmc_gpu_lz4_decompress(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, void* stream)
 {
     if (int r = ensure_device()) return r;
-    HIP_TRY(fourmc_launch_lz4_decode(d_src, d_dst, d_blocks, n, 0, static_cast<hipStream_t>(stream)));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WsLease ws; void* work = nullptr;
+    if (int r = ws.get(s, fourmc_lz4_decode_work_bytes(n), &work)) return r;
+    HIP_TRY(fourmc_launch_lz4_decode(d_src, d_dst, d_blocks, n, 0, work, s));
     return FOURMC_OK;
 }
 
@@ -142,8 +163,8 @@ int fourmc_gpu_lz4_compress_hc(const void* d_src, void* d_dst, fourmc_block* d_b
 {
     if (int r = ensure_device()) return r;
     if (level < 1 || level > 8) { snprintf(g_err, sizeof g_err, "LZ4 HC level %d not on the device (hash-chain levels 1..8 are)", level); return FOURMC_EUNSUP; }
-    void* work = nullptr;
-    if (int r = zstd_scratch_bytes(fourmc_lz4hc_work_bytes(n), &work)) return r;
+    WsLease ws; void* work = nullptr;
+    if (int r = ws.get(static_cast<hipStream_t>(stream), fourmc_lz4hc_work_bytes(n), &work)) return r;
     HIP_TRY(fourmc_launch_lz4hc_encode(d_src, d_dst, d_blocks, n, work, level, 0, static_cast<hipStream_t>(stream)));
     return FOURMC_OK;
 }
@@ -151,8 +172,8 @@ int fourmc_gpu_lz4_compress_hc(const void* d_src, void* d_dst, fourmc_block* d_b
 int fourmc_gpu_lz4_compress_mc(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, void* stream)
 {
     if (int r = ensure_device()) return r;
-    void* work = nullptr;
-    if (int r = zstd_scratch_bytes(fourmc_lz4hc_work_bytes(n), &work)) return r;     // same 256 KiB/block layout as HC
+    WsLease ws; void* work = nullptr;
+    if (int r = ws.get(static_cast<hipStream_t>(stream), fourmc_lz4hc_work_bytes(n), &work)) return r;     // same layout as HC
     HIP_TRY(fourmc_launch_lz4mc_encode(d_src, d_dst, d_blocks, n, work, 0, static_cast<hipStream_t>(stream)));
     return FOURMC_OK;
 }
@@ -162,17 +183,35 @@ int fourmc_gpu_lz4_compress_mc(const void* d_src, void* d_dst, fourmc_block* d_b
 int fourmc_gpu_debug_read_workspace(void* host, size_t offset, size_t bytes)
 {
     if (int r = ensure_device()) return r;
-    if (!g_zscratch || offset + bytes > g_zscratch_cap) { snprintf(g_err, sizeof g_err, "workspace range out of bounds"); return FOURMC_EINVAL; }
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(host, static_cast<char*>(g_zscratch) + offset, bytes, hipMemcpyDeviceToHost));
+    std::lock_guard<std::mutex> lk(g_wsmu);                 // the workspace of the stream that was served last
+    if (!g_ws_last || !g_ws_last->p || offset + bytes > g_ws_last->cap) { snprintf(g_err, sizeof g_err, "workspace range out of bounds"); return FOURMC_EINVAL; }
+    HIP_TRY(hipMemcpy(host, static_cast<char*>(g_ws_last->p) + offset, bytes, hipMemcpyDeviceToHost));
+    return FOURMC_OK;
+}
+
+/* test aid: run ONLY the parser of the block-parallel LZ4 decoder and copy the first `bytes` of block 0's workspace slot
+ * (header, window descriptors, token positions: lz4par.h) to the host */
+int fourmc_gpu_debug_lz4_parse(const void* d_src, const void* d_dst, fourmc_block* d_blocks, uint32_t n, int container_mode,
+                               void* host, size_t bytes, size_t* layout)
+{
+    if (int r = ensure_device()) return r;
+    if (layout) { layout[0] = fourmc_lz4_decode_work_bytes(1); layout[1] = 64; layout[2] = fourmc_lz4_decode_tok_offset(); }
+    if (n == 0) return FOURMC_OK;
+    WsLease ws; void* work = nullptr;
+    if (int r = ws.get(nullptr, fourmc_lz4_decode_work_bytes(n), &work)) return r;
+    HIP_TRY(fourmc_launch_lz4_parse(d_src, d_dst, d_blocks, n, container_mode, work, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t have = fourmc_lz4_decode_work_bytes(n);
+    if (host && bytes) HIP_TRY(hipMemcpy(host, work, bytes < have ? bytes : have, hipMemcpyDeviceToHost));
     return FOURMC_OK;
 }
 
 int fourmc_gpu_zstd_decompress(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, void* stream)
 {
     if (int r = ensure_device()) return r;
-    void* scratch = nullptr;
-    if (int r = zstd_scratch(n, &scratch)) return r;
+    WsLease ws; void* scratch = nullptr;
+    if (int r = ws.get(static_cast<hipStream_t>(stream), fourmc_zstd_scratch_bytes(n), &scratch)) return r;
     HIP_TRY(fourmc_launch_zstd_decode(d_src, d_dst, d_blocks, n, scratch, 0, static_cast<hipStream_t>(stream)));
     return FOURMC_OK;
 }
@@ -192,8 +231,8 @@ int fourmc_gpu_zstd_compress(const void* d_src, void* d_dst, fourmc_block* d_blo
 {
     if (int r = ensure_device()) return r;
     if (int r = zstd_level_ok(d_blocks, n, level, static_cast<hipStream_t>(stream))) return r;
-    void* work = nullptr;
-    if (int r = zstd_scratch_bytes(fourmc_zstd_enc_work_bytes(n, level), &work)) return r;
+    WsLease ws; void* work = nullptr;
+    if (int r = ws.get(static_cast<hipStream_t>(stream), fourmc_zstd_enc_work_bytes(n, level), &work)) return r;
     HIP_TRY(fourmc_launch_zstd_encode(d_src, d_dst, d_blocks, n, work, 0, level, zstd_enc_serial(), static_cast<hipStream_t>(stream)));
     return FOURMC_OK;
 }
@@ -212,23 +251,23 @@ int fourmc_gpu_4mc_encode_blocks(const void* d_src, void* d_dst, fourmc_block* d
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (codec == FOURMC_CODEC_LZ4_HC) {
         if (level < 1 || level > 8) { snprintf(g_err, sizeof g_err, "LZ4 HC level %d not on the device", level); return FOURMC_EUNSUP; }
-        void* work = nullptr;
-        if (int r = zstd_scratch_bytes(fourmc_lz4hc_work_bytes(n), &work)) return r;
+        WsLease ws; void* work = nullptr;
+        if (int r = ws.get(s, fourmc_lz4hc_work_bytes(n), &work)) return r;
         HIP_TRY(fourmc_launch_lz4hc_encode(d_src, d_dst, d_blocks, n, work, level, 1, s));
         HIP_TRY(fourmc_launch_xxh32(d_dst, d_blocks, n, 0, FOURMC_HASH_DST_RESULT, s));
         return FOURMC_OK;
     }
     if (codec == FOURMC_CODEC_LZ4_MC) {
-        void* work = nullptr;
-        if (int r = zstd_scratch_bytes(fourmc_lz4hc_work_bytes(n), &work)) return r;
+        WsLease ws; void* work = nullptr;
+        if (int r = ws.get(s, fourmc_lz4hc_work_bytes(n), &work)) return r;
         HIP_TRY(fourmc_launch_lz4mc_encode(d_src, d_dst, d_blocks, n, work, 1, s));
         HIP_TRY(fourmc_launch_xxh32(d_dst, d_blocks, n, 0, FOURMC_HASH_DST_RESULT, s));
         return FOURMC_OK;
     }
     if (codec == FOURMC_CODEC_ZSTD) {
         if (int r = zstd_level_ok(d_blocks, n, level, s)) return r;
-        void* work = nullptr;
-        if (int r = zstd_scratch_bytes(fourmc_zstd_enc_work_bytes(n, level), &work)) return r;
+        WsLease ws; void* work = nullptr;
+        if (int r = ws.get(s, fourmc_zstd_enc_work_bytes(n, level), &work)) return r;
         HIP_TRY(fourmc_launch_zstd_encode(d_src, d_dst, d_blocks, n, work, 1, level, zstd_enc_serial(), s));
         HIP_TRY(fourmc_launch_xxh32(d_dst, d_blocks, n, 0, FOURMC_HASH_DST_RESULT, s));
         return FOURMC_OK;
@@ -248,8 +287,8 @@ int fourmc_gpu_4mc_decode_blocks(const void* d_src, void* d_dst, fourmc_block* d
     if (int r = ensure_device()) return r;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (codec == FOURMC_CODEC_ZSTD) {              // .4mz: every level decodes with the same kernel
-        void* scratch = nullptr;
-        if (int r = zstd_scratch(n, &scratch)) return r;
+        WsLease ws; void* scratch = nullptr;
+        if (int r = ws.get(s, fourmc_zstd_scratch_bytes(n), &scratch)) return r;
         HIP_TRY(fourmc_launch_xxh32(d_src, d_blocks, n, 0, FOURMC_VERIFY_SRC, s));
         HIP_TRY(fourmc_launch_zstd_decode(d_src, d_dst, d_blocks, n, scratch, 1, s));
         return FOURMC_OK;
@@ -258,8 +297,10 @@ int fourmc_gpu_4mc_decode_blocks(const void* d_src, void* d_dst, fourmc_block* d
         snprintf(g_err, sizeof g_err, "codec %d not implemented on the device yet", codec);
         return FOURMC_EUNSUP;
     }
+    WsLease ws; void* work = nullptr;
+    if (int r = ws.get(s, fourmc_lz4_decode_work_bytes(n), &work)) return r;
     HIP_TRY(fourmc_launch_xxh32(d_src, d_blocks, n, 0, FOURMC_VERIFY_SRC, s));
-    HIP_TRY(fourmc_launch_lz4_decode(d_src, d_dst, d_blocks, n, 1, s));
+    HIP_TRY(fourmc_launch_lz4_decode(d_src, d_dst, d_blocks, n, 1, work, s));
     return FOURMC_OK;
 }
 

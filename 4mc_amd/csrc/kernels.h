@@ -17,8 +17,14 @@ enum {
                                   // match -> result = 0
 };
 
+size_t     fourmc_lz4_decode_work_bytes(uint32_t n);
+size_t     fourmc_lz4_decode_tok_offset(void);
 hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, fourmc_block* d_blocks,
-                                    uint32_t n, int container_mode, hipStream_t stream);
+                                    uint32_t n, int container_mode, void* d_work, hipStream_t stream);
+hipError_t fourmc_launch_lz4_parse(const void* d_src, const void* d_dst, fourmc_block* d_blocks, uint32_t n,
+                                   int container_mode, void* d_work, hipStream_t stream);
+hipError_t fourmc_launch_lz4_exec(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
+                                  const void* d_work, hipStream_t stream);
 hipError_t fourmc_launch_lz4_encode_fast(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                                          uint32_t n, int container_mode, hipStream_t stream);
 hipError_t fourmc_launch_pack_image(const void* d_staging, void* d_image, const fourmc_block* d_blocks,

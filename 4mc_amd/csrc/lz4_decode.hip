@@ -22,6 +22,8 @@
 #include "fourmc_gpu.h"
 #include "kernels.h"
 #include "devcopy.h"
+#include "lz4par.h"
+#include <string.h>
 
 namespace {
 
@@ -568,18 +570,39 @@ void lz4_decode_retry_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
 
 } // namespace
 
+// Block-parallel path (lz4_parse.hip + lz4_exec.hip) for every block, then the exact walker for whatever they handed back
+// (rule violations, blocks beyond the parallel path's size limits), so results and error codes stay the reference's.
+extern "C" size_t fourmc_lz4_decode_tok_offset(void) { return lz4par::kTokOff; }
+extern "C" size_t fourmc_lz4_decode_work_bytes(uint32_t n)
+{
+    const uint32_t m = n < lz4par::kMaxBatch ? n : lz4par::kMaxBatch;
+    return size_t(m ? m : 1) * lz4par::kSlotBytes;
+}
+
 extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, fourmc_block* d_blocks,
-                                               uint32_t n, int container_mode, hipStream_t stream)
+                                               uint32_t n, int container_mode, void* d_work, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
     const uint8_t* s8 = static_cast<const uint8_t*>(d_src);
     uint8_t* d8 = static_cast<uint8_t*>(d_dst);
-    static const bool exact_only = getenv("FOURMC_DECODE_EXACT") != nullptr;     // debugging / A-B switch
-    if (exact_only) {
+    static const char* mode = getenv("FOURMC_DECODE");          // debugging / A-B switch: "exact", "old"
+    if (mode && !strcmp(mode, "exact")) {
         hipLaunchKernelGGL(lz4_decode_exact_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(lz4_decode_fast_kernel, dim3(n), dim3(64 * (kCopiers + 1)), 0, stream, s8, d8, d_blocks, n, container_mode);
+    if (mode && !strcmp(mode, "old")) {
+        hipLaunchKernelGGL(lz4_decode_fast_kernel, dim3(n), dim3(64 * (kCopiers + 1)), 0, stream, s8, d8, d_blocks, n, container_mode);
+        hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
+        return hipGetLastError();
+    }
+    for (uint32_t b0 = 0; b0 < n; b0 += lz4par::kMaxBatch) {
+        const uint32_t m = n - b0 < lz4par::kMaxBatch ? n - b0 : lz4par::kMaxBatch;
+        hipError_t e = fourmc_launch_lz4_parse(d_src, d_dst, d_blocks + b0, m, container_mode, d_work, stream);
+        if (e != hipSuccess) return e;
+        e = fourmc_launch_lz4_exec(d_src, d_dst, d_blocks + b0, m, d_work, stream);
+        if (e != hipSuccess) return e;
+    }
+    if (mode && !strcmp(mode, "paronly")) return hipGetLastError();      // test aid: show what the parallel path alone did
     hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
     return hipGetLastError();
 }

@@ -79,6 +79,11 @@ int fourmc_gpu_lz4_compress_mc(const void* d_src, void* d_dst, fourmc_block* d_b
 /* Profiling aid (not part of the reference boundary): copy a range of the engine's per-block device
  * workspace to the host; the zstd kernels leave per-phase cycle counters there (tools/zstd_timing.py). */
 int fourmc_gpu_debug_read_workspace(void* host, size_t offset, size_t bytes);
+/* Test aid: runs only the parser kernel of the block-parallel LZ4 decoder on `n` blocks and copies the first `bytes` of
+ * the workspace (block 0's slot first: header, window descriptors, token positions) to `host`; layout[0..2] = slot bytes,
+ * descriptor offset, token offset. */
+int fourmc_gpu_debug_lz4_parse(const void* d_src, const void* d_dst, fourmc_block* d_blocks, uint32_t n, int container_mode,
+                               void* host, size_t bytes, size_t* layout);
 /* one-block host calls (LZ4_* / ZSTD_* twins, JNI) made so far, and the launches that served them (concurrent calls share one) */
 void fourmc_debug_one_block_counters(unsigned long long* calls, unsigned long long* launches);
 
