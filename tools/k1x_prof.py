@@ -12,7 +12,7 @@ names = ["text", "binary", "pcm6", "sdf", "binary", "db", "text", "code", "pcm11
 layout = (C.c_size_t * 3)()
 p.lib().fourmc_gpu_debug_lz4_parse(0, 0, 0, 0, 0, 0, 0, layout)
 slot = layout[0]; dbg_off = slot - 1024
-NP = 4
+NW = 6
 want = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 5, 10]
 data = helpers.corpus(12 * B)
 for b in want:
@@ -30,10 +30,8 @@ for b in want:
     t = host.view(np.uint64).reshape(-1, 8)
     ok = bool(torch.equal(d_dst[:B].cpu(), torch.from_numpy(src)))
     print(f"== {names[b]}: {s.elapsed_time(e):.2f} ms, roundtrip {'ok' if ok else 'BAD'}; counters in Mclk")
-    for w in range(NP):
+    for w in range(NW):
         v = t[w] / 1e6
-        print(f"  pre{w}: wait-window {v[0]:7.2f}  decode {v[1]:7.2f}  wait-slot {v[2]:7.2f}  literals {v[3]:7.2f}  ring-matches {v[4]:7.2f}  hbm-matches {v[5]:7.2f}  queue {v[6]:7.2f}  near entries {int(t[w][7])}")
-    v = t[NP] / 1e6
-    print(f"  chain: wait-ready {v[0]:7.2f}  copy {v[1]:7.2f}  publish {v[2]:7.2f}  rounds {int(t[NP][3])}  entries {int(t[NP][4])}  slots {int(t[NP][5])}")
-    v = t[NP + 1] / 1e6
+        print(f"  worker{w}: gate {v[0]:7.2f}  decode {v[1]:7.2f}  literals {v[3]:7.2f}  copy rounds {v[4]:7.2f}  empty rounds {v[5]:7.2f}   rounds {int(t[w][6])}  of which empty {int(t[w][7])}")
+    v = t[NW] / 1e6
     print(f"  flush: wait {v[0]:7.2f}  work {v[1]:7.2f}")
