@@ -1,21 +1,22 @@
 // 4mc_amd/csrc/lz4_exec.hip - K1x: executes the sequence records of lz4_parse.hip; the LZ77 copy loop of the reference
-// (native/lz4/lz4.c:2060-2110, :2300-2325) as a dataflow over a 32 KiB window of the output held in LDS.
+// (native/lz4/lz4.c:2060-2110, :2300-2325) over a 16 KiB window of the output held in LDS.
 //
-// One workgroup per block, output produced in WINDOWS of 1 KiB (lz4par.h).  What a match copies is the only thing that
-// depends on earlier output.  Instead of walking the sequences in order, every output byte of the ring has a DONE BIT
-// (4 KiB bitmap in LDS); a match may run as soon as the bits of its source are set, whoever produced them:
-//   * kNW worker waves take windows round robin.  A lane is one sequence (clipped to the window): it decodes its token
-//     from the wave's private copy of the stream (prefetched a window ahead), copies its literals into the ring, sets
-//     their bits, and then copies its match when the source is ready - from the ring while the source is younger than
-//     the ring guarantees, from the block's flushed output in HBM otherwise (always ready).  Lanes whose source is not
-//     ready yet are retried in rounds; only they ever wait, and only for the bytes they need.
-//   * ONE flush wave writes windows whose bits are all set to HBM with aligned 16-byte stores, clears the bits of ring
-//     slots nobody may read any more, and publishes F_vis, which also bounds how far workers run ahead.
+// One workgroup of three waves per block, output produced in WINDOWS of 1 KiB (lz4par.h):
+//   * the LITERAL wave walks the windows a few ahead of the chain wave.  A lane is one sequence (clipped to the window):
+//     it decodes its token from the wave's staged copy of the stream (prefetched a window ahead), copies its literals
+//     into the ring, copies its match straight from the block's flushed output in HBM when the source has left the part
+//     of the ring that is guaranteed to be intact, and queues every other match (<= 64 per slot) for the chain wave.
+//     Nothing it does depends on recent output.
+//   * the CHAIN wave executes the queued matches strictly in order.  It reads and writes the LDS only; the LDS executes
+//     one wave's accesses in order, so a copy sees every earlier copy without any flag or wait.  Inside a slot the entries
+//     whose source lies below the first entry still missing run together; dependency chains (the usual shape of
+//     structured data) degenerate to one or two entries per step, which the whole wave copies byte-parallel.
+//   * the FLUSH wave writes completed windows to HBM with aligned 16-byte stores and publishes F_vis.
 // All irregular, byte-granular accesses stay in the LDS (byte-unaligned wider LDS accesses cost 64 clk per instruction
 // on gfx950, byte accesses 2-4: profiles/r02_ubench_lds_unaligned.txt); loads are always issued in batches before the
 // stores that depend on them.  HBM sees the coalesced stream reads, the far match gathers and the 16-byte flush stores.
 // Ring reuse: window w overwrites window w - kRW, which has been flushed and which no reader may touch any more because
-// readers never reach further back than kRW - kAhead windows through the ring.  Every wait is bounded; a wave that
+// readers never reach further back than kRW - kAhead - 1 windows through the ring.  Every wait is bounded; a wave that
 // waits too long aborts the block to the exact kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,23 +29,18 @@ using namespace lz4par;
 
 namespace {
 
-constexpr int kNW    = 6;                     // worker waves
-constexpr int kRW    = 32;                    // windows in the ring
+constexpr int kRW    = 16;                    // windows in the ring
 constexpr int kRing  = kRW * kWin;
 constexpr uint32_t kRM = kRing - 1;
-constexpr int kAhead = 14;                    // windows a worker may be ahead of the flushed output (2 * kAhead <= kRW)
+constexpr int kAhead = 3;                     // windows the literal wave may be ahead of the chain wave
 constexpr int kLag   = 6;                     // flush stores in flight before the oldest one is waited for
-constexpr int kCB    = 2048;                  // bytes of the stream a worker stages per window
+constexpr int kCB    = 2048;                  // bytes of the stream staged per window
 constexpr int kGuard = 64;                    // readable bytes behind the ring / the staged stream (batched reads overshoot)
 constexpr int kShort = 32;                    // pieces up to this length are copied by their own lane
+constexpr int kNS    = 4;                     // slots between the literal wave and the chain wave
 constexpr uint32_t kSpinLimit = 1u << 21;
-constexpr int kXT    = 64 * (kNW + 1);
-constexpr uint32_t kBW = kRing / 32;          // words of the done bitmap
+constexpr int kXT    = 64 * 3;
 
-struct XSync {
-    uint32_t F_vis;                           // windows flushed to HBM and visible
-    uint32_t abort;
-};
 
 // sync words: relaxed workgroup-scope atomics (a volatile access makes the backend wait for every single load / store)
 __device__ __forceinline__ uint32_t ldv(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -188,62 +184,27 @@ __device__ __forceinline__ void wave_copy_hbm(ring_t ring, uint32_t dst, const u
     }
 }
 
-// ---------------------------------------------------------------------------------------------- done bits
-// bit (pos & kRM) of bm = the ring byte of output position pos is final
-__device__ __forceinline__ void set_bits(uint32_t* bm, uint32_t pos, uint32_t n)        // n <= 32, inside one window
-{
-    if (!n) return;
-    const uint32_t p = pos & kRM, i = p >> 5, b = p & 31;
-    const unsigned long long m = (n >= 32 ? 0xffffffffull : ((1ull << n) - 1)) << b;
-    cbar();
-    __hip_atomic_fetch_or(&bm[i], uint32_t(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (m >> 32) __hip_atomic_fetch_or(&bm[i + 1], uint32_t(m >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ bool bits_set(const uint32_t* bm, uint32_t pos, uint32_t n)  // n <= 32, any position
-{
-    const uint32_t p = pos & kRM, i = p >> 5, b = p & 31;
-    const unsigned long long m = (n >= 32 ? 0xffffffffull : ((1ull << n) - 1)) << b;
-    const unsigned long long v = uint64_t(ldv(&bm[i])) | (uint64_t(ldv(&bm[(i + 1) & (kBW - 1)])) << 32);
-    return (v & m) == m;
-}
-// bits of [lo, hi) inside the 32-bit word that starts at bit position word_lo (plain, unwrapped positions)
-__device__ __forceinline__ uint32_t range_mask(uint32_t word_lo, uint32_t lo, uint32_t hi)
-{
-    const uint32_t a = max(lo, word_lo), e = min(hi, word_lo + 32);
-    if (e <= a) return 0u;
-    const uint32_t cnt = e - a;
-    return (cnt >= 32 ? 0xffffffffu : ((1u << cnt) - 1)) << (a - word_lo);
-}
-// whole wave, wave-uniform range inside one window
-__device__ __forceinline__ void wave_set_bits(uint32_t* bm, uint32_t pos, uint32_t n, int lane)
-{
-    const uint32_t p = pos & kRM, w0 = p & ~uint32_t(kWin - 1);
-    if (lane < 32) {
-        const uint32_t m = range_mask(w0 + 32 * lane, p, p + n);
-        cbar();
-        if (m) __hip_atomic_fetch_or(&bm[(w0 >> 5) + lane], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-}
-// whole wave, wave-uniform range anywhere, n <= kWin: at most 33 words, lane j looks at word first + j
-__device__ __forceinline__ bool wave_bits_set(const uint32_t* bm, uint32_t pos, uint32_t n, int lane)
-{
-    const uint32_t p = pos & kRM, first = p >> 5;
-    bool ok = true;
-    if (lane < 34) {
-        const uint32_t wi = first + lane;                                    // unwrapped word index
-        const uint32_t m = range_mask(32 * wi, p, p + n);
-        if (m) ok = (ldv(&bm[wi & (kBW - 1)]) & m) == m;
-    }
-    return __ballot(!ok) == 0;
-}
-
+// ---------------------------------------------------------------------------------------------- the three waves
 struct Blk {
     const uint8_t* src; uint8_t* dst; const uint4* wdesc; const uint32_t* tok; unsigned long long* dbg;
     uint32_t iend, nseq, total, nwin, a0;
 };
 
-// stream byte at position p: from the wave's staged copy [cs, cs + kCB) or from HBM
+struct Slot {                                 // the ring matches of (at most) 64 consecutive sequences, in order
+    uint32_t n, epos, last, maxlen;
+    uint32_t dst[64];
+    uint32_t ol[64];                          // offset | length << 16
+};
+struct XSync {
+    uint32_t E_win;                           // windows whose every byte is in the ring
+    uint32_t F_vis;                           // windows flushed to HBM and visible
+    uint32_t ready;                           // slots published by the literal wave
+    uint32_t consumed;                        // slots the chain wave is done with
+    uint32_t abort;
+};
+
 typedef const __attribute__((address_space(3))) uint8_t* lds_bytes;   // keeps the two sides of the choice below apart (no flat loads)
+// stream byte at position p: from the wave's staged copy [cs, cs + kCB) or from HBM
 __device__ __forceinline__ uint32_t sbyte(const Blk& B, const uint8_t* cbuf, uint32_t cs, uint32_t p)
 {
     const uint32_t i = p - cs;
@@ -258,15 +219,18 @@ __device__ __forceinline__ bool spin_fail(XSync* sy, uint32_t& spins)
     return ldv(&sy->abort) != 0;
 }
 
-// ------------------------------------------------------------------------------------------------ worker wave
-__device__ __forceinline__ void worker_wave(const Blk& B, ring_t ring, uint32_t* bm, uint8_t* cbuf, XSync* sy, int ww, int lane)
+// ------------------------------------------------------------------------------------------------ literal wave
+// Walks the windows in order, up to kAhead windows ahead of the chain wave: token decode, literals into the ring, matches
+// whose source has left the ring's guaranteed part straight from the flushed output, and for every batch of 64 sequences
+// one slot with the matches that read the ring.
+__device__ __forceinline__ void literal_wave(const Blk& B, ring_t ring, uint8_t* cbuf, Slot* slots, XSync* sy, int lane)
 {
     const uint32_t endp = B.total + B.a0;
+    uint32_t produced = 0;
     PROF_DECL
-
     // prefetch registers: descriptors two windows ahead, stream bytes and token positions one window ahead
-    auto load_desc = [&](uint32_t w) -> uint4 {
-        const uint32_t i = min(w + uint32_t(lane & 1), B.nwin);
+    auto load_desc = [&](uint32_t w) -> uint4 {                              // lanes 0..3: A(w), B(w), A(w+1), B(w+1)
+        const uint32_t i = min(2 * w + uint32_t(lane & 3), 2 * B.nwin + 1);
         return B.wdesc[i];
     };
     struct Data { uint4 c[kCB / 1024]; uint32_t t[3]; };
@@ -278,9 +242,10 @@ __device__ __forceinline__ void worker_wave(const Blk& B, ring_t ring, uint32_t*
             uint4 v = make_uint4(0, 0, 0, 0);
             if (g + 16 <= B.iend) v = ld16u(B.src + g);
             else if (g < B.iend) {
-                uint32_t wv[4] = {0, 0, 0, 0};
-                for (uint32_t i = 0; i < B.iend - g; i++) wv[i >> 2] |= uint32_t(B.src[g + i]) << (8 * (i & 3));
-                v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+                for (uint32_t i = 0; i < B.iend - g; i++) {
+                    const uint32_t by = uint32_t(B.src[g + i]) << (8 * (i & 3));
+                    if (i < 4) v.x |= by; else if (i < 8) v.y |= by; else if (i < 12) v.z |= by; else v.w |= by;
+                }
             }
             d.c[q] = v;
         }
@@ -288,49 +253,50 @@ __device__ __forceinline__ void worker_wave(const Blk& B, ring_t ring, uint32_t*
         for (int q = 0; q < 3; q++) { const uint32_t i = first + 64u * q + lane; d.t[q] = i < B.nseq ? B.tok[i] : 0; }
     };
 
-    uint32_t w = ww;
-    if (w >= B.nwin) { PROF_OUT(B, ww, lane); return; }
-    uint4 dcur = load_desc(w);
-    uint4 dnext = load_desc(w + kNW);
+    uint4 dcur = load_desc(0);
+    uint4 dnext = load_desc(1);
     Data cur; load_data(dcur, cur);
     Data nxt = cur;
-    for (; w < B.nwin; w += kNW) {
-        const bool have_next = w + kNW < B.nwin;
+    for (uint32_t w = 0; w < B.nwin; w++) {
+        const bool have_next = w + 1 < B.nwin;
         uint4 dnn = dnext;
-        if (have_next) { load_data(dnext, nxt); dnn = load_desc(w + 2 * kNW); }
-        const uint32_t first = rl(dcur.x, 0), opos0 = rl(dcur.y, 0), cs = rl(dcur.z, 0);
-        const uint32_t last = min(rl(dcur.x, 1), B.nseq - 1);
+        if (have_next) { load_data(dnext, nxt); dnn = load_desc(w + 2); }
+        const uint32_t first = rl(dcur.x, 0), opos0 = rl(dcur.y, 0), cs = rl(dcur.z, 0), lit0 = rl(dcur.w, 0);
+        const uint32_t ll0 = rl(dcur.x, 1), ml0 = rl(dcur.y, 1), off0 = rl(dcur.z, 1);
+        const uint32_t last = min(rl(dcur.x, 2), B.nseq - 1);
         const uint32_t W0 = w << kWinLog, W1 = min(W0 + uint32_t(kWin), endp);
-        const int lbw = int(w) + kAhead - kRW;
+        const int lbw = int(w) + kAhead - kRW + 1;
         const uint32_t lowb = lbw > 0 ? uint32_t(lbw) << kWinLog : 0u;     // the ring is guaranteed from here on
         PT(1);
-        // may this window be produced yet?
-        for (uint32_t spins = 0; ldv(&sy->F_vis) + kAhead <= w; ) if (spin_fail(sy, spins)) return;
+        // may this window be produced yet?  (not too far ahead of the chain wave; the ring slot's previous window flushed)
+        for (uint32_t spins = 0; ldv(&sy->E_win) + kAhead < w || ldv(&sy->F_vis) + kRW <= w; ) if (spin_fail(sy, spins)) return;
         cbar();
         PT(0);
-        // stage the stream
 #pragma unroll
         for (int q = 0; q < kCB / 1024; q++) *reinterpret_cast<uint4*>(cbuf + 1024 * q + 16 * lane) = cur.c[q];
         uint32_t obase = opos0;
         for (uint32_t j0 = 0; first + j0 <= last; j0 += 64) {
             const uint32_t sidx = first + j0 + lane;
             const bool act = sidx <= last;
-            uint32_t tp = j0 == 0 ? cur.t[0] : j0 == 64 ? cur.t[1] : j0 == 128 ? cur.t[2] : (act ? B.tok[sidx] : 0u);
-            // ---- decode (every rule was checked by the parser)
+            const uint32_t tp = j0 == 0 ? cur.t[0] : j0 == 64 ? cur.t[1] : j0 == 128 ? cur.t[2] : (act ? B.tok[sidx] : 0u);
+            // ---- decode (every rule was checked by the parser; the window's first sequence comes decoded)
             uint32_t ll = 0, ml = 0, off = 0, litpos = 0;
             if (act) {
-                const uint32_t tk = sbyte(B, cbuf, cs, tp);
-                uint32_t p = tp + 1;
-                ll = tk >> 4;
-                if (ll == 15) { uint32_t bb; do { bb = sbyte(B, cbuf, cs, p); p++; ll += bb; } while (bb == 255); }
-                litpos = p;
-                if (sidx != B.nseq - 1) {
-                    p += ll;
-                    off = sbyte(B, cbuf, cs, p) | (sbyte(B, cbuf, cs, p + 1) << 8);
-                    p += 2;
-                    ml = tk & 15;
-                    if (ml == 15) { uint32_t bb; do { bb = sbyte(B, cbuf, cs, p); p++; ml += bb; } while (bb == 255); }
-                    ml += 4;
+                if (j0 == 0 && lane == 0) { ll = ll0; ml = ml0; off = off0; litpos = lit0; }
+                else {
+                    const uint32_t tk = sbyte(B, cbuf, cs, tp);
+                    uint32_t p = tp + 1;
+                    ll = tk >> 4;
+                    if (ll == 15) { uint32_t bb; do { bb = sbyte(B, cbuf, cs, p); p++; ll += bb; } while (bb == 255); }
+                    litpos = p;
+                    if (sidx != B.nseq - 1) {
+                        p += ll;
+                        off = sbyte(B, cbuf, cs, p) | (sbyte(B, cbuf, cs, p + 1) << 8);
+                        p += 2;
+                        ml = tk & 15;
+                        if (ml == 15) { uint32_t bb; do { bb = sbyte(B, cbuf, cs, p); p++; ml += bb; } while (bb == 255); }
+                        ml += 4;
+                    }
                 }
             }
             const uint32_t len = ll + ml;
@@ -338,6 +304,10 @@ __device__ __forceinline__ void worker_wave(const Blk& B, ring_t ring, uint32_t*
             const uint32_t sp = obase + (incl - len) + B.a0;                 // shifted output position of the sequence
             obase += rl(incl, 63);
             PT(1);
+            // ---- a free slot for this batch
+            for (uint32_t spins = 0; produced >= ldv(&sy->consumed) + kNS; ) if (spin_fail(sy, spins)) return;
+            cbar();
+            PT(2);
             // ---- literals
             {
                 const uint32_t ls = max(sp, W0), le = min(sp + ll, W1);
@@ -346,7 +316,6 @@ __device__ __forceinline__ void worker_wave(const Blk& B, ring_t ring, uint32_t*
                 const bool staged = cp - cs + n <= uint32_t(kCB);           // cp >= cs always
                 const bool shortl = n && n <= uint32_t(kShort) && staged;
                 copy_upto32_lds(lds_addr(ring) + (shortl ? (ls & kRM) : 0u), lds_addr(cbuf) + (shortl ? cp - cs : 0u), shortl ? n : 0u);
-                if (shortl) set_bits(bm, ls, n);
                 unsigned long long lg = __ballot(n && !shortl);
                 while (lg) {
                     const int l = __builtin_ctzll(lg); lg &= lg - 1;
@@ -354,100 +323,148 @@ __device__ __forceinline__ void worker_wave(const Blk& B, ring_t ring, uint32_t*
                     if (c0 - cs + nn <= uint32_t(kCB)) {
                         for (uint32_t k = lane; k < nn; k += 64) ring[(d0 + k) & kRM] = cbuf[c0 - cs + k];
                     } else wave_copy_hbm(ring, d0, B.src + c0, nn, lane);
-                    wave_set_bits(bm, d0, nn, lane);
                 }
             }
             PT(3);
-            // ---- match
+            // ---- matches: from HBM here, through the slot otherwise
             const uint32_t mstart = sp + ll;
             const uint32_t ds = max(mstart, W0), de = min(mstart + ml, W1);
             const uint32_t mn = (act && ml && de > ds) ? de - ds : 0;
             const uint32_t s0 = ds - off;
-            const uint32_t need = min(mn, off);                              // source bytes somebody else produces
-            const bool in_ring = s0 >= lowb;
-            const bool shortm = mn <= uint32_t(kShort);
-            unsigned long long pending = __ballot(mn != 0);
-            uint32_t idle = 0, spins = 0;
-            while (pending) {
-                const bool mine = ((pending >> lane) & 1) != 0;
-                // short pieces: every lane for itself
-                const bool ready = mine && shortm && (!in_ring || bits_set(bm, s0, need));
+            const bool far = mn && s0 < lowb;                                // never overlapping: off > kWin >= mn
+            const bool near = mn && !far;
+            if (__ballot(far)) {
+                uint32_t need = far ? ((s0 + mn - 1) >> kWinLog) + 1 : 0;
+                for (int o = 32; o; o >>= 1) need = max(need, uint32_t(__shfl_xor(int(need), o)));
+                for (uint32_t spins = 0; ldv(&sy->F_vis) < need; ) if (spin_fail(sy, spins)) return;
                 cbar();
-                const bool r1 = ready && in_ring, r2 = ready && !in_ring;
-                if (__ballot(r1)) lane_copy_ring(ring, ds, off, r1 ? mn : 0u);
-                if (__ballot(r2))        // far source: flushed long ago (kAhead bounds it), never overlapping
-                    copy_upto32_hbm(lds_addr(ring) + (r2 ? (ds & kRM) : 0u), B.dst + (r2 ? s0 - B.a0 : 0u), r2 ? mn : 0u);
-                if (ready) set_bits(bm, ds, mn);
-                unsigned long long fin = __ballot(ready);
-                // long pieces: the whole wave, one at a time
-                unsigned long long lg = __ballot(mine && !shortm);
+                const bool fs = far && mn <= uint32_t(kShort);
+                copy_upto32_hbm(lds_addr(ring) + (fs ? (ds & kRM) : 0u), B.dst + (fs ? s0 - B.a0 : 0u), fs ? mn : 0u);
+                unsigned long long lg = __ballot(far && !fs);
                 while (lg) {
                     const int l = __builtin_ctzll(lg); lg &= lg - 1;
-                    const uint32_t d0 = rl(ds, l), nn = rl(mn, l), ss = rl(s0, l), oo = rl(off, l), nd = rl(need, l);
-                    if (ss >= lowb) { if (!wave_bits_set(bm, ss, nd, lane)) continue; cbar(); wave_copy_ring(ring, d0, oo, nn, lane); }
-                    else wave_copy_hbm(ring, d0, B.dst + ss - B.a0, nn, lane);
-                    wave_set_bits(bm, d0, nn, lane);
-                    fin |= 1ull << l;
-                }
-                pending &= ~fin;
-                PADD(6, 1);
-                if (fin) PT(4); else PT(5);
-                if (pending) {
-                    PADD(7, fin ? 0 : 1);
-                    if (fin) idle = 0;
-                    else {
-                        if (++idle > 2) __builtin_amdgcn_s_sleep(1);
-                        if (++spins > kSpinLimit) { stv(&sy->abort, 1); return; }
-                        if (ldv(&sy->abort)) return;
-                    }
+                    wave_copy_hbm(ring, rl(ds, l), B.dst + rl(s0, l) - B.a0, rl(mn, l), lane);
                 }
             }
             PT(4);
+            Slot* s = slots + (produced % kNS);
+            const unsigned long long nb = __ballot(near);
+            if (near) {
+                const uint32_t idx = __builtin_amdgcn_mbcnt_hi(uint32_t(nb >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(nb), 0));
+                s->dst[idx] = ds; s->ol[idx] = off | (mn << 16);
+            }
+            uint32_t mx = near ? mn : 0u;
+            for (int o = 32; o; o >>= 1) mx = max(mx, uint32_t(__shfl_xor(int(mx), o)));
+            const bool lastb = first + j0 + 64 > last;
+            if (lane == 0) { s->n = uint32_t(__builtin_popcountll(nb)); s->epos = lastb ? W1 : min(W1, obase + B.a0); s->last = lastb ? 1u : 0u; s->maxlen = mx; }
+            lds_fence();                                  // every byte of the batch is in the LDS before the slot is published
+            produced++;
+            if (lane == 0) stv(&sy->ready, produced);
+            PT(5);
         }
         dcur = dnext; dnext = dnn; cur = nxt;
     }
-    PROF_OUT(B, ww, lane);
+    PROF_OUT(B, 0, lane);
+}
+
+// ------------------------------------------------------------------------------------------------ chain wave
+// Executes the slots strictly in order.  Everything below a slot's first entry that is not one of its entries is final;
+// inside a slot an entry may run once no earlier entry that is still missing can overlap its source (entries are sorted by
+// destination and disjoint, so "nothing missing below the first missing entry's destination" is the test).
+__device__ __forceinline__ uint32_t chain_slot(ring_t ring, const Slot* s, uint32_t n, uint32_t maxlen, int lane)
+{
+    const uint32_t ra = lds_addr(ring);
+    const bool act = uint32_t(lane) < n;
+    const uint32_t dst = act ? s->dst[lane] : 0xffffffffu;
+    const uint32_t ol = act ? s->ol[lane] : 0;
+    const uint32_t off = ol & 0xffff, len = ol >> 16;
+    const uint32_t hi = min(dst - off + len, dst);              // end of the part of the source that others produce
+    const float roff = __builtin_amdgcn_rcpf(float(max(off, 1u)));
+    unsigned long long undone = __ballot(act);
+    uint32_t rounds = 0;
+    while (undone) {
+        const int f = __builtin_ctzll(undone);
+        const uint32_t Df = rl(dst, f);
+        const bool mine = ((undone >> lane) & 1) != 0;
+        const bool ready = mine && (hi <= Df || lane == f);     // nothing that is still missing lies below Df
+        const unsigned long long rb = __ballot(ready);
+        if (__builtin_popcountll(rb) <= 3 || maxlen > uint32_t(kShort)) {
+            // few entries (the usual state of a dependency chain) or long ones: the whole wave copies one entry at a time
+            unsigned long long q = rb;
+            while (q) {
+                const int l = __builtin_ctzll(q); q &= q - 1;
+                const uint32_t d0 = rl(dst, l), oo = rl(off, l), nn = rl(len, l);
+                if (nn <= 64) {
+                    // byte k of the entry = source byte k mod off (all of [d0 - off, d0) is final): one step for any overlap
+                    const float ro = __builtin_bit_cast(float, rl(__builtin_bit_cast(uint32_t, roff), l));
+                    const uint32_t k = uint32_t(lane);
+                    const uint32_t qd = uint32_t((float(k) + 0.5f) * ro);      // k / off, exact for k, off < 2^16 apart from k >= off * 2^.. (k < 64 here)
+                    const uint32_t km = oo >= 64 ? k : k - qd * oo;
+                    const uint32_t sa = ra + ((d0 - oo + km) & kRM), da = ra + ((d0 + k) & kRM);
+                    uint32_t v;
+                    asm volatile("s_nop 1\n\tds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(sa) : "memory");
+                    if (k < nn) st_lo<0>(da, v);
+                } else wave_copy_ring(ring, d0, oo, nn, lane);
+            }
+        } else {
+            lane_copy_ring(ring, dst, off, ready ? len : 0u);
+        }
+        undone &= ~rb;
+        rounds++;
+    }
+    return rounds;
+}
+
+__device__ __forceinline__ void chain_wave(const Blk& B, ring_t ring, Slot* slots, XSync* sy, int lane)
+{
+    uint32_t cons = 0;
+    __builtin_amdgcn_s_setprio(3);
+    PROF_DECL
+    for (uint32_t w = 0; w < B.nwin; w++) {
+        for (;;) {
+            for (uint32_t spins = 0; ldv(&sy->ready) <= cons; ) if (spin_fail(sy, spins)) return;
+            cbar();
+            PT(0);
+            const Slot* s = slots + (cons % kNS);
+            const uint32_t n = s->n, last = s->last, maxlen = s->maxlen;
+            if (n) { const uint32_t rounds = chain_slot(ring, s, n, maxlen, lane); PADD(3, rounds); PADD(4, n); }
+            PADD(5, 1);
+            lds_fence();
+            PT(1);
+            cons++;
+            if (lane == 0) { stv(&sy->consumed, cons); if (last) stv(&sy->E_win, w + 1); }
+            PT(2);
+            if (last) break;
+        }
+    }
+    PROF_OUT(B, 1, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ flush wave
-__device__ __forceinline__ void flush_wave(const Blk& B, ring_t ring, uint32_t* bm, XSync* sy, int lane)
+__device__ __forceinline__ void flush_wave(const Blk& B, ring_t ring, XSync* sy, int lane)
 {
     const uint32_t endp = B.total + B.a0;
-    uint32_t cleared = 0;                       // windows whose bits have been cleared for the slot's next user
     PROF_DECL
-    // publishing F_vis = x lets windows < x + kAhead start, i.e. reuse the slots of windows < x + kAhead - kRW; nobody reads
-    // those any more (their readers sit in windows < x, all flushed)
-    auto publish = [&](uint32_t x) {
-        for (; cleared + uint32_t(kRW - kAhead) < x; cleared++)
-            if (lane < 32) stv(&bm[(((cleared << kWinLog) & kRM) >> 5) + lane], 0u);
-        lds_fence();
-        if (lane == 0) stv(&sy->F_vis, x);
-    };
     for (uint32_t f = 0; f < B.nwin; f++) {
         PT(1);
-        // all bits of the window set?
-        const uint32_t wpos = f << kWinLog;
-        const uint32_t exp = lane < 32 ? range_mask(wpos + 32 * lane, max(wpos, B.a0), min(wpos + uint32_t(kWin), endp)) : 0u;
-        for (uint32_t spins = 0;;) {
-            const uint32_t v = lane < 32 ? ldv(&bm[((wpos & kRM) >> 5) + lane]) : 0u;
-            if (__ballot((v & exp) != exp) == 0) break;
-            if (spin_fail(sy, spins)) return;
-        }
+        for (uint32_t spins = 0; ldv(&sy->E_win) <= f; ) if (spin_fail(sy, spins)) return;
         cbar();
         PT(0);
-        const uint32_t p0 = wpos + 16u * lane;
+        const uint32_t p0 = (f << kWinLog) + 16u * lane;
         const uint4 v = *reinterpret_cast<const uint4*>(const_cast<const uint8_t*>(ring) + (p0 & kRM));   // behind the barrier above
         uint8_t* g = B.dst + p0 - B.a0;        // 16-byte aligned by construction of a0
         if (p0 >= B.a0 && p0 + 16 <= endp) *reinterpret_cast<uint4*>(g) = v;
         else {
-            const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
-            for (uint32_t k = 0; k < 16; k++) if (p0 + k >= B.a0 && p0 + k < endp) g[k] = uint8_t(wv[k >> 2] >> (8 * (k & 3)));
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint32_t wv = k < 4 ? v.x : k < 8 ? v.y : k < 12 ? v.z : v.w;
+                if (p0 + k >= B.a0 && p0 + k < endp) g[k] = uint8_t(wv >> (8 * (k & 3)));
+            }
         }
-        if (f == 0 || f + 1 == B.nwin) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); publish(f + 1); }
-        else { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); if (f >= uint32_t(kLag)) publish(f + 1 - kLag); }
+        if (f == 0 || f + 1 == B.nwin) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) stv(&sy->F_vis, f + 1); }
+        else { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); if (lane == 0 && f >= uint32_t(kLag)) stv(&sy->F_vis, f + 1 - kLag); }
     }
     PT(1);
-    PROF_OUT(B, kNW, lane);
+    PROF_OUT(B, 2, lane);
 }
 
 } // namespace
@@ -457,8 +474,8 @@ void lz4_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fo
                      const uint8_t* work)
 {
     __shared__ __attribute__((aligned(16))) uint8_t ring[kRing + kGuard];
-    __shared__ __attribute__((aligned(16))) uint32_t bm[kBW];
-    __shared__ __attribute__((aligned(16))) uint8_t cbuf[kNW][kCB + kGuard];
+    __shared__ __attribute__((aligned(16))) uint8_t cbuf[kCB + kGuard];
+    __shared__ Slot slots[kNS];
     __shared__ XSync sy;
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
@@ -472,13 +489,13 @@ void lz4_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fo
     B.tok = reinterpret_cast<const uint32_t*>(slot + kTokOff);
     B.dbg = reinterpret_cast<unsigned long long*>(const_cast<uint8_t*>(slot) + kDbgOff);
     B.iend = blk.src_len; B.nseq = hdr->nseq; B.total = hdr->total; B.nwin = hdr->nwin; B.a0 = hdr->a0;
-    for (int i = threadIdx.x; i < int(kBW); i += kXT) bm[i] = 0;
-    if (threadIdx.x == 0) { sy.F_vis = 0; sy.abort = 0; }
+    if (threadIdx.x == 0) { sy.E_win = 0; sy.F_vis = 0; sy.ready = 0; sy.consumed = 0; sy.abort = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
-    if (wave < kNW) worker_wave(B, ring, bm, cbuf[wave], &sy, wave, lane);
+    if (wave == 0) literal_wave(B, ring, cbuf, slots, &sy, lane);
+    else if (wave == 1) chain_wave(B, ring, slots, &sy, lane);
     else {
-        flush_wave(B, ring, bm, &sy, lane);
+        flush_wave(B, ring, &sy, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) blocks[b].result = ldv(&sy.abort) ? kRetryCode : int(B.total);
     }

@@ -113,6 +113,9 @@ __device__ __forceinline__ bool sdecode(const Ctx& c, int i, uint32_t& ll, uint3
     return !esc;
 }
 
+// continuation bytes of a match length ml (>= 19 means the nibble was 15): 1 + (ml - 19) / 255
+__device__ __forceinline__ uint32_t ml_ext_bytes(uint32_t ml) { return ml >= 19u ? 1u + (ml - 19u) / 255u : 0u; }
+
 // first chain position at or behind the end of pos's row, for a chain that passes through pos (local, < kPch)
 __device__ int step(const Ctx& c, const uint8_t* tab, int pos, int cap)
 {
@@ -186,7 +189,7 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
     Ctx c; c.src = src; c.iend = int(blk.src_len); c.oend = int(blk.dst_cap); c.c0 = 0; c.tile = tile;
     const uint32_t a0 = uint32_t(reinterpret_cast<uintptr_t>(dst_base + blk.dst_off) & 127);
     uint32_t seq_base = 0, out_base = 0;
-    if (t == 0) wdesc[0] = make_uint4(0, 0, 0, 0);
+    
     uint32_t* stage = reinterpret_cast<uint32_t*>(tab);
 
     for (;;) {
@@ -346,7 +349,11 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
                     if (!ok) { atomicOr(&sh.flags, 1); break; }
                     stage[k - r0] = uint32_t(c.c0 + pos);
                     const uint32_t sp0 = opos + a0, sp1 = sp0 + ll + ml;
-                    for (uint32_t w = (sp0 + kWin - 1) >> kWinLog; (w << kWinLog) < sp1; w++) wdesc[w] = make_uint4(seq_base + k, opos, uint32_t(c.c0 + pos), 0);
+                    const uint4 dA = make_uint4(seq_base + k, opos, uint32_t(c.c0 + pos), uint32_t(c.c0 + nx) - (kind == kFinal ? 0u : 2u + ml_ext_bytes(ml)) - ll);
+                    const uint4 dB = make_uint4(ll, ml, off, 0);
+                    uint32_t w = (sp0 + kWin - 1) >> kWinLog;
+                    if (seq_base + k == 0) w = 0;                          // the block's first sequence also owns window 0 (shift a0)
+                    for (; (w << kWinLog) < sp1 || (w == 0 && seq_base + k == 0); w++) { wdesc[2 * w] = dA; wdesc[2 * w + 1] = dB; }
                     if (kind == kFinal) { sh.fin_total = opos + ll; atomicOr(&sh.flags, 2); }
                 }
                 if (kind == kFinal) break;
@@ -367,7 +374,8 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
     if (t == 0) {
         const uint32_t total = sh.fin_total;
         const uint32_t nwin = (total + a0 + kWin - 1) >> kWinLog;
-        wdesc[nwin] = make_uint4(seq_base - 1, total, uint32_t(c.iend), 0);
+        wdesc[2 * nwin] = make_uint4(seq_base - 1, total, uint32_t(c.iend), uint32_t(c.iend));
+        wdesc[2 * nwin + 1] = make_uint4(0, 0, 0, 0);
         hdr->nseq = seq_base; hdr->total = total; hdr->nwin = nwin; hdr->a0 = a0;
         hdr->status = total ? kParsed : kDone;
         if (!total) blocks[b].result = 0;

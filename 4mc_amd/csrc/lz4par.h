@@ -3,8 +3,9 @@
 //
 // Per block the parser leaves, in the block's slot of the device workspace:
 //   ParHdr              status, number of sequences, decoded size, number of output windows
-//   wdesc[w] (uint4)    for output window w: index, output start and token position of the sequence that covers the
-//                       window's first byte
+//   wdesc[w] (2 x uint4) for output window w, about the sequence that covers the window's first byte:
+//                       {index, output start, token position, literal start}, {literal length, match length, offset, 0}
+//                       (decoded once here: a sequence that spans many windows is not parsed again in each of them)
 //   tok[i]  (uint32)    stream position of the token of sequence i
 // Output windows are kWin bytes of the block's output counted from a 128-byte aligned ADDRESS at or below the block's
 // first output byte (a0 = address & 127 is the shift), so that a window is flushed with aligned 16-byte stores and a
@@ -35,7 +36,7 @@ enum : int32_t { kParsed = 0, kDone = 1, kRetry = 2 };
 
 constexpr size_t kHdrBytes   = 64;
 constexpr size_t kWdescOff   = kHdrBytes;
-constexpr size_t kWdescBytes = size_t(kMaxWin + 2) * 16;
+constexpr size_t kWdescBytes = size_t(kMaxWin + 2) * 32;
 constexpr size_t kTokOff     = (kWdescOff + kWdescBytes + 255) & ~size_t(255);
 constexpr size_t kTokBytes   = size_t(kMaxSeq) * 4;
 constexpr size_t kDbgOff     = (kTokOff + kTokBytes + 255) & ~size_t(255);   // cycle counters of profiling builds

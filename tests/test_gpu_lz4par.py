@@ -84,7 +84,7 @@ def test_parser_records_equal_the_oracle_sequence_list(gpu):
             assert nwin == (total + a0 + WIN - 1) // WIN
             gtok = host[toff: toff + 4 * nseq].view(np.uint32)
             assert np.array_equal(gtok, tok), (name, shift, int(np.argmax(gtok != tok)))
-            wd = host[woff: woff + 16 * (nwin + 1)].view(np.uint32).reshape(-1, 4)
+            wd = host[woff: woff + 32 * (nwin + 1)].view(np.uint32).reshape(-1, 8)
             # window w's descriptor names the sequence that covers (shifted) position w * WIN
             ends = np.concatenate([opos[1:], [total]]).astype(np.int64)
             for w in range(nwin):
@@ -93,6 +93,14 @@ def test_parser_records_equal_the_oracle_sequence_list(gpu):
                 while i < n - 1 and ends[i] == opos[i] and pos >= ends[i]:
                     i += 1
                 assert wd[w, 0] == i and wd[w, 1] == opos[i] and wd[w, 2] == tok[i], (name, shift, w, wd[w].tolist(), i)
+                # the decoded fields of that sequence: literal start / literal length / match length
+                nxt_o = int(opos[i + 1]) if i + 1 < n else total
+                assert int(wd[w, 4]) + int(wd[w, 5]) == nxt_o - int(opos[i]), (name, shift, w, wd[w].tolist())
+                tk = int(comp[tok[i]])
+                assert (tk >> 4) == min(int(wd[w, 4]), 15) and (i == n - 1 or (tk & 15) == min(int(wd[w, 5]) - 4, 15))
+                lit = int(wd[w, 3]); ll = int(wd[w, 4])
+                if i < n - 1:
+                    assert int(comp[lit + ll]) | (int(comp[lit + ll + 1]) << 8) == int(wd[w, 6]), (name, shift, w)
             assert wd[nwin, 0] == n - 1
 
 

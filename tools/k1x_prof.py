@@ -30,8 +30,9 @@ for b in want:
     t = host.view(np.uint64).reshape(-1, 8)
     ok = bool(torch.equal(d_dst[:B].cpu(), torch.from_numpy(src)))
     print(f"== {names[b]}: {s.elapsed_time(e):.2f} ms, roundtrip {'ok' if ok else 'BAD'}; counters in Mclk")
-    for w in range(NW):
-        v = t[w] / 1e6
-        print(f"  worker{w}: gate {v[0]:7.2f}  decode {v[1]:7.2f}  literals {v[3]:7.2f}  copy rounds {v[4]:7.2f}  empty rounds {v[5]:7.2f}   rounds {int(t[w][6])}  of which empty {int(t[w][7])}")
-    v = t[NW] / 1e6
-    print(f"  flush: wait {v[0]:7.2f}  work {v[1]:7.2f}")
+    v = t[0] / 1e6
+    print(f"  literal: gate {v[0]:7.2f}  decode {v[1]:7.2f}  wait-slot {v[2]:7.2f}  literals {v[3]:7.2f}  far matches {v[4]:7.2f}  publish {v[5]:7.2f}")
+    v = t[1] / 1e6
+    print(f"  chain:   wait {v[0]:7.2f}  copy {v[1]:7.2f}  publish {v[2]:7.2f}   rounds {int(t[1][3])}  entries {int(t[1][4])}  slots {int(t[1][5])}")
+    v = t[2] / 1e6
+    print(f"  flush:   wait {v[0]:7.2f}  work {v[1]:7.2f}")
