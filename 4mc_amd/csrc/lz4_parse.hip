@@ -34,11 +34,12 @@ constexpr int kTile  = kPch + kMarg;
 constexpr int kTilePhys = kTile + 4 * (kTile / 64) + 8;
 constexpr int kTabPhys  = kPch + 4 * (kPch / 64);
 constexpr int kStageCap = kTabPhys / 4;       // the exit table's space carries the records of a piece on their way out
-constexpr int kWarm  = 4;                     // rows of warm-up for a guess
-constexpr int kSpecCap = 48;                  // length bytes a speculative walk follows before it gives up
 constexpr int POS_END = 0x3fffffff;           // the chain ended with a valid last sequence
 constexpr int POS_BAD = 0x40000000;           // the chain ran into something the strict rules reject
 constexpr int POS_UNK = 0x40000001;           // a speculative walk gave up
+constexpr int POS_NONE = 0x40000002;
+constexpr int kSpecCap = 4;                   // length bytes a walk from an arbitrary entry offset follows before it gives up (the real chain never does)
+constexpr int kGroup = 1024;                 // rows are grouped by 16 for the two-level chain walk
 
 // rows are padded by one bank so that lanes working on the same column of 64 different rows hit 32 different banks
 __device__ __forceinline__ int phys(int i) { return i + ((i >> 6) << 2); }
@@ -142,12 +143,27 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)       // inclusive
     return v;
 }
 
+// profiling build (make prof): thread 0 charges the cycles since the previous mark to a phase counter (units of 256 clk)
+#ifdef K1X_PROF
+#define PPROF_DECL unsigned long long pp_[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long pl_ = __builtin_readcyclecounter();
+#define PPT(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); pp_[i] += n_ - pl_; pl_ = n_; } while (0)
+#define PPADD(i, v) do { pp_[i] += (v); } while (0)
+#define PPROF_OUT(h) do { if (t == 0) for (int i_ = 0; i_ < 10; i_++) (h)->dbg[i_] = uint32_t(pp_[i_] >> (i_ < 8 ? 8 : 0)); } while (0)
+#else
+#define PPROF_DECL
+#define PPT(i) do {} while (0)
+#define PPADD(i, v) do {} while (0)
+#define PPROF_OUT(h) do {} while (0)
+#endif
+
 struct PShared {
     uint32_t wsum[2][4];        // wave totals of the two scans
     int      gmin;
     int      flags;             // bit 0: a token broke a rule, bit 1: the last sequence was seen
     uint32_t fin_total;
-    int      xs[kPT];           // exit of every row
+    int      xs[kPT];           // first chain position of every row (POS_NONE: the chain does not touch the row)
+    int      gmap[kPch / 1024][64];
+    int      gentry[kPch / 1024 + 1];
 };
 
 } // namespace
@@ -191,8 +207,11 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
     uint32_t seq_base = 0, out_base = 0;
     
     uint32_t* stage = reinterpret_cast<uint32_t*>(tab);
+    PPROF_DECL
 
     for (;;) {
+        PPT(7);
+        PPADD(9, 1);
         // ---------------------------------------------------------------- stage [c0, c0 + kTile)
         __syncthreads();
         if (t == 0) { sh.flags = 0; }
@@ -209,6 +228,7 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
         __syncthreads();
+        PPT(0);
         // ---------------------------------------------------------------- A: distance to the next token, per byte
         for (int i = 4 * t; i < kPch; i += 4 * kPT) {
             const uint32_t w0 = *reinterpret_cast<const uint32_t*>(tile + phys(i));
@@ -232,6 +252,7 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
             *reinterpret_cast<uint32_t*>(tab + phys(i)) = out;
         }
         __syncthreads();
+        PPT(1);
         // ---------------------------------------------------------------- B: exits of every row, backwards
         {
             uint8_t* row = tab + 68 * t;
@@ -260,47 +281,49 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
             }
         }
         __syncthreads();
-        // ---------------------------------------------------------------- C: where the chain enters every row
-        int E, X;
+        PPT(2);
+        // ---------------------------------------------------------------- C: where the chain enters every row (exact, two levels)
+        // C1: for each group of 16 rows and each of the 64 offsets a chain can enter its first row at: where it leaves the group
         {
-            int pos = t >= kWarm ? 64 * (t - kWarm) : 0;
-            const int cap = t >= kWarm ? kSpecCap : 0x7fffffff;          // rows that start on the real chain walk it to the end
-            while (pos < 64 * t) pos = step(c, tab, pos, cap);
-            E = pos;
-            X = E < 64 * (t + 1) ? step(c, tab, E, cap) : E;
-            sh.xs[t] = X;
+            const int g = t >> 4;
+            int pos[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) pos[i] = kGroup * g + (t & 15) + 16 * i;
+            const int lim = kGroup * (g + 1);
+            for (int it = 0; it < kGroup / 64; it++) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) if (pos[i] < lim) pos[i] = step(c, tab, pos[i], kSpecCap);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) sh.gmap[g][(t & 15) + 16 * i] = pos[i];
+        }
+        for (int r = t; r < kPT; r += kPT) sh.xs[r] = POS_NONE;
+        __syncthreads();
+        // C2: the real chain from group to group (one lane; at most one table lookup per group unless a long token lands deep)
+        if (t == 0) {
+            int pos = 0;
+            for (int g = 0; g < kPch / kGroup; g++) {
+                sh.gentry[g] = pos;
+                const int lim = kGroup * (g + 1);
+                if (pos >= lim) continue;
+                const int o = pos - kGroup * g;
+                int v = o < 64 ? sh.gmap[g][o] : POS_UNK;
+                if (v == POS_UNK) { v = pos; while (v < lim) v = step(c, tab, v, 0x7fffffff); }
+                pos = v;
+            }
+            sh.gentry[kPch / kGroup] = pos;
         }
         __syncthreads();
-        for (int rounds = 0;; rounds++) {
-            if (rounds > 2 * kPT + 8) { leave(kRetry, kRetryCode, true); return; }      // cannot happen: every round makes one more row exact
-            const int left = t > 0 ? sh.xs[t - 1] : 0;
-            const bool bad = t > 0 && (left == POS_UNK || E != left);
-            if (t == 0) sh.gmin = kPT;
-            if (!__syncthreads_or(bad)) break;
-            if (bad) atomicMin(&sh.gmin, t);
-            __syncthreads();
-            const int g = sh.gmin;                              // rows < g are exact
-            const int Y = sh.xs[g - 1];
-            int newE = E; bool full = false, redo = false;
-            if (Y == POS_UNK) { if (t == g - 1) { redo = true; full = true; } }      // the last exact row gave up on its exit: walk it out
-            else {
-                if (t >= g && (64 * t <= Y)) { newE = Y; full = true; redo = newE != E || X == POS_UNK; }   // exact from here on
-                else if (bad && left != POS_UNK) { newE = left; redo = true; }
-            }
-            __syncthreads();
-            if (redo) {
-                E = newE;
-                X = E < 64 * (t + 1) ? step(c, tab, E, full ? 0x7fffffff : kSpecCap) : E;
-                sh.xs[t] = X;
-            }
-            __syncthreads();
+        // C3: inside every group, from its real entry: the first chain position of every row
+        if (t < kPch / kGroup) {
+            int pos = sh.gentry[t];
+            const int lim = kGroup * (t + 1);
+            while (pos < lim) { sh.xs[pos >> 6] = pos; pos = step(c, tab, pos, 0x7fffffff); }
         }
-        if (sh.xs[kPT - 1] == POS_UNK) {                        // every row is exact now; the piece's own exit has to be, too
-            __syncthreads();
-            if (t == kPT - 1) { X = E < 64 * kPT ? step(c, tab, E, 0x7fffffff) : E; sh.xs[t] = X; }
-            __syncthreads();
-        }
-        const int next_local = sh.xs[kPT - 1];
+        __syncthreads();
+        const int E = sh.xs[t];
+        const int next_local = sh.gentry[kPch / kGroup];
+        PPT(3);
         // ---------------------------------------------------------------- D: this row's tokens
         const int lim = 64 * (t + 1);
         uint32_t n_tok = 0, n_out = 0;
@@ -319,6 +342,7 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
             }
         }
         __syncthreads();        // everyone is done with the exit table: its space now stages records
+        PPT(4);
         uint32_t pn, po, N, O;
         {
             const uint32_t in = wave_scan_add(n_tok), io = wave_scan_add(n_out);
@@ -330,6 +354,7 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
             pn = bn + in - n_tok; po = bo + io - n_out;
         }
         if (sh.flags & 1) { leave(kRetry, kRetryCode, true); return; }
+        PPT(5);
         for (uint32_t r0 = 0; r0 < N; r0 += kStageCap) {
             uint32_t k = pn, opos = out_base + po;
             int pos = E;
@@ -364,6 +389,7 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
             for (uint32_t i = t; i < cnt; i += kPT) tok[seq_base + r0 + i] = stage[i];
             __syncthreads();
         }
+        PPT(6);
         const int flags = sh.flags;
         if (flags & 1) { leave(kRetry, kRetryCode, true); return; }
         seq_base += N; out_base += O;
@@ -377,6 +403,7 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
         wdesc[2 * nwin] = make_uint4(seq_base - 1, total, uint32_t(c.iend), uint32_t(c.iend));
         wdesc[2 * nwin + 1] = make_uint4(0, 0, 0, 0);
         hdr->nseq = seq_base; hdr->total = total; hdr->nwin = nwin; hdr->a0 = a0;
+        PPROF_OUT(hdr);
         hdr->status = total ? kParsed : kDone;
         if (!total) blocks[b].result = 0;
     }

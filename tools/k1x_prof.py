@@ -25,6 +25,11 @@ for b in want:
     for _ in range(2):
         s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
         s.record(); p.lz4_decompress(d_src, d_dst, batch); e.record(); torch.cuda.synchronize()
+    hh = np.zeros(64, np.uint8)
+    p.binding.check(p.lib().fourmc_gpu_debug_read_workspace(hh.ctypes.data, 0, 64), "read")
+    pd = hh.view(np.uint32)[5:15].astype(np.float64)
+    names_p = ["stage", "A next", "B exits", "C entries", "D1 count", "scan", "D2 records", "loop"]
+    print("  parse (Mclk): " + "  ".join(f"{nm} {pd[i] * 256 / 1e6:.2f}" for i, nm in enumerate(names_p)) + f"   repair rounds {int(pd[8])}  pieces {int(pd[9])}")
     host = np.zeros(1024, np.uint8)
     p.binding.check(p.lib().fourmc_gpu_debug_read_workspace(host.ctypes.data, dbg_off, 1024), "read")
     t = host.view(np.uint64).reshape(-1, 8)
