@@ -37,13 +37,15 @@ constexpr int kLag   = 6;                     // flush stores in flight before t
 constexpr int kCB    = 2048;                  // bytes of the stream staged per window
 constexpr int kGuard = 64;                    // readable bytes behind the ring / the staged stream (batched reads overshoot)
 constexpr int kShort = 32;                    // pieces up to this length are copied by their own lane
+constexpr int kPF    = 4;                     // dwords prefetched per piece by the literal wave (longer pieces: whole-wave copy on demand)
 constexpr int kNS    = 4;                     // slots between the literal wave and the chain wave
 constexpr uint32_t kSpinLimit = 1u << 21;
 constexpr int kXT    = 64 * 3;
 
 
 // sync words: relaxed workgroup-scope atomics (a volatile access makes the backend wait for every single load / store)
-__device__ __forceinline__ uint32_t ldv(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// (the value is wave-uniform: readfirstlane moves it to an SGPR, so that loops on it are scalar branches, not exec-mask loops)
+__device__ __forceinline__ uint32_t ldv(const uint32_t* p) { return uint32_t(__builtin_amdgcn_readfirstlane(int(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)))); }
 __device__ __forceinline__ void stv(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }
@@ -57,6 +59,13 @@ __device__ __forceinline__ uint32_t xscan_add(uint32_t v)
     v += xdpp0<0x142, 0xa>(v); v += xdpp0<0x143, 0xc>(v);
     return v;
 }
+__device__ __forceinline__ uint32_t xscan_max(uint32_t v)      // values >= 0
+{
+    v = max(v, xdpp0<0x111, 0xf>(v)); v = max(v, xdpp0<0x112, 0xf>(v)); v = max(v, xdpp0<0x114, 0xf>(v)); v = max(v, xdpp0<0x118, 0xf>(v));
+    v = max(v, xdpp0<0x142, 0xa>(v)); v = max(v, xdpp0<0x143, 0xc>(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
 __device__ __forceinline__ uint32_t rl(uint32_t v, int l) { return uint32_t(__builtin_amdgcn_readlane(int(v), l)); }
 
 typedef uint8_t* ring_t;       // LDS; the hot copies address it through 32-bit LDS addresses and inline asm
@@ -86,12 +95,15 @@ template <int OFF> __device__ __forceinline__ void st_hi(uint32_t a, uint32_t r)
 
 // m <= 32 bytes per lane from LDS address s to LDS address d, not overlapping, s readable up to 34 bytes past its start
 // whatever m is (also for lanes with m = 0).  All loads of all lanes are issued before the first store.
-__device__ __forceinline__ void copy_upto32_lds(uint32_t d, uint32_t s, uint32_t m)
+// G (wave-uniform) = m / 4 of the longest piece, or -1 to find out here.
+__device__ __forceinline__ void copy_upto32_lds(uint32_t d, uint32_t s, uint32_t m, int G = -1)
 {
-    if (__ballot(m != 0) == 0) return;
-    int G = 0;
+    if (G < 0) {
+        if (__ballot(m != 0) == 0) return;
+        G = 0;
 #pragma unroll
-    for (int g = 1; g <= 8; g++) if (__ballot(m >= uint32_t(4 * g)) != 0) G = g;
+        for (int g = 1; g <= 8; g++) if (__ballot(m >= uint32_t(4 * g)) != 0) G = g;
+    }
     switch (G) {
         case 0: cp32_g0(d, s, m); break;
         case 1: cp32_g1(d, s, m); break;
@@ -127,7 +139,7 @@ __device__ __forceinline__ void copy_upto32_hbm(uint32_t d, const uint8_t* g, ui
 
 // one lane, n <= kShort bytes inside the ring with LZ4 (byte-serial) semantics dst[k] = dst[k - off]: copied in steps
 // whose distance doubles (off, 2 off, ..: always a multiple of the period), so that every step is a plain copy
-__device__ __forceinline__ void lane_copy_ring(ring_t ring, uint32_t dst, uint32_t off, uint32_t n)
+__device__ __forceinline__ void lane_copy_ring(ring_t ring, uint32_t dst, uint32_t off, uint32_t n, int G = -1)
 {
     const uint32_t ra = lds_addr(ring);
     uint32_t done = 0, span = off;
@@ -135,7 +147,7 @@ __device__ __forceinline__ void lane_copy_ring(ring_t ring, uint32_t dst, uint32
         const uint32_t m = done < n ? min(span, n - done) : 0u;
         const uint32_t sa = (dst + done - span) & kRM, da = (dst + done) & kRM;
         const bool wraps = m && sa + m > uint32_t(kRing);
-        copy_upto32_lds(ra + da, ra + sa, wraps ? 0u : m);
+        copy_upto32_lds(ra + da, ra + sa, wraps ? 0u : m, G);
         if (__ballot(wraps)) { if (wraps) for (uint32_t k = 0; k < m; k++) { const uint8_t a = ring[(sa + k) & kRM]; cbar(); ring[da + k] = a; cbar(); } }
         done += m; span <<= 1;
     }
@@ -186,7 +198,7 @@ __device__ __forceinline__ void wave_copy_hbm(ring_t ring, uint32_t dst, const u
 
 // ---------------------------------------------------------------------------------------------- the three waves
 struct Blk {
-    const uint8_t* src; uint8_t* dst; const uint4* wdesc; const uint32_t* tok; unsigned long long* dbg;
+    const uint8_t* src; uint8_t* dst; const uint4* wdesc; const uint2* rec; unsigned long long* dbg;
     uint32_t iend, nseq, total, nwin, a0;
 };
 
@@ -203,15 +215,6 @@ struct XSync {
     uint32_t abort;
 };
 
-typedef const __attribute__((address_space(3))) uint8_t* lds_bytes;   // keeps the two sides of the choice below apart (no flat loads)
-// stream byte at position p: from the wave's staged copy [cs, cs + kCB) or from HBM
-__device__ __forceinline__ uint32_t sbyte(const Blk& B, const uint8_t* cbuf, uint32_t cs, uint32_t p)
-{
-    const uint32_t i = p - cs;
-    if (i < uint32_t(kCB)) return ((lds_bytes)cbuf)[i];
-    return B.src[p];
-}
-
 __device__ __forceinline__ bool spin_fail(XSync* sy, uint32_t& spins)
 {
     __builtin_amdgcn_s_sleep(1);
@@ -220,149 +223,184 @@ __device__ __forceinline__ bool spin_fail(XSync* sy, uint32_t& spins)
 }
 
 // ------------------------------------------------------------------------------------------------ literal wave
-// Walks the windows in order, up to kAhead windows ahead of the chain wave: token decode, literals into the ring, matches
-// whose source has left the ring's guaranteed part straight from the flushed output, and for every batch of 64 sequences
-// one slot with the matches that read the ring.
-__device__ __forceinline__ void literal_wave(const Blk& B, ring_t ring, uint8_t* cbuf, Slot* slots, XSync* sy, int lane)
+// Walks the windows in order, up to kAhead windows ahead of the chain wave.  A batch is 64 consecutive sequences of a
+// window (records decoded by the parser, clipped to the window).  Software pipeline: while batch k is stored into the
+// ring, batch k + 1 is already unpacked and its HBM loads - literal bytes from the stream, bytes of matches whose source has
+// left the ring's guaranteed part from the flushed output - are in flight; the wave never waits for a load it has just
+// issued.  Every other match goes into the batch's slot for the chain wave.
+struct Batch {                                  // per lane unless marked uniform
+    uint32_t w, W1, lastb, valid;               // uniform: window, its end, last batch of the window
+    uint32_t ls, ln;                            // literal piece: destination (shifted position), length
+    uint32_t ds, off, mn, s0;                   // match piece: destination, offset, length, source
+    uint32_t cp;                                // stream position of the literal piece
+    uint32_t far;                               // the match is copied from HBM here
+    uint32_t epos;                              // uniform: completed position once the batch is in the ring
+    uint32_t L[kPF], F[kPF];                    // first 4 * kPF bytes of the literal piece / of the far match source
+};
+
+struct __attribute__((packed, aligned(1))) U4u { uint32_t v; };
+// bytes [0, m) of the dwords w -> LDS address d (m <= 4 * kPF)
+__device__ __forceinline__ void store_upto32(uint32_t d, const uint32_t (&w)[kPF], uint32_t m)
+{
+    if (__ballot(m != 0) == 0) return;
+#define FOURMC_ST4(q) if (__ballot(m > uint32_t(4 * q)) != 0) { \
+        if (m >= uint32_t(4 * q + 4)) { st_lo<4 * q>(d, w[q]); st_lo<4 * q + 1>(d, w[q] >> 8); st_hi<4 * q + 2>(d, w[q]); st_hi<4 * q + 3>(d, w[q] >> 8); } \
+        else if (m > uint32_t(4 * q)) { st_lo<4 * q>(d, w[q]); if (m > uint32_t(4 * q + 1)) st_lo<4 * q + 1>(d, w[q] >> 8); if (m > uint32_t(4 * q + 2)) st_hi<4 * q + 2>(d, w[q]); } }
+    FOURMC_ST4(0) FOURMC_ST4(1) FOURMC_ST4(2) FOURMC_ST4(3)
+    static_assert(kPF == 4, "store_upto32 is written for four dwords");
+#undef FOURMC_ST4
+}
+
+__device__ __forceinline__ void literal_wave(const Blk& B, ring_t ring, Slot* slots, XSync* sy, int lane)
 {
     const uint32_t endp = B.total + B.a0;
+    const uint32_t ra = lds_addr(ring);
     uint32_t produced = 0;
     PROF_DECL
-    // prefetch registers: descriptors two windows ahead, stream bytes and token positions one window ahead
+    // window-level prefetch: descriptors two windows ahead, the records of a window's first three batches one window ahead
     auto load_desc = [&](uint32_t w) -> uint4 {                              // lanes 0..3: A(w), B(w), A(w+1), B(w+1)
         const uint32_t i = min(2 * w + uint32_t(lane & 3), 2 * B.nwin + 1);
         return B.wdesc[i];
     };
-    struct Data { uint4 c[kCB / 1024]; uint32_t t[3]; };
-    auto load_data = [&](const uint4& dl, Data& d) {
-        const uint32_t first = rl(dl.x, 0), cs = rl(dl.z, 0);
+    struct Recs { uint2 r[3]; };
+    auto load_recs = [&](const uint4& dl, Recs& d) {
+        const uint32_t first = rl(dl.x, 0);
 #pragma unroll
-        for (int q = 0; q < kCB / 1024; q++) {
-            const uint32_t g = cs + 1024u * q + 16u * lane;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (g + 16 <= B.iend) v = ld16u(B.src + g);
-            else if (g < B.iend) {
-                for (uint32_t i = 0; i < B.iend - g; i++) {
-                    const uint32_t by = uint32_t(B.src[g + i]) << (8 * (i & 3));
-                    if (i < 4) v.x |= by; else if (i < 8) v.y |= by; else if (i < 12) v.z |= by; else v.w |= by;
-                }
-            }
-            d.c[q] = v;
-        }
-#pragma unroll
-        for (int q = 0; q < 3; q++) { const uint32_t i = first + 64u * q + lane; d.t[q] = i < B.nseq ? B.tok[i] : 0; }
+        for (int q = 0; q < 3; q++) { const uint32_t i = first + 64u * q + lane; d.r[q] = i < B.nseq ? B.rec[i] : make_uint2(0, 0); }
     };
+    // iteration state
+    uint32_t w = 0, j0 = 0, obase = 0;
+    uint4 dcur = load_desc(0), dnext = load_desc(1), dnn = dnext;
+    Recs cur; load_recs(dcur, cur);
+    Recs nxt = cur;
+    bool win_fresh = true;                      // the first batch of window w is next
 
-    uint4 dcur = load_desc(0);
-    uint4 dnext = load_desc(1);
-    Data cur; load_data(dcur, cur);
-    Data nxt = cur;
-    for (uint32_t w = 0; w < B.nwin; w++) {
-        const bool have_next = w + 1 < B.nwin;
-        uint4 dnn = dnext;
-        if (have_next) { load_data(dnext, nxt); dnn = load_desc(w + 2); }
-        const uint32_t first = rl(dcur.x, 0), opos0 = rl(dcur.y, 0), cs = rl(dcur.z, 0), lit0 = rl(dcur.w, 0);
-        const uint32_t ll0 = rl(dcur.x, 1), ml0 = rl(dcur.y, 1), off0 = rl(dcur.z, 1);
-        const uint32_t last = min(rl(dcur.x, 2), B.nseq - 1);
+    // unpack batch (w, j0), clip it to the window, issue its HBM loads
+    auto prepare = [&](Batch& b) {
+        if (win_fresh) {
+            win_fresh = false;
+            if (w + 1 < B.nwin) { load_recs(dnext, nxt); dnn = load_desc(w + 2); }
+            obase = rl(dcur.y, 0);
+        }
+        const uint32_t first = rl(dcur.x, 0), last = min(rl(dcur.x, 2), B.nseq - 1);
         const uint32_t W0 = w << kWinLog, W1 = min(W0 + uint32_t(kWin), endp);
         const int lbw = int(w) + kAhead - kRW + 1;
         const uint32_t lowb = lbw > 0 ? uint32_t(lbw) << kWinLog : 0u;     // the ring is guaranteed from here on
+        const uint32_t sidx = first + j0 + lane;
+        const bool act = sidx <= last;
+        uint2 r = j0 == 0 ? cur.r[0] : j0 == 64 ? cur.r[1] : j0 == 128 ? cur.r[2] : (act ? B.rec[sidx] : make_uint2(0, 0));
+        uint32_t litpos = r.x & 0x7fffffu, ll = (r.x >> 23) | ((r.y >> 27) << 9), ml = (r.y >> 16) & 2047u, off = r.y & 0xffffu;
+        if (ll == kRecLLSat || ml == kRecMLSat) {                           // at least a window long: the last of this window, exact in the next descriptor
+            litpos = rl(dcur.w, 2); ll = rl(dcur.x, 3); ml = rl(dcur.y, 3); off = rl(dcur.z, 3);
+        }
+        if (j0 == 0 && lane == 0) { litpos = rl(dcur.w, 0); ll = rl(dcur.x, 1); ml = rl(dcur.y, 1); off = rl(dcur.z, 1); }   // the window's first sequence
+        if (!act) { ll = 0; ml = 0; }
+        const uint32_t len = ll + ml;
+        const uint32_t incl = xscan_add(len);
+        const uint32_t sp = obase + (incl - len) + B.a0;                     // shifted output position of the sequence
+        obase += rl(incl, 63);
+        b.w = w; b.W1 = W1; b.valid = 1;
+        b.lastb = first + j0 + 64 > last ? 1u : 0u;
+        b.epos = b.lastb ? W1 : min(W1, obase + B.a0);
+        // literal piece
+        const uint32_t ls = max(sp, W0), le = min(sp + ll, W1);
+        b.ls = ls; b.ln = le > ls ? le - ls : 0u;
+        b.cp = litpos + (ls - sp);
+        // match piece
+        const uint32_t mstart = sp + ll;
+        const uint32_t ds = max(mstart, W0), de = min(mstart + ml, W1);
+        b.ds = ds; b.off = off; b.mn = (ml && de > ds) ? de - ds : 0u; b.s0 = ds - off;
+        b.far = (b.mn && b.s0 < lowb) ? 1u : 0u;                             // never overlapping: off > kWin >= mn
+        // loads: up to 32 literal bytes (clamped inside the stream; what lies behind the piece is never stored)
+        {
+            const uint32_t G = b.ln <= 4u * kPF ? (b.ln + 3) >> 2 : 0u;
+            const uint8_t* g = B.src + b.cp;
+#pragma unroll
+            for (int q = 0; q < kPF; q++) { b.L[q] = 0; if (__ballot(G > uint32_t(q)) != 0) { if (G > uint32_t(q)) b.L[q] = reinterpret_cast<const U4u*>(b.cp + 4 * q + 4 <= B.iend ? g + 4 * q : B.src + B.iend - 4)->v; } }
+        }
+        if (__ballot(b.far)) {
+            uint32_t need = b.far ? ((b.s0 + b.mn - 1) >> kWinLog) + 1 : 0;
+            need = rl(xscan_max(need), 63);
+            for (uint32_t spins = 0; ldv(&sy->F_vis) < need; ) if (spin_fail(sy, spins)) { b.valid = 0; return; }
+            cbar();
+            const uint32_t G = (b.far && b.mn <= 4u * kPF) ? (b.mn + 3) >> 2 : 0u;
+            const uint8_t* g = B.dst + (b.far ? b.s0 - B.a0 : 0u);
+#pragma unroll
+            for (int q = 0; q < kPF; q++) { b.F[q] = 0; if (__ballot(G > uint32_t(q)) != 0) { if (G > uint32_t(q)) b.F[q] = reinterpret_cast<const U4u*>(g + 4 * q)->v; } }
+        }
+        // advance
+        j0 += 64;
+        if (first + j0 > last) { w++; j0 = 0; dcur = dnext; dnext = dnn; cur = nxt; win_fresh = true; }
+    };
+
+    // first touch of what prepare() loaded: the wait for those loads sits here, after the OTHER batch's stores
+    // (a piece that ends in the last 3 bytes of the stream has its tail loaded a few bytes early: shift it back)
+    auto finalize = [&](Batch& b) {
+        const uint32_t G = b.ln <= 4u * kPF ? (b.ln + 3) >> 2 : 0u;
+#pragma unroll
+        for (int q = 0; q < kPF; q++) if (G > uint32_t(q) && b.cp + 4 * q + 4 > B.iend) b.L[q] >>= 8 * (b.cp + 4 * q + 4 - B.iend);
+        asm volatile("" : "+v"(b.L[0]), "+v"(b.F[0]));
+    };
+
+    // store batch b into the ring and publish its slot
+    auto commit = [&](Batch& b) -> bool {
         PT(1);
-        // may this window be produced yet?  (not too far ahead of the chain wave; the ring slot's previous window flushed)
-        for (uint32_t spins = 0; ldv(&sy->E_win) + kAhead < w || ldv(&sy->F_vis) + kRW <= w; ) if (spin_fail(sy, spins)) return;
+        for (uint32_t spins = 0; ldv(&sy->E_win) + kAhead < b.w || ldv(&sy->F_vis) + kRW <= b.w; ) if (spin_fail(sy, spins)) return false;
+        for (uint32_t spins = 0; produced >= ldv(&sy->consumed) + kNS; ) if (spin_fail(sy, spins)) return false;
         cbar();
         PT(0);
-#pragma unroll
-        for (int q = 0; q < kCB / 1024; q++) *reinterpret_cast<uint4*>(cbuf + 1024 * q + 16 * lane) = cur.c[q];
-        uint32_t obase = opos0;
-        for (uint32_t j0 = 0; first + j0 <= last; j0 += 64) {
-            const uint32_t sidx = first + j0 + lane;
-            const bool act = sidx <= last;
-            const uint32_t tp = j0 == 0 ? cur.t[0] : j0 == 64 ? cur.t[1] : j0 == 128 ? cur.t[2] : (act ? B.tok[sidx] : 0u);
-            // ---- decode (every rule was checked by the parser; the window's first sequence comes decoded)
-            uint32_t ll = 0, ml = 0, off = 0, litpos = 0;
-            if (act) {
-                if (j0 == 0 && lane == 0) { ll = ll0; ml = ml0; off = off0; litpos = lit0; }
-                else {
-                    const uint32_t tk = sbyte(B, cbuf, cs, tp);
-                    uint32_t p = tp + 1;
-                    ll = tk >> 4;
-                    if (ll == 15) { uint32_t bb; do { bb = sbyte(B, cbuf, cs, p); p++; ll += bb; } while (bb == 255); }
-                    litpos = p;
-                    if (sidx != B.nseq - 1) {
-                        p += ll;
-                        off = sbyte(B, cbuf, cs, p) | (sbyte(B, cbuf, cs, p + 1) << 8);
-                        p += 2;
-                        ml = tk & 15;
-                        if (ml == 15) { uint32_t bb; do { bb = sbyte(B, cbuf, cs, p); p++; ml += bb; } while (bb == 255); }
-                        ml += 4;
-                    }
-                }
+        // literals
+        {
+            const bool sh = b.ln <= 4u * kPF;
+            store_upto32(ra + (b.ls & kRM), b.L, sh ? b.ln : 0u);
+            unsigned long long lg = __ballot(!sh);
+            while (lg) {
+                const int l = __builtin_ctzll(lg); lg &= lg - 1;
+                wave_copy_hbm(ring, rl(b.ls, l), B.src + rl(b.cp, l), rl(b.ln, l), lane);
             }
-            const uint32_t len = ll + ml;
-            const uint32_t incl = xscan_add(len);
-            const uint32_t sp = obase + (incl - len) + B.a0;                 // shifted output position of the sequence
-            obase += rl(incl, 63);
-            PT(1);
-            // ---- a free slot for this batch
-            for (uint32_t spins = 0; produced >= ldv(&sy->consumed) + kNS; ) if (spin_fail(sy, spins)) return;
-            cbar();
-            PT(2);
-            // ---- literals
-            {
-                const uint32_t ls = max(sp, W0), le = min(sp + ll, W1);
-                const uint32_t n = (act && le > ls) ? le - ls : 0;
-                const uint32_t cp = litpos + (ls - sp);
-                const bool staged = cp - cs + n <= uint32_t(kCB);           // cp >= cs always
-                const bool shortl = n && n <= uint32_t(kShort) && staged;
-                copy_upto32_lds(lds_addr(ring) + (shortl ? (ls & kRM) : 0u), lds_addr(cbuf) + (shortl ? cp - cs : 0u), shortl ? n : 0u);
-                unsigned long long lg = __ballot(n && !shortl);
-                while (lg) {
-                    const int l = __builtin_ctzll(lg); lg &= lg - 1;
-                    const uint32_t d0 = rl(ls, l), nn = rl(n, l), c0 = rl(cp, l);
-                    if (c0 - cs + nn <= uint32_t(kCB)) {
-                        for (uint32_t k = lane; k < nn; k += 64) ring[(d0 + k) & kRM] = cbuf[c0 - cs + k];
-                    } else wave_copy_hbm(ring, d0, B.src + c0, nn, lane);
-                }
-            }
-            PT(3);
-            // ---- matches: from HBM here, through the slot otherwise
-            const uint32_t mstart = sp + ll;
-            const uint32_t ds = max(mstart, W0), de = min(mstart + ml, W1);
-            const uint32_t mn = (act && ml && de > ds) ? de - ds : 0;
-            const uint32_t s0 = ds - off;
-            const bool far = mn && s0 < lowb;                                // never overlapping: off > kWin >= mn
-            const bool near = mn && !far;
-            if (__ballot(far)) {
-                uint32_t need = far ? ((s0 + mn - 1) >> kWinLog) + 1 : 0;
-                for (int o = 32; o; o >>= 1) need = max(need, uint32_t(__shfl_xor(int(need), o)));
-                for (uint32_t spins = 0; ldv(&sy->F_vis) < need; ) if (spin_fail(sy, spins)) return;
-                cbar();
-                const bool fs = far && mn <= uint32_t(kShort);
-                copy_upto32_hbm(lds_addr(ring) + (fs ? (ds & kRM) : 0u), B.dst + (fs ? s0 - B.a0 : 0u), fs ? mn : 0u);
-                unsigned long long lg = __ballot(far && !fs);
-                while (lg) {
-                    const int l = __builtin_ctzll(lg); lg &= lg - 1;
-                    wave_copy_hbm(ring, rl(ds, l), B.dst + rl(s0, l) - B.a0, rl(mn, l), lane);
-                }
-            }
-            PT(4);
-            Slot* s = slots + (produced % kNS);
-            const unsigned long long nb = __ballot(near);
-            if (near) {
-                const uint32_t idx = __builtin_amdgcn_mbcnt_hi(uint32_t(nb >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(nb), 0));
-                s->dst[idx] = ds; s->ol[idx] = off | (mn << 16);
-            }
-            uint32_t mx = near ? mn : 0u;
-            for (int o = 32; o; o >>= 1) mx = max(mx, uint32_t(__shfl_xor(int(mx), o)));
-            const bool lastb = first + j0 + 64 > last;
-            if (lane == 0) { s->n = uint32_t(__builtin_popcountll(nb)); s->epos = lastb ? W1 : min(W1, obase + B.a0); s->last = lastb ? 1u : 0u; s->maxlen = mx; }
-            lds_fence();                                  // every byte of the batch is in the LDS before the slot is published
-            produced++;
-            if (lane == 0) stv(&sy->ready, produced);
-            PT(5);
         }
-        dcur = dnext; dnext = dnn; cur = nxt;
+        PT(3);
+        // matches from HBM
+        if (__ballot(b.far)) {
+            const bool sh = b.far && b.mn <= 4u * kPF;
+            store_upto32(ra + (b.ds & kRM), b.F, sh ? b.mn : 0u);
+            unsigned long long lg = __ballot(b.far && !sh);
+            while (lg) {
+                const int l = __builtin_ctzll(lg); lg &= lg - 1;
+                wave_copy_hbm(ring, rl(b.ds, l), B.dst + rl(b.s0, l) - B.a0, rl(b.mn, l), lane);
+            }
+        }
+        PT(4);
+        // the rest goes to the chain wave
+        Slot* s = slots + (produced % kNS);
+        const bool near = b.mn && !b.far;
+        const unsigned long long nb = __ballot(near);
+        if (near) {
+            const uint32_t idx = __builtin_amdgcn_mbcnt_hi(uint32_t(nb >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(nb), 0));
+            s->dst[idx] = b.ds; s->ol[idx] = b.off | (b.mn << 16);
+        }
+        const uint32_t mx = rl(xscan_max(near ? b.mn : 0u), 63);
+        if (lane == 0) { s->n = uint32_t(__builtin_popcountll(nb)); s->epos = b.epos; s->last = b.lastb; s->maxlen = mx; }
+        lds_fence();                                  // every byte of the batch is in the LDS before the slot is published
+        produced++;
+        if (lane == 0) stv(&sy->ready, produced);
+        PT(5);
+        return true;
+    };
+
+    Batch a, b2;                                 // ping-pong: a register copy of a batch would wait for its loads
+    prepare(a); finalize(a);
+    for (;;) {
+        bool more = w < B.nwin;
+        if (more) prepare(b2);
+        if (!a.valid || !commit(a)) return;
+        if (!more) break;
+        finalize(b2);
+        more = w < B.nwin;
+        if (more) prepare(a);
+        if (!b2.valid || !commit(b2)) return;
+        if (!more) break;
+        finalize(a);
     }
     PROF_OUT(B, 0, lane);
 }
@@ -407,7 +445,7 @@ __device__ __forceinline__ uint32_t chain_slot(ring_t ring, const Slot* s, uint3
                 } else wave_copy_ring(ring, d0, oo, nn, lane);
             }
         } else {
-            lane_copy_ring(ring, dst, off, ready ? len : 0u);
+            lane_copy_ring(ring, dst, off, ready ? len : 0u, int(maxlen >> 2));
         }
         undone &= ~rb;
         rounds++;
@@ -421,12 +459,14 @@ __device__ __forceinline__ void chain_wave(const Blk& B, ring_t ring, Slot* slot
     __builtin_amdgcn_s_setprio(3);
     PROF_DECL
     for (uint32_t w = 0; w < B.nwin; w++) {
+        w = rfl(w);
         for (;;) {
+            cons = rfl(cons);
             for (uint32_t spins = 0; ldv(&sy->ready) <= cons; ) if (spin_fail(sy, spins)) return;
             cbar();
             PT(0);
             const Slot* s = slots + (cons % kNS);
-            const uint32_t n = s->n, last = s->last, maxlen = s->maxlen;
+            const uint32_t n = ldv(&s->n), last = ldv(&s->last), maxlen = ldv(&s->maxlen);
             if (n) { const uint32_t rounds = chain_slot(ring, s, n, maxlen, lane); PADD(3, rounds); PADD(4, n); }
             PADD(5, 1);
             lds_fence();
@@ -469,12 +509,11 @@ __device__ __forceinline__ void flush_wave(const Blk& B, ring_t ring, XSync* sy,
 
 } // namespace
 
-__global__ __launch_bounds__(kXT)
+__global__ __launch_bounds__(kXT, 6)
 void lz4_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks, uint32_t nblocks,
                      const uint8_t* work)
 {
     __shared__ __attribute__((aligned(16))) uint8_t ring[kRing + kGuard];
-    __shared__ __attribute__((aligned(16))) uint8_t cbuf[kCB + kGuard];
     __shared__ Slot slots[kNS];
     __shared__ XSync sy;
     const uint32_t b = blockIdx.x;
@@ -486,13 +525,15 @@ void lz4_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fo
     Blk B;
     B.src = src_base + blk.src_off; B.dst = dst_base + blk.dst_off;
     B.wdesc = reinterpret_cast<const uint4*>(slot + kWdescOff);
-    B.tok = reinterpret_cast<const uint32_t*>(slot + kTokOff);
+    B.rec = reinterpret_cast<const uint2*>(slot + kTokOff);
     B.dbg = reinterpret_cast<unsigned long long*>(const_cast<uint8_t*>(slot) + kDbgOff);
-    B.iend = blk.src_len; B.nseq = hdr->nseq; B.total = hdr->total; B.nwin = hdr->nwin; B.a0 = hdr->a0;
+    // wave-uniform by construction; loaded per lane, so tell the compiler (scalar loop control instead of exec-mask loops)
+    auto uni = [](uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); };
+    B.iend = uni(blk.src_len); B.nseq = uni(hdr->nseq); B.total = uni(hdr->total); B.nwin = uni(hdr->nwin); B.a0 = uni(hdr->a0);
     if (threadIdx.x == 0) { sy.E_win = 0; sy.F_vis = 0; sy.ready = 0; sy.consumed = 0; sy.abort = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
-    if (wave == 0) literal_wave(B, ring, cbuf, slots, &sy, lane);
+    if (wave == 0) literal_wave(B, ring, slots, &sy, lane);
     else if (wave == 1) chain_wave(B, ring, slots, &sy, lane);
     else {
         flush_wave(B, ring, &sy, lane);

@@ -33,7 +33,7 @@ constexpr int kPT    = 256;                   // threads = rows of 64 bytes
 constexpr int kTile  = kPch + kMarg;
 constexpr int kTilePhys = kTile + 4 * (kTile / 64) + 8;
 constexpr int kTabPhys  = kPch + 4 * (kPch / 64);
-constexpr int kStageCap = kTabPhys / 4;       // the exit table's space carries the records of a piece on their way out
+constexpr int kStageCap = kTabPhys / 8;       // the exit table's space carries the records of a piece on their way out
 constexpr int POS_END = 0x3fffffff;           // the chain ended with a valid last sequence
 constexpr int POS_BAD = 0x40000000;           // the chain ran into something the strict rules reject
 constexpr int POS_UNK = 0x40000001;           // a speculative walk gave up
@@ -98,13 +98,14 @@ __device__ Tok gdecode(const Ctx& c, int p, int cap)
 }
 
 // the common token shapes straight from the tile: i < kPch is the local position; false = take gdecode
-__device__ __forceinline__ bool sdecode(const Ctx& c, int i, uint32_t& ll, uint32_t& ml, uint32_t& off, int& nexti)
+__device__ __forceinline__ bool sdecode(const Ctx& c, int i, uint32_t& ll, uint32_t& ml, uint32_t& off, int& nexti, int& liti)
 {
     const uint32_t tk = c.tile[phys(i)], b1 = c.tile[phys(i + 1)];
     const uint32_t ll0 = tk >> 4, ml0 = tk & 15;
     bool esc = (ll0 == 15) & (b1 == 255);
     ll = ll0 == 15 ? 15 + b1 : ll0;
-    const int q = i + 1 + (ll0 == 15 ? 1 : 0) + int(ll);
+    liti = i + 1 + (ll0 == 15 ? 1 : 0);
+    const int q = liti + int(ll);
     const uint32_t o0 = c.tile[phys(q)], o1 = c.tile[phys(q + 1)], e1 = c.tile[phys(q + 2)];
     off = o0 | (o1 << 8);
     esc |= (ml0 == 15) & (e1 == 255);
@@ -182,7 +183,7 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
     uint8_t* slot = work + size_t(b) * kSlotBytes;
     ParHdr* hdr = reinterpret_cast<ParHdr*>(slot);
     uint4* wdesc = reinterpret_cast<uint4*>(slot + kWdescOff);
-    uint32_t* tok = reinterpret_cast<uint32_t*>(slot + kTokOff);
+    uint2* rec = reinterpret_cast<uint2*>(slot + kTokOff);
     const uint8_t* src = src_base + blk.src_off;
 
     auto leave = [&](int32_t status, int result, bool set_result) {
@@ -200,13 +201,13 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
             return;
         }
     }
-    if (blk.dst_cap < 64 || blk.src_len < 1 || blk.src_len > kSrcMax || blk.dst_cap > kDstMax) { leave(kRetry, kRetryCode, true); return; }
+    if (blk.dst_cap < 64 || blk.src_len < 16 || blk.src_len > kSrcMax || blk.dst_cap > kDstMax) { leave(kRetry, kRetryCode, true); return; }
 
     Ctx c; c.src = src; c.iend = int(blk.src_len); c.oend = int(blk.dst_cap); c.c0 = 0; c.tile = tile;
     const uint32_t a0 = uint32_t(reinterpret_cast<uintptr_t>(dst_base + blk.dst_off) & 127);
     uint32_t seq_base = 0, out_base = 0;
     
-    uint32_t* stage = reinterpret_cast<uint32_t*>(tab);
+    uint2* stage = reinterpret_cast<uint2*>(tab);
     PPROF_DECL
 
     for (;;) {
@@ -330,8 +331,8 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
         {
             int pos = E;
             while (pos < lim) {
-                uint32_t ll, ml, off; int nx; int kind = kSeq;
-                if (!sdecode(c, pos, ll, ml, off, nx)) {
+                uint32_t ll, ml, off; int nx, li; int kind = kSeq;
+                if (!sdecode(c, pos, ll, ml, off, nx, li)) {
                     const Tok tk = gdecode(c, c.c0 + pos, 0x7fffffff);
                     ll = tk.ll; ml = tk.ml; nx = tk.next - c.c0; kind = tk.kind;
                 }
@@ -359,12 +360,14 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
             uint32_t k = pn, opos = out_base + po;
             int pos = E;
             while (pos < lim && k < r0 + kStageCap) {
-                uint32_t ll, ml, off; int nx; int kind = kSeq;
-                if (!sdecode(c, pos, ll, ml, off, nx)) {
+                uint32_t ll, ml, off; int nx, li; int kind = kSeq;
+                if (!sdecode(c, pos, ll, ml, off, nx, li)) {
                     const Tok tk = gdecode(c, c.c0 + pos, 0x7fffffff);
                     ll = tk.ll; ml = tk.ml; off = tk.off; nx = tk.next - c.c0; kind = tk.kind;
+                    li = nx - (kind == kFinal ? 0 : 2 + int(ml_ext_bytes(ml))) - int(ll);
                 }
-                if (kind == kFinal) ml = 0;
+                if (kind == kFinal) { ml = 0; off = 0; }
+                const uint32_t litpos = uint32_t(c.c0 + li);
                 if (k >= r0) {
                     // output-side rules (lz4.c:2175-2225 literals, :2250 / :2315-2317 match)
                     bool ok;
@@ -372,9 +375,9 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
                     if (kind == kFinal) ok = op + ll <= oe;
                     else ok = op + ll <= oe - 12 && off != 0 && (long long)off <= op + ll && op + ll + ml <= oe - 5;
                     if (!ok) { atomicOr(&sh.flags, 1); break; }
-                    stage[k - r0] = uint32_t(c.c0 + pos);
+                    { const uint32_t lc = min(ll, kRecLLSat); stage[k - r0] = make_uint2(litpos | ((lc & 511u) << 23), off | (min(ml, kRecMLSat) << 16) | ((lc >> 9) << 27)); }
                     const uint32_t sp0 = opos + a0, sp1 = sp0 + ll + ml;
-                    const uint4 dA = make_uint4(seq_base + k, opos, uint32_t(c.c0 + pos), uint32_t(c.c0 + nx) - (kind == kFinal ? 0u : 2u + ml_ext_bytes(ml)) - ll);
+                    const uint4 dA = make_uint4(seq_base + k, opos, uint32_t(c.c0 + pos), litpos);
                     const uint4 dB = make_uint4(ll, ml, off, 0);
                     uint32_t w = (sp0 + kWin - 1) >> kWinLog;
                     if (seq_base + k == 0) w = 0;                          // the block's first sequence also owns window 0 (shift a0)
@@ -386,7 +389,7 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
             }
             __syncthreads();
             const uint32_t cnt = min(uint32_t(kStageCap), N - r0);
-            for (uint32_t i = t; i < cnt; i += kPT) tok[seq_base + r0 + i] = stage[i];
+            for (uint32_t i = t; i < cnt; i += kPT) rec[seq_base + r0 + i] = stage[i];
             __syncthreads();
         }
         PPT(6);

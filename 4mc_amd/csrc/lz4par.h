@@ -6,7 +6,9 @@
 //   wdesc[w] (2 x uint4) for output window w, about the sequence that covers the window's first byte:
 //                       {index, output start, token position, literal start}, {literal length, match length, offset, 0}
 //                       (decoded once here: a sequence that spans many windows is not parsed again in each of them)
-//   tok[i]  (uint32)    stream position of the token of sequence i
+//   rec[i]  (uint2)     sequence i decoded: x = literal start | (ll & 511) << 23,  y = offset | min(ml, 2047) << 16 | (min(ll, 16383) >> 9) << 27
+//                       (a saturated field means the sequence is at least a window long: it is the last of its window and the
+//                       next window's descriptor has it exact)
 // Output windows are kWin bytes of the block's output counted from a 128-byte aligned ADDRESS at or below the block's
 // first output byte (a0 = address & 127 is the shift), so that a window is flushed with aligned 16-byte stores and a
 // 128-byte line of the output belongs to exactly one window.
@@ -38,12 +40,13 @@ constexpr size_t kHdrBytes   = 64;
 constexpr size_t kWdescOff   = kHdrBytes;
 constexpr size_t kWdescBytes = size_t(kMaxWin + 2) * 32;
 constexpr size_t kTokOff     = (kWdescOff + kWdescBytes + 255) & ~size_t(255);
-constexpr size_t kTokBytes   = size_t(kMaxSeq) * 4;
+constexpr size_t kTokBytes   = size_t(kMaxSeq) * 8;
 constexpr size_t kDbgOff     = (kTokOff + kTokBytes + 255) & ~size_t(255);   // cycle counters of profiling builds
 constexpr size_t kDbgBytes   = 1024;
 constexpr size_t kSlotBytes  = kDbgOff + kDbgBytes;
 
 constexpr uint32_t kMaxBatch = 2048;         // blocks per launch pair: bounds the workspace (kMaxBatch * kSlotBytes)
+constexpr uint32_t kRecLLSat = 16383, kRecMLSat = 2047;
 constexpr int kRetryCode = -1000000003;     // blocks[b].result while a block waits for the exact kernel
 
 } // namespace lz4par

@@ -262,9 +262,10 @@ err:
 /* Sequence list of a stream under the rules of the SAFE loop alone (safe_literals / copy_match above, lz4.c:2114-2325):
  * the subset of streams every path of the decoder accepts with one meaning.  tokpos[i] / outpos[i] = stream position of
  * the token and output position of sequence i; the last sequence is the literal-only tail.  Returns the number of
- * sequences and *total = decoded size, or -1 if a rule of the safe loop is broken (such streams are left to
+ * sequences and *total = decoded size (fields, if given: literal start, literal length, match length, offset per sequence),
+ * or -1 if a rule of the safe loop is broken (such streams are left to
  * orc_lz4_decompress_safe).  Checker of the GPU parser kernel (tests/test_gpu_lz4par.py). */
-int orc_lz4_sequences(const uint8_t* src, int csize, int cap, uint32_t* tokpos, uint32_t* outpos, int maxseq, int* total)
+int orc_lz4_sequences_ex(const uint8_t* src, int csize, int cap, uint32_t* tokpos, uint32_t* outpos, uint32_t* fields, int maxseq, int* total)
 {
     const int64_t iend = csize, oend = cap;
     int64_t ip = 0, op = 0, lit, mlen, off;
@@ -277,6 +278,7 @@ int orc_lz4_sequences(const uint8_t* src, int csize, int cap, uint32_t* tokpos, 
         token = src[ip++];
         lit = token >> 4;
         if (lit == 15) { if (more_len(src, &ip, iend - 15, 1, &lit)) return -1; }
+        if (fields) { fields[4 * (n - 1)] = (uint32_t)ip; fields[4 * (n - 1) + 1] = (uint32_t)lit; fields[4 * (n - 1) + 2] = 0; fields[4 * (n - 1) + 3] = 0; }
         if (op + lit > oend - MFLIMIT || ip + lit > iend - (2 + 1 + LASTLITERALS)) {
             if (ip + lit != iend || op + lit > oend) return -1;
             *total = (int)(op + lit);
@@ -289,9 +291,13 @@ int orc_lz4_sequences(const uint8_t* src, int csize, int cap, uint32_t* tokpos, 
         mlen += 4;
         if (off == 0 || op - off < 0) return -1;
         if (op + mlen > oend - LASTLITERALS) return -1;
+        if (fields) { fields[4 * (n - 1) + 2] = (uint32_t)mlen; fields[4 * (n - 1) + 3] = (uint32_t)off; }
         op += mlen;
     }
 }
+
+int orc_lz4_sequences(const uint8_t* src, int csize, int cap, uint32_t* tokpos, uint32_t* outpos, int maxseq, int* total)
+{ return orc_lz4_sequences_ex(src, csize, cap, tokpos, outpos, NULL, maxseq, total); }
 
 int orc_codec_lz4_fast(void* ctx, const uint8_t* src, int n, uint8_t* dst, int cap)
 { (void)ctx; return orc_lz4_compress_fast(src, dst, n, cap); }

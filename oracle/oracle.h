@@ -42,6 +42,7 @@ int orc_lz4hc_compress(const uint8_t* src, uint8_t* dst, int n, int cap, int lev
  * Returns decoded size (>=0) or a negative error. */
 int orc_lz4_decompress_safe(const uint8_t* src, uint8_t* dst, int csize, int cap);
 int orc_lz4_sequences(const uint8_t* src, int csize, int cap, uint32_t* tokpos, uint32_t* outpos, int maxseq, int* total);
+int orc_lz4_sequences_ex(const uint8_t* src, int csize, int cap, uint32_t* tokpos, uint32_t* outpos, uint32_t* fields, int maxseq, int* total);
 
 /* ---- container (native/4mc.c:220-386 writer, :560-707 reader; format spec 4mc-format-spec) */
 typedef int (*orc_block_codec_fn)(void* ctx, const uint8_t* src, int n, uint8_t* dst, int cap);

@@ -15,13 +15,16 @@ pytestmark = pytest.mark.gpu
 WIN = 1024
 
 
-def _sequences(comp, cap):
+def _sequences(comp, cap, fields=False):
+    """oracle's sequence list: token positions, output positions and (fields=True) [literal start, ll, ml, offset] rows"""
     L = helpers.oracle()
-    L.orc_lz4_sequences.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
-    L.orc_lz4_sequences.restype = C.c_int
+    L.orc_lz4_sequences_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_lz4_sequences_ex.restype = C.c_int
     mx = len(comp) // 3 + 16
-    tok = np.zeros(mx, np.uint32); out = np.zeros(mx, np.uint32); total = C.c_int(0)
-    n = L.orc_lz4_sequences(comp.ctypes.data, len(comp), cap, tok.ctypes.data, out.ctypes.data, mx, C.byref(total))
+    tok = np.zeros(mx, np.uint32); out = np.zeros(mx, np.uint32); fl = np.zeros((mx, 4), np.uint32); total = C.c_int(0)
+    n = L.orc_lz4_sequences_ex(comp.ctypes.data, len(comp), cap, tok.ctypes.data, out.ctypes.data, fl.ctypes.data, mx, C.byref(total))
+    if fields:
+        return n, tok[:max(n, 0)], out[:max(n, 0)], total.value, fl[:max(n, 0)]
     return n, tok[:max(n, 0)], out[:max(n, 0)], total.value
 
 
@@ -66,7 +69,7 @@ def test_parser_records_equal_the_oracle_sequence_list(gpu):
             continue                                            # below 64 bytes of capacity the exact kernel decodes
         r, comp = orc_compress(src)
         assert r > 0
-        n, tok, opos, total = _sequences(comp, len(src))
+        n, tok, opos, total, fl = _sequences(comp, len(src), fields=True)
         assert n > 0 and total == len(src), name
         for shift in (0, 37):                                   # output address alignment moves the window grid
             d_src = torch.from_numpy(comp).cuda()
@@ -82,8 +85,14 @@ def test_parser_records_equal_the_oracle_sequence_list(gpu):
             assert status == 0, (name, shift, "parser handed the block back")
             assert (nseq, tot, a0) == (n, total, shift), (name, shift, nseq, n, tot, total, a0)
             assert nwin == (total + a0 + WIN - 1) // WIN
-            gtok = host[toff: toff + 4 * nseq].view(np.uint32)
-            assert np.array_equal(gtok, tok), (name, shift, int(np.argmax(gtok != tok)))
+            rec = host[toff: toff + 8 * nseq].view(np.uint32).reshape(-1, 2).astype(np.int64)
+            g_lit = rec[:, 0] & 0x7fffff; g_ll = (rec[:, 0] >> 23) | ((rec[:, 1] >> 27) << 9)
+            g_ml = (rec[:, 1] >> 16) & 2047; g_off = rec[:, 1] & 0xffff
+            want = fl.astype(np.int64)
+            assert np.array_equal(g_lit, want[:, 0]), (name, shift, "literal start", int(np.argmax(g_lit != want[:, 0])))
+            assert np.array_equal(g_ll, np.minimum(want[:, 1], 16383)), (name, shift, "ll")
+            assert np.array_equal(g_ml, np.minimum(want[:, 2], 2047)), (name, shift, "ml")
+            assert np.array_equal(g_off, want[:, 3]), (name, shift, "offset")
             wd = host[woff: woff + 32 * (nwin + 1)].view(np.uint32).reshape(-1, 8)
             # window w's descriptor names the sequence that covers (shifted) position w * WIN
             ends = np.concatenate([opos[1:], [total]]).astype(np.int64)
@@ -96,11 +105,7 @@ def test_parser_records_equal_the_oracle_sequence_list(gpu):
                 # the decoded fields of that sequence: literal start / literal length / match length
                 nxt_o = int(opos[i + 1]) if i + 1 < n else total
                 assert int(wd[w, 4]) + int(wd[w, 5]) == nxt_o - int(opos[i]), (name, shift, w, wd[w].tolist())
-                tk = int(comp[tok[i]])
-                assert (tk >> 4) == min(int(wd[w, 4]), 15) and (i == n - 1 or (tk & 15) == min(int(wd[w, 5]) - 4, 15))
-                lit = int(wd[w, 3]); ll = int(wd[w, 4])
-                if i < n - 1:
-                    assert int(comp[lit + ll]) | (int(comp[lit + ll + 1]) << 8) == int(wd[w, 6]), (name, shift, w)
+                assert [int(wd[w, 3]), int(wd[w, 4]), int(wd[w, 5]), int(wd[w, 6])] == fl[i].tolist(), (name, shift, w, wd[w].tolist(), fl[i].tolist())
             assert wd[nwin, 0] == n - 1
 
 
