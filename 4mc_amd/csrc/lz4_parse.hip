@@ -163,13 +163,13 @@ struct PShared {
     int      flags;             // bit 0: a token broke a rule, bit 1: the last sequence was seen
     uint32_t fin_total;
     int      xs[kPT];           // first chain position of every row (POS_NONE: the chain does not touch the row)
-    int      gmap[kPch / 1024][64];
+    uint16_t gmap[kPch / 1024][64];   // positions are < 2^15; POS_* are stored as 0xFFF0 + (value - POS_END)
     int      gentry[kPch / 1024 + 1];
 };
 
 } // namespace
 
-__global__ __launch_bounds__(kPT)
+__global__ __launch_bounds__(kPT, 4)
 void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_base, fourmc_block* blocks,
                       uint32_t nblocks, int container_mode, uint8_t* work)
 {
@@ -296,7 +296,7 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
                 for (int i = 0; i < 4; i++) if (pos[i] < lim) pos[i] = step(c, tab, pos[i], kSpecCap);
             }
 #pragma unroll
-            for (int i = 0; i < 4; i++) sh.gmap[g][(t & 15) + 16 * i] = pos[i];
+            for (int i = 0; i < 4; i++) sh.gmap[g][(t & 15) + 16 * i] = uint16_t(pos[i] >= POS_END ? 0xFFF0 + (pos[i] - POS_END) : pos[i]);
         }
         for (int r = t; r < kPT; r += kPT) sh.xs[r] = POS_NONE;
         __syncthreads();
@@ -308,7 +308,8 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
                 const int lim = kGroup * (g + 1);
                 if (pos >= lim) continue;
                 const int o = pos - kGroup * g;
-                int v = o < 64 ? sh.gmap[g][o] : POS_UNK;
+                int v = o < 64 ? int(sh.gmap[g][o]) : POS_UNK;
+                if (o < 64 && v >= 0xFFF0) v = POS_END + (v - 0xFFF0);
                 if (v == POS_UNK) { v = pos; while (v < lim) v = step(c, tab, v, 0x7fffffff); }
                 pos = v;
             }
