@@ -579,18 +579,39 @@ extern "C" size_t fourmc_lz4_decode_work_bytes(uint32_t n)
     return size_t(m ? m : 1) * lz4par::kSlotBytes;
 }
 
+// Which fast path serves LZ4 decode launches.  Both produce identical results (anything irregular goes to the exact
+// walker either way); they differ in how a block is parallelised:
+//   0  "wave trio"       one parser wave walks the token chain, two copier waves execute (lz4_decode_fast_kernel)
+//   1  "block parallel"  parse kernel (token chain found by the whole workgroup, records in HBM) + executor kernel
+//                        (16 KiB LDS ring, literal / chain / flush waves)            lz4_parse.hip, lz4_exec.hip
+// Measured on 2048 x 4 MiB of S-mix (profiles/r02_*): 0 = 57 ms, 1 = 38 + 52 ms, so 0 stays the default; the
+// environment variable FOURMC_DECODE (exact | trio | par | paronly) or fourmc_gpu_set_lz4_decode_path() select.
+static int g_decode_path = -1;
+extern "C" void fourmc_gpu_set_lz4_decode_path(int path) { g_decode_path = path; }
+extern "C" int fourmc_gpu_get_lz4_decode_path(void)
+{
+    if (g_decode_path < 0) {
+        const char* mode = getenv("FOURMC_DECODE");
+        g_decode_path = 0;
+        if (mode && !strcmp(mode, "exact")) g_decode_path = 2;
+        if (mode && !strcmp(mode, "par")) g_decode_path = 1;
+        if (mode && !strcmp(mode, "paronly")) g_decode_path = 3;
+    }
+    return g_decode_path;
+}
+
 extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                                                uint32_t n, int container_mode, void* d_work, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
     const uint8_t* s8 = static_cast<const uint8_t*>(d_src);
     uint8_t* d8 = static_cast<uint8_t*>(d_dst);
-    static const char* mode = getenv("FOURMC_DECODE");          // debugging / A-B switch: "exact", "old"
-    if (mode && !strcmp(mode, "exact")) {
+    const int path = fourmc_gpu_get_lz4_decode_path();
+    if (path == 2) {
         hipLaunchKernelGGL(lz4_decode_exact_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
         return hipGetLastError();
     }
-    if (mode && !strcmp(mode, "old")) {
+    if (path == 0) {
         hipLaunchKernelGGL(lz4_decode_fast_kernel, dim3(n), dim3(64 * (kCopiers + 1)), 0, stream, s8, d8, d_blocks, n, container_mode);
         hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
         return hipGetLastError();
@@ -602,7 +623,7 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
         e = fourmc_launch_lz4_exec(d_src, d_dst, d_blocks + b0, m, d_work, stream);
         if (e != hipSuccess) return e;
     }
-    if (mode && !strcmp(mode, "paronly")) return hipGetLastError();      // test aid: show what the parallel path alone did
+    if (path == 3) return hipGetLastError();              // test aid: show what the parallel path alone did
     hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
     return hipGetLastError();
 }

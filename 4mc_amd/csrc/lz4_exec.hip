@@ -417,40 +417,37 @@ __device__ __forceinline__ uint32_t chain_slot(ring_t ring, const Slot* s, uint3
     const uint32_t ol = act ? s->ol[lane] : 0;
     const uint32_t off = ol & 0xffff, len = ol >> 16;
     const uint32_t hi = min(dst - off + len, dst);              // end of the part of the source that others produce
-    const float roff = __builtin_amdgcn_rcpf(float(max(off, 1u)));
+    const float flane = float(lane) + 0.5f;
     unsigned long long undone = __ballot(act);
-    uint32_t rounds = 0;
-    while (undone) {
-        const int f = __builtin_ctzll(undone);
-        const uint32_t Df = rl(dst, f);
-        const bool mine = ((undone >> lane) & 1) != 0;
-        const bool ready = mine && (hi <= Df || lane == f);     // nothing that is still missing lies below Df
+    // 1) everything whose source ends below the slot's first entry is independent of the slot: one batched copy
+    if (maxlen <= uint32_t(kShort)) {
+        const uint32_t D0 = rl(dst, 0);
+        const bool ready = act && (hi <= D0 || lane == 0);
         const unsigned long long rb = __ballot(ready);
-        if (__builtin_popcountll(rb) <= 3 || maxlen > uint32_t(kShort)) {
-            // few entries (the usual state of a dependency chain) or long ones: the whole wave copies one entry at a time
-            unsigned long long q = rb;
-            while (q) {
-                const int l = __builtin_ctzll(q); q &= q - 1;
-                const uint32_t d0 = rl(dst, l), oo = rl(off, l), nn = rl(len, l);
-                if (nn <= 64) {
-                    // byte k of the entry = source byte k mod off (all of [d0 - off, d0) is final): one step for any overlap
-                    const float ro = __builtin_bit_cast(float, rl(__builtin_bit_cast(uint32_t, roff), l));
-                    const uint32_t k = uint32_t(lane);
-                    const uint32_t qd = uint32_t((float(k) + 0.5f) * ro);      // k / off, exact for k, off < 2^16 apart from k >= off * 2^.. (k < 64 here)
-                    const uint32_t km = oo >= 64 ? k : k - qd * oo;
-                    const uint32_t sa = ra + ((d0 - oo + km) & kRM), da = ra + ((d0 + k) & kRM);
-                    uint32_t v;
-                    asm volatile("s_nop 1\n\tds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(sa) : "memory");
-                    if (k < nn) st_lo<0>(da, v);
-                } else wave_copy_ring(ring, d0, oo, nn, lane);
-            }
-        } else {
+        if (__builtin_popcountll(rb) > 2) {
             lane_copy_ring(ring, dst, off, ready ? len : 0u, int(maxlen >> 2));
+            undone &= ~rb;
         }
-        undone &= ~rb;
-        rounds++;
     }
-    return rounds;
+    // 2) what is left depends on entries of this slot: strictly in order, the whole wave copies one entry byte-parallel
+    //    (byte k of an entry = source byte k mod off, and all of [dst - off, dst) is final when its turn comes)
+    uint32_t steps = 0;
+    while (undone) {
+        const int l = __builtin_ctzll(undone); undone &= undone - 1;
+        const uint32_t d0 = rl(dst, l), oo = rl(off, l), nn = rl(len, l);
+        steps++;
+        if (nn > 64) { wave_copy_ring(ring, d0, oo, nn, lane); continue; }
+        uint32_t km = uint32_t(lane);
+        if (oo < nn) {                                          // overlapping: lane mod off (exact: lane, off < 64)
+            const uint32_t qd = uint32_t(flane * __builtin_amdgcn_rcpf(float(oo)));
+            km = uint32_t(lane) - qd * oo;
+        }
+        const uint32_t sa = ra + ((d0 - oo + km) & kRM), da = ra + ((d0 + uint32_t(lane)) & kRM);
+        uint32_t v;
+        asm volatile("s_nop 1\n\tds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(sa) : "memory");
+        if (uint32_t(lane) < nn) st_lo<0>(da, v);
+    }
+    return steps;
 }
 
 __device__ __forceinline__ void chain_wave(const Blk& B, ring_t ring, Slot* slots, XSync* sy, int lane)

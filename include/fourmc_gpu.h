@@ -79,6 +79,10 @@ int fourmc_gpu_lz4_compress_mc(const void* d_src, void* d_dst, fourmc_block* d_b
 /* Profiling aid (not part of the reference boundary): copy a range of the engine's per-block device
  * workspace to the host; the zstd kernels leave per-phase cycle counters there (tools/zstd_timing.py). */
 int fourmc_gpu_debug_read_workspace(void* host, size_t offset, size_t bytes);
+/* Tuning knob (not part of the reference boundary): which LZ4 decode fast path serves the launches, 0 = parser wave + two
+ * copier waves per block (default), 1 = block-parallel parse kernel + executor kernel; results are identical. */
+void fourmc_gpu_set_lz4_decode_path(int path);
+int  fourmc_gpu_get_lz4_decode_path(void);
 /* Test aid: runs only the parser kernel of the block-parallel LZ4 decoder on `n` blocks and copies the first `bytes` of
  * the workspace (block 0's slot first: header, window descriptors, token positions) to `host`; layout[0..2] = slot bytes,
  * descriptor offset, token offset. */

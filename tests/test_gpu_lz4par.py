@@ -57,8 +57,12 @@ def _inputs():
 
 @pytest.fixture(scope="module")
 def gpu():
+    """the block-parallel path is opt-in (the wave-trio path is faster today): select it for this module"""
     p = pkg(); p.gpu_init()
-    return p
+    before = p.lib().fourmc_gpu_get_lz4_decode_path()
+    p.lib().fourmc_gpu_set_lz4_decode_path(1)
+    yield p
+    p.lib().fourmc_gpu_set_lz4_decode_path(before)
 
 
 def test_parser_records_equal_the_oracle_sequence_list(gpu):

@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers, test_gpu_lz4par as T
 p = importlib.import_module("4mc_amd"); p.gpu_init(0)
+if os.environ.get("FOURMC_DECODE") is None and "k1x" in __file__: p.lib().fourmc_gpu_set_lz4_decode_path(1)
 ins = T._inputs()
 for name, src in ins.items():
     if len(src) < 64: continue
