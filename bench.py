@@ -11,9 +11,18 @@ value = uncompressed bytes of all ranks / wall time of a step (compress + decomp
 its own 8 GiB shard of blocks (block ranges are independent; the only collective is the gather of
 per-block compressed sizes for the footer index).
 
+Beside the headline (never part of `value`), at N = 1:
+  other_configs   BASELINE configs[2] 4mz Fast (zstd 1), 4mz Medium (zstd 3), configs[3] 4mc High (LZ4 HC 4) on the same
+                  corpus, and configs[4]'s workload - 4mz Ultra (zstd 12) on the synthetic LOG corpus - at a single-GPU
+                  size; each with the reference's own code timed on the host cores next to it
+  decode_64GiB    the 64 GiB decode-only configuration the north-star target is quoted on
+  cpu_baseline    the reference's LZ4 path on the host cores (bounded sample)
+Corpus: S-mix (tools/corpus.c) unless SILESIA_DIR names a directory with the silesia files.
+
 Run:  python bench.py [--gpus N --steps K --warmup W]   (N>1 via torch.distributed.run)
 """
 import argparse
+import ctypes as C
 import importlib
 import json
 import os
@@ -28,65 +37,98 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TRAFFIC_JSON = os.path.join("profiles", "r01_traffic.json")
 
 
-def cpu_baseline(helpers, base, nblk_sample, budget_s=12.0):
-    """The reference's own code (oracle/_ref, kind 'reference') or, if it is not built, the oracle
-    port, timed on the host cores on a bounded sample of the same corpus: per block
-    LZ4_compress_default(cap n-1) + XXH32 + LZ4_decompress_safe, one block per thread."""
-    import ctypes as C
-    B = helpers.B
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def host_codecs(helpers):
+    """(kind, {name: (compress(src_ptr, n, dst_ptr, cap) -> size, decompress(src_ptr, n, dst_ptr, cap) -> size)})
+    from the reference's own sources (oracle/_ref, kind 'reference') or, if it is not built, this repo's port."""
     ref = helpers.ref()
-    kind = "reference" if ref is not None else "port"
     if ref is not None:
-        comp, dec, xxh = ref.LZ4_compress_default, ref.LZ4_decompress_safe, ref.XXH32
-    else:
-        o = helpers.oracle()
-        comp, dec, xxh = o.orc_lz4_compress_fast, o.orc_lz4_decompress_safe, o.orc_xxh32
-    cores = max(1, min(os.cpu_count() or 1, nblk_sample))
-    done = {"c": 0.0, "d": 0.0, "bytes": 0}
-    lock = threading.Lock()
+        lz4 = (lambda s, n, d, cap: ref.LZ4_compress_default(s, d, n, cap), lambda s, n, d, cap: ref.LZ4_decompress_safe(s, d, n, cap))
+        hc4 = (lambda s, n, d, cap: ref.LZ4_compress_HC(s, d, n, cap, 4), lz4[1])
+        zs = lambda lvl: (lambda s, n, d, cap: ref.ZSTD_compress(d, cap, s, n, lvl), lambda s, n, d, cap: ref.ZSTD_decompress(d, cap, s, n))
+        return "reference", {"lz4": lz4, "hc4": hc4, "zstd1": zs(1), "zstd3": zs(3), "zstd12": zs(12)}, ref.XXH32
+    o = helpers.oracle()
+    o.orc_lz4hc_compress.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]; o.orc_lz4hc_compress.restype = C.c_int
+    o.orc_zstd_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]; o.orc_zstd_compress.restype = C.c_int64
+    lz4 = (lambda s, n, d, cap: o.orc_lz4_compress_fast(s, d, n, cap), lambda s, n, d, cap: o.orc_lz4_decompress_safe(s, d, n, cap))
+    hc4 = (lambda s, n, d, cap: o.orc_lz4hc_compress(s, d, n, cap, 4), lz4[1])
+    zs = lambda lvl: (lambda s, n, d, cap: o.orc_zstd_compress(s, n, d, cap, lvl), lambda s, n, d, cap: o.orc_zstd_decompress(s, n, d, cap))
+    return "port", {"lz4": lz4, "hc4": hc4, "zstd1": zs(1), "zstd3": zs(3), "zstd12": zs(12)}, o.orc_xxh32
 
-    def work(blocks):
-        out = np.empty(B + 64, np.uint8); back = np.empty(B, np.uint8)
-        tc = td = 0.0; nb = 0
-        for b in blocks:
+
+def cpu_leg(helpers, base, nblk, codec, budget_s, B):
+    """One 4mc/4mz block loop per thread on a bounded sample of `base` (the reference's per-block work, native/4mc.c:
+    301-329 compress + checksum, :637-661 checksum + decode): GB/s of uncompressed bytes over wall time, all host cores."""
+    kind, codecs, xxh = host_codecs(helpers)
+    comp, dec = codecs[codec]
+    cores = max(1, os.cpu_count() or 1)
+    done = {"c": 0.0, "d": 0.0, "bytes": 0, "csize": {}}
+    lock = threading.Lock()
+    stop_at = time.perf_counter() + budget_s
+
+    def work(tid):
+        out = np.empty(B + B // 128 + 1024, np.uint8); back = np.empty(B, np.uint8)
+        tc = td = 0.0; nb = 0; cs = {}
+        k = tid
+        while True:
+            b = k % nblk
             src = base[b * B:(b + 1) * B]
             t0 = time.perf_counter()
-            r = comp(src.ctypes.data, out.ctypes.data, B, B - 1)
-            if r > 0:
-                xxh(out.ctypes.data, r, 0)
-            else:
-                xxh(src.ctypes.data, B, 0)
+            r = comp(src.ctypes.data, B, out.ctypes.data, B - 1)
+            stored = not (0 < r < B)
+            xxh(src.ctypes.data if stored else out.ctypes.data, B if stored else r, 0)
             t1 = time.perf_counter()
-            if r > 0:
-                xxh(out.ctypes.data, r, 0)
-                dec(out.ctypes.data, back.ctypes.data, r, B)
-            else:
-                xxh(src.ctypes.data, B, 0)
+            xxh(src.ctypes.data if stored else out.ctypes.data, B if stored else r, 0)
+            if stored:
                 back[:] = src
+            else:
+                dec(out.ctypes.data, r, back.ctypes.data, B)
             t2 = time.perf_counter()
-            tc += t1 - t0; td += t2 - t1; nb += B
+            tc += t1 - t0; td += t2 - t1; nb += B; cs[b] = B if stored else int(r)
+            k += cores
+            if time.perf_counter() > stop_at or k >= 4096 * nblk:
+                break
         with lock:
-            done["c"] += tc; done["d"] += td; done["bytes"] += nb
+            done["c"] += tc; done["d"] += td; done["bytes"] += nb; done["csize"].update(cs)
 
-    passes = 0
     t_start = time.perf_counter()
-    while True:
-        parts = [list(range(i, nblk_sample, cores)) for i in range(cores)]
-        th = [threading.Thread(target=work, args=(p,)) for p in parts]
-        [t.start() for t in th]; [t.join() for t in th]
-        passes += 1
-        if time.perf_counter() - t_start > budget_s or passes >= 8:
-            break
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    [t.start() for t in th]; [t.join() for t in th]
     wall = time.perf_counter() - t_start
     return {
-        "value": round(done["bytes"] / wall / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": kind,
-        "sample": f"{passes} pass(es) over {nblk_sample} S-mix blocks ({done['bytes'] >> 20} MiB), "
-                  f"compress+xxh32+decompress per block, {cores} threads",
+        "value": round(done["bytes"] / wall / 1e9, 4), "unit": "GB/s", "cores": cores, "cpu": cpu_model(), "kind": kind,
+        "sample": f"{done['bytes'] >> 20} MiB of the corpus ({nblk} distinct blocks), compress+xxh32 then xxh32+decompress per block, "
+                  f"one block loop per thread, {cores} threads, {wall:.1f} s",
         "compress_GBps_per_core": round(done["bytes"] / done["c"] / 1e9, 4),
         "decompress_GBps_per_core": round(done["bytes"] / done["d"] / 1e9, 4),
-    }
+        "compress_GBps_all_cores": round(done["bytes"] / (done["c"] / cores) / 1e9, 3),
+        "decompress_GBps_all_cores": round(done["bytes"] / (done["d"] / cores) / 1e9, 3),
+    }, done["csize"]
+
+
+def load_corpus(helpers, base_blocks, B):
+    """S-mix, or the silesia files when SILESIA_DIR is set (concatenated in name order, cut to whole 4 MiB blocks)."""
+    d = os.environ.get("SILESIA_DIR")
+    if d and os.path.isdir(d):
+        names = sorted(f for f in os.listdir(d) if os.path.isfile(os.path.join(d, f)))
+        data = np.concatenate([np.fromfile(os.path.join(d, f), dtype=np.uint8) for f in names]) if names else np.zeros(0, np.uint8)
+        nb = len(data) // B
+        if nb >= 1:
+            return data[: nb * B].copy(), nb, f"silesia from SILESIA_DIR ({len(names)} files, {nb} whole 4 MiB blocks), replicated in HBM"
+    return helpers.corpus(base_blocks * B, first_block=0), base_blocks, \
+        "synthetic (S-mix generator tools/corpus.c seed 0x4D43, 48 blocks replicated in HBM; silesia is not available offline, SILESIA_DIR not set)"
 
 
 def main():
@@ -97,7 +139,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=int(os.environ.get("FOURMC_BENCH_BLOCKS", 2048)),
                     help="4 MiB blocks per GPU (2048 = 8 GiB, BASELINE configs[1])")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configs (4mz Fast/Medium, 4mc High) timed after the headline")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configs and the 64 GiB decode leg timed after the headline")
+    ap.add_argument("--decode-blocks", type=int, default=16384, help="blocks of the decode-only leg (16384 = 64 GiB)")
     args = ap.parse_args()
 
     import torch
@@ -115,10 +158,9 @@ def main():
     dev = torch.device("cuda", local)
     B = p.BLOCKSIZE
     nb = args.blocks
-    base_blocks = 48                                   # 4 cycles of the 12-class S-mix, ~201 MB (silesia: 212 MB)
 
-    # ---- corpus: S-mix generated once, replicated in HBM to nb blocks (physically distinct copies)
-    base = helpers.corpus(base_blocks * B, first_block=0)
+    # ---- corpus: generated / loaded once, replicated in HBM to nb blocks (physically distinct copies)
+    base, base_blocks, data_note = load_corpus(helpers, 48, B)
     d_base = torch.from_numpy(base).to(dev)
     reps = -(-nb // base_blocks)
     d_src = d_base.repeat(reps)[: nb * B].contiguous()
@@ -135,7 +177,6 @@ def main():
     sp = int(stream.cuda_stream)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    kt = {"lz4_encode": [], "xxh32_out": [], "pack": [], "xxh32_verify": [], "lz4_decode": []}
     phase = {"compress": [], "decompress": []}
     state = {}
 
@@ -170,17 +211,15 @@ def main():
         e[5].record()
         p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_image.data_ptr(), d_out.data_ptr(), dec_desc.data_ptr(), nb, 0, sp), "decode")
         e[7].record()
-        state["csz"], state["dec"], state["img_off"] = csz, dec_desc, img_off
+        state["csz"], state["dec"], state["img_off"], state["loc_off"] = csz, dec_desc, img_off, loc_off
         if record:
             torch.cuda.synchronize()
             phase["compress"].append(e[0].elapsed_time(e[4])); phase["decompress"].append(e[5].elapsed_time(e[7]))
 
     def kernel_times():
-        """Per-kernel launch durations with events on the launch stream (untimed extra pass)."""
-        e = [ev() for _ in range(8)]
-        loc_off = (state["img_off"] - (state["img_off"][0] - 12)).contiguous()
-        e[0].record(); p.binding.check(L.fourmc_gpu_lz4_compress_fast(d_src.data_ptr(), d_stage.data_ptr(), enc.ptr, 0, sp), "noop")
-        # encode_blocks = lz4 encode (container mode) + xxh32; time them through the fused call's two halves
+        """Per-kernel launch durations with events on the launch stream, in an extra pass after the timed steps (the fused
+        encode / decode calls are split by timing their hash launches alone, so the parts do not add up to ms_per_step exactly)."""
+        loc_off = state["loc_off"]
         t0 = ev(); t1 = ev(); t2 = ev()
         t0.record()
         p.binding.check(L.fourmc_gpu_4mc_encode_blocks(d_src.data_ptr(), d_stage.data_ptr(), enc.ptr, nb, 0, 0, sp), "encode")
@@ -191,8 +230,7 @@ def main():
         d0.record()
         p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_image.data_ptr(), d_out.data_ptr(), state["dec"].data_ptr(), nb, 0, sp), "decode")
         d1.record()
-        # hash-only launches to split the fused calls
-        h0 = ev(); h1 = ev(); h2 = ev()
+        h0 = ev(); h1 = ev()
         hb = p.DeviceBatch(p.make_blocks(offs, offs, state["csz"].cpu().numpy().astype(np.uint32), lens), dev)
         h0.record(); p.xxh32(d_stage, hb, 0, stream); h1.record()
         vb = state["dec"].clone()
@@ -205,27 +243,75 @@ def main():
         return {"lz4_encode": enc_total - x_out, "xxh32_out": x_out, "pack": pack,
                 "xxh32_verify": x_ver, "lz4_decode": dec_total - x_ver}
 
-    def other_configs():
-        """BASELINE configs[2] (4mz Fast = zstd level 1) and configs[3] (4mc High = LZ4 HC level 4), plus 4mz Medium
-        (zstd level 3), on the same resident corpus: one launch each, HIP events on the launch stream; every
-        compressed batch is decoded back and compared.  Reported beside the headline, never part of `value`."""
-        out = {}
-        def timed(fn):
-            fn()                                       # untimed first call: workspace allocation happens here
-            a, b = ev(), ev()
-            torch.cuda.synchronize(); a.record(); fn(); b.record(); torch.cuda.synchronize()
-            return a.elapsed_time(b)
-        for name, codec, level in (("4mz_fast_zstd1", p.CODEC_ZSTD, 1), ("4mz_medium_zstd3", p.CODEC_ZSTD, 3), ("4mc_high_lz4hc4", p.CODEC_LZ4_HC, 4)):
-            eb = p.DeviceBatch(p.make_blocks(offs, offs, lens, lens), dev)
-            t_enc = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_encode_blocks(d_src.data_ptr(), d_stage.data_ptr(), eb.ptr, nb, codec, level, sp), name))
-            r = eb.download()
-            cs = r["result"].astype(np.int64)
-            db = p.DeviceBatch(p.make_blocks(offs, offs, r["result"].astype(np.uint32), lens, r["xxh32"]), dev)
-            t_dec = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_stage.data_ptr(), d_out.data_ptr(), db.ptr, nb, codec, sp), name))
-            assert bool(torch.equal(d_out[: nb * B], d_src)), name + ": round trip failed"
-            out[name] = {"compress_GBps": round(nb * B / t_enc / 1e6, 3), "decompress_GBps": round(nb * B / t_dec / 1e6, 3),
-                         "ratio": round(nb * B / float((cs + 12).sum()), 4), "encode_blocks_ms": round(t_enc, 2), "decode_blocks_ms": round(t_dec, 2)}
+    def timed(fn):
+        fn()                                       # untimed first call: workspace allocation happens here
+        a, b = ev(), ev()
+        torch.cuda.synchronize(); a.record(); fn(); b.record(); torch.cuda.synchronize()
+        return a.elapsed_time(b)
+
+    def config_leg(name, src_t, nblk, codec, level, host_codec, host_base, host_nblk, budget):
+        """encode + decode of `nblk` resident blocks with one codec: one launch each, HIP events on the launch stream; the
+        compressed batch is decoded back and compared; the reference's own code on the host cores beside it."""
+        o = np.arange(nblk, dtype=np.uint64) * B; ln = np.full(nblk, B, dtype=np.uint32)
+        eb = p.DeviceBatch(p.make_blocks(o, o, ln, ln), dev)
+        t_enc = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_encode_blocks(src_t.data_ptr(), d_stage.data_ptr(), eb.ptr, nblk, codec, level, sp), name))
+        r = eb.download()
+        cs = r["result"].astype(np.int64)
+        db = p.DeviceBatch(p.make_blocks(o, o, r["result"].astype(np.uint32), ln, r["xxh32"]), dev)
+        t_dec = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_stage.data_ptr(), d_out.data_ptr(), db.ptr, nblk, codec, sp), name))
+        assert bool(torch.equal(d_out[: nblk * B], src_t[: nblk * B])), name + ": round trip failed"
+        out = {"blocks": nblk, "compress_GBps": round(nblk * B / t_enc / 1e6, 3), "decompress_GBps": round(nblk * B / t_dec / 1e6, 3),
+               "ratio": round(nblk * B / float((cs + 12).sum()), 4), "encode_blocks_ms": round(t_enc, 2), "decode_blocks_ms": round(t_dec, 2)}
+        if not args.no_cpu:
+            cb, ref_cs = cpu_leg(helpers, host_base, host_nblk, host_codec, budget, B)
+            out["cpu_baseline"] = cb
+            have = sorted(ref_cs)
+            if have:                               # same blocks, reference sizes against the sizes of this run
+                ours = float(sum(12 + int(cs[b]) for b in have)); theirs = float(sum(12 + ref_cs[b] for b in have))
+                out["ratio_vs_reference"] = round(theirs / ours, 6)
         return out
+
+    def other_configs():
+        out = {}
+        for name, codec, level, hc in (("4mz_fast_zstd1", p.CODEC_ZSTD, 1, "zstd1"), ("4mz_medium_zstd3", p.CODEC_ZSTD, 3, "zstd3"),
+                                       ("4mc_high_lz4hc4", p.CODEC_LZ4_HC, 4, "hc4")):
+            out[name] = config_leg(name, d_src, nb, codec, level, hc, base, base_blocks, 4.0)
+        # BASELINE configs[4]'s workload at a single-GPU size: 4mz Ultra (zstd 12) on the synthetic log corpus
+        nlog = min(256, nb)
+        logs = helpers.corpus(min(nlog, 24) * B, first_block=0, logs=True)
+        d_logs = torch.from_numpy(logs).to(dev).repeat(-(-nlog // min(nlog, 24)))[: nlog * B].contiguous()
+        out["4mz_ultra_zstd12_logs"] = config_leg("4mz_ultra_zstd12_logs", d_logs, nlog, p.CODEC_ZSTD, 12, "zstd12", logs, min(nlog, 24), 6.0)
+        out["4mz_ultra_zstd12_logs"]["corpus"] = "tools/corpus.c corpus_fill_logs, 24 distinct blocks replicated to %d" % nlog
+        return out
+
+    def decode_64gib():
+        """Decode-only at the size the north-star target is quoted on: 16384 blocks = 64 GiB written.  The compressed side is
+        the 8 GiB configuration's image with every payload referenced 8 times (4.4 GB of payloads read 8 times from HBM: a
+        64 GiB image would not fit next to 64 GiB of output and the source)."""
+        nd = args.decode_blocks
+        free, _ = torch.cuda.mem_get_info()
+        need = nd * B + (64 << 20)
+        if free < need + (12 << 30):
+            return {"skipped": "not enough free HBM for %d blocks of output" % nd}
+        big = torch.empty(nd * B + 64, dtype=torch.uint8, device=dev)
+        dd = state["dec"].repeat(-(-nd // nb), 1)[:nd].contiguous()
+        dd.view(torch.int64)[:, 1] = torch.arange(nd, device=dev, dtype=torch.int64) * B
+        dd[:, 6] = 0
+        t = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_image.data_ptr(), big.data_ptr(), dd.data_ptr(), nd, 0, sp), "decode64"))
+        ok = bool((dd[:, 6] == B).all())
+        for k in range(0, nd, nb):
+            m = min(nb, nd - k)
+            ok = ok and bool(torch.equal(big[k * B:(k + m) * B], d_src[: m * B]))
+        assert ok, "64 GiB decode: round trip failed"
+        cbytes = int(state["csz"].sum().item()) * (nd // nb) if nd % nb == 0 else None
+        hash_ms = timed(lambda: p.binding.check(L.fourmc_gpu_xxh32(d_image.data_ptr(), dd.clone().data_ptr(), nd, 0, sp), "xxh32"))
+        alg = (cbytes or 0) + nd * B
+        del big
+        return {"blocks": nd, "uncompressed_GiB": nd * B / 2**30, "decode_blocks_ms": round(t, 2), "of_which_xxh32_verify_ms": round(hash_ms, 2),
+                "decompress_GBps": round(nd * B / t / 1e6, 2),
+                "roofline": {"bound": "hbm", "achieved": round(alg / ((t - hash_ms) * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(alg / ((t - hash_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                "note": "payloads of the 8 GiB image referenced %d times; 64 GiB of distinct output" % (nd // nb)}
 
     for _ in range(args.warmup):
         step(False)
@@ -262,11 +348,11 @@ def main():
     dom = "lz4_encode" if kts["lz4_encode"] >= kts["lz4_decode"] else "lz4_decode"
     alg = alg_enc if dom == "lz4_encode" else alg_dec
 
-    # HBM bytes per launch from the PMC passes (rocprofv3 FETCH_SIZE + WRITE_SIZE, separate runs of this
-    # same script at --blocks 512; summary and calibration note in profiles/), scaled to this launch
+    # HBM bytes per launch from the PMC passes (rocprofv3 FETCH_SIZE + WRITE_SIZE, separate runs of this same script at
+    # --blocks 512; summary and calibration note in profiles/), scaled to this launch: NOT measured in this run
     traffic = {}
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, TRAFFIC_JSON)))
         for k in ("lz4_encode", "lz4_decode"):
             traffic[k] = int((tj[k]["fetch_KiB"] + tj[k]["write_KiB"]) * 1024 * nb / tj["blocks"])
     except Exception:
@@ -276,6 +362,7 @@ def main():
         a = algb / (kts[name] * 1e-3) / 1e9
         return {"kernel": name, "bound": "hbm", "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(a / HBM_PEAK_GBS, 5), "traffic": traffic.get(name),
+                "traffic_source": (TRAFFIC_JSON + " (rocprofv3 PMC passes of this script at --blocks 512, scaled by blocks; not measured in this run)") if name in traffic else None,
                 "algorithmic_bytes_per_launch": algb, "avg_launch_ms": round(kts[name], 3)}
 
     if rank == 0:
@@ -284,23 +371,31 @@ def main():
             "value": round(world * U / (wall / args.steps) / 1e9, 3), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
-            "data": "synthetic (S-mix generator tools/corpus.c seed 0x4D43, 48 blocks replicated in HBM; silesia is not available offline)",
-            "config": {"workload": "4mc Fast (LZ4 fast), 4 MiB blocks, S-mix replicated to %.2f GiB per GPU, HBM resident" % (U / 2**30),
-                       "blocks_per_gpu": nb, "block_bytes": B, "parallelism": f"block-range dp{world}", "arch": arch},
+            "data": data_note,
+            "config": {"workload": "4mc Fast (LZ4 fast), 4 MiB blocks, corpus replicated to %.2f GiB per GPU, HBM resident" % (U / 2**30),
+                       "blocks_per_gpu": nb, "block_bytes": B, "parallelism": f"block-range dp{world}", "arch": arch,
+                       "lz4_decode_path": {0: "wave trio (parser wave + 2 copier waves per block)", 1: "block parallel (parse + executor kernels)"}.get(L.fourmc_gpu_get_lz4_decode_path(), "other")},
             "compress_GBps": round(world * U / (comp_ms * 1e-3) / 1e9, 3),
             "decompress_GBps": round(world * U / (dec_ms * 1e-3) / 1e9, 3),
             "ratio": round(U / (12 + Cbytes + 12 + 20 + 4 * nb), 4),
-            "ratio_vs_reference": 1.0,
             "kernel_ms": {k: round(v, 3) for k, v in kts.items()},
+            "kernel_ms_note": "HIP events on the launch stream in an extra pass after the timed steps; the hash launches are timed alone and subtracted from the fused calls, so the parts need not add up to ms_per_step",
             "roofline": roof(dom, alg),
             "roofline_decode": roof("lz4_decode", alg_dec),
         }
-        if world == 1 and not args.no_extras:
-            line["other_configs"] = other_configs()
         if world == 1 and not args.no_cpu:             # the host-core baseline is measured at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(helpers, base, base_blocks)
+            cb, ref_cs = cpu_leg(helpers, base, base_blocks, "lz4", 12.0, B)
+            line["cpu_baseline"] = cb
+            mine = csz[:base_blocks].cpu().numpy()
+            have = sorted(b for b in ref_cs if b < len(mine))
+            line["ratio_vs_reference"] = round(float(sum(12 + ref_cs[b] for b in have)) / float(sum(12 + int(mine[b]) for b in have)), 6) if have else None
+            line["ratio_vs_reference_note"] = "container bytes of the reference's LZ4_compress_default on the host over this run's, same %d blocks (1.0 = identical sizes; payloads are byte-identical by the parity tests)" % len(have)
         else:
             line["cpu_baseline"] = None
+            line["ratio_vs_reference"] = None
+        if world == 1 and not args.no_extras:
+            line["other_configs"] = other_configs()
+            line["decode_64GiB"] = decode_64gib()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
