@@ -74,6 +74,10 @@ _FILE_API = {
     "fourMZDecompressFileName": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_char_p]),
     "fourmc_file_block_count": (C.c_int64, [C.c_char_p, C.c_void_p]),
     "fourmc_file_decode_blocks": (C.c_int64, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]),
+    "fourmc_shard_range": (None, [C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "fourmc_shard_offsets": (None, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "fourmc_shard_write": (C.c_int, [C.c_int, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fourmc_file_compress_sharded": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "fourmc_frame_header": (None, [C.c_void_p, C.c_uint32]),
     "fourmc_frame_check_header": (C.c_int, [C.c_void_p, C.c_uint32]),
     "fourmc_frame_block_header": (None, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),

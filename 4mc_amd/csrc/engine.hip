@@ -7,6 +7,7 @@
 #include <mutex>
 #include <condition_variable>
 #include <vector>
+#include <algorithm>
 #include <map>
 #include <atomic>
 #include <stdio.h>
@@ -41,7 +42,22 @@ struct Arena {
     void* d_dst = nullptr; size_t dst_cap = 0;
     fourmc_block* d_blk = nullptr; size_t blk_cap = 0;
     hipStream_t stream = nullptr;
-} g_arena;
+    int device = -1;
+};
+// Shard 0 serves every host-buffer call; with FOURMC_GPUS=N > 1 a batch of blocks is cut into N contiguous block ranges,
+// one arena (device buffers + stream) per range, placed round robin on the visible devices starting at the selected one.
+// N may exceed the number of devices: the surplus shards share devices (that is how the sharding is exercised on a
+// one-GPU box).  One process, several devices: the per-range results come back to host memory, so the "gather of the
+// per-rank block index" of the multi-process layout (bench.py, container.py: RCCL all_gather) is a plain array here.
+constexpr int kMaxShards = 16;
+Arena g_arenas[kMaxShards];
+Arena& g_arena = g_arenas[0];
+
+int host_shards()
+{
+    static int n = [] { const char* e = getenv("FOURMC_GPUS"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > kMaxShards ? kMaxShards : v; }();
+    return n;
+}
 
 // Device workspaces (per-block scratch of the kernels: LZ4 decode records, LZ4 HC/MC tables, zstd literals / sequence
 // areas / encoder tables).  ONE GROWABLE BUFFER PER STREAM: launches on a stream are ordered, so consecutive calls on the
@@ -82,7 +98,7 @@ public:
     }
 };
 
-int arena_reserve(size_t src_bytes, size_t dst_bytes, size_t nblk)
+int arena_reserve(Arena& g_arena, size_t src_bytes, size_t dst_bytes, size_t nblk)
 {
     if (!g_arena.stream) HIP_TRY(hipStreamCreateWithFlags(&g_arena.stream, hipStreamNonBlocking));
     auto grow = [](void** p, size_t* cap, size_t need) -> hipError_t {
@@ -315,19 +331,78 @@ int fourmc_gpu_4mc_pack_image(const void* d_staging, void* d_image, const fourmc
 // ------------------------------------------------------------------------ host-buffer API
 int fourmc_LZ4_compressBound(int n) { return (unsigned)n > 0x7E000000u ? 0 : n + n / 255 + 16; }
 
-static int launch_host_op(int op, int codec, int level, uint32_t n, hipStream_t s)
+// d_src / d_dst: the bases the descriptors' offsets are relative to (they may point below an arena's allocation when only
+// a slice of the host buffers was staged)
+static int launch_host_op(int op, int codec, int level, const void* d_src, void* d_dst, fourmc_block* d_blk, uint32_t n, hipStream_t s)
 {
     switch (op) {
-        case 0: return fourmc_gpu_4mc_encode_blocks(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, codec, level, s);
-        case 1: return fourmc_gpu_4mc_decode_blocks(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, codec, s);
-        case 2: return fourmc_gpu_lz4_compress_fast(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s);
-        case 3: return fourmc_gpu_lz4_decompress(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s);
-        case 5: return fourmc_gpu_zstd_decompress(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s);
-        case 8: return fourmc_gpu_zstd_compress(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, level, s);
-        case 7: return fourmc_gpu_lz4_compress_mc(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s);
-        case 6: return fourmc_gpu_lz4_compress_hc(g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, level, s);
-        default: return fourmc_gpu_xxh32(g_arena.d_src, g_arena.d_blk, n, (uint32_t)level, s);
+        case 0: return fourmc_gpu_4mc_encode_blocks(d_src, d_dst, d_blk, n, codec, level, s);
+        case 1: return fourmc_gpu_4mc_decode_blocks(d_src, d_dst, d_blk, n, codec, s);
+        case 2: return fourmc_gpu_lz4_compress_fast(d_src, d_dst, d_blk, n, s);
+        case 3: return fourmc_gpu_lz4_decompress(d_src, d_dst, d_blk, n, s);
+        case 5: return fourmc_gpu_zstd_decompress(d_src, d_dst, d_blk, n, s);
+        case 8: return fourmc_gpu_zstd_compress(d_src, d_dst, d_blk, n, level, s);
+        case 7: return fourmc_gpu_lz4_compress_mc(d_src, d_dst, d_blk, n, s);
+        case 6: return fourmc_gpu_lz4_compress_hc(d_src, d_dst, d_blk, n, level, s);
+        default: return fourmc_gpu_xxh32(d_src, d_blk, n, (uint32_t)level, s);
     }
+}
+
+// FOURMC_GPUS > 1: contiguous block ranges, one per shard, all in flight together (native/4mc.c:280-333 is the serial
+// loop this replaces; the ranges are independent, nothing crosses between devices)
+static int host_roundtrip_sharded(const void* src, void* dst, fourmc_block* blocks, uint32_t n, int op, int codec, int level, int shards)
+{
+    int ndev = fourmc_gpu_device_count();
+    if (ndev <= 0) return FOURMC_ENODEV;
+    const int dev0 = g_device.load(std::memory_order_acquire);
+    const uint32_t per = (n + uint32_t(shards) - 1) / uint32_t(shards);
+    struct Range { uint32_t lo, hi; uint64_t smin, smax, dmin, dmax; };
+    std::vector<Range> rg;
+    for (int k = 0; k < shards; k++) {
+        Range r; r.lo = std::min(n, uint32_t(k) * per); r.hi = std::min(n, r.lo + per);
+        if (r.lo >= r.hi) break;
+        r.smin = r.dmin = ~0ull; r.smax = r.dmax = 0;
+        for (uint32_t b = r.lo; b < r.hi; b++) {
+            r.smin = std::min<uint64_t>(r.smin, blocks[b].src_off); r.smax = std::max<uint64_t>(r.smax, blocks[b].src_off + blocks[b].src_len);
+            r.dmin = std::min<uint64_t>(r.dmin, blocks[b].dst_off); r.dmax = std::max<uint64_t>(r.dmax, blocks[b].dst_off + blocks[b].dst_cap);
+        }
+        rg.push_back(r);
+    }
+    int rc = FOURMC_OK;
+    for (size_t k = 0; k < rg.size() && rc == FOURMC_OK; k++) {                      // stage + launch every range
+        Arena& a = g_arenas[k]; const Range& r = rg[k];
+        a.device = (dev0 + int(k)) % ndev;
+        HIP_TRY(hipSetDevice(a.device));
+        if ((rc = arena_reserve(a, size_t(r.smax - r.smin), size_t(r.dmax - r.dmin), r.hi - r.lo))) break;
+        HIP_TRY(hipMemcpyAsync(a.d_src, static_cast<const char*>(src) + r.smin, size_t(r.smax - r.smin), hipMemcpyHostToDevice, a.stream));
+        HIP_TRY(hipMemcpyAsync(a.d_blk, blocks + r.lo, (r.hi - r.lo) * sizeof(fourmc_block), hipMemcpyHostToDevice, a.stream));
+        rc = launch_host_op(op, codec, level, static_cast<char*>(a.d_src) - r.smin, static_cast<char*>(a.d_dst) - r.dmin, a.d_blk, r.hi - r.lo, a.stream);
+        if (rc) break;
+        HIP_TRY(hipMemcpyAsync(blocks + r.lo, a.d_blk, (r.hi - r.lo) * sizeof(fourmc_block), hipMemcpyDeviceToHost, a.stream));
+    }
+    for (size_t k = 0; k < rg.size(); k++) {                                          // results, then what each block produced
+        Arena& a = g_arenas[k]; const Range& r = rg[k];
+        if (!a.stream) continue;
+        (void)hipSetDevice(a.device);
+        hipError_t e = hipStreamSynchronize(a.stream);
+        if (e != hipSuccess && rc == FOURMC_OK) rc = fail_hip(e, "hipStreamSynchronize");
+        if (rc != FOURMC_OK || op == 4) continue;
+        for (uint32_t b = r.lo; b < r.hi; b++)
+            if (blocks[b].result > 0) {
+                e = hipMemcpyAsync(static_cast<char*>(dst) + blocks[b].dst_off, static_cast<char*>(a.d_dst) + (blocks[b].dst_off - r.dmin),
+                                   (size_t)blocks[b].result, hipMemcpyDeviceToHost, a.stream);
+                if (e != hipSuccess && rc == FOURMC_OK) rc = fail_hip(e, "hipMemcpyAsync");
+            }
+    }
+    for (size_t k = 0; k < rg.size(); k++) {
+        Arena& a = g_arenas[k];
+        if (!a.stream) continue;
+        (void)hipSetDevice(a.device);
+        hipError_t e = hipStreamSynchronize(a.stream);
+        if (e != hipSuccess && rc == FOURMC_OK) rc = fail_hip(e, "hipStreamSynchronize");
+    }
+    (void)hipSetDevice(dev0);
+    return rc;
 }
 
 static int host_roundtrip_many(const void* src, size_t src_bytes, void* dst, size_t dst_bytes,
@@ -335,11 +410,12 @@ static int host_roundtrip_many(const void* src, size_t src_bytes, void* dst, siz
 {
     if (int r = ensure_device()) return r;
     std::lock_guard<std::mutex> lk(g_mu);
-    if (int r = arena_reserve(src_bytes, dst_bytes, n)) return r;
+    if (host_shards() > 1 && n > 1) return host_roundtrip_sharded(src, dst, blocks, n, op, codec, level, host_shards());
+    if (int r = arena_reserve(g_arena, src_bytes, dst_bytes, n)) return r;
     hipStream_t s = g_arena.stream;
     HIP_TRY(hipMemcpyAsync(g_arena.d_src, src, src_bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(g_arena.d_blk, blocks, n * sizeof(fourmc_block), hipMemcpyHostToDevice, s));
-    if (int r = launch_host_op(op, codec, level, n, s)) return r;
+    if (int r = launch_host_op(op, codec, level, g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s)) return r;
     HIP_TRY(hipMemcpyAsync(blocks, g_arena.d_blk, n * sizeof(fourmc_block), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (op != 4) {
@@ -381,12 +457,12 @@ static int serve_group(std::vector<OneReq*>& g)
         blocks[i].src_off = so; blocks[i].dst_off = dof;
         so += (g[i]->src_bytes + 63) & ~size_t(63); dof += (g[i]->dst_bytes + 63) & ~size_t(63);
     }
-    if (int r = arena_reserve(so, dof, n)) return r;
+    if (int r = arena_reserve(g_arena, so, dof, n)) return r;
     hipStream_t s = g_arena.stream;
     for (uint32_t i = 0; i < n; i++)
         if (g[i]->src_bytes) HIP_TRY(hipMemcpyAsync(static_cast<char*>(g_arena.d_src) + blocks[i].src_off, g[i]->src, g[i]->src_bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(g_arena.d_blk, blocks.data(), n * sizeof(fourmc_block), hipMemcpyHostToDevice, s));
-    if (int r = launch_host_op(g[0]->op, g[0]->codec, g[0]->level, n, s)) return r;
+    if (int r = launch_host_op(g[0]->op, g[0]->codec, g[0]->level, g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s)) return r;
     HIP_TRY(hipMemcpyAsync(blocks.data(), g_arena.d_blk, n * sizeof(fourmc_block), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     for (uint32_t i = 0; i < n; i++) {

@@ -1,0 +1,145 @@
+/*
+ * 4mc_amd/csrc/shard.c - one .4mc / .4mz file written by several ranks (one process per GPU).
+ *
+ * The reference writes a file with ONE loop (native/4mc.c:280-333): block header, payload, next block; the footer index
+ * (native/4mc.c:344-358) is the list of the file offsets the loop passed through.  Blocks are independent, so here rank r
+ * of `world` compresses the contiguous block range [first, first + count) on its own GPU, and the only thing the ranks
+ * have to tell each other is how many bytes each block became: ONE all-gather of 4 bytes per block.  After it every rank
+ * holds the same exclusive prefix sum - the footer index - and writes its own byte range with pwrite(); rank 0 adds the file
+ * header (native/4mc.c:264-268), the end mark (:336-340) and the footer.  The file is byte-identical to the serial one.
+ *
+ * The collective is injected (fourmc_allgather_fn): torch.distributed over RCCL / gloo from a Python launcher, ncclAllGather
+ * or MPI_Allgather from a C one.  libhadoop-4mc.so itself links no communication library - it keeps the dependency set of
+ * the reference's library (libc, libstdc++, HIP).
+ */
+#define _FILE_OFFSET_BITS 64
+#define _POSIX_C_SOURCE 200809L
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/stat.h>
+#include "fourmc.h"
+#include "fourmc_gpu.h"
+
+void fourmc_shard_range(uint64_t nblocks, int rank, int world, uint64_t* first, uint64_t* count)
+{
+    const uint64_t per = world > 0 ? (nblocks + (uint64_t)world - 1) / (uint64_t)world : nblocks;
+    uint64_t lo = (uint64_t)rank * per, hi;
+    if (lo > nblocks) lo = nblocks;
+    hi = lo + per; if (hi > nblocks) hi = nblocks;
+    *first = lo; *count = hi - lo;
+}
+
+/* off_all[b] = file offset of block b's 12-byte header = 12 + sum_{j<b} (12 + csize_j)   (native/4mc.c:293) */
+void fourmc_shard_offsets(const uint32_t* csize_all, uint64_t nblocks, uint64_t* off_all)
+{
+    uint64_t pos = 12, b;
+    for (b = 0; b < nblocks; b++) { off_all[b] = pos; pos += 12ull + csize_all[b]; }
+}
+
+static int pwrite_all(int fd, const void* buf, size_t n, uint64_t at)
+{
+    const uint8_t* p = (const uint8_t*)buf;
+    while (n) {
+        ssize_t w = pwrite(fd, p, n, (off_t)at);
+        if (w <= 0) return -1;
+        p += w; n -= (size_t)w; at += (uint64_t)w;
+    }
+    return 0;
+}
+
+/* usize / csize / xxh32 / payload_off: this rank's `count` blocks; payload b = payloads + payload_off[b].
+ * off_all: all nblocks offsets.  Returns 0, or -1 on a write error. */
+int fourmc_shard_write(int fd, uint32_t magic, int rank, uint64_t first, uint64_t count, uint64_t nblocks, const uint64_t* off_all,
+                       const uint32_t* csize_all, const uint32_t* usize, const uint32_t* xxh32, const uint8_t* payloads, const uint64_t* payload_off)
+{
+    uint8_t hdr[12];
+    uint64_t b;
+    if (rank == 0) {
+        fourmc_frame_header(hdr, magic);
+        if (pwrite_all(fd, hdr, 12, 0)) return -1;
+    }
+    for (b = 0; b < count; b++) {
+        const uint32_t cs = csize_all[first + b];
+        fourmc_frame_block_header(hdr, usize[b], cs, xxh32[b]);
+        if (pwrite_all(fd, hdr, 12, off_all[first + b])) return -1;
+        if (pwrite_all(fd, payloads + payload_off[b], cs, off_all[first + b] + 12)) return -1;
+    }
+    if (rank == 0) {
+        const uint64_t end = nblocks ? off_all[nblocks - 1] + 12ull + csize_all[nblocks - 1] : 12;
+        const size_t fsz = FOURMC_FOOTERSIZE(nblocks);
+        uint8_t* foot = (uint8_t*)malloc(fsz);
+        if (!foot) return -1;
+        memset(hdr, 0, 12);
+        fourmc_frame_footer(foot, magic, off_all, (uint32_t)nblocks);
+        if (pwrite_all(fd, hdr, 12, end) || pwrite_all(fd, foot, fsz, end + 12)) { free(foot); return -1; }
+        free(foot);
+    }
+    return 0;
+}
+
+/* Every rank calls this with the same arguments and its own rank, after selecting its device (fourmc_gpu_init).
+ * level / magic as fourM{C,Z}compressFilename.  Returns 0; -1 input, -2 output, -3 engine, -4 collective, -5 memory. */
+int fourmc_file_compress_sharded(const char* in_name, const char* out_name, int level, uint32_t magic, int rank, int world,
+                                 fourmc_allgather_fn allgather, void* ctx)
+{
+    struct stat st;
+    uint64_t nblocks, first, count, b, per, in_bytes;
+    uint8_t *in_buf = NULL, *out_buf = NULL;
+    fourmc_block* blk = NULL;
+    uint32_t *cs_mine = NULL, *cs_pad = NULL, *cs_all = NULL, *usz = NULL, *xs = NULL;
+    uint64_t *off_all = NULL, *poff = NULL;
+    int codec, codec_level = 0, rc = 0, fd = -1;
+    FILE* fin;
+
+    if (magic == FOURMC_MAGIC_4MC) {                                  /* native/4mc.c:243-253   */
+        if (level <= 1) codec = FOURMC_CODEC_LZ4_FAST;
+        else if (level == 2) codec = FOURMC_CODEC_LZ4_MC;
+        else { codec = FOURMC_CODEC_LZ4_HC; codec_level = (level == 3) ? 4 : 8; }
+    } else {                                                          /* native/4mc.c:411-419   */
+        codec = FOURMC_CODEC_ZSTD;
+        codec_level = level <= 1 ? 1 : level == 2 ? 3 : level == 3 ? 6 : 12;
+    }
+    if (stat(in_name, &st) != 0) return -1;
+    nblocks = ((uint64_t)st.st_size + FOURMC_BLOCKSIZE - 1) / FOURMC_BLOCKSIZE;
+    fourmc_shard_range(nblocks, rank, world, &first, &count);
+    per = world > 0 ? (nblocks + (uint64_t)world - 1) / (uint64_t)world : nblocks;
+    in_bytes = count ? ((first + count == nblocks ? (uint64_t)st.st_size : (first + count) * FOURMC_BLOCKSIZE) - first * FOURMC_BLOCKSIZE) : 0;
+
+    in_buf = (uint8_t*)malloc(in_bytes + 1); out_buf = (uint8_t*)malloc(count * FOURMC_BLOCKSIZE + 1);
+    blk = (fourmc_block*)calloc(count + 1, sizeof *blk);
+    cs_pad = (uint32_t*)calloc(per + 1, 4); cs_all = (uint32_t*)calloc(per * (uint64_t)(world > 0 ? world : 1) + 1, 4);
+    usz = (uint32_t*)calloc(count + 1, 4); xs = (uint32_t*)calloc(count + 1, 4);
+    off_all = (uint64_t*)calloc(nblocks + 1, 8); poff = (uint64_t*)calloc(count + 1, 8);
+    cs_mine = cs_pad;
+    if (!in_buf || !out_buf || !blk || !cs_pad || !cs_all || !usz || !xs || !off_all || !poff) { rc = -5; goto done; }
+
+    fin = fopen(in_name, "rb");
+    if (!fin) { rc = -1; goto done; }
+    if (fseeko(fin, (off_t)(first * FOURMC_BLOCKSIZE), SEEK_SET) != 0 || fread(in_buf, 1, in_bytes, fin) != in_bytes) { fclose(fin); rc = -1; goto done; }
+    fclose(fin);
+    for (b = 0; b < count; b++) {
+        const uint64_t left = in_bytes - b * FOURMC_BLOCKSIZE;
+        blk[b].src_off = b * FOURMC_BLOCKSIZE; blk[b].dst_off = b * FOURMC_BLOCKSIZE;
+        blk[b].src_len = (uint32_t)(left < FOURMC_BLOCKSIZE ? left : FOURMC_BLOCKSIZE);
+        blk[b].dst_cap = blk[b].src_len;
+    }
+    if (count && fourmc_host_4mc_encode(in_buf, in_bytes, out_buf, count * FOURMC_BLOCKSIZE, blk, (uint32_t)count, codec, codec_level) != FOURMC_OK) { rc = -3; goto done; }
+    for (b = 0; b < count; b++) { cs_mine[b] = (uint32_t)blk[b].result; usz[b] = blk[b].src_len; xs[b] = blk[b].xxh32; poff[b] = blk[b].dst_off; }
+
+    /* the one exchange of the path: per-block compressed sizes, padded to equal counts per rank */
+    if (world > 1) { if (allgather(ctx, cs_pad, per * 4, cs_all) != 0) { rc = -4; goto done; } }
+    else memcpy(cs_all, cs_pad, per * 4);
+    {   /* ranks' padded rows -> one array in block order (row r holds blocks [r * per, ..)) : already contiguous */
+        fourmc_shard_offsets(cs_all, nblocks, off_all);
+    }
+    fd = open(out_name, O_WRONLY | O_CREAT, 0644);
+    if (fd < 0) { rc = -2; goto done; }
+    if (fourmc_shard_write(fd, magic, rank, first, count, nblocks, off_all, cs_all, usz, xs, out_buf, poff) != 0) rc = -2;
+    if (close(fd) != 0 && rc == 0) rc = -2;
+done:
+    free(in_buf); free(out_buf); free(blk); free(cs_pad); free(cs_all); free(usz); free(xs); free(off_all); free(poff);
+    return rc;
+}

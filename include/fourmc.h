@@ -68,6 +68,20 @@ int64_t  fourmc_file_block_count(const char* path, int* is_zstd);           /* b
 /* decodes blocks [first, first+count) into dst; returns the decoded byte count */
 int64_t  fourmc_file_decode_blocks(const char* path, uint32_t first, uint32_t count, void* dst, size_t dst_cap);
 
+/* ---- one file written by several ranks, one process per GPU (4mc_amd/csrc/shard.c) ----------------------------
+ * Rank r of `world` owns the contiguous block range fourmc_shard_range() gives; the only exchange is one all-gather of
+ * the per-block compressed sizes, after which every rank knows the footer index (fourmc_shard_offsets) and pwrite()s its
+ * own byte range; rank 0 adds header, end mark and footer (native/4mc.c:264-268,:336-362).  The collective is the
+ * caller's: recv_all receives `world` rows of `bytes` bytes in rank order; return 0 on success. */
+typedef int (*fourmc_allgather_fn)(void* ctx, const void* send, size_t bytes, void* recv_all);
+void fourmc_shard_range(uint64_t nblocks, int rank, int world, uint64_t* first, uint64_t* count);
+void fourmc_shard_offsets(const uint32_t* csize_all, uint64_t nblocks, uint64_t* off_all);
+int  fourmc_shard_write(int fd, uint32_t magic, int rank, uint64_t first, uint64_t count, uint64_t nblocks, const uint64_t* off_all,
+                        const uint32_t* csize_all, const uint32_t* usize, const uint32_t* xxh32, const uint8_t* payloads, const uint64_t* payload_off);
+/* 0 ok; -1 input, -2 output, -3 engine (fourmc_gpu_last_error()), -4 collective, -5 memory */
+int  fourmc_file_compress_sharded(const char* in_name, const char* out_name, int level, uint32_t magic, int rank, int world,
+                                  fourmc_allgather_fn allgather, void* ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,3 +58,67 @@ def test_shard_range_partitions():
             r = [p.shard_range(n, k, w) for k in range(w)]
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+
+
+# ---- a REAL .4mc file assembled by two ranks (4mc_amd/csrc/shard.c) ----------------------------------------------------
+def _blocks_of_rank(data, lo, hi):
+    """what a rank's GPU produces for its block range, restated by the oracle: (usize, csize, xxh32, payload) per block
+    with the container's stored fallback (native/4mc.c:301-329)"""
+    B = helpers.B
+    out = []
+    for b in range(lo, hi):
+        src = data[b * B:(b + 1) * B]
+        r, comp = helpers.orc_compress(src, len(src) - 1)
+        payload = comp if 0 < r < len(src) else src
+        out.append((len(src), len(payload), helpers.orc_xxh32(payload), np.ascontiguousarray(payload)))
+    return out
+
+
+def _file_worker(rank, world, port, path, q):
+    import ctypes as C
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, helpers.ROOT)
+    p = helpers.pkg(); L = p.lib()
+    man = __import__("json").load(open(os.path.join(helpers.ROOT, "tests", "golden", "corpus_manifest.json")))
+    data = helpers.corpus(man["corpus"]["bytes"], first_block=man["corpus"]["first_block"], seed=man["corpus"]["seed"])
+    nblocks = -(-len(data) // helpers.B)
+    first, count = C.c_uint64(), C.c_uint64()
+    L.fourmc_shard_range(nblocks, rank, world, C.byref(first), C.byref(count))
+    lo, n = first.value, count.value
+    mine = _blocks_of_rank(data, lo, lo + n)
+    # the one collective: compressed sizes, padded to equal counts per rank
+    per = -(-nblocks // world)
+    pad = torch.zeros(per, dtype=torch.int32); pad[:n] = torch.tensor([m[1] for m in mine], dtype=torch.int32)
+    allc = torch.empty(per * world, dtype=torch.int32)
+    dist.all_gather_into_tensor(allc, pad)
+    cs_all = allc.numpy().astype(np.uint32)
+    off_all = np.zeros(nblocks, np.uint64)
+    L.fourmc_shard_offsets(cs_all.ctypes.data, nblocks, off_all.ctypes.data)
+    usz = np.array([m[0] for m in mine], np.uint32); xs = np.array([m[2] for m in mine], np.uint32)
+    pay = np.concatenate([m[3] for m in mine]) if mine else np.zeros(1, np.uint8)
+    poff = np.concatenate([[0], np.cumsum([m[1] for m in mine])[:-1]]).astype(np.uint64) if mine else np.zeros(1, np.uint64)
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT, 0o644)
+    rc = L.fourmc_shard_write(fd, p.MAGIC_4MC, rank, lo, n, nblocks, off_all.ctypes.data, cs_all.ctypes.data, usz.ctypes.data, xs.ctypes.data,
+                              pay.ctypes.data, poff.ctypes.data)
+    os.close(fd)
+    dist.barrier()
+    q.put((rank, rc, lo, n))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_write_one_4mc_file(tmp_path):
+    """both ranks pwrite their own byte ranges, rank 0 adds header / end mark / footer: the file equals the reference CLI's"""
+    import hashlib, json
+    man = json.load(open(os.path.join(helpers.ROOT, "tests", "golden", "corpus_manifest.json")))
+    path = str(tmp_path / "two_ranks.4mc")
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+    ps = [ctx.Process(target=_file_worker, args=(r, 2, port, path, q)) for r in range(2)]
+    [p.start() for p in ps]
+    got = sorted(q.get(timeout=300) for _ in range(2))
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps) and all(g[1] == 0 for g in got), got
+    assert got[0][2] == 0 and got[0][2] + got[0][3] == got[1][2]            # contiguous ranges
+    blob = open(path, "rb").read()
+    assert len(blob) == man["levels"]["4mc-1"]["file_bytes"]
+    assert hashlib.sha256(blob).hexdigest() == man["levels"]["4mc-1"]["sha256"]
