@@ -438,6 +438,7 @@ static int host_roundtrip_many(const void* src, size_t src_bytes, void* dst, siz
 struct OneReq {
     const void* src; size_t src_bytes; void* dst; size_t dst_bytes; fourmc_block* blk;
     int op, codec, level, rc; bool done; OneReq* next;
+    char err[256];                      // fourmc_gpu_last_error() of the launch that served the request
 };
 static std::mutex g_qmu;
 static std::condition_variable g_qcv;
@@ -476,17 +477,18 @@ static int serve_group(std::vector<OneReq*>& g)
 
 static int host_one(const void* src, size_t src_bytes, void* dst, size_t dst_bytes, fourmc_block* blk, int op, int codec, int level)
 {
-    OneReq me = {src, src_bytes, dst, dst_bytes, blk, op, codec, level, FOURMC_OK, false, nullptr};
+    OneReq me = {src, src_bytes, dst, dst_bytes, blk, op, codec, level, FOURMC_OK, false, nullptr, {0}};
     std::unique_lock<std::mutex> lk(g_qmu);
     g_one_calls++;
     if (g_qtail) g_qtail->next = &me; else g_qhead = &me;
     g_qtail = &me;
-    if (g_qserving) {                                   // somebody is serving: it will not leave before the queue is empty
-        g_qcv.wait(lk, [&] { return me.done; });
-        return me.rc;
-    }
-    g_qserving = true;
-    while (g_qhead) {
+    // Whoever finds nobody serving serves ONE group (the oldest request's kind) and hands the role on: a caller never
+    // keeps serving other threads' requests after its own has been answered.
+    for (;;) {
+        if (me.done) { if (me.rc) snprintf(g_err, sizeof g_err, "%s", me.err); return me.rc; }
+        if (g_qserving) { g_qcv.wait(lk, [&] { return me.done || !g_qserving; }); continue; }
+        g_qserving = true;
+        {
         // everything queued for the same operation as the oldest request, in arrival order
         std::vector<OneReq*> grp;
         OneReq* keep_head = nullptr; OneReq* keep_tail = nullptr;
@@ -501,12 +503,13 @@ static int host_one(const void* src, size_t src_bytes, void* dst, size_t dst_byt
         g_one_launches++;
         lk.unlock();
         const int rc = serve_group(grp);
+        char err[256]; snprintf(err, sizeof err, "%s", g_err);
         lk.lock();
-        for (OneReq* r : grp) { r->rc = rc; r->done = true; }
+        for (OneReq* r : grp) { r->rc = rc; if (rc) memcpy(r->err, err, sizeof err); r->done = true; }
+        }
+        g_qserving = false;
         g_qcv.notify_all();
     }
-    g_qserving = false;
-    return me.rc;
 }
 
 static int host_roundtrip(const void* src, size_t src_bytes, void* dst, size_t dst_bytes,

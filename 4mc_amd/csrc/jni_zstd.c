@@ -136,8 +136,15 @@ JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_Zstd_dStreamOutSize
 static jfieldID zs_src_pos, zs_dst_pos, zds_src_pos, zds_dst_pos;
 JNIEXPORT void JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamCompressor_initIDs(JNIEnv* env, jclass cls)
 { zs_src_pos = (*env)->GetFieldID(env, cls, "srcPos", "J"); zs_dst_pos = (*env)->GetFieldID(env, cls, "dstPos", "J"); }
+/* the streaming ZstCodec (native/jniZStreamCompressor.c:96-134, jniZStreamDecompressor.c:112) is not part of the block path:
+ * fail at creation, loudly, instead of handing Java a null stream handle */
+static void throw_unsupported(JNIEnv* env)
+{
+    jclass cls = (*env)->FindClass(env, "java/lang/UnsupportedOperationException");
+    if (cls) { (*env)->ThrowNew(env, cls, "streaming zstd (ZstCodec) is not served by the MI355X block build; use the 4mz block codecs"); (*env)->DeleteLocalRef(env, cls); }
+}
 JNIEXPORT jlong JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamCompressor_createCStream(JNIEnv* env, jclass c)
-{ (void)env; (void)c; return 0; }
+{ (void)c; throw_unsupported(env); return 0; }
 JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamCompressor_freeCStream(JNIEnv* env, jclass c, jlong s)
 { (void)env; (void)c; (void)s; return 0; }
 JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamCompressor_initCStream(JNIEnv* env, jclass c, jlong s, jint level)
@@ -150,7 +157,7 @@ JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamCompresso
 JNIEXPORT void JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamDecompressor_initIDs(JNIEnv* env, jclass cls)
 { zds_src_pos = (*env)->GetFieldID(env, cls, "srcPos", "J"); zds_dst_pos = (*env)->GetFieldID(env, cls, "dstPos", "J"); }
 JNIEXPORT jlong JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamDecompressor_createDStream(JNIEnv* env, jclass c)
-{ (void)env; (void)c; return 0; }
+{ (void)c; throw_unsupported(env); return 0; }
 JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamDecompressor_freeDStream(JNIEnv* env, jclass c, jlong s)
 { (void)env; (void)c; (void)s; return 0; }
 JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamDecompressor_initDStream(JNIEnv* env, jclass c, jlong s)

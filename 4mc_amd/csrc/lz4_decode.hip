@@ -102,7 +102,8 @@ __device__ __forceinline__ bool more_len(Stream& s, int& ip, int lim, bool check
             done = true;
         }
         if (ip + n > lim) { ip = (ip + 1 > lim + 1) ? ip + 1 : lim + 1; return false; }
-        ip += n; len += add;
+        ip += n;
+        len = len > 0x40000000 - add ? 0x40000000 : len + add;     // saturates far above any buffer: every later bound check fails as the reference's pointer-wrap tests do (lz4.c:1903-1928)
         if (done) return true;
     }
 }

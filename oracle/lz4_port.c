@@ -12,7 +12,7 @@
  *             reproduced here so that accept/reject and the negative return codes agree).
  *
  * Parity: pinned — byte-identical to oracle/_ref on the seeded corpus and on fuzzed/corrupted
- * streams (tests/test_oracle_vs_ref.py), and to the golden vectors in tests/golden/.
+ * streams (tests/test_oracle_golden.py), and to the golden vectors in tests/golden/.
  * Documented deviation: a match with offset 0 reads not-yet-written output in the reference
  * (undefined result); the port returns ORC_LZ4_ERR_OFFSET0 for it.
  */

@@ -114,7 +114,7 @@ int main(int argc, char** argv)
                          {"compressedDirectBuf", 1, 0, comp}, {"directBufferSize", 0, cap, 0}}, 6};
             g_thrown[0] = 0;
             jint r = ((call1_fn)sym(lib, ccls, "compressBytesDirectHC"))(&env, &co, 9);
-            printf("Zstd_compressBytesDirectHC12 %d %s | ulen_after=%d\n", r, g_thrown[0] ? g_thrown : "-", co.f[3].ival);
+            printf("Zstd_compressBytesDirectHC_level9 %d %s | ulen_after=%d\n", r, g_thrown[0] ? g_thrown : "-", co.f[3].ival);
         }
         {   /* corrupt input: the decompressor throws InternalError and returns the codec's error */
             obj_t dob = {{{"finished", 0, 0, 0}, {"compressedDirectBuf", 1, 0, raw}, {"compressedDirectBufLen", 0, n > 1000 ? 1000 : n, 0},

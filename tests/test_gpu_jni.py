@@ -44,7 +44,7 @@ def test_jni_entry_points_through_mock_env(gpu, tmp_path):
         d, rest = out[name + "_roundtrip"]
         assert d == n and "same=1" in rest and "clen_after=0" in rest, (name, d, rest)
     # a zstd level that is not on the device: error code returned AND InternalError thrown, buffer length untouched
-    r6, rest = out["Zstd_compressBytesDirectHC12"]
+    r6, rest = out["Zstd_compressBytesDirectHC_level9"]
     assert "java/lang/InternalError: ZSTD_compress returned: " in rest and ("ulen_after=%d" % n) in rest
     for codec, fn in (("Lz4", "LZ4_decompress_safe"), ("Zstd", "LZ4_decompress_safe")):   # zstd reuses the text (jniZstdDecompressor.c:96)
         d, rest = out[codec + "_decompress_garbage"]

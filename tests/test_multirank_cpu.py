@@ -110,6 +110,7 @@ def _file_worker(rank, world, port, path, q):
 def test_two_ranks_write_one_4mc_file(tmp_path):
     """both ranks pwrite their own byte ranges, rank 0 adds header / end mark / footer: the file equals the reference CLI's"""
     import hashlib, json
+    helpers.oracle(); helpers.corpus_lib()                       # build the checkers once, not in both ranks at the same time
     man = json.load(open(os.path.join(helpers.ROOT, "tests", "golden", "corpus_manifest.json")))
     path = str(tmp_path / "two_ranks.4mc")
     ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
