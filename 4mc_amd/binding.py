@@ -64,6 +64,8 @@ _GPU_API = {
     "fourmc_ZSTD_compress": (C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]),
     "fourmc_ZSTD_compressBound": (C.c_size_t, [C.c_size_t]),
     "fourmc_XXH32": (C.c_uint32, [C.c_void_p, C.c_size_t, C.c_uint32]),
+    "fourmc_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "fourmc_host_free": (None, [C.c_void_p]),
     "fourmc_host_4mc_encode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
     "fourmc_host_4mc_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_int]),
 }

@@ -526,6 +526,17 @@ void fourmc_debug_one_block_counters(unsigned long long* calls, unsigned long lo
     if (launches) *launches = g_one_launches;
 }
 
+/* page-locked host buffers for the file API's staging (H2D / D2H at PCIe rate instead of the pageable path's bounce copies);
+ * NULL when no device is usable or the allocation fails - the caller then falls back to malloc() */
+void* fourmc_host_alloc(size_t bytes)
+{
+    if (ensure_device() != FOURMC_OK) return nullptr;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void fourmc_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 int fourmc_host_4mc_encode(const void* src, size_t src_bytes, void* dst, size_t dst_bytes,
                            fourmc_block* blocks, uint32_t n, int codec, int level)
 { return host_roundtrip(src, src_bytes, dst, dst_bytes, blocks, n, 0, codec, level); }

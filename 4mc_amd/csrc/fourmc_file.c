@@ -22,6 +22,7 @@
 #include <string.h>
 #include <time.h>
 #include <sys/stat.h>
+#include <pthread.h>
 #include "fourmc.h"
 #include "fourmc_gpu.h"
 
@@ -39,6 +40,39 @@ static unsigned batch_blocks(void)
     if (v > 4096) v = 4096;
     return (unsigned)v;
 }
+
+/* Staging buffers: page-locked when the engine can provide them (H2D / D2H at PCIe rate), malloc otherwise. */
+typedef struct { void* p; int pinned; } hbuf;
+static hbuf hbuf_alloc(size_t n)
+{
+    hbuf b; b.p = fourmc_host_alloc(n); b.pinned = b.p != NULL;
+    if (!b.p) b.p = malloc(n);
+    return b;
+}
+static void hbuf_free(hbuf b) { if (b.pinned) fourmc_host_free(b.p); else free(b.p); }
+
+/* One batch in flight on the engine while the caller reads the next one / writes the previous one: the engine call runs
+ * on a helper thread, the two stdio streams stay on the calling thread (two buffer sets, strict alternation). */
+typedef struct {
+    pthread_t th; int running;
+    int encode; const void* src; size_t src_bytes; void* dst; size_t dst_bytes; fourmc_block* blk; uint32_t n; int codec, level;
+    int rc; char err[256];
+} job_t;
+static void* job_main(void* arg)
+{
+    job_t* j = (job_t*)arg;
+    j->rc = j->encode ? fourmc_host_4mc_encode(j->src, j->src_bytes, j->dst, j->dst_bytes, j->blk, j->n, j->codec, j->level)
+                      : fourmc_host_4mc_decode(j->src, j->src_bytes, j->dst, j->dst_bytes, j->blk, j->n, j->codec);
+    if (j->rc != FOURMC_OK) snprintf(j->err, sizeof j->err, "%s", fourmc_gpu_last_error());   /* last_error is per thread */
+    return NULL;
+}
+static void job_start(job_t* j)
+{
+    j->rc = FOURMC_OK; j->err[0] = 0;
+    if (pthread_create(&j->th, NULL, job_main, j) == 0) j->running = 1;
+    else { j->running = 0; job_main(j); }                 /* no thread: run it here, nothing overlaps */
+}
+static int job_wait(job_t* j) { if (j->running) { pthread_join(j->th, NULL); j->running = 0; } return j->rc; }
 
 /* native/4mc.c:164-209 */
 static void open_io(int displayLevel, int overwrite, const char* in_name, const char* out_name, FILE** fin, FILE** fout)
@@ -82,8 +116,9 @@ static int compress_file(int displayLevel, int overwrite, char* in_name, char* o
     uint64_t* offsets = NULL; size_t noff = 0, capoff = 0;
     uint8_t *in_buf, *out_buf, hdr[12];
     fourmc_block* blk;
+    hbuf hin[2], hout[2]; fourmc_block* blks[2]; job_t jobs[2];
     FILE *fin, *fout;
-    int codec, codec_level = 0;
+    int codec, codec_level = 0, k, have_prev = 0;
     clock_t t0 = clock(), t1;
     size_t got;
 
@@ -98,43 +133,64 @@ static int compress_file(int displayLevel, int overwrite, char* in_name, char* o
     }
     open_io(displayLevel, overwrite, in_name, out_name, &fin, &fout);
 
-    in_buf  = (uint8_t*)malloc((size_t)nbatch * BLOCKSIZE);
-    out_buf = (uint8_t*)malloc((size_t)nbatch * BLOCKSIZE);
-    blk     = (fourmc_block*)calloc(nbatch, sizeof *blk);
-    if (!in_buf || !out_buf || !blk) DIE(1, "Allocation error : not enough memory");
+    for (k = 0; k < 2; k++) {
+        hin[k] = hbuf_alloc((size_t)nbatch * BLOCKSIZE); hout[k] = hbuf_alloc((size_t)nbatch * BLOCKSIZE);
+        blks[k] = (fourmc_block*)calloc(nbatch, sizeof *blk);
+        if (!hin[k].p || !hout[k].p || !blks[k]) DIE(1, "Allocation error : not enough memory");
+        memset(&jobs[k], 0, sizeof jobs[k]);
+    }
 
     fourmc_frame_header(hdr, magic);
     if (fwrite(hdr, 1, 12, fout) != 12) DIE(3, "Write error : cannot write header");
     outsize = 12;
 
-    while ((got = fread(in_buf, 1, (size_t)nbatch * BLOCKSIZE, fin)) > 0) {
-        const unsigned nb = (unsigned)((got + BLOCKSIZE - 1) / BLOCKSIZE);
-        unsigned b;
-        for (b = 0; b < nb; b++) {
-            blk[b].src_off = (uint64_t)b * BLOCKSIZE;
-            blk[b].dst_off = (uint64_t)b * BLOCKSIZE;
-            blk[b].src_len = (uint32_t)((got - (size_t)b * BLOCKSIZE < BLOCKSIZE) ? got - (size_t)b * BLOCKSIZE : BLOCKSIZE);
-            blk[b].dst_cap = blk[b].src_len;
-            blk[b].result = 0; blk[b].xxh32 = 0;
-        }
-        engine_or_die(displayLevel, fourmc_host_4mc_encode(in_buf, got, out_buf, (size_t)nb * BLOCKSIZE, blk, nb, codec, codec_level));
-        for (b = 0; b < nb; b++) {
-            const uint32_t usize = blk[b].src_len, csize = (uint32_t)blk[b].result;
-            if (noff == capoff) {
-                capoff = capoff ? capoff * 2 : 1024;
-                offsets = (uint64_t*)realloc(offsets, capoff * sizeof *offsets);
-                if (!offsets) DIE(1, "Allocation error : not enough memory");
+    /* batch i is read while batch i - 1 is on the GPU; its results are written while batch i + 1 is */
+    for (k = 0;; k ^= 1) {
+        unsigned nb = 0, b;
+        in_buf = (uint8_t*)hin[k].p; blk = blks[k];
+        got = fread(in_buf, 1, (size_t)nbatch * BLOCKSIZE, fin);
+        if (got > 0) {
+            nb = (unsigned)((got + BLOCKSIZE - 1) / BLOCKSIZE);
+            for (b = 0; b < nb; b++) {
+                blk[b].src_off = (uint64_t)b * BLOCKSIZE;
+                blk[b].dst_off = (uint64_t)b * BLOCKSIZE;
+                blk[b].src_len = (uint32_t)((got - (size_t)b * BLOCKSIZE < BLOCKSIZE) ? got - (size_t)b * BLOCKSIZE : BLOCKSIZE);
+                blk[b].dst_cap = blk[b].src_len;
+                blk[b].result = 0; blk[b].xxh32 = 0;
             }
-            offsets[noff++] = outsize;
-            filesize += usize;
-            PRINT_LEVEL(3, "\rRead : %i MB   ", (int)(filesize >> 20));
-            fourmc_frame_block_header(hdr, usize, csize, blk[b].xxh32);
-            if (fwrite(hdr, 1, 12, fout) != 12) DIE(3, "Write error : cannot write block header");
-            if (fwrite(out_buf + blk[b].dst_off, 1, csize, fout) != csize)
-                DIE(3, csize == usize ? "Write error : cannot write block" : "Write error : cannot write compressed block");
-            outsize += 12ull + csize;
-            PRINT_LEVEL(3, "==> %.2f%%   ", (double)outsize / filesize * 100);
         }
+        if (have_prev) {                                  /* results of the previous batch */
+            const int p = k ^ 1;
+            if (job_wait(&jobs[p]) != FOURMC_OK) DIE(1, "GPU engine error %d : %s", jobs[p].rc, jobs[p].err);
+        }
+        if (got > 0) {
+            jobs[k].encode = 1; jobs[k].src = in_buf; jobs[k].src_bytes = got; jobs[k].dst = hout[k].p; jobs[k].dst_bytes = (size_t)nb * BLOCKSIZE;
+            jobs[k].blk = blk; jobs[k].n = nb; jobs[k].codec = codec; jobs[k].level = codec_level;
+            job_start(&jobs[k]);
+        }
+        if (have_prev) {
+            const int p = k ^ 1;
+            out_buf = (uint8_t*)hout[p].p; blk = blks[p];
+            for (b = 0; b < jobs[p].n; b++) {
+                const uint32_t usize = blk[b].src_len, csize = (uint32_t)blk[b].result;
+                if (noff == capoff) {
+                    capoff = capoff ? capoff * 2 : 1024;
+                    offsets = (uint64_t*)realloc(offsets, capoff * sizeof *offsets);
+                    if (!offsets) DIE(1, "Allocation error : not enough memory");
+                }
+                offsets[noff++] = outsize;
+                filesize += usize;
+                PRINT_LEVEL(3, "\rRead : %i MB   ", (int)(filesize >> 20));
+                fourmc_frame_block_header(hdr, usize, csize, blk[b].xxh32);
+                if (fwrite(hdr, 1, 12, fout) != 12) DIE(3, "Write error : cannot write block header");
+                if (fwrite(out_buf + blk[b].dst_off, 1, csize, fout) != csize)
+                    DIE(3, csize == usize ? "Write error : cannot write block" : "Write error : cannot write compressed block");
+                outsize += 12ull + csize;
+                PRINT_LEVEL(3, "==> %.2f%%   ", (double)outsize / filesize * 100);
+            }
+        }
+        have_prev = got > 0;
+        if (!have_prev) break;
     }
     memset(hdr, 0, 12);                                               /* end of stream mark     */
     if (fwrite(hdr, 1, 12, fout) != 12) DIE(3, "Write error : cannot write end of stream");
@@ -148,7 +204,8 @@ static int compress_file(int displayLevel, int overwrite, char* in_name, char* o
         outsize += fsz;
         free(foot);
     }
-    free(in_buf); free(out_buf); free(blk); free(offsets);
+    for (k = 0; k < 2; k++) { hbuf_free(hin[k]); hbuf_free(hout[k]); free(blks[k]); }
+    free(offsets);
     fclose(fin); fclose(fout);
 
     t1 = clock();
@@ -170,6 +227,7 @@ static unsigned long long decode_stream(int displayLevel, FILE* fin, FILE* fout,
     const unsigned nbatch = batch_blocks();
     unsigned long long filesize = 0;
     uint8_t hdr[12], *in_buf, *out_buf;
+    hbuf hin, hout;
     fourmc_block* blk;
     size_t n;
     int done = 0;
@@ -186,8 +244,8 @@ static unsigned long long decode_stream(int displayLevel, FILE* fin, FILE* fout,
         case 3: DIE(4, "Wrong header checksum");
         default: break;
     }
-    in_buf  = (uint8_t*)malloc((size_t)nbatch * BLOCKSIZE);
-    out_buf = (uint8_t*)malloc((size_t)nbatch * BLOCKSIZE);
+    hin = hbuf_alloc((size_t)nbatch * BLOCKSIZE); hout = hbuf_alloc((size_t)nbatch * BLOCKSIZE);
+    in_buf = (uint8_t*)hin.p; out_buf = (uint8_t*)hout.p;
     blk     = (fourmc_block*)calloc(nbatch, sizeof *blk);
     if (!in_buf || !out_buf || !blk) DIE(1, "Allocation error : not enough memory");
 
@@ -254,7 +312,7 @@ static unsigned long long decode_stream(int displayLevel, FILE* fin, FILE* fout,
         (void)r;
         free(foot);
     }
-    free(in_buf); free(out_buf); free(blk);
+    hbuf_free(hin); hbuf_free(hout); free(blk);
     return filesize;
 }
 

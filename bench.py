@@ -313,6 +313,32 @@ def main():
                              "frac": round(alg / ((t - hash_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
                 "note": "payloads of the 8 GiB image referenced %d times; 64 GiB of distinct output" % (nd // nb)}
 
+    def cli_wallclock():
+        """The drop-in CLI end to end (file in, file out, PCIe and stdio included) next to the reference CLI built from the
+        reference's sources (oracle/_ref/4mc_ref), same 2 GiB file, page cache warm."""
+        import subprocess, tempfile
+        ref_cli = helpers.ref_cli()
+        nblk = 512
+        out = {"file_GiB": nblk * B / 2**30}
+        with tempfile.TemporaryDirectory(dir=os.environ.get("FOURMC_BENCH_TMP", "/tmp")) as d:
+            src = os.path.join(d, "in.bin")
+            with open(src, "wb") as f:
+                for k in range(0, nblk, base_blocks):
+                    f.write(base[: min(base_blocks, nblk - k) * B].tobytes())
+            for name, exe in (("gpu_cli", p.cli_path()), ("reference_cli", ref_cli)):
+                if not exe or not os.path.exists(exe):
+                    continue
+                c = os.path.join(d, name + ".4mc"); back = os.path.join(d, name + ".back")
+                t0 = time.perf_counter(); r1 = subprocess.run([exe, "-f", src, c], capture_output=True); t1 = time.perf_counter()
+                r2 = subprocess.run([exe, "-d", "-f", c, back], capture_output=True); t2 = time.perf_counter()
+                ok = r1.returncode == 0 and r2.returncode == 0 and os.path.getsize(back) == nblk * B
+                out[name] = {"compress_MBps": round(nblk * B / (t1 - t0) / 1e6, 1), "decompress_MBps": round(nblk * B / (t2 - t1) / 1e6, 1), "ok": ok,
+                             "file_bytes": os.path.getsize(c) if os.path.exists(c) else None}
+                os.remove(back)
+            if "gpu_cli" in out and "reference_cli" in out:
+                out["files_identical"] = out["gpu_cli"]["file_bytes"] == out["reference_cli"]["file_bytes"]
+        return out
+
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
@@ -396,6 +422,10 @@ def main():
         if world == 1 and not args.no_extras:
             line["other_configs"] = other_configs()
             line["decode_64GiB"] = decode_64gib()
+            try:
+                line["cli_wallclock"] = cli_wallclock()
+            except Exception as e:                          # never lose the line over a temp-file problem
+                line["cli_wallclock"] = {"error": str(e)[:200]}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -143,6 +143,9 @@ unsigned fourmc_XXH32(const void* input, size_t len, unsigned seed);    /* host 
 
 /* Host batch: `n` blocks described by host-side descriptors over host buffers; the engine does
  * one H2D of the inputs, one launch, one D2H of outputs + descriptors.  Used by the file API.  */
+/* Page-locked host memory for staging buffers handed to the two calls below (NULL if it cannot be had: use malloc then). */
+void* fourmc_host_alloc(size_t bytes);
+void  fourmc_host_free(void* p);
 int fourmc_host_4mc_encode(const void* src, size_t src_bytes, void* dst, size_t dst_bytes,
                            fourmc_block* blocks, uint32_t n, int codec, int level);
 int fourmc_host_4mc_decode(const void* src, size_t src_bytes, void* dst, size_t dst_bytes,

@@ -232,3 +232,18 @@ def test_zstd12_golden_manifest_and_every_size_class(gpu, tmp_path):
     assert int(b1["src_len"]) == want_r and np.array_equal(img[int(b1["src_off"]): int(b1["src_off"]) + want_r], want)
     assert subprocess.run([gpu.cli_path(), "-d", "-z", "-f", str(tmp_path / "tail.4mz"), str(tmp_path / "tail.back")], capture_output=True).returncode == 0
     assert (tmp_path / "tail.back").read_bytes() == tail.tobytes()
+
+
+def test_zstd12_log_corpus_blocks(gpu):
+    """BASELINE configs[4]'s workload (4mz Ultra on the synthetic log corpus) at a size the oracle covers: frames of whole
+    4 MiB log blocks and of a short tail equal the oracle's (itself pinned to the reference's ZSTD_compress level 12)."""
+    logs = helpers.corpus(2 * B + 150001, first_block=5, logs=True)
+    srcs = [logs[:B], logs[B:2 * B], logs[2 * B:], logs[1000:1000 + 300000]]
+    caps = [len(s) - 1 for s in srcs]                    # the container's capacity (native/4mc.c:467)
+    _check(gpu, ["log0", "log1", "tail", "mid300k"], srcs, caps, "logs", level=12)
+    ref = helpers.ref()
+    if ref is not None:                                  # and the reference itself, when it is built
+        out = np.empty(B + 4096, np.uint8)
+        r = ref.ZSTD_compress(out.ctypes.data, B - 1, srcs[0].ctypes.data, B, 12)
+        res, outs = _encode(gpu, [srcs[0]], [B - 1], 12)
+        assert int(res[0]) == int(r) and np.array_equal(outs[0], out[:r])
