@@ -34,7 +34,6 @@ constexpr int kRing  = kRW * kWin;
 constexpr uint32_t kRM = kRing - 1;
 constexpr int kAhead = 3;                     // windows the literal wave may be ahead of the chain wave
 constexpr int kLag   = 6;                     // flush stores in flight before the oldest one is waited for
-constexpr int kCB    = 2048;                  // bytes of the stream staged per window
 constexpr int kGuard = 64;                    // readable bytes behind the ring / the staged stream (batched reads overshoot)
 constexpr int kShort = 32;                    // pieces up to this length are copied by their own lane
 constexpr int kPF    = 4;                     // dwords prefetched per piece by the literal wave (longer pieces: whole-wave copy on demand)
@@ -464,7 +463,7 @@ __device__ __forceinline__ void chain_wave(const Blk& B, ring_t ring, Slot* slot
             PT(0);
             const Slot* s = slots + (cons % kNS);
             const uint32_t n = ldv(&s->n), last = ldv(&s->last), maxlen = ldv(&s->maxlen);
-            if (n) { const uint32_t rounds = chain_slot(ring, s, n, maxlen, lane); PADD(3, rounds); PADD(4, n); }
+            if (n) { const uint32_t steps = chain_slot(ring, s, n, maxlen, lane); (void)steps; PADD(3, steps); PADD(4, n); }
             PADD(5, 1);
             lds_fence();
             PT(1);

@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_JSON = os.path.join("profiles", "r01_traffic.json")
+TRAFFIC_JSON = os.path.join("profiles", "r02_traffic.json")
 
 
 def cpu_model():
@@ -313,6 +313,22 @@ def main():
                              "frac": round(alg / ((t - hash_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
                 "note": "payloads of the 8 GiB image referenced %d times; 64 GiB of distinct output" % (nd // nb)}
 
+    def decode_path_comparison():
+        """Both LZ4 decode fast paths on the same launch (identical results): the default wave trio and the block-parallel
+        parse + executor pair, HIP events around the decode_blocks call minus the hash launch."""
+        out = {}
+        before = L.fourmc_gpu_get_lz4_decode_path()
+        vb = state["dec"].clone()
+        x_ver = timed(lambda: p.binding.check(L.fourmc_gpu_xxh32(d_image.data_ptr(), vb.data_ptr(), nb, 0, sp), "xxh32"))
+        for path, name in ((0, "wave_trio"), (1, "block_parallel")):
+            L.fourmc_gpu_set_lz4_decode_path(path)
+            dd = state["dec"].clone(); dd[:, 6] = 0
+            t = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_image.data_ptr(), d_out.data_ptr(), dd.data_ptr(), nb, 0, sp), name))
+            ok = bool((dd[:, 6] == B).all()) and bool(torch.equal(d_out[: nb * B], d_src))
+            out[name] = {"lz4_decode_ms": round(t - x_ver, 3), "round_trip": ok}
+        L.fourmc_gpu_set_lz4_decode_path(before)
+        return out
+
     def cli_wallclock():
         """The drop-in CLI end to end (file in, file out, PCIe and stdio included) next to the reference CLI built from the
         reference's sources (oracle/_ref/4mc_ref), same 2 GiB file, page cache warm."""
@@ -421,6 +437,7 @@ def main():
             line["ratio_vs_reference"] = None
         if world == 1 and not args.no_extras:
             line["other_configs"] = other_configs()
+            line["decode_paths"] = decode_path_comparison()
             line["decode_64GiB"] = decode_64gib()
             try:
                 line["cli_wallclock"] = cli_wallclock()

@@ -7,20 +7,22 @@ o = f"gpurun_out/{tag}/"
 def rows(f, per=5):
     d = {}
     for l in open(f):
-        m = re.match(r"\| ([\w<>]+) \| (\w+) \| (\d+) \| (\d+) \| (\d+) \|", l)
+        m = re.match(r"\| ([\w<>]+)[^|]* \| (\w+) \| (\d+) \| (\d+) \| (\d+) \|", l)
         if m: d.setdefault(m.group(1), {})[m.group(2)] = int(m.group(per))
     return d
 fe, wr = rows(o + "summary_fetch.md"), rows(o + "summary_write.md")
 xk = [k for k in fe if k.startswith("xxh32")][0]
-t = json.load(open("profiles/r01_traffic.json"))
+rnd = re.match(r"(r\d+)", name).group(1)
+traffic_json = f"profiles/{rnd}_traffic.json"
+t = json.load(open(traffic_json if os.path.exists(traffic_json) else "profiles/r01_traffic.json"))
 t["lz4_encode"] = {"fetch_KiB": fe["lz4_encode_fast_kernel"]["FETCH_SIZE"], "write_KiB": wr["lz4_encode_fast_kernel"]["WRITE_SIZE"]}
 t["lz4_decode"] = {"fetch_KiB": fe["lz4_decode_fast_kernel"]["FETCH_SIZE"] + fe.get("lz4_decode_retry_kernel", {}).get("FETCH_SIZE", 0),
                    "write_KiB": wr["lz4_decode_fast_kernel"]["WRITE_SIZE"]}
 t["xxh32"] = {"fetch_KiB": fe[xk]["FETCH_SIZE"], "write_KiB": wr[xk]["WRITE_SIZE"]}
 t["pack"] = {"fetch_KiB": fe["pack_image_kernel"]["FETCH_SIZE"], "write_KiB": wr["pack_image_kernel"]["WRITE_SIZE"]}
-json.dump(t, open("profiles/r01_traffic.json", "w"), indent=1)
+json.dump(t, open(traffic_json, "w"), indent=1)
 open(f"profiles/{name}_kernel_stats.md", "w").write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1   (tools/profile_round.sh)\n\n" + open(o + "summary_stats.md").read())
-open(f"profiles/{name}_hbm_traffic.md", "w").write("# rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) -- python bench.py --blocks 512 --no-extras --no-cpu --steps 2 --warmup 1\n# per-dispatch values are KiB (see the calibration note in r01_traffic.json)\n\n" + open(o + "summary_fetch.md").read() + "\n" + open(o + "summary_write.md").read())
+open(f"profiles/{name}_hbm_traffic.md", "w").write("# rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) -- python bench.py --blocks 512 --no-extras --no-cpu --steps 2 --warmup 1\n# per-dispatch values are KiB (see the calibration note in the round's *_traffic.json)\n\n" + open(o + "summary_fetch.md").read() + "\n" + open(o + "summary_write.md").read())
 open(f"profiles/{name}_bench_under_rocprof.json", "w").write(open(o + "bench_stats.json").read())
 open(f"profiles/{name}_bench.json", "w").write(open(o + "bench_stats.json").read())
 a, b = rows(o + "summary_sq.md"), rows(o + "summary_sq2.md")
@@ -32,5 +34,19 @@ for k in ("lz4_encode_fast_kernel", "lz4_decode_fast_kernel", [k for k in a if k
     out += "| %s | %.0f %% | %.0f %% | %.0f %% | %.0f %% | %.2f | %.1f | %.2e | %.2e / %.2e |\n" % (k, 100 * x["SQ_WAIT_ANY"] / wc, 100 * x["SQ_ACTIVE_INST_ANY"] / wc, 100 * x["SQ_WAIT_INST_ANY"] / wc, 100 * 4 * x["SQ_ACTIVE_INST_VALU"] / (1024 * cyc), x["SQ_INSTS_SALU"] / x["SQ_INSTS_VALU"], 4 * x["SQ_ACTIVE_INST_ANY"] / n, y["SQ_INSTS_LDS"], y["SQ_INSTS_VMEM_RD"], y["SQ_INSTS_VMEM_WR"])
 out += "\n" + open(o + "summary_sq.md").read() + "\n" + open(o + "summary_sq2.md").read()
 open(f"profiles/{name}_sq_counters.md", "w").write(out)
+# the opt-in block-parallel LZ4 decode path (tools/k1_timing.py under FOURMC_DECODE=par)
+if os.path.exists(o + "summary_par_stats.md"):
+    pa, pb = rows(o + "summary_par_sq.md"), rows(o + "summary_par_sq2.md")
+    txt = "# FOURMC_DECODE=par rocprofv3 ... -- python tools/k1_timing.py   (2048 blocks of S-mix, decode only; three passes: kernel trace, two SQ groups)\n\n"
+    txt += open(o + "summary_par_stats.md").read() + "\n"
+    txt += "| kernel | waves' time parked (s_waitcnt) | issuing | issue stalls | SALU : VALU | cycles per issued instruction | LDS instr | LDS bank-conflict cycles / LDS active cycles |\n|---|---|---|---|---|---|---|---|\n"
+    for k in pa:
+        if not (k.startswith("lz4_exec") or k.startswith("lz4_parse")): continue
+        x, y = pa[k], pb.get(k, {})
+        wc = x["SQ_WAVE_CYCLES"]; n = x["SQ_INSTS_VALU"] + x["SQ_INSTS_SALU"] + x["SQ_INSTS_LDS"] + y.get("SQ_INSTS_VMEM_RD", 0) + y.get("SQ_INSTS_VMEM_WR", 0)
+        txt += "| %s | %.0f %% | %.0f %% | %.0f %% | %.2f | %.1f | %.2e | %.2f |\n" % (k, 100 * x["SQ_WAIT_ANY"] / wc, 100 * x["SQ_ACTIVE_INST_ANY"] / wc, 100 * x["SQ_WAIT_INST_ANY"] / wc,
+                x["SQ_INSTS_SALU"] / x["SQ_INSTS_VALU"], 4 * x["SQ_ACTIVE_INST_ANY"] / n, x["SQ_INSTS_LDS"], y.get("SQ_LDS_BANK_CONFLICT", 0) / max(y.get("SQ_LDS_IDX_ACTIVE", 1), 1))
+    txt += "\n" + open(o + "summary_par_sq.md").read() + "\n" + open(o + "summary_par_sq2.md").read()
+    open(f"profiles/{name}_block_parallel_decode.md", "w").write(txt)
 d = json.load(open(o + "bench_stats.json"))
 print(d["value"], d["ms_per_step"], d["kernel_ms"], d["compress_GBps"], d["decompress_GBps"])

@@ -3,16 +3,24 @@
 #   tools/profile_round.sh <tag>      -> gpurun_out/<tag>/{stats,fetch,write,sq}/ + gpurun_out/<tag>/summary_*.md
 # Kernel trace + stats in one pass; every PMC group in a pass of its own (no trace domains next to --pmc).
 set -u
-tag=${1:-prof}; out=gpurun_out/$tag; mkdir -p $out
+tag=${1:-prof}; out=gpurun_out/$tag; raw=/tmp/prof_$tag; mkdir -p $out $raw     # raw rocprofv3 output stays on the box (only <= 64 MiB come back)
 export TMPDIR=/tmp
-run() { name=$1; shift; rocprofv3 "$@" -d $out/$name -o $name -- python bench.py --steps 2 --warmup 1 ${BENCH_ARGS:-} > $out/$name.log 2>&1; }
-run stats --kernel-trace --stats
+run() { name=$1; shift; rocprofv3 "$@" -d $raw/$name -o $name -- python bench.py --steps 2 --warmup 1 ${BENCH_ARGS:-} > $out/$name.log 2>&1; }
+BENCH_ARGS="--no-cpu" run stats --kernel-trace --stats
 BENCH_ARGS="--blocks 512 --no-extras --no-cpu" run fetch --pmc FETCH_SIZE
 BENCH_ARGS="--blocks 512 --no-extras --no-cpu" run write --pmc WRITE_SIZE
 BENCH_ARGS="--no-extras --no-cpu" run sq --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU
 BENCH_ARGS="--no-extras --no-cpu" run sq2 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
 for p in stats fetch write sq sq2; do
-    db=$(find $out/$p -name "*_results.db" | head -1)
+    db=$(find $raw/$p -name "*_results.db" | head -1)
     [ -n "$db" ] && python tools/rocpd_summary.py $db > $out/summary_$p.md
     grep "^{\"metric\"" $out/$p.log | tail -1 > $out/bench_$p.json
+done
+# the block-parallel LZ4 decode path (opt-in): kernel stats and SQ counters of the decode-only timing tool
+FOURMC_DECODE=par rocprofv3 --kernel-trace --stats -d $raw/par_stats -o par_stats -- python tools/k1_timing.py > $out/par_stats.log 2>&1
+FOURMC_DECODE=par rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $raw/par_sq -o par_sq -- python tools/k1_timing.py > $out/par_sq.log 2>&1
+FOURMC_DECODE=par rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE -d $raw/par_sq2 -o par_sq2 -- python tools/k1_timing.py > $out/par_sq2.log 2>&1
+for p in par_stats par_sq par_sq2; do
+    db=$(find $raw/$p -name "*_results.db" | head -1)
+    [ -n "$db" ] && python tools/rocpd_summary.py $db > $out/summary_$p.md
 done

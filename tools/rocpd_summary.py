@@ -20,7 +20,7 @@ for f in sys.argv[1:]:
         if rows:
             print("| kernel | counter | sum over dispatches | dispatches | per dispatch |\n|---|---|---|---|---|")
             for k, c, v, n in rows:
-                k = k.split("::")[1].split("(")[0] if "::" in k else k[:40]
+                k = k.split("::")[1].split("(")[0] if "::" in k else k.split("(")[0][:40]
                 print(f"| {k} | {c} | {v:.0f} | {n} | {v/max(n,1):.0f} |")
             print()
     except sqlite3.OperationalError:
