@@ -40,7 +40,7 @@ constexpr uint32_t kSeqCap = 32768 + 64;
 constexpr size_t   kSeqBytes  = size_t(kSeqCap) * 4;
 constexpr size_t   kCodeBytes = kSeqCap;
 constexpr size_t   kLitPad    = 64;
-constexpr size_t   kLitBytes  = kLitPad + kSub + 192;
+constexpr size_t   kLitBytes  = kLitPad + kSub + 256;
 // per-block workspace: [sequence store | codes | literal buffer (+ profile counters) | previous FSE tables | scratch] [tables]
 constexpr size_t   kOffCodes  = 3 * kSeqBytes;
 constexpr size_t   kOffLit    = kOffCodes + 3 * kCodeBytes;
@@ -56,6 +56,8 @@ __host__ __device__ constexpr size_t table_bytes(int level)
 struct __attribute__((packed, aligned(1))) S4B { uint32_t v; };
 __device__ __forceinline__ void st4(uint8_t* p, uint32_t v) { reinterpret_cast<S4B*>(p)->v = v; }
 __device__ __forceinline__ uint32_t U(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
+__device__ __forceinline__ int Ui(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned long long U64(unsigned long long v) { return (uint64_t(U(uint32_t(v >> 32))) << 32) | U(uint32_t(v)); }
 __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t l) { return uint32_t(__builtin_amdgcn_readlane(int(v), int(l))); }
 __device__ __forceinline__ int hibit(uint32_t v) { return 31 - __clz(v); }
 template <int CTRL, int ROWMASK>
@@ -815,7 +817,11 @@ __device__ __forceinline__ int build_seq_table(ZLds& L, int which, uint8_t* dst,
     return r;
 }
 
-struct SeqStore { uint32_t *ll, *ml, *off; uint8_t *llc, *ofc, *mlc; uint8_t* lit; uint32_t nseq, nlit; };
+struct SeqStore { uint32_t *ll, *ml, *off; uint8_t *llc, *ofc, *mlc; uint8_t* lit; uint32_t nseq, nlit;
+#ifdef Z1_PROF
+    uint64_t prof[16];      // 0..9 event counts, 10..14 cycles per phase, 15 last time stamp
+#endif
+};
 
 // sequences section (tail of ZSTD_entropyCompressSeqStore_internal); bytes, 0 or kErr*
 __device__ __forceinline__ int encode_sequences(ZLds& L, uint8_t* dst, uint32_t cap, const SeqStore& S, uint32_t strat,
@@ -980,17 +986,36 @@ __device__ __forceinline__ void gather_literals(const SeqStore& S, const uint8_t
     }
 }
 
-// after a match ending at ip0: table refills and the repcode-2 loop (zstd_fast.c:263-281)
+// 16 bytes at p, any alignment, as four dwords (one global_load_dwordx4)
+struct Q16 { uint32_t d0, d1, d2, d3; };
+__device__ __forceinline__ Q16 ld16(const uint8_t* p) { const U16B t = *reinterpret_cast<const U16B*>(p); return Q16{uint32_t(t.a), uint32_t(t.a >> 32), uint32_t(t.b), uint32_t(t.b >> 32)}; }
+__device__ __forceinline__ uint64_t u64(uint32_t lo, uint32_t hi) { return (uint64_t(hi) << 32) | lo; }
+// hash table read of the "fast" strategy.  The dense window commits its table writes with atomic max (performed in L2),
+// so every read of that table goes to L2 as well (a plain load could hit a stale line of the CU's L1).
+__device__ __forceinline__ uint32_t tld(const uint32_t* t, uint32_t h) { return __hip_atomic_load(t + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+#ifdef Z1_PROF   // one-off counters of the dense window (tools/zstd_timing.py reads them behind the phase cycle counters)
+#define ZCNT(i) do { S.prof[i]++; } while (0)
+#define ZADD(i, v) do { S.prof[i] += (v); } while (0)
+#define ZPT(i) do { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); const uint64_t zt_ = __builtin_readcyclecounter(); S.prof[i] += zt_ - S.prof[15]; S.prof[15] = zt_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ZPT(i) do { } while (0)
+#define ZCNT(i) do { } while (0)
+#define ZADD(i, v) do { } while (0)
+#endif
+
+// after a match ending at ip0: table refills and the repcode-2 loop (zstd_fast.c:263-281).  `fill_cur` = false when the
+// refill of current0 + 2 has been made already (dense window: it was one of the window's lanes).
 __device__ __forceinline__ void after_match(SeqStore& S, uint32_t* tab, const Params& P, const uint8_t* s, uint32_t& ip0, uint32_t& anchor,
-                                            uint32_t cur0_idx, uint32_t& rep1, uint32_t& rep2, uint32_t end, int64_t ilimit, int lane)
+                                            uint32_t cur0_idx, uint32_t& rep1, uint32_t& rep2, uint32_t end, int64_t ilimit, int lane, bool fill_cur = true)
 {
     if (int64_t(ip0) > ilimit) return;
     // the four reads of this step in one round trip, ahead of the table stores
-    const uint64_t w_a = ld8(s + cur0_idx), w_b = ld8(s + ip0 - 2);
+    const uint64_t w_a = fill_cur ? ld8(s + cur0_idx) : 0, w_b = ld8(s + ip0 - 2);
     uint32_t r_cur = ld4(s + ip0), r_rep = ld4(s + ip0 - rep2);         // (rep2 == 0 reads ip0 itself: not used then)
     {
         const uint32_t h_a = zhash(w_a, P.hlog, P.mml), h_b = zhash(w_b, P.hlog, P.mml);
-        if (lane == 0) { tab[h_a] = cur0_idx + 2; tab[h_b] = ip0; }
+        if (lane == 0) { if (fill_cur) tab[h_a] = cur0_idx + 2; tab[h_b] = ip0; }
     }
     if (rep2 > 0)
         for (bool first = true; int64_t(ip0) <= ilimit; first = false) {
@@ -1006,17 +1031,34 @@ __device__ __forceinline__ void after_match(SeqStore& S, uint32_t* tab, const Pa
         }
 }
 
-// ZSTD_compressBlock_fast_noDict_generic over s[start, end), 64 position pairs per batch
+// ZSTD_compressBlock_fast_noDict_generic over s[start, end).
+//
+// Two shapes reproduce the reference's serial walk (pairs of positions ip0, ip0+1 with a repcode test at ip0+step; every tested
+// position reads, then overwrites its hash slot; after a match: two refills and the repcode-2 loop):
+//   * dense window (step 2, i.e. the first 124 bytes of a search - where nearly all sequences of compressible data are found).
+//     Lane l takes position sp+l whatever role the walk will give it and prepares, against the table as it stands: its
+//     candidate, the 4-byte test, up to 4 equal bytes backwards and 24 (56) forwards; and, for both repeat offsets, whether its 4
+//     bytes repeat at that distance (ballots: the repcode tests of all 64 positions at once, and per-byte equality, whose runs
+//     are the lengths of repcode matches).  Lanes sharing a table slot are found with an LDS scoreboard and made exact by a
+//     ballot per group.  A scalar walk then only CHOOSES: per sequence it orders the first hash hit against the first repcode
+//     hit of the right parity, takes lengths from the prepared lanes, and marks which lanes the reference would have written
+//     into the table.  A hash match changes the repeat offset: the repcode ballots are redone for the lanes behind it (one
+//     read).  All sequences of the window are stored at once, the marked lanes enter the table with one atomic max each (the
+//     latest position of a slot wins).  Whatever the window does not hold (long matches, long catch-up, a lane whose slot an
+//     earlier lane of the window also wrote and that could match there, an immediate repcode-2 match) is left to
+//   * the batched search: lane j speculatively executes pair j of the running search (16..64 pairs per batch, any step),
+//     one event (sequence) per batch; wave-wide extension; the serial tail of the reference (`after_match`).
 __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* tab, const Params& P, uint32_t rep[3],
                                                const uint8_t* s, uint32_t start, uint32_t end, uint32_t n_total, bool serial, int lane)
 {
-    const uint32_t hlog = P.hlog, wsize = 1u << P.wlog, mls = P.mml;
-    const uint32_t step0 = P.tlen > 1 ? P.tlen + 1 : 2;
+    start = U(start); end = U(end);                                            // (wave-uniform: keep what derives from them on the scalar unit)
+    const uint32_t hlog = U(P.hlog), wsize = 1u << U(P.wlog), mls = U(P.mml);
+    const uint32_t step0 = U(P.tlen > 1 ? P.tlen + 1 : 2);
     const uint32_t prefix_idx = end > wsize ? end + 2 - wsize : 2;
     const uint32_t prefix = prefix_idx - 2;
     const int64_t ilimit = int64_t(end) - 8;
     uint32_t anchor = start, ip0 = start;
-    uint32_t rep1 = rep[0], rep2 = rep[1], saved1 = 0, saved2 = 0;
+    uint32_t rep1 = U(rep[0]), rep2 = U(rep[1]), saved1 = 0, saved2 = 0;
 
     ip0 += (ip0 == prefix) ? 1 : 0;
     {
@@ -1026,10 +1068,207 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
         if (rep2 > max_rep) { saved2 = rep2; rep2 = 0; }
         if (rep1 > max_rep) { saved1 = rep1; rep1 = 0; }
     }
-    for (;;) {                                                   // one search per iteration (_start)
+    // Walk state: ip0 is the start of the running search, sp its next pair (sp - ip0 even; sp > ip0 only while the step is still
+    // 2).  `owed`: a match has just ended at ip0 == sp and the refill of ip0 - 2 and the repcode-2 loop are still to do.
+    uint32_t sp = ip0;
+    bool owed = false, gen_tail = false, gen_search = false;
+    for (;;) {
+        if (owed && (gen_tail || serial || step0 != 2 || sp < max(rep1, rep2) + 4 || int64_t(sp) + 200 > ilimit)) {
+            after_match(S, tab, P, s, ip0, anchor, 0, rep1, rep2, end, ilimit, lane, false);
+            sp = ip0; owed = false;
+        }
+        gen_tail = false;
+        if (!serial && !gen_search && step0 == 2 && sp - ip0 <= 60 && sp >= max(rep1, rep2) + 4 && sp >= 4 && int64_t(sp) + 200 <= ilimit) {
+            // ------------------------------------------------------------------------------------------ dense window
+            ZPT(14);                                                                    // (everything outside the dense window)
+            const uint32_t sp0 = U(sp);
+            ip0 = U(ip0); anchor = U(anchor); rep1 = U(rep1); rep2 = U(rep2);
+            const uint32_t pos = sp0 + uint32_t(lane);
+            const Q16 q0 = ld16(s + pos - 4), q1 = ld16(s + pos + 12);                  // [pos - 4, pos + 28)
+            uint64_t ra = 0, rb = 0;                                                    // [pos - rep - 4, pos - rep + 4) for both repeat offsets
+            if (rep1) ra = ld8(s + pos - rep1 - 4);
+            if (rep2) rb = ld8(s + pos - rep2 - 4);
+            ZCNT(0); ZPT(10);
+            const uint32_t h = zhash(u64(q0.d1, q0.d2), hlog, mls);
+            uint32_t ent = tld(tab, h);
+            if (owed) {                                                                 // the owed refill of sp - 2 comes before every read of this window
+                const uint32_t lo = __builtin_amdgcn_alignbit(q0.d1, q0.d0, 16), hi = __builtin_amdgcn_alignbit(q0.d2, q0.d1, 16);
+                const uint32_t hf = rl(zhash(u64(lo, hi), hlog, mls), 0);
+                if (lane == 0) atomicMax(&tab[hf], sp0);
+                if (h == hf) ent = sp0;
+            }
+            // lanes that share a table slot: candidates from a folded scoreboard, then one ballot per group makes it exact.
+            // first lane of a slot: clean; second: its only predecessor in the window is `pred`; later ones: dirty.
+            bool second = false, dirty = false; uint32_t pred = 0;
+            {
+                uint32_t* const sc = &L.score[h & 1023];
+                atomicMin(sc, uint32_t(lane));
+                const bool poss = *sc != uint32_t(lane);
+                *sc = 0xFFFFFFFFu;
+                unsigned long long mp = __ballot(poss);
+#ifdef Z1_TRACE
+                if (lane == 0) printf("prep sp0 %u poss %llx h9 %u h18 %u\n", sp0, mp, rl(h, 9), rl(h, 18));
+#endif
+                while (mp) {
+                    const int e = __builtin_ctzll(mp);
+                    const unsigned long long g = __ballot(h == rl(h, uint32_t(e)));
+                    mp &= ~g;
+                    if (g & (g - 1)) {
+                        const uint32_t below = __builtin_amdgcn_mbcnt_hi(uint32_t(g >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(g), 0));
+                        if (h == rl(h, uint32_t(e)) && below) {
+                            const unsigned long long gb = g & ((1ull << lane) - 1);
+                            pred = 63u - uint32_t(__builtin_clzll(gb));
+                            second = below == 1; dirty = below > 1;
+                        }
+                    }
+                }
+            }
+            ZPT(11);
+            const bool valid = ent >= prefix_idx;
+            const uint32_t c = ent - 2;
+            bool hit = false, slow = false;
+            uint32_t fw = 0, bk = 0;
+            if (valid) {
+                if (c >= 4) {
+                    const Q16 c0 = ld16(s + c - 4), c1 = ld16(s + c + 12);
+                    const Q16 x0 = {q0.d0 ^ c0.d0, q0.d1 ^ c0.d1, q0.d2 ^ c0.d2, q0.d3 ^ c0.d3}, x1 = {q1.d0 ^ c1.d0, q1.d1 ^ c1.d1, q1.d2 ^ c1.d2, q1.d3 ^ c1.d3};
+                    hit = x0.d1 == 0;
+                    bk = x0.d0 ? uint32_t(__builtin_clz(x0.d0) >> 3) : 4u;              // byte 3 (MSB) is position -1
+                    const uint64_t y0 = u64(x0.d2, x0.d3), y1 = u64(x1.d0, x1.d1), y2 = u64(x1.d2, x1.d3);
+                    fw = y0 ? uint32_t(__builtin_ctzll(y0) >> 3) : (y1 ? 8u + uint32_t(__builtin_ctzll(y1) >> 3)
+                                           : (y2 ? 16u + uint32_t(__builtin_ctzll(y2) >> 3) : 24u));
+                    // which of the 32 bytes held equal the candidate's: kept for the walk (a chosen match makes its offset the
+                    // repeat offset, and these bytes answer the repcode tests behind it)
+                    uint4* const xr = reinterpret_cast<uint4*>(L.ncount) + 2 * lane;
+                    xr[0] = make_uint4(x0.d0, x0.d1, x0.d2, x0.d3); xr[1] = make_uint4(x1.d0, x1.d1, x1.d2, x1.d3);
+                } else { hit = ld4(s + c) == q0.d1; slow = true; }
+            }
+            const uint32_t info = fw | (bk << 8);
+            const uint32_t wpred = __shfl(q0.d1, int(pred));                            // (every lane takes part: the source lane must be active)
+            const bool hitA = second && wpred == q0.d1;
+            const unsigned long long m_dirty = __ballot(dirty), m_cond = __ballot(second && (hitA || hit)),
+                                     m_slow = __ballot(!second && !dirty && hit && slow), m_hit = __ballot(!second && !dirty && hit && !slow);
+            const unsigned long long m_stop = m_dirty | m_cond | m_slow;
+#ifdef Z1_TRACE
+            { const unsigned long long bs = __ballot(second), ba = __ballot(hitA), bh = __ballot(hit); if (lane == 0) printf("prep2 second %llx hitA %llx hit %llx pred18 %u\n", bs, ba, bh, rl(pred, 18)); }
+#endif
+            // repcode tests of every position, for both repeat offsets
+            const uint64_t own = u64(q0.d0, q0.d1);
+            // MR: the 4 bytes repeat; EQB: the byte repeats; EQM1: the byte before repeats.  H4 / HB: last lane for which MR / EQB
+            // is known (63 when read from memory; a chosen match knows 28 bytes behind its position)
+            unsigned long long MR1 = 0, EQB1 = 0, EQM1 = 0, MR2 = 0;
+            int H41 = 63, HB1 = 63, H42 = 63;
+            if (rep1) { const uint64_t x = ra ^ own; MR1 = __ballot(uint32_t(x >> 32) == 0); EQB1 = __ballot((uint32_t(x >> 32) & 0xFFu) == 0); EQM1 = __ballot((uint32_t(x) >> 24) == 0); }
+            if (rep2) { const uint64_t x = rb ^ own; MR2 = __ballot(uint32_t(x >> 32) == 0); }
+            auto read_rep = [&](uint32_t off, int lo, unsigned long long& mr, unsigned long long& eqb, unsigned long long& eqm1) {
+                uint64_t x = ~0ull;                                                     // (lanes >= lo lie behind a match at that offset: the read stays inside the input)
+                if (lane >= lo) x = ld8(s + pos - off - 4) ^ own;
+                mr = __ballot(uint32_t(x >> 32) == 0); eqb = __ballot((uint32_t(x >> 32) & 0xFFu) == 0); eqm1 = __ballot((uint32_t(x) >> 24) == 0);
+                ZCNT(9);
+            };
+            // ---- the walk (scalar).  Lanes are window positions; s_l: start of the running search, cur: its next pair,
+            // anc: the anchor (both may lie before the window: negative).
+            ZPT(12);
+            int s_l = -int(sp0 - ip0), cur = 0, anc = -int(sp0 - anchor);
+            bool pend = owed;                                                           // the repcode-2 test at lane cur == s_l comes first
+            unsigned long long vis = 0;                                                 // lanes the reference writes into the table
+            uint32_t nsq = 0, litsum = 0, sq_ll = 0, sq_ml = 0, sq_of = 0;              // lane k keeps sequence k of this window
+            uint32_t r1 = rep1, r2 = rep2;
+            int endk;                                                                   // 0: search goes on at cur, 1: fresh search at cur, 2: batched search at cur, 3: repcode-2 loop at cur
+            for (;;) {
+                cur = Ui(cur); s_l = Ui(s_l); anc = Ui(anc); nsq = U(nsq); litsum = U(litsum); r1 = U(r1); r2 = U(r2);   // (all wave-uniform: keep the walk on the scalar unit)
+                H41 = Ui(H41); HB1 = Ui(HB1); H42 = Ui(H42);
+                vis = U64(vis); MR1 = U64(MR1); EQB1 = U64(EQB1); EQM1 = U64(EQM1); MR2 = U64(MR2);
+                if (pend) {
+                    if (cur >= 62) { endk = 1; break; }
+                    if (r2) {
+                        if (cur > H42) { unsigned long long t0, t1; read_rep(r2, cur, MR2, t0, t1); H42 = 63; }
+                        if ((MR2 >> cur) & 1) { endk = 3; break; }
+                    }
+                    pend = false;
+                }
+                const int amax = 60 - ((60 - s_l) & 1);                                 // last pair handled here: its refills stay inside the window
+                if (cur > amax) { endk = cur == s_l ? 1 : 0; break; }
+                const unsigned long long from = ~0ull << cur;
+                const unsigned long long pm = (s_l & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
+                const unsigned long long k4 = H41 >= 63 ? ~0ull : (2ull << H41) - 1;    // lanes whose repcode test is known
+                const unsigned long long evh = (m_hit | m_stop) & from, evr = MR1 & pm & (from << 2) & k4, unk = pm & (from << 2) & ~k4;
+                const int lh = evh ? __builtin_ctzll(evh) : 64, lr = evr ? __builtin_ctzll(evr) : 999, lu = unk ? __builtin_ctzll(unk) : 999;   // (999: none)
+                if (r1 && lr > lh + 2 && lu <= lh + 2 && lu - 2 <= amax) {              // a repcode test that is not known comes first: read it
+                    read_rep(r1, cur, MR1, EQB1, EQM1); H41 = HB1 = 63;
+                    continue;
+                }
+                if (lr <= lh + 2) {                                                     // (lr < 64) the repcode test at lr comes before the hash tests of lr-2, lr-1
+                    const int q = lr, a = q - 2;
+                    if (a > amax) { vis |= from & ~(~0ull << (amax + 2)); cur = amax + 2; endk = 0; break; }
+                    const unsigned long long t = q + 4 < 64 ? ~(EQB1 >> (q + 4)) : 1ull;
+                    const int fwv = t ? __builtin_ctzll(t) : 64;
+                    if (q + 4 + fwv > HB1 && HB1 < 63) { read_rep(r1, cur, MR1, EQB1, EQM1); H41 = HB1 = 63; continue; }   // the run reaches the last byte known
+                    if (q + 4 + fwv >= 64) {                                            // the match runs to the end of the window: its length is not known here
+                        vis |= from & ~(~0ull << a);
+                        if (a > 0) { cur = a; endk = a == s_l ? 1 : 0; break; }         // a window starting at its pair sees 58 bytes of it
+                        cur = a; endk = 2; break;
+                    }
+                    const uint32_t b = uint32_t(EQM1 >> q) & 1u;
+                    const int e = q + 4 + fwv;
+                    const uint32_t ll = uint32_t(q - anc) - b;
+                    if (uint32_t(lane) == nsq) { sq_ll = ll; sq_ml = 1 + b + uint32_t(fwv); sq_of = 1; }
+                    nsq++; litsum += ll; ZCNT(1);
+                    vis |= (from & ~(~0ull << q)) | (1ull << q) | (1ull << (e - 2));
+                    anc = s_l = cur = e; pend = true;
+                    continue;
+                }
+                if (lh >= 64) { vis |= from & ~(~0ull << (amax + 2)); cur = amax + 2; endk = 0; break; }
+                const int m = lh, a = m - ((m - s_l) & 1);
+                if (a > amax) { vis |= from & ~(~0ull << (amax + 2)); cur = amax + 2; endk = 0; break; }
+                if ((m_stop >> m) & 1) {
+                    vis |= from & ~(~0ull << a);
+                    cur = a;
+                    if ((m_dirty >> m) & 1) { endk = a == s_l ? 1 : 0; ZCNT(4); }       // a window starting at its pair reads the table
+                    else endk = 2;
+                    break;
+                }
+                const uint32_t cm = rl(c, uint32_t(m)), inf = rl(info, uint32_t(m));
+                const uint32_t bmax = min(uint32_t(m - anc), cm - prefix), bkm = (inf >> 8) & 7;
+                if (bkm == 4 && bmax > 4) { vis |= from & ~(~0ull << a); cur = a; endk = 2; break; }   // the catch-up goes on in memory
+                // the 32 byte-equalities of lane m's candidate (lanes 0..31 read one each)
+                const unsigned long long E = __ballot(lane < 32 && reinterpret_cast<const uint8_t*>(L.ncount)[32 * m + (lane & 31)] == 0);
+                const uint32_t b = min(bkm, bmax);
+                uint32_t fwm = inf & 63;
+                if (fwm == 24) fwm = 24 + count_fwd(s, sp0 + uint32_t(m) + 28, cm + 28, end, lane);   // the match runs past the 28 bytes held
+                const int e = m + 4 + int(fwm);
+                const uint32_t ll = uint32_t(m - anc) - b, off = sp0 + uint32_t(m) - cm;
+                if (uint32_t(lane) == nsq) { sq_ll = ll; sq_ml = 1 + b + fwm; sq_of = off + 3; }
+                nsq++; litsum += ll; ZCNT(2);
+                vis |= (from & ~(~0ull << (m + 1))) | (3ull << (m + 1));
+                if (e < 64) vis |= 1ull << (e - 2);
+                r2 = r1; r1 = off; MR2 = MR1; H42 = H41;
+                anc = s_l = cur = e; pend = true;
+                // the repcode tests behind the match, at the new offset: from the bytes lane m holds
+                EQB1 = ((E >> 4) & 0xFFFFFFFull) << m; EQM1 = EQB1 << 1; MR1 = EQB1 & (EQB1 >> 1) & (EQB1 >> 2) & (EQB1 >> 3);
+                HB1 = min(63, m + 27); H41 = HB1 - 3;
+            }
+            ZPT(13);
+            // all sequences of the window at once (ZSTD_storeSeq), then the table
+            if (uint32_t(lane) < nsq) { S.ll[S.nseq + lane] = sq_ll; S.ml[S.nseq + lane] = sq_ml; S.off[S.nseq + lane] = sq_of; }
+            S.nseq += nsq; S.nlit += litsum;
+            if ((vis >> lane) & 1) atomicMax(&tab[h], pos + 2);
+            anchor = uint32_t(int(sp0) + anc); ip0 = uint32_t(int(sp0) + s_l); sp = sp0 + uint32_t(cur);
+            rep1 = r1; rep2 = r2;
+            owed = (endk == 1 && pend) || endk == 3;
+            gen_tail = endk == 3; gen_search = endk == 2;
+            ZCNT(5 + endk);
+#ifdef Z1_TRACE
+            if (lane == 0) printf("win sp0 %u endk %d cur %d s_l %d anc %d nsq %u hit %llx stop %llx dirty %llx cond %llx vis %llx r1 %u r2 %u\n", sp0, endk, cur, s_l, anc, nsq, m_hit, m_stop, m_dirty, m_cond, vis, r1, r2);
+#endif
+            anchor = U(anchor); ip0 = U(ip0); sp = U(sp); rep1 = U(rep1); rep2 = U(rep2);
+            continue;
+        }
+        gen_search = false;
+        // ---------------------------------------------------------------------------------------------- one search, one sequence
         uint32_t match0 = 0, mlen = 0, off_base = 0, cur0 = 0;
         bool found = false;
-        if (int64_t(ip0) + step0 + 1 >= ilimit) break;
+        if (sp == ip0 && int64_t(ip0) + step0 + 1 >= ilimit) break;
         if (serial) {
             // wave-uniform transcription of the reference loop (debug / cross-check path)
             uint32_t step = step0, next_step = ip0 + 128, ip1 = ip0 + 1, ip2 = ip0 + step, ip3 = ip2 + 1;
@@ -1065,7 +1304,7 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
             found = true;
         } else {
             // ---- batched search: lane j owns pair j = positions (b, b+1) and the repcode test at b+sj
-            uint32_t B = ip0, SJ = step0, V = step0, NS = ip0 + 128, width = 16;
+            uint32_t B = sp, SJ = step0, V = step0, NS = ip0 + 128, width = 16;
             int ev_kind = 0;                                     // 0 none yet, 1 rep, 2 hit at b, 3 hit at b+1, 4 end of block
             uint32_t ev_b = 0, ev_s = 0, ev_v = 0, ev_idx = 0;
             for (;;) {
@@ -1095,7 +1334,7 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
                 const uint32_t h0 = zhash(w0, hlog, mls), h1 = zhash(w1, hlog, mls);
                 uint32_t i0 = 0, i1 = 0; bool shared = false;
                 if (act && inb) {
-                    i0 = tab[h0]; i1 = (h1 == h0) ? b + 2 : tab[h1];
+                    i0 = tld(tab, h0); i1 = (h1 == h0) ? b + 2 : tld(tab, h1);
                     uint32_t* const sc0 = &L.score[h0 & 1023]; uint32_t* const sc1 = &L.score[h1 & 1023];
                     atomicMin(sc0, uint32_t(lane)); atomicMin(sc1, uint32_t(lane));
                     shared = (*sc0 != uint32_t(lane)) || (*sc1 != uint32_t(lane));
@@ -1128,6 +1367,10 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
                 width = min(64u, width * 2);
             }
             if (ev_kind == 4) break;                             // _cleanup
+            ZCNT(3);
+#ifdef Z1_TRACE
+            if (lane == 0) printf("gen sp %u ip0 %u kind %d b %u idx %u\n", sp, ip0, ev_kind, ev_b, ev_idx);
+#endif
             uint32_t room;
             if (ev_kind == 1) {
                 cur0 = ev_b + 2;
@@ -1185,6 +1428,7 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
         store_seq(S, s, anchor, ip0 - anchor, off_base, mlen, lane);
         ip0 += mlen; anchor = ip0;
         after_match(S, tab, P, s, ip0, anchor, cur0, rep1, rep2, end, ilimit, lane);
+        sp = ip0;
     }
     saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;
     rep[0] = rep1 ? rep1 : saved1;
@@ -2079,16 +2323,23 @@ __device__ __forceinline__ bool is_rle(const uint8_t* s, uint32_t n, int lane)
 // kTree: the instance for the binary-tree strategies of level 12 (btlazy2 up to 256 KiB, btopt up to 16 KiB: a file's short last
 // block), compiled into a kernel of its own so that their code does not weigh on the register allocation of the fast /
 // dfast / lazy paths every full block takes (with the tree finder inlined next to it, dfast ran 7 % slower)
-template <bool kTree>
+// kFast: the level-1 kernel's instance (strategy "fast" only: the other match finders are not compiled into it, so its
+// registers are allocated for the dense window alone)
+template <bool kTree, bool kFast>
 __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* work, int level, bool serial, int lane)
 {
-    const Params P = level_params(n, level);
+    Params P = level_params(n, kFast ? 1 : level);
+    if (kFast) P.strat = 1;
     uint32_t* const tab = reinterpret_cast<uint32_t*>(work + kStoreBytes);
     uint32_t* const tab_s = reinterpret_cast<uint32_t*>(work + kStoreBytes + (size_t(4) << 17));      // level 3: short-hash table
     SeqStore S;
     S.ll = reinterpret_cast<uint32_t*>(work); S.ml = S.ll + kSeqCap; S.off = S.ml + kSeqCap;
     S.llc = work + kOffCodes; S.ofc = S.llc + kCodeBytes; S.mlc = S.ofc + kCodeBytes;
     S.lit = work + kOffLit + kLitPad;
+#ifdef Z1_PROF
+    for (int i = 0; i < 15; i++) S.prof[i] = 0;
+    S.prof[15] = __builtin_readcyclecounter();
+#endif
     FseCt* const prevfse = reinterpret_cast<FseCt*>(work + kOffPrev);
     uint8_t* const tmp = work + kOffTmp;
     LazyState Z;
@@ -2162,11 +2413,12 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
             ZPH(t_out);
             if (pos + 2 > Z.ntu + 384) { const uint32_t gap = pos + 2 - Z.ntu - 384; Z.ntu = pos + 2 - min(gap, 192u); }   // ZSTD_buildSeqStore :2890-2896
             uint32_t tail;
-            if constexpr (kTree) tail = P.strat == 7 ? opt_block(L, S, Z, P, ne.rep, Z.chain + (size_t(1) << P.clog), src, pos, pos + len, lane)
+            if constexpr (kFast) tail = fast_block(L, S, tab, P, ne.rep, src, pos, pos + len, n, serial, lane);
+            else if constexpr (kTree) tail = P.strat == 7 ? opt_block(L, S, Z, P, ne.rep, Z.chain + (size_t(1) << P.clog), src, pos, pos + len, lane)
                                                      : lazy_block<true>(L, S, Z, P, ne.rep, src, pos, pos + len, n, lane);
             else if (P.strat >= 4) tail = lazy_block<false>(L, S, Z, P, ne.rep, src, pos, pos + len, n, lane);
-            else tail = P.strat == 2 ? dfast_block(L, S, tab, tab_s, P, ne.rep, src, pos, pos + len, lane)
-                                     : fast_block(L, S, tab, P, ne.rep, src, pos, pos + len, n, serial, lane);
+            else if (P.strat == 2) tail = dfast_block(L, S, tab, tab_s, P, ne.rep, src, pos, pos + len, lane);
+            else return kErrGeneric;                               // level 1 is the other kernel's (zstd_encode_fast_kernel)
             gather_literals(S, src, pos, lane);
             copy_bytes(S.lit + S.nlit, src + pos + len - tail, tail, lane);
             S.nlit += tail;
@@ -2207,7 +2459,12 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
         pos += len; first = false;
     }
     ZPH(t_out);
-    if (lane == 0) { uint64_t* c = reinterpret_cast<uint64_t*>(S.lit + kSub + 64); c[0] = t_mf; c[1] = t_lit; c[2] = t_seq; c[3] = t_out; }
+    if (lane == 0) { uint64_t* c = reinterpret_cast<uint64_t*>(S.lit + kSub + 64); c[0] = t_mf; c[1] = t_lit; c[2] = t_seq; c[3] = t_out;
+#ifdef Z1_PROF
+        for (int i = 0; i < 12; i++) c[4 + i] = S.prof[i < 10 ? i : i];
+        for (int i = 10; i < 15; i++) c[4 + i] = S.prof[i];
+#endif
+    }
     return int(o);
 }
 
@@ -2215,7 +2472,7 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
 // container_mode 1: native/4mc.c:467-489 (capacity n-1; an error stores the block raw)
 __device__ __forceinline__ bool tree_sized(int level, uint32_t n) { return level == 12 && n <= 256 * 1024; }   // clevels.h:66,92,118: btlazy2, btopt
 
-template <bool kTree>
+template <bool kTree, bool kFast>
 __device__ __forceinline__ void zstd_encode_one(ZLds& L, const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks, uint32_t nblocks,
                                                 uint8_t* work_base, int container_mode, int level, int serial)
 {
@@ -2223,12 +2480,14 @@ __device__ __forceinline__ void zstd_encode_one(ZLds& L, const uint8_t* __restri
     if (b >= nblocks) return;
     const int lane = threadIdx.x;
     const fourmc_block blk = blocks[b];
-    const uint32_t n = blk.src_len;
+    // (the descriptor arrives through a vector load: pin what is derived from it to scalar registers, or every length, limit and
+    // loop counter of the block is computed on the vector unit)
+    const uint32_t n = U(blk.src_len);
     if (tree_sized(level, n) != kTree) return;                  // the other kernel's block
-    const uint8_t* src = src_base + blk.src_off;
-    uint8_t* dst = dst_base + blk.dst_off;
-    const uint32_t cap = container_mode ? (n ? n - 1 : 0) : blk.dst_cap;
-    int r = zstd_encode_frame<kTree>(L, src, n, dst, cap, work_base + size_t(b) * (kStoreBytes + table_bytes(level)), level, serial != 0, lane);
+    const uint8_t* src = src_base + U64(blk.src_off);
+    uint8_t* dst = dst_base + U64(blk.dst_off);
+    const uint32_t cap = container_mode ? (n ? n - 1 : 0) : U(blk.dst_cap);
+    int r = zstd_encode_frame<kTree, kFast>(L, src, n, dst, cap, work_base + size_t(b) * (kStoreBytes + table_bytes(level)), level, serial != 0, lane);
     if (container_mode && r <= 0) { copy_bytes(dst, src, n, lane); r = int(n); }
     if (lane == 0) blocks[b].result = r;
 }
@@ -2238,7 +2497,16 @@ void zstd_encode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
                         uint8_t* work_base, int container_mode, int level, int serial)
 {
     __shared__ ZLds L;
-    zstd_encode_one<false>(L, src_base, dst_base, blocks, nblocks, work_base, container_mode, level, serial);
+    zstd_encode_one<false, false>(L, src_base, dst_base, blocks, nblocks, work_base, container_mode, level, serial);
+}
+
+// level 1 (4mz "fast", the configuration the bench quotes)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void zstd_encode_fast_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks, uint32_t nblocks,
+                             uint8_t* work_base, int container_mode, int level, int serial)
+{
+    __shared__ ZLds L;
+    zstd_encode_one<false, true>(L, src_base, dst_base, blocks, nblocks, work_base, container_mode, level, serial);
 }
 
 // level 12, blocks of 256 KiB and less (a file's short last block): binary-tree finder, optimal parser below 16 KiB
@@ -2247,7 +2515,7 @@ void zstd_encode_tree_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
                             uint8_t* work_base, int container_mode, int level, int serial)
 {
     __shared__ ZLds L;
-    zstd_encode_one<true>(L, src_base, dst_base, blocks, nblocks, work_base, container_mode, level, serial);
+    zstd_encode_one<true, false>(L, src_base, dst_base, blocks, nblocks, work_base, container_mode, level, serial);
 }
 
 } // namespace
@@ -2258,7 +2526,7 @@ extern "C" hipError_t fourmc_launch_zstd_encode(const void* d_src, void* d_dst, 
                                                 void* d_work, int container_mode, int level, int serial, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(zstd_encode_kernel, dim3(n), dim3(64), 0, stream,
+    hipLaunchKernelGGL(level == 1 ? zstd_encode_fast_kernel : zstd_encode_kernel, dim3(n), dim3(64), 0, stream,
                        static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n,
                        static_cast<uint8_t*>(d_work), container_mode, level, serial);
     if (level == 12)

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Debug aid for the zstd level-1 match finder: encodes ONE input of <= 128 KiB (one inner block) twice - with the
+wave-uniform transcription of the reference loop (FOURMC_ZSTD_SERIAL=1) and with the product path - and prints the first
+sequences where the two sequence stores differ.    python tools/z1_debug.py text_30k | <size> <class> <seed>"""
+import ctypes as C, importlib, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers
+p = importlib.import_module("4mc_amd"); p.gpu_init(0)
+SEQCAP = 32768 + 64
+
+def seqs(src, serial):
+    os.environ["FOURMC_ZSTD_SERIAL"] = "1" if serial else "0"
+    n = len(src)
+    batch = p.DeviceBatch(p.make_blocks([0], [0], [n], [n + 1024]))
+    out = torch.zeros(n + 2048, dtype=torch.uint8, device="cuda")
+    buf = np.zeros(n + 64, np.uint8); buf[:n] = src
+    p.zstd_compress(torch.from_numpy(buf).cuda(), out, batch, 1)
+    torch.cuda.synchronize()
+    r = int(batch.download()["result"][0])
+    raw = (C.c_uint32 * (3 * SEQCAP))()
+    assert p.lib().fourmc_gpu_debug_read_workspace(raw, 0, 12 * SEQCAP) == 0
+    a = np.frombuffer(raw, np.uint32).reshape(3, SEQCAP).copy()
+    return r, a, out[:max(r, 0)].cpu().numpy()
+
+if sys.argv[1] == "sizes":                                   # the inputs of tests/test_gpu_zstd_enc.py::test_zstd_size_classes_and_tails
+    rng = np.random.default_rng(5)
+    big = helpers.corpus(3 * (4 << 20), first_block=5)
+    sizes = [7, 8, 18, 19, 20, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 16383, 16384, 16385, 65791, 65792,
+             131071, 131072, 131073, 131078, 131079, 131080, 262144, 262145, 262151, 393216 + 3, 524288, 524289, 1500001,
+             2 * 1024 * 1024 + 77, 3 * 1024 * 1024]
+    offs = rng.integers(0, 4 << 20, len(sizes))
+    if len(sys.argv) == 2:
+        for n, o in zip(sizes, offs):
+            if n > 128 * 1024: continue
+            d = big[int(o): int(o) + n].copy()
+            r1, _, o1 = seqs(d, False); wr, w = helpers.orc_zstd_compress(d, 1, n + 1024)
+            print(n, "ok" if r1 == wr and np.array_equal(o1, w) else "MISMATCH %d %d" % (r1, wr))
+        sys.exit(0)
+    i = sizes.index(int(sys.argv[2])); src = big[int(offs[i]): int(offs[i]) + sizes[i]].copy()
+elif len(sys.argv) == 2:
+    src = np.ascontiguousarray(helpers.golden_zstd_inputs()[sys.argv[1]])
+else:
+    n, cls, seed = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    src = helpers.corpus(4 << 20, first_block=cls, seed=seed)[:n].copy()
+assert len(src) <= 128 * 1024
+r0, a0, o0 = seqs(src, True)
+r1, a1, o1 = seqs(src, False)
+want_r, want = helpers.orc_zstd_compress(src, 1, len(src) + 1024)
+print("serial", r0, "product", r1, "oracle", want_r, "serial==oracle", r0 == want_r and np.array_equal(o0, want))
+pos0 = pos1 = 0
+for i in range(SEQCAP):
+    t0, t1 = a0[:, i], a1[:, i]
+    if (t0 != t1).any():
+        print("first difference at sequence", i, "position", pos0)
+        for j in range(max(0, i - 3), i + 4):
+            print(j, "serial ll/ml/of", a0[0, j], a0[1, j] + 3, a0[2, j], "| product", a1[0, j], a1[1, j] + 3, a1[2, j])
+        lo = max(0, pos0 - 16)
+        print("input around:", bytes(src[lo:pos0 + 80]))
+        break
+    pos0 += int(t0[0]) + int(t0[1]) + 3
+    if pos0 >= len(src) - 8: print("no difference in", i + 1, "sequences"); break
