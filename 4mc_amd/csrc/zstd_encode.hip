@@ -819,7 +819,7 @@ __device__ __forceinline__ int build_seq_table(ZLds& L, int which, uint8_t* dst,
 
 struct SeqStore { uint32_t *ll, *ml, *off; uint8_t *llc, *ofc, *mlc; uint8_t* lit; uint32_t nseq, nlit;
 #ifdef Z1_PROF
-    uint64_t prof[16];      // 0..9 event counts, 10..14 cycles per phase, 15 last time stamp
+    uint64_t prof[20];      // 0..10 event counts, 11..15 cycles per phase, 19 last time stamp
 #endif
 };
 
@@ -863,42 +863,98 @@ __device__ __forceinline__ int encode_sequences(ZLds& L, uint8_t* dst, uint32_t 
         o += uint32_t(r);
         if (lane == 0) *head = uint8_t((tll << 6) + (tof << 4) + (tml << 2));
     }
-    {   // ZSTD_encodeSequences_body: last sequence first; 64 sequences per chunk, lane l holds sequence top - l
-        BitW w;
-        if (!w.init(dst + o, cap - o)) return kErrTooSmall;
+    {   // ZSTD_encodeSequences_body (zstd_compress_sequences.c:302-400): last sequence first, 64 sequences per chunk, lane l
+        // holds sequence top - l.  What is serial are the three FSE state chains (a table look-up per sequence and stream):
+        // they run on lanes 0..2 (of, ml, ll - the order their bits are written in), fed from and answering into LDS.
+        // Putting the bits together (state bits, then the extra bits of ll, ml, of), their positions (prefix sum) and
+        // the stream itself (LDS atomic-or staging, as the Huffman streams do) are wave-parallel.
+        if (cap - o <= 8) return kErrTooSmall;                           // BIT_initCStream
+        uint8_t* const out = dst + o; const uint32_t ocap = cap - o;
+        struct SeqStage { uint32_t d[3][64]; int32_t f[3][64]; uint32_t o[3][64]; };                 // 2304 B over the Huffman builder's scratch (idle here)
+        static_assert(sizeof(SeqStage) <= sizeof(L.ncount) + sizeof(L.nparent), "stage fits");
+        SeqStage& st = *reinterpret_cast<SeqStage*>(&L.ncount[0]);
         const FseCt& cll = L.ct[0]; const FseCt& cof = L.ct[1]; const FseCt& cml = L.ct[2];
-        uint32_t sll = 0, sof = 0, sml = 0;
+        const FseCt* const myct = &L.ct[lane == 0 ? 1 : lane == 1 ? 2 : 0];                         // lane 0: of, 1: ml, 2: ll
+        const int me = lane < 3 ? lane : 0;
+        uint32_t sst = 0;                                                // lanes 0..2: the state of their stream
+        uint32_t total = 0, pos = 0, carry = 0, carry_nb = 0;
         bool first = true;
         for (int32_t top = int32_t(nseq) - 1; top >= 0; top -= 64) {
             const int32_t i = top - lane;
             uint32_t cl = 0, co = 0, cm = 0, x0 = 0, x1 = 0, n0 = 0, n1 = 0;
-            uint32_t dl = 0, dof = 0, dm = 0; int32_t fl = 0, fo = 0, fm = 0;
             if (i >= 0) {
                 cl = S.llc[i]; co = S.ofc[i]; cm = S.mlc[i];
                 const uint32_t bl = ll_bits(cl), bm = ml_bits(cm);
                 const uint64_t ext = uint64_t(S.ll[i] & ((1u << bl) - 1)) | (uint64_t(S.ml[i] & ((1u << bm) - 1)) << bl);
                 x0 = uint32_t(ext); n0 = bl + bm;                      // <= 32 bits
                 x1 = S.off[i] & ((1u << co) - 1); n1 = co;              // <= 31 bits
-                dl = cll.dbits[cl]; fl = cll.dfind[cl]; dof = cof.dbits[co]; fo = cof.dfind[co]; dm = cml.dbits[cm]; fm = cml.dfind[cm];
+                st.d[0][lane] = cof.dbits[co]; st.f[0][lane] = cof.dfind[co];
+                st.d[1][lane] = cml.dbits[cm]; st.f[1][lane] = cml.dfind[cm];
+                st.d[2][lane] = cll.dbits[cl]; st.f[2][lane] = cll.dfind[cl];
             }
             const int cnt = top >= 63 ? 64 : top + 1;
-            for (int k = 0; k < cnt; k++) {
-                const uint32_t kl = rl(cl, k), ko = rl(co, k), km = rl(cm, k);
-                if (first) {
-                    sml = fse_first_state(cml, km); sof = fse_first_state(cof, ko); sll = fse_first_state(cll, kl);
-                    first = false;
-                } else {
-                    const uint32_t a = rl(dof, k), b = rl(dm, k), c = rl(dl, k);
-                    uint32_t nb = (sof + a) >> 16; w.put(sof, nb, lane); sof = cof.next[int32_t(sof >> nb) + int32_t(rl(uint32_t(fo), k))];
-                    nb = (sml + b) >> 16; w.put(sml, nb, lane); sml = cml.next[int32_t(sml >> nb) + int32_t(rl(uint32_t(fm), k))];
-                    nb = (sll + c) >> 16; w.put(sll, nb, lane); sll = cll.next[int32_t(sll >> nb) + int32_t(rl(uint32_t(fl), k))];
-                }
-                w.put(rl(x0, k), rl(n0, k), lane);
-                w.put(rl(x1, k), rl(n1, k), lane);
+            int k0 = 0;
+            if (first) {                                                 // FSE_initCState2 with the last sequence's symbols: no bits
+                const uint32_t sym = lane == 0 ? rl(co, 0) : lane == 1 ? rl(cm, 0) : rl(cl, 0);
+                if (lane < 3) { sst = fse_first_state(*myct, sym); st.o[me][0] = 0; }
+                first = false; k0 = 1;
             }
+            if (lane < 3) {
+                uint32_t dn = st.d[me][k0 & 63]; int32_t fn = st.f[me][k0 & 63];
+                for (int k = k0; k < cnt; k++) {
+                    const uint32_t d = dn; const int32_t f = fn;
+                    dn = st.d[me][(k + 1) & 63]; fn = st.f[me][(k + 1) & 63];                        // (next step's, off the state chain)
+                    const uint32_t nb = (sst + d) >> 16;
+                    st.o[me][k] = (sst & ((1u << nb) - 1)) | (nb << 16);
+                    sst = myct->next[int32_t(sst >> nb) + f];
+                }
+            }
+            // this lane's sequence: state bits of, ml, ll; extra bits ll | ml; extra bits of
+            uint64_t v0 = 0, v1 = 0; uint32_t len = 0;
+            if (i >= 0) {
+                const uint32_t o0 = st.o[0][lane], o1 = st.o[1][lane], o2 = st.o[2][lane];
+                const uint32_t b0 = o0 >> 16, b1 = o1 >> 16, b2 = o2 >> 16;
+                const uint32_t nbf = b0 + b1 + b2;                                                   // <= 8 + 9 + 9
+                v0 = uint64_t((o0 & 0xFFFFu) | ((o1 & 0xFFFFu) << b0) | ((o2 & 0xFFFFu) << (b0 + b1))) | (uint64_t(x0) << nbf);
+                const uint32_t p = nbf + n0;                                                         // <= 58
+                v0 |= uint64_t(x1) << p;
+                if (p + n1 > 64) v1 = uint64_t(x1) >> (64 - p);
+                len = p + n1;
+            }
+            const uint32_t incl = scan_add(len);
+            const uint32_t round_bits = rl(incl, 63);
+            const uint32_t off = incl - len + carry_nb;
+            for (int w = lane; w < 200; w += 64) L.stage[w] = (w == 0) ? carry : 0u;
+            if (len) {
+                const uint32_t w0 = off >> 5, sh = off & 31;
+                const uint64_t lo = v0 << sh;
+                const uint64_t mid = (sh ? (v0 >> (64 - sh)) : 0ull) | (v1 << sh);
+                if (uint32_t(lo)) atomicOr(&L.stage[w0], uint32_t(lo));
+                if (uint32_t(lo >> 32)) atomicOr(&L.stage[w0 + 1], uint32_t(lo >> 32));
+                if (uint32_t(mid)) atomicOr(&L.stage[w0 + 2], uint32_t(mid));
+                if (uint32_t(mid >> 32)) atomicOr(&L.stage[w0 + 3], uint32_t(mid >> 32));
+            }
+            const uint32_t bits = carry_nb + round_bits, nbytes = bits >> 3;
+            for (uint32_t wi = lane; 4 * wi < nbytes; wi += 64) {
+                const uint32_t v = L.stage[wi];
+                if (4 * wi + 4 <= nbytes && pos + 4 * wi + 4 <= ocap) st4(out + pos + 4 * wi, v);
+                else for (uint32_t k = 0; k < 4; k++) if (4 * wi + k < nbytes && pos + 4 * wi + k < ocap) out[pos + 4 * wi + k] = uint8_t(v >> (8 * k));
+            }
+            carry_nb = bits & 7;
+            carry = (L.stage[nbytes >> 2] >> (8 * (nbytes & 3))) & ((1u << carry_nb) - 1);
+            pos += nbytes; total += round_bits;
         }
-        w.put(sml, cml.log, lane); w.put(sof, cof.log, lane); w.put(sll, cll.log, lane);
-        const uint32_t bytes = w.close(lane);
+        {   // FSE_flushCState of ml, of, ll, then the end mark (BIT_closeCStream)
+            const uint32_t sof = rl(sst, 0), sml = rl(sst, 1), sll = rl(sst, 2);
+            const uint32_t lm = cml.log, lo = cof.log, lg = cll.log;
+            const uint32_t tb = lm + lo + lg + 1;                                                    // <= 28
+            const uint64_t t = uint64_t((sml & ((1u << lm) - 1)) | ((sof & ((1u << lo) - 1)) << lm) | ((sll & ((1u << lg) - 1)) << (lm + lo)) | (1u << (lm + lo + lg)));
+            const uint64_t v = uint64_t(carry) | (t << carry_nb);
+            const uint32_t nb = carry_nb + tb, nbytes = (nb + 7) >> 3;
+            if (uint32_t(lane) < nbytes && pos + lane < ocap) out[pos + lane] = uint8_t(v >> (8 * lane));
+            total += tb;
+        }
+        const uint32_t bytes = ((total >> 3) + 8 < ocap) ? (total + 7) >> 3 : 0u;
         if (!bytes) return kErrTooSmall;
         o += bytes;
         if (last_count && last_count + bytes < 4) return 0;             // zstd <= 1.3.4 decoder workaround
@@ -992,12 +1048,14 @@ __device__ __forceinline__ Q16 ld16(const uint8_t* p) { const U16B t = *reinterp
 __device__ __forceinline__ uint64_t u64(uint32_t lo, uint32_t hi) { return (uint64_t(hi) << 32) | lo; }
 // hash table read of the "fast" strategy.  The dense window commits its table writes with atomic max (performed in L2),
 // so every read of that table goes to L2 as well (a plain load could hit a stale line of the CU's L1).
+constexpr uint32_t kFwHeld = 40;                                                // bytes behind pos + 4 that a dense-window lane holds of itself and of its candidate
+__device__ __forceinline__ uint64_t rl64(uint64_t v, uint32_t l) { return u64(rl(uint32_t(v), l), rl(uint32_t(v >> 32), l)); }
 __device__ __forceinline__ uint32_t tld(const uint32_t* t, uint32_t h) { return __hip_atomic_load(t + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 #ifdef Z1_PROF   // one-off counters of the dense window (tools/zstd_timing.py reads them behind the phase cycle counters)
 #define ZCNT(i) do { S.prof[i]++; } while (0)
 #define ZADD(i, v) do { S.prof[i] += (v); } while (0)
-#define ZPT(i) do { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); const uint64_t zt_ = __builtin_readcyclecounter(); S.prof[i] += zt_ - S.prof[15]; S.prof[15] = zt_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ZPT(i) do { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); const uint64_t zt_ = __builtin_readcyclecounter(); S.prof[i] += zt_ - S.prof[19]; S.prof[19] = zt_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define ZPT(i) do { } while (0)
 #define ZCNT(i) do { } while (0)
@@ -1080,7 +1138,7 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
         gen_tail = false;
         if (!serial && !gen_search && step0 == 2 && sp - ip0 <= 60 && sp >= max(rep1, rep2) + 4 && sp >= 4 && int64_t(sp) + 200 <= ilimit) {
             // ------------------------------------------------------------------------------------------ dense window
-            ZPT(14);                                                                    // (everything outside the dense window)
+            ZPT(16);                                                                    // (everything outside the dense window)
             const uint32_t sp0 = U(sp);
             ip0 = U(ip0); anchor = U(anchor); rep1 = U(rep1); rep2 = U(rep2);
             const uint32_t pos = sp0 + uint32_t(lane);
@@ -1088,18 +1146,19 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
             uint64_t ra = 0, rb = 0;                                                    // [pos - rep - 4, pos - rep + 4) for both repeat offsets
             if (rep1) ra = ld8(s + pos - rep1 - 4);
             if (rep2) rb = ld8(s + pos - rep2 - 4);
-            ZCNT(0); ZPT(10);
+            ZCNT(0); ZPT(11);
             const uint32_t h = zhash(u64(q0.d1, q0.d2), hlog, mls);
             uint32_t ent = tld(tab, h);
-            if (owed) {                                                                 // the owed refill of sp - 2 comes before every read of this window
+            uint32_t hfill = 0;
+            if (owed) {                                                                 // the owed refill of sp - 2 comes before every read of this window (written with the window's own)
                 const uint32_t lo = __builtin_amdgcn_alignbit(q0.d1, q0.d0, 16), hi = __builtin_amdgcn_alignbit(q0.d2, q0.d1, 16);
-                const uint32_t hf = rl(zhash(u64(lo, hi), hlog, mls), 0);
-                if (lane == 0) atomicMax(&tab[hf], sp0);
-                if (h == hf) ent = sp0;
+                hfill = rl(zhash(u64(lo, hi), hlog, mls), 0);
+                if (h == hfill) ent = sp0;
             }
             // lanes that share a table slot: candidates from a folded scoreboard, then one ballot per group makes it exact.
             // first lane of a slot: clean; second: its only predecessor in the window is `pred`; later ones: dirty.
             bool second = false, dirty = false; uint32_t pred = 0;
+            unsigned long long grp = 0;                                                 // the lanes of this lane's slot, if it shares it
             {
                 uint32_t* const sc = &L.score[h & 1023];
                 atomicMin(sc, uint32_t(lane));
@@ -1114,6 +1173,7 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
                     const unsigned long long g = __ballot(h == rl(h, uint32_t(e)));
                     mp &= ~g;
                     if (g & (g - 1)) {
+                        if (h == rl(h, uint32_t(e))) grp = g;
                         const uint32_t below = __builtin_amdgcn_mbcnt_hi(uint32_t(g >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(g), 0));
                         if (h == rl(h, uint32_t(e)) && below) {
                             const unsigned long long gb = g & ((1ull << lane) - 1);
@@ -1123,27 +1183,26 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
                     }
                 }
             }
-            ZPT(11);
+            ZPT(12);
             const bool valid = ent >= prefix_idx;
             const uint32_t c = ent - 2;
             bool hit = false, slow = false;
-            uint32_t fw = 0, bk = 0;
+            uint32_t fw = 0, bk = 0; uint64_t E = 0;                                    // E: which of the 48 bytes at [pos - 4, pos + 44) equal the candidate's (bit i: byte pos - 4 + i)
             if (valid) {
                 if (c >= 4) {
-                    const Q16 c0 = ld16(s + c - 4), c1 = ld16(s + c + 12);
-                    const Q16 x0 = {q0.d0 ^ c0.d0, q0.d1 ^ c0.d1, q0.d2 ^ c0.d2, q0.d3 ^ c0.d3}, x1 = {q1.d0 ^ c1.d0, q1.d1 ^ c1.d1, q1.d2 ^ c1.d2, q1.d3 ^ c1.d3};
-                    hit = x0.d1 == 0;
-                    bk = x0.d0 ? uint32_t(__builtin_clz(x0.d0) >> 3) : 4u;              // byte 3 (MSB) is position -1
-                    const uint64_t y0 = u64(x0.d2, x0.d3), y1 = u64(x1.d0, x1.d1), y2 = u64(x1.d2, x1.d3);
-                    fw = y0 ? uint32_t(__builtin_ctzll(y0) >> 3) : (y1 ? 8u + uint32_t(__builtin_ctzll(y1) >> 3)
-                                           : (y2 ? 16u + uint32_t(__builtin_ctzll(y2) >> 3) : 24u));
-                    // which of the 32 bytes held equal the candidate's: kept for the walk (a chosen match makes its offset the
-                    // repeat offset, and these bytes answer the repcode tests behind it)
-                    uint4* const xr = reinterpret_cast<uint4*>(L.ncount) + 2 * lane;
-                    xr[0] = make_uint4(x0.d0, x0.d1, x0.d2, x0.d3); xr[1] = make_uint4(x1.d0, x1.d1, x1.d2, x1.d3);
+                    const Q16 c0 = ld16(s + c - 4), c1 = ld16(s + c + 12), c2 = ld16(s + c + 28), q2 = ld16(s + pos + 28);
+                    // zero bytes of the XOR words -> bit 7 of each byte; two words' flags gathered into one byte by a multiply
+                    auto zb = [](uint32_t x) -> uint32_t { return ~((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x)) & 0x80808080u; };
+                    auto two = [&](uint32_t xa, uint32_t xb) -> uint32_t { return ((((zb(xa) >> 7) | (zb(xb) >> 3)) * 0x00204081u) >> 21) & 0xFFu; };
+                    const uint32_t Elo = two(q0.d0 ^ c0.d0, q0.d1 ^ c0.d1) | (two(q0.d2 ^ c0.d2, q0.d3 ^ c0.d3) << 8) | (two(q1.d0 ^ c1.d0, q1.d1 ^ c1.d1) << 16) | (two(q1.d2 ^ c1.d2, q1.d3 ^ c1.d3) << 24);
+                    E = u64(Elo, two(q2.d0 ^ c2.d0, q2.d1 ^ c2.d1) | (two(q2.d2 ^ c2.d2, q2.d3 ^ c2.d3) << 8));
+                    hit = ((Elo >> 4) & 15u) == 15u;
+                    fw = uint32_t(__builtin_ctzll(~(E >> 8)));                          // (bit 40 of the complement is set: at most kFwHeld)
+                    const uint32_t nb = ~Elo & 15u;                                       // bit 3 is position -1
+                    bk = nb ? uint32_t(__builtin_clz(nb)) - 28u : 4u;
                 } else { hit = ld4(s + c) == q0.d1; slow = true; }
             }
-            const uint32_t info = fw | (bk << 8);
+            const uint32_t info = fw | (bk << 8) | (uint32_t(bk == 4 && c - prefix > 4) << 12);   // bit 12: the catch-up may go beyond the 4 bytes held
             const uint32_t wpred = __shfl(q0.d1, int(pred));                            // (every lane takes part: the source lane must be active)
             const bool hitA = second && wpred == q0.d1;
             const unsigned long long m_dirty = __ballot(dirty), m_cond = __ballot(second && (hitA || hit)),
@@ -1166,19 +1225,49 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
                 mr = __ballot(uint32_t(x >> 32) == 0); eqb = __ballot((uint32_t(x >> 32) & 0xFFu) == 0); eqm1 = __ballot((uint32_t(x) >> 24) == 0);
                 ZCNT(9);
             };
+            // Where the walk goes from a chosen hash hit at this lane, if nothing but another plain hash hit follows: the search
+            // behind the match (start e) meets its first event at lane nx, all repcode tests in between (offsets known from E) fail,
+            // and the match at nx needs nothing the lanes do not hold.  64: anything else - the walk's general step decides.
+            uint32_t nxt = 64;
+            {
+                const int e = lane + 4 + int(fw);
+                const unsigned long long sh = e < 64 ? (m_hit | m_stop) >> e : 0ull;
+                const int nx = e + (sh ? __builtin_ctzll(sh) : 64);
+                const int a = nx - ((nx - e) & 1), amax = 60 - ((60 - e) & 1);
+                const uint32_t infn = __shfl(info, nx & 63);                            // (every lane takes part)
+                const bool plain = ((m_hit >> lane) & 1) && fw < kFwHeld && e < 58 && a <= amax && !((m_stop >> (nx & 63)) & 1) && a + 5 - lane <= kFwHeld + 3;
+                if (plain) {
+                    const uint64_t Es = E >> 4, M4 = Es & (Es >> 1) & (Es >> 2) & (Es >> 3);         // bit d: the 4 bytes at pos + d repeat
+                    const uint64_t T = (0x5555555555555555ull << (e + 2 - lane)) & ((2ull << (a + 2 - lane)) - 1); // the tests of that search: e+2, e+4 .. a+2
+                    if (!(M4 & T) && !(((infn >> 12) & 1) && nx - e > 4) && (infn & 63) != kFwHeld) nxt = uint32_t(nx);
+                }
+            }
             // ---- the walk (scalar).  Lanes are window positions; s_l: start of the running search, cur: its next pair,
-            // anc: the anchor (both may lie before the window: negative).
-            ZPT(12);
+            // anc: the anchor (both may lie before the window: negative).  The walk only CHOOSES: which hash-hit lanes (selH) and
+            // which repcode-hit lanes (selR) start a match; lengths, literal runs, sequence numbers and the table writes follow
+            // from the chosen lanes for all lanes at once, behind the walk.
+            // Repeat-offset knowledge comes in two forms: masks over the window (k = 0; MR: the 4 bytes repeat, EQB: the byte
+            // repeats, EQM1: the byte before repeats; H4 / HB: last lane for which MR / EQB is known - 63 when read from memory),
+            // or the 32 byte-equalities E of the hash match at lane m that made the offset (k = 1): masks are built from them
+            // only when a step needs them.
+            ZPT(13);
             int s_l = -int(sp0 - ip0), cur = 0, anc = -int(sp0 - anchor);
+            const int anc0 = anc;
             bool pend = owed;                                                           // the repcode-2 test at lane cur == s_l comes first
-            unsigned long long vis = 0;                                                 // lanes the reference writes into the table
-            uint32_t nsq = 0, litsum = 0, sq_ll = 0, sq_ml = 0, sq_of = 0;              // lane k keeps sequence k of this window
+            unsigned long long selH = 0, selR = 0;
+            uint32_t endv = uint32_t(lane) + 4 + fw, brep = 0;                          // per lane: end of the match starting here; rep lanes: the byte before repeats
             uint32_t r1 = rep1, r2 = rep2;
+            int k1 = 0, k2 = 0, m1 = 0, m2 = 0; uint64_t E1 = 0, E2 = 0;
             int endk;                                                                   // 0: search goes on at cur, 1: fresh search at cur, 2: batched search at cur, 3: repcode-2 loop at cur
+            const unsigned long long m_ev = m_hit | m_stop;
+            // (all of the walk's state is wave-uniform: pinned to scalar registers on every way into the loop head, or the loop runs on the vector unit)
+#define WPIN() do { cur = Ui(cur); s_l = Ui(s_l); anc = Ui(anc); r1 = U(r1); r2 = U(r2); k1 = Ui(k1); k2 = Ui(k2); m1 = Ui(m1); m2 = Ui(m2); E1 = U64(E1); E2 = U64(E2); \
+                    H41 = Ui(H41); HB1 = Ui(HB1); H42 = Ui(H42); pend = Ui(int(pend)) != 0; selH = U64(selH); selR = U64(selR); MR1 = U64(MR1); EQB1 = U64(EQB1); EQM1 = U64(EQM1); MR2 = U64(MR2); } while (0)
+            WPIN();
             for (;;) {
-                cur = Ui(cur); s_l = Ui(s_l); anc = Ui(anc); nsq = U(nsq); litsum = U(litsum); r1 = U(r1); r2 = U(r2);   // (all wave-uniform: keep the walk on the scalar unit)
-                H41 = Ui(H41); HB1 = Ui(HB1); H42 = Ui(H42);
-                vis = U64(vis); MR1 = U64(MR1); EQB1 = U64(EQB1); EQM1 = U64(EQM1); MR2 = U64(MR2);
+                // ---- general step
+                if (k1) { EQB1 = ((E1 >> 4) & ((1ull << (kFwHeld + 4)) - 1)) << m1; EQM1 = EQB1 << 1; MR1 = EQB1 & (EQB1 >> 1) & (EQB1 >> 2) & (EQB1 >> 3); HB1 = min(63, m1 + kFwHeld + 3); H41 = HB1 - 3; k1 = 0; }
+                if (k2) { const unsigned long long q = ((E2 >> 4) & ((1ull << (kFwHeld + 4)) - 1)) << m2; MR2 = q & (q >> 1) & (q >> 2) & (q >> 3); H42 = min(63, m2 + kFwHeld + 3) - 3; k2 = 0; }
                 if (pend) {
                     if (cur >= 62) { endk = 1; break; }
                     if (r2) {
@@ -1192,74 +1281,137 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
                 const unsigned long long from = ~0ull << cur;
                 const unsigned long long pm = (s_l & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
                 const unsigned long long k4 = H41 >= 63 ? ~0ull : (2ull << H41) - 1;    // lanes whose repcode test is known
-                const unsigned long long evh = (m_hit | m_stop) & from, evr = MR1 & pm & (from << 2) & k4, unk = pm & (from << 2) & ~k4;
+                const unsigned long long evh = m_ev & from, evr = MR1 & pm & (from << 2) & k4, unk = pm & (from << 2) & ~k4;
                 const int lh = evh ? __builtin_ctzll(evh) : 64, lr = evr ? __builtin_ctzll(evr) : 999, lu = unk ? __builtin_ctzll(unk) : 999;   // (999: none)
                 if (r1 && lr > lh + 2 && lu <= lh + 2 && lu - 2 <= amax) {              // a repcode test that is not known comes first: read it
                     read_rep(r1, cur, MR1, EQB1, EQM1); H41 = HB1 = 63;
-                    continue;
+                    { WPIN(); continue; }
                 }
-                if (lr <= lh + 2) {                                                     // (lr < 64) the repcode test at lr comes before the hash tests of lr-2, lr-1
+                if (lr <= lh + 2) {                                                     // the repcode test at lr comes before the hash tests of lr-2, lr-1
                     const int q = lr, a = q - 2;
-                    if (a > amax) { vis |= from & ~(~0ull << (amax + 2)); cur = amax + 2; endk = 0; break; }
+                    if (a > amax) { cur = amax + 2; endk = 0; break; }
                     const unsigned long long t = q + 4 < 64 ? ~(EQB1 >> (q + 4)) : 1ull;
                     const int fwv = t ? __builtin_ctzll(t) : 64;
-                    if (q + 4 + fwv > HB1 && HB1 < 63) { read_rep(r1, cur, MR1, EQB1, EQM1); H41 = HB1 = 63; continue; }   // the run reaches the last byte known
+                    if (q + 4 + fwv > HB1 && HB1 < 63) { read_rep(r1, cur, MR1, EQB1, EQM1); H41 = HB1 = 63; { WPIN(); continue; } }   // the run reaches the last byte known
                     if (q + 4 + fwv >= 64) {                                            // the match runs to the end of the window: its length is not known here
-                        vis |= from & ~(~0ull << a);
-                        if (a > 0) { cur = a; endk = a == s_l ? 1 : 0; break; }         // a window starting at its pair sees 58 bytes of it
-                        cur = a; endk = 2; break;
+                        cur = a;
+                        if (a > 0) endk = a == s_l ? 1 : 0;                             // a window starting at its pair sees 58 bytes of it
+                        else endk = 2;
+                        break;
                     }
-                    const uint32_t b = uint32_t(EQM1 >> q) & 1u;
                     const int e = q + 4 + fwv;
-                    const uint32_t ll = uint32_t(q - anc) - b;
-                    if (uint32_t(lane) == nsq) { sq_ll = ll; sq_ml = 1 + b + uint32_t(fwv); sq_of = 1; }
-                    nsq++; litsum += ll; ZCNT(1);
-                    vis |= (from & ~(~0ull << q)) | (1ull << q) | (1ull << (e - 2));
+                    selR |= 1ull << q;
+                    if (lane == q) { endv = uint32_t(e); brep = uint32_t(EQM1 >> q) & 1u; }
+                    ZCNT(1);
                     anc = s_l = cur = e; pend = true;
-                    continue;
+                    { WPIN(); continue; }
                 }
-                if (lh >= 64) { vis |= from & ~(~0ull << (amax + 2)); cur = amax + 2; endk = 0; break; }
+                if (lh >= 64) { cur = amax + 2; endk = 0; break; }
                 const int m = lh, a = m - ((m - s_l) & 1);
-                if (a > amax) { vis |= from & ~(~0ull << (amax + 2)); cur = amax + 2; endk = 0; break; }
+                if (a > amax) { cur = amax + 2; endk = 0; break; }
                 if ((m_stop >> m) & 1) {
-                    vis |= from & ~(~0ull << a);
                     cur = a;
                     if ((m_dirty >> m) & 1) { endk = a == s_l ? 1 : 0; ZCNT(4); }       // a window starting at its pair reads the table
                     else endk = 2;
                     break;
                 }
-                const uint32_t cm = rl(c, uint32_t(m)), inf = rl(info, uint32_t(m));
-                const uint32_t bmax = min(uint32_t(m - anc), cm - prefix), bkm = (inf >> 8) & 7;
-                if (bkm == 4 && bmax > 4) { vis |= from & ~(~0ull << a); cur = a; endk = 2; break; }   // the catch-up goes on in memory
-                // the 32 byte-equalities of lane m's candidate (lanes 0..31 read one each)
-                const unsigned long long E = __ballot(lane < 32 && reinterpret_cast<const uint8_t*>(L.ncount)[32 * m + (lane & 31)] == 0);
-                const uint32_t b = min(bkm, bmax);
+                const uint32_t inf = rl(info, uint32_t(m));
+                if (((inf >> 12) & 1) && m - anc > 4) { cur = a; endk = 2; break; }     // the catch-up goes on in memory
+                const uint32_t cm = rl(c, uint32_t(m));
                 uint32_t fwm = inf & 63;
-                if (fwm == 24) fwm = 24 + count_fwd(s, sp0 + uint32_t(m) + 28, cm + 28, end, lane);   // the match runs past the 28 bytes held
+                if (fwm == kFwHeld) fwm = kFwHeld + count_fwd(s, sp0 + uint32_t(m) + 4 + kFwHeld, cm + 4 + kFwHeld, end, lane);   // the match runs past the bytes held
                 const int e = m + 4 + int(fwm);
-                const uint32_t ll = uint32_t(m - anc) - b, off = sp0 + uint32_t(m) - cm;
-                if (uint32_t(lane) == nsq) { sq_ll = ll; sq_ml = 1 + b + fwm; sq_of = off + 3; }
-                nsq++; litsum += ll; ZCNT(2);
-                vis |= (from & ~(~0ull << (m + 1))) | (3ull << (m + 1));
-                if (e < 64) vis |= 1ull << (e - 2);
-                r2 = r1; r1 = off; MR2 = MR1; H42 = H41;
+                selH |= 1ull << m;
+                if (lane == m) endv = uint32_t(e);
+                ZCNT(2);
+                // repcode-2 test behind this match (offset: the previous repeat offset), as far as it is known here
+                bool bad0 = false;
+                if (r1) {
+                    if (k1) { const int d = e - m1; bad0 = d > int(kFwHeld) || ((E1 >> ((d + 4) & 63)) & 15u) == 15u; }
+                    else bad0 = e > H41 || ((MR1 >> (e & 63)) & 1);
+                }
+                r2 = r1; r1 = sp0 + uint32_t(m) - cm; MR2 = MR1; H42 = H41; k2 = 0;
+                k1 = 1; m1 = m; E1 = rl64(E, uint32_t(m));
                 anc = s_l = cur = e; pend = true;
-                // the repcode tests behind the match, at the new offset: from the bytes lane m holds
-                EQB1 = ((E >> 4) & 0xFFFFFFFull) << m; EQM1 = EQB1 << 1; MR1 = EQB1 & (EQB1 >> 1) & (EQB1 >> 2) & (EQB1 >> 3);
-                HB1 = min(63, m + 27); H41 = HB1 - 3;
+                // ---- the chain of plain hash hits behind it: one readlane per sequence
+                unsigned long long selc = 0;
+                for (int t = m;;) {
+                    t = int(rl(nxt, uint32_t(t)));
+                    if (t >= 64) break;
+                    selc |= 1ull << t;
+                }
+                if (selc) {
+                    // every link took the repcode-2 test behind its predecessor p for granted (offset: that of p's predecessor pp,
+                    // whose bytes know it up to 24 bytes behind pp): check them all at once, cut the chain at the first that fails
+                    const unsigned long long C = selc | (1ull << m);
+                    const unsigned long long lt = (1ull << lane) - 1;
+                    const unsigned long long bl = C & lt;
+                    const int P = bl ? 63 - __builtin_clzll(bl) : 0;
+                    const uint32_t packP = __shfl(uint32_t(P) | (uint32_t(bl != 0) << 8), P);     // my predecessor's predecessor (| it has one << 8)
+                    const int PP = int(packP & 63);
+                    const int eP = int(__shfl(endv, P));
+                    const uint64_t Epp = u64(__shfl(uint32_t(E), PP), __shfl(uint32_t(E >> 32), PP));
+                    const int d = eP - PP;
+                    const bool bad = ((selc >> lane) & 1) && (((packP >> 8) & 1) ? (d > int(kFwHeld) || ((Epp >> ((d + 4) & 63)) & 15u) == 15u) : bad0);
+                    const unsigned long long badm = __ballot(bad);
+                    if (badm) selc &= (1ull << __builtin_ctzll(badm)) - 1;
+                    ZADD(10, uint32_t(__builtin_popcountll(selc)));
+                    if (selc) {
+                        const int Lst = 63 - __builtin_clzll(selc);
+                        const unsigned long long bL = (selc | (1ull << m)) & ((1ull << Lst) - 1);
+                        const int Lp = 63 - __builtin_clzll(bL);                         // (m at least)
+                        selH |= selc;
+                        r2 = sp0 + uint32_t(Lp) - rl(c, uint32_t(Lp)); r1 = sp0 + uint32_t(Lst) - rl(c, uint32_t(Lst));
+                        k2 = 1; m2 = Lp; E2 = rl64(E, uint32_t(Lp)); m1 = Lst; E1 = rl64(E, uint32_t(Lst));
+                        anc = s_l = cur = int(rl(endv, uint32_t(Lst)));
+                    }
+                }
+                { WPIN(); }
             }
-            ZPT(13);
-            // all sequences of the window at once (ZSTD_storeSeq), then the table
-            if (uint32_t(lane) < nsq) { S.ll[S.nseq + lane] = sq_ll; S.ml[S.nseq + lane] = sq_ml; S.off[S.nseq + lane] = sq_of; }
-            S.nseq += nsq; S.nlit += litsum;
-            if ((vis >> lane) & 1) atomicMax(&tab[h], pos + 2);
+            ZPT(14);
+            // ---- behind the walk, all lanes at once: the sequences (ZSTD_storeSeq) and the table writes of the chosen matches
+            {
+                const unsigned long long chosen = selH | selR;
+                const bool isH = (selH >> lane) & 1, isR = (selR >> lane) & 1;
+                const uint32_t nbelow = __builtin_amdgcn_mbcnt_hi(uint32_t(chosen >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(chosen), 0));
+                const unsigned long long below = chosen & ((1ull << lane) - 1);
+                const int P = below ? 63 - __builtin_clzll(below) : 0;
+                const uint32_t endP = __shfl(endv, P), kindP = __shfl(uint32_t(isH), P);
+                const int ancl = below ? int(endP) : anc0;                              // my anchor: the end of the match chosen before me
+                uint32_t ll = 0;
+                if (isH || isR) {
+                    const uint32_t b = isH ? min(bk, min(uint32_t(lane - ancl), c - prefix)) : brep;
+                    ll = uint32_t(lane - ancl) - b;
+                    const uint32_t at = S.nseq + nbelow;
+                    S.ll[at] = ll; S.ml[at] = 1 + b + (endv - uint32_t(lane) - 4); S.off[at] = isH ? pos - c + 3 : 1u;
+                }
+                S.nseq += uint32_t(__builtin_popcountll(chosen));
+                S.nlit += rl(scan_add(ll), 63);
+                // lanes the reference writes into the table: every lane the walk passed as a probe; of a match starting at lane
+                // P and ending at e: P (+1, +2 behind a hash hit) and e - 2
+                const int Pl = (isH || isR) ? lane : P;
+                const bool any = (isH || isR) || below != 0;
+                const int eP = (isH || isR) ? int(endv) : int(endP);
+                const bool hP = (isH || isR) ? isH : kindP != 0;
+                const int d = lane - Pl;
+                const bool visited = lane < cur && (!any || lane >= eP || d == 0 || (hP && d <= 2) || lane == eP - 2);
+                // plain stores; of the lanes of one slot the last one writes (and the owed refill only if no lane has its slot)
+                const unsigned long long vism = __ballot(visited);
+                if (visited && !(grp & vism & ~((2ull << lane) - 1))) tab[h] = pos + 2;
+#ifdef Z1_DOUBLECOMMIT
+                asm volatile("" ::: "memory");
+                if (visited && !(grp & vism & ~((2ull << lane) - 1))) __builtin_nontemporal_store(pos + 2, &tab[h]);
+#endif
+                const unsigned long long fillm = __ballot(visited && h == hfill);
+                if (owed && lane == 0 && !fillm) tab[hfill] = sp0;
+            }
             anchor = uint32_t(int(sp0) + anc); ip0 = uint32_t(int(sp0) + s_l); sp = sp0 + uint32_t(cur);
             rep1 = r1; rep2 = r2;
             owed = (endk == 1 && pend) || endk == 3;
             gen_tail = endk == 3; gen_search = endk == 2;
-            ZCNT(5 + endk);
+            ZCNT(5 + endk); ZPT(15);
 #ifdef Z1_TRACE
-            if (lane == 0) printf("win sp0 %u endk %d cur %d s_l %d anc %d nsq %u hit %llx stop %llx dirty %llx cond %llx vis %llx r1 %u r2 %u\n", sp0, endk, cur, s_l, anc, nsq, m_hit, m_stop, m_dirty, m_cond, vis, r1, r2);
+            if (lane == 0) printf("win sp0 %u endk %d cur %d s_l %d anc %d selH %llx selR %llx hit %llx stop %llx dirty %llx cond %llx r1 %u r2 %u\n", sp0, endk, cur, s_l, anc, selH, selR, m_hit, m_stop, m_dirty, m_cond, r1, r2);
 #endif
             anchor = U(anchor); ip0 = U(ip0); sp = U(sp); rep1 = U(rep1); rep2 = U(rep2);
             continue;
@@ -2337,8 +2489,8 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
     S.llc = work + kOffCodes; S.ofc = S.llc + kCodeBytes; S.mlc = S.ofc + kCodeBytes;
     S.lit = work + kOffLit + kLitPad;
 #ifdef Z1_PROF
-    for (int i = 0; i < 15; i++) S.prof[i] = 0;
-    S.prof[15] = __builtin_readcyclecounter();
+    for (int i = 0; i < 19; i++) S.prof[i] = 0;
+    S.prof[19] = __builtin_readcyclecounter();
 #endif
     FseCt* const prevfse = reinterpret_cast<FseCt*>(work + kOffPrev);
     uint8_t* const tmp = work + kOffTmp;
@@ -2461,8 +2613,7 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
     ZPH(t_out);
     if (lane == 0) { uint64_t* c = reinterpret_cast<uint64_t*>(S.lit + kSub + 64); c[0] = t_mf; c[1] = t_lit; c[2] = t_seq; c[3] = t_out;
 #ifdef Z1_PROF
-        for (int i = 0; i < 12; i++) c[4 + i] = S.prof[i < 10 ? i : i];
-        for (int i = 10; i < 15; i++) c[4 + i] = S.prof[i];
+        for (int i = 0; i < 17; i++) c[4 + i] = S.prof[i];
 #endif
     }
     return int(o);

@@ -32,14 +32,14 @@ def run(src, nb, tag):
     out = torch.empty(nb * B + 64, dtype=torch.uint8, device="cuda")
     ec = counters(ENC_WORK, ENC_CTR, ("match", "literals", "sequences", "frame")) if nb == 1 else ""
     dn = ""
-    if nb == 1 and "zprof" in os.environ.get("FOURMC_LIB", ""):                         # make -C 4mc_amd/csrc zprof: dense-window counters of the level-1 finder
+    if "zprof" in os.environ.get("FOURMC_LIB", ""):                                     # (of block 0 when there are several)                         # make -C 4mc_amd/csrc zprof: dense-window counters of the level-1 finder
         import ctypes as C
-        buf = (C.c_uint64 * 15)()
-        assert p.lib().fourmc_gpu_debug_read_workspace(buf, ENC_CTR + 32, 120) == 0
-        k = ("windows", "rep-seq", "hash-seq", "batched-seq", "dirty-cut", "end:go-on", "end:fresh", "end:batched", "end:rep2-loop", "rep-reads")
+        buf = (C.c_uint64 * 17)()
+        assert p.lib().fourmc_gpu_debug_read_workspace(buf, ENC_CTR + 32, 136) == 0
+        k = ("windows", "rep-seq", "hash-seq", "batched-seq", "dirty-cut", "end:go-on", "end:fresh", "end:batched", "end:rep2-loop", "rep-reads", "fast-steps")
         dn = "             dense: " + " ".join(f"{n} {int(v)}" for n, v in zip(k, buf))
-        ph = [int(v) for v in buf[10:15]]; tot = sum(ph) or 1
-        dn += "\n" + ("             dense cycles: " + " ".join(f"{n} {100 * v / tot:4.1f}%" for n, v in zip(("input", "table+slots", "candidates", "walk", "rest(store,commit,batched)"), ph)) + f"  per window {tot / max(int(buf[0]), 1):.0f} clk")
+        ph = [int(v) for v in buf[11:17]]; tot = sum(ph) or 1
+        dn += "\n" + ("             dense cycles: " + " ".join(f"{n} {100 * v / tot:4.1f}%" for n, v in zip(("input", "table+slots", "candidates", "walk", "store+commit", "outside(batched,entropy)"), ph)) + f"  per window {tot / max(int(buf[0]), 1):.0f} clk")
     td = t(lambda: p.decode_blocks(stage, out, dec, codec=p.CODEC_ZSTD))
     import ctypes as C
     p.lib().fourmc_zstd_dec_counter_offset.restype = C.c_size_t
