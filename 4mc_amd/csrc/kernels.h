@@ -47,4 +47,19 @@ hipError_t fourmc_launch_xxh32(const void* d_base, fourmc_block* d_blocks, uint3
 #ifdef __cplusplus
 }
 #endif
+
+#ifdef __HIPCC__
+// A block descriptor arrives through a vector load.  Everything a wave-per-block kernel derives from it (lengths, limits, loop
+// counters, pointers) is wave-uniform: pin the fields to scalar registers, or those values live in vector registers and the
+// kernel's scalar control flow is computed on the vector unit.
+__device__ __forceinline__ fourmc_block uniform_block(const fourmc_block& v)
+{
+    auto u32 = [](uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); };
+    auto u64 = [&](uint64_t x) { return (uint64_t(u32(uint32_t(x >> 32))) << 32) | u32(uint32_t(x)); };
+    fourmc_block r;
+    r.src_off = u64(v.src_off); r.dst_off = u64(v.dst_off); r.src_len = u32(v.src_len); r.dst_cap = u32(v.dst_cap);
+    r.result = int32_t(u32(uint32_t(v.result))); r.xxh32 = u32(v.xxh32);
+    return r;
+}
+#endif
 #endif

@@ -206,7 +206,7 @@ void lz4_decode_exact_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
     __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
-    const fourmc_block blk = blocks[b];
+    const fourmc_block blk = uniform_block(blocks[b]);
     const uint8_t* src = src_base + blk.src_off;
     uint8_t* dst = dst_base + blk.dst_off;
     int r;
@@ -532,7 +532,7 @@ void lz4_decode_fast_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_b
     __shared__ DSync sy;
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
-    const fourmc_block blk = blocks[b];
+    const fourmc_block blk = uniform_block(blocks[b]);
     if (container_mode && blk.result == FOURMC_BLK_BADSUM) return;
     if (threadIdx.x == 0) {
         sy.produced = 0; sy.total = 0xFFFFFFFFu; sy.failed = 0; sy.end_value = kRetry;
@@ -561,7 +561,7 @@ void lz4_decode_retry_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
     __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
-    const fourmc_block blk = blocks[b];
+    const fourmc_block blk = uniform_block(blocks[b]);
     if (blk.result != kRetry) return;
     int r = lz4_decode_block(src_base + blk.src_off, int(blk.src_len), dst_base + blk.dst_off, int(blk.dst_cap),
                              ring, threadIdx.x);

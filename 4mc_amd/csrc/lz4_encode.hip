@@ -603,7 +603,7 @@ void lz4_encode_fast_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_b
     __shared__ uint32_t score[kScore];
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
-    const fourmc_block blk = blocks[b];
+    const fourmc_block blk = uniform_block(blocks[b]);
     const uint8_t* src = src_base + blk.src_off;
     uint8_t* dst = dst_base + blk.dst_off;
     const int n = int(blk.src_len);

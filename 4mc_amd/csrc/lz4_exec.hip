@@ -517,7 +517,7 @@ void lz4_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fo
     const uint8_t* slot = work + size_t(b) * kSlotBytes;
     const ParHdr* hdr = reinterpret_cast<const ParHdr*>(slot);
     if (hdr->status != kParsed) return;
-    const fourmc_block blk = blocks[b];
+    const fourmc_block blk = uniform_block(blocks[b]);
     Blk B;
     B.src = src_base + blk.src_off; B.dst = dst_base + blk.dst_off;
     B.wdesc = reinterpret_cast<const uint4*>(slot + kWdescOff);

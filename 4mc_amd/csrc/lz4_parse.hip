@@ -179,7 +179,7 @@ void lz4_parse_kernel(const uint8_t* __restrict__ src_base, const uint8_t* dst_b
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const fourmc_block blk = blocks[b];
+    const fourmc_block blk = uniform_block(blocks[b]);
     uint8_t* slot = work + size_t(b) * kSlotBytes;
     ParHdr* hdr = reinterpret_cast<ParHdr*>(slot);
     uint4* wdesc = reinterpret_cast<uint4*>(slot + kWdescOff);

@@ -576,7 +576,7 @@ void lz4hc_encode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base
     if (threadIdx.x == 0) { sync.built = 0; sync.keep = 0; sync.done = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const fourmc_block blk = blocks[b];
+    const fourmc_block blk = uniform_block(blocks[b]);
     const uint8_t* src = src_base + blk.src_off;
     const int n = int(blk.src_len);
     uint8_t* work = work_base + size_t(b) * kWorkBytes;

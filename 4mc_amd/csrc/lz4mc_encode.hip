@@ -158,7 +158,7 @@ void lz4mc_encode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base
 {
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
-    const fourmc_block blk = blocks[b];
+    const fourmc_block blk = uniform_block(blocks[b]);
     const uint8_t* src = src_base + blk.src_off;
     uint8_t* dst = dst_base + blk.dst_off;
     const int n = int(blk.src_len);

@@ -1120,7 +1120,7 @@ void zstd_decode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
     __shared__ ZState zs;
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
-    const fourmc_block blk = blocks[b];
+    const fourmc_block blk = uniform_block(blocks[b]);
     const uint8_t* src = src_base + blk.src_off;
     uint8_t* dst = dst_base + blk.dst_off;
     uint8_t* const work = scratch + size_t(b) * kV2Bytes;

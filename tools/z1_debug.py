@@ -61,3 +61,13 @@ for i in range(SEQCAP):
         break
     pos0 += int(t0[0]) + int(t0[1]) + 3
     if pos0 >= len(src) - 8: print("no difference in", i + 1, "sequences"); break
+
+if os.environ.get("POS"):                                    # both sequence lists around a position
+    P = int(os.environ["POS"])
+    for name, a in (("serial", a0), ("product", a1)):
+        pos = 0
+        for i in range(SEQCAP):
+            ll, ml, of = int(a[0, i]), int(a[1, i]) + 3, int(a[2, i])
+            if pos + ll + ml > P - 80 and pos < P + 40: print(name, i, "at", pos, "ll", ll, "match", pos + ll, "ml", ml, "of", of, "end", pos + ll + ml)
+            pos += ll + ml
+            if pos > P + 40: break
