@@ -1130,6 +1130,8 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
     // 2).  `owed`: a match has just ended at ip0 == sp and the refill of ip0 - 2 and the repcode-2 loop are still to do.
     uint32_t sp = ip0;
     bool owed = false, gen_tail = false, gen_search = false;
+    // the next window's input and repeat-offset bytes, read while this window's sequences and table writes are produced
+    bool pf_ok = false; uint32_t pf_sp = 0; Q16 pf_q0 = {0, 0, 0, 0}, pf_q1 = {0, 0, 0, 0}; uint64_t pf_ra = 0, pf_rb = 0;
     for (;;) {
         if (owed && (gen_tail || serial || step0 != 2 || sp < max(rep1, rep2) + 4 || int64_t(sp) + 200 > ilimit)) {
             after_match(S, tab, P, s, ip0, anchor, 0, rep1, rep2, end, ilimit, lane, false);
@@ -1142,10 +1144,15 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
             const uint32_t sp0 = U(sp);
             ip0 = U(ip0); anchor = U(anchor); rep1 = U(rep1); rep2 = U(rep2);
             const uint32_t pos = sp0 + uint32_t(lane);
-            const Q16 q0 = ld16(s + pos - 4), q1 = ld16(s + pos + 12);                  // [pos - 4, pos + 28)
+            Q16 q0, q1;                                                                 // [pos - 4, pos + 28)
             uint64_t ra = 0, rb = 0;                                                    // [pos - rep - 4, pos - rep + 4) for both repeat offsets
-            if (rep1) ra = ld8(s + pos - rep1 - 4);
-            if (rep2) rb = ld8(s + pos - rep2 - 4);
+            if (pf_ok && pf_sp == sp0) { q0 = pf_q0; q1 = pf_q1; ra = pf_ra; rb = pf_rb; }
+            else {
+                q0 = ld16(s + pos - 4); q1 = ld16(s + pos + 12);
+                if (rep1) ra = ld8(s + pos - rep1 - 4);
+                if (rep2) rb = ld8(s + pos - rep2 - 4);
+            }
+            pf_ok = false;
             ZCNT(0); ZPT(11);
             const uint32_t h = zhash(u64(q0.d1, q0.d2), hlog, mls);
             uint32_t ent = tld(tab, h);
@@ -1369,6 +1376,15 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
                 { WPIN(); }
             }
             ZPT(14);
+            {   // where the next window starts is known: its reads go out now
+                const uint32_t nsp = sp0 + uint32_t(cur), nip = uint32_t(int(sp0) + s_l);
+                if (endk < 2 && nsp - nip <= 60 && nsp >= max(r1, r2) + 4 && int64_t(nsp) + 200 <= ilimit) {
+                    const uint32_t np = nsp + uint32_t(lane);
+                    pf_q0 = ld16(s + np - 4); pf_q1 = ld16(s + np + 12);
+                    pf_ra = r1 ? ld8(s + np - r1 - 4) : 0; pf_rb = r2 ? ld8(s + np - r2 - 4) : 0;
+                    pf_ok = true; pf_sp = nsp;
+                }
+            }
             // ---- behind the walk, all lanes at once: the sequences (ZSTD_storeSeq) and the table writes of the chosen matches
             {
                 const unsigned long long chosen = selH | selR;
@@ -1416,7 +1432,7 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
             anchor = U(anchor); ip0 = U(ip0); sp = U(sp); rep1 = U(rep1); rep2 = U(rep2);
             continue;
         }
-        gen_search = false;
+        gen_search = false; pf_ok = false;
         // ---------------------------------------------------------------------------------------------- one search, one sequence
         uint32_t match0 = 0, mlen = 0, off_base = 0, cur0 = 0;
         bool found = false;
