@@ -38,7 +38,7 @@ constexpr int POS_END = 0x3fffffff;           // the chain ended with a valid la
 constexpr int POS_BAD = 0x40000000;           // the chain ran into something the strict rules reject
 constexpr int POS_UNK = 0x40000001;           // a speculative walk gave up
 constexpr int POS_NONE = 0x40000002;
-constexpr int kSpecCap = 4;                   // length bytes a walk from an arbitrary entry offset follows before it gives up (the real chain never does)
+constexpr int kSpecCap = 0;                   // length bytes a walk from an arbitrary entry offset follows before it gives up (the real chain never does)
 constexpr int kGroup = 1024;                 // rows are grouped by 16 for the two-level chain walk
 
 // rows are padded by one bank so that lanes working on the same column of 64 different rows hit 32 different banks
