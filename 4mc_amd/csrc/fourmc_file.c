@@ -101,12 +101,6 @@ static void open_io(int displayLevel, int overwrite, const char* in_name, const 
     if (!*fout) DIE(3, "Cannot open output file: %s", out_name);
 }
 
-static void engine_or_die(int displayLevel, int rc)
-{
-    if (rc == FOURMC_OK) return;
-    DIE(1, "GPU engine error %d : %s", rc, fourmc_gpu_last_error());
-}
-
 /* ------------------------------------------------------------------------------------------ */
 static int compress_file(int displayLevel, int overwrite, char* in_name, char* out_name, int level,
                          uint32_t magic)
@@ -227,10 +221,10 @@ static unsigned long long decode_stream(int displayLevel, FILE* fin, FILE* fout,
     const unsigned nbatch = batch_blocks();
     unsigned long long filesize = 0;
     uint8_t hdr[12], *in_buf, *out_buf;
-    hbuf hin, hout;
+    hbuf hin[2], hout[2]; fourmc_block* blks[2]; job_t jobs[2];
     fourmc_block* blk;
     size_t n;
-    int done = 0;
+    int done = 0, k, have_prev = 0;
 
     *eof = 0;
     n = fread(hdr, 1, 4, fin);
@@ -244,18 +238,22 @@ static unsigned long long decode_stream(int displayLevel, FILE* fin, FILE* fout,
         case 3: DIE(4, "Wrong header checksum");
         default: break;
     }
-    hin = hbuf_alloc((size_t)nbatch * BLOCKSIZE); hout = hbuf_alloc((size_t)nbatch * BLOCKSIZE);
-    in_buf = (uint8_t*)hin.p; out_buf = (uint8_t*)hout.p;
-    blk     = (fourmc_block*)calloc(nbatch, sizeof *blk);
-    if (!in_buf || !out_buf || !blk) DIE(1, "Allocation error : not enough memory");
+    for (k = 0; k < 2; k++) {
+        hin[k] = hbuf_alloc((size_t)nbatch * BLOCKSIZE); hout[k] = hbuf_alloc((size_t)nbatch * BLOCKSIZE);
+        blks[k] = (fourmc_block*)calloc(nbatch, sizeof *blk);
+        if (!hin[k].p || !hout[k].p || !blks[k]) DIE(1, "Allocation error : not enough memory");
+        memset(&jobs[k], 0, sizeof jobs[k]);
+    }
 
-    while (!done) {
-        /* gather up to nbatch blocks; a framing error found while gathering is raised only after
-         * the blocks before it have been decoded and written, as the serial reference would. */
+    /* batch i is gathered while batch i - 1 is on the GPU; the output of batch i - 1 is written while batch i is.  A framing
+     * error found while gathering is raised only after the blocks before it have been decoded and written, as the serial
+     * reference would; nothing exits while an engine call is still running on the helper thread. */
+    for (k = 0;; k ^= 1) {
         unsigned nb = 0, b;
         size_t in_used = 0;
         int pending_code = 0; const char* pending_msg = NULL;
-        while (nb < nbatch) {
+        in_buf = (uint8_t*)hin[k].p; blk = blks[k];
+        while (!done && nb < nbatch) {
             uint32_t usize, csize, sum;
             if (fread(hdr, 1, 12, fin) != 12) { pending_code = 2; pending_msg = "Read error : cannot read next block size"; break; }
             fourmc_frame_parse_block_header(hdr, &usize, &csize, &sum);
@@ -273,17 +271,37 @@ static unsigned long long decode_stream(int displayLevel, FILE* fin, FILE* fout,
             blk[nb].result = 0;        blk[nb].xxh32 = sum;
             in_used += csize; nb++;
         }
+        if (have_prev) {
+            const int p = k ^ 1;
+            if (job_wait(&jobs[p]) != FOURMC_OK) DIE(1, "GPU engine error %d : %s", jobs[p].rc, jobs[p].err);
+        }
         if (nb) {
-            engine_or_die(displayLevel, fourmc_host_4mc_decode(in_buf, in_used, out_buf, (size_t)nb * BLOCKSIZE, blk, nb, codec));
-            for (b = 0; b < nb; b++) {
-                if (blk[b].result == FOURMC_BLK_BADSUM)  DIE(4, "Error : invalid block checksum detected");
-                if (blk[b].result < 0)                   DIE(4, "Decoding Failed ! Corrupted input detected !");
-                if (fwrite(out_buf + blk[b].dst_off, 1, (size_t)blk[b].result, fout) != (size_t)blk[b].result)
-                    DIE(3, blk[b].src_len == blk[b].dst_cap ? "Write error : cannot write data block" : "Write error : cannot write decoded block\n");
-                filesize += (unsigned long long)blk[b].result;
+            jobs[k].encode = 0; jobs[k].src = in_buf; jobs[k].src_bytes = in_used; jobs[k].dst = hout[k].p; jobs[k].dst_bytes = (size_t)nb * BLOCKSIZE;
+            jobs[k].blk = blk; jobs[k].n = nb; jobs[k].codec = codec; jobs[k].level = 0;
+            job_start(&jobs[k]);
+        }
+        for (;;) {                                            /* the previous batch; then, at the end of the stream, this one too */
+            if (have_prev) {
+                const int p = k ^ 1;
+                const fourmc_block* pb = blks[p];
+                out_buf = (uint8_t*)hout[p].p;
+                for (b = 0; b < jobs[p].n; b++) {
+                    const char* msg = NULL; int code = 4;
+                    if (pb[b].result == FOURMC_BLK_BADSUM)  msg = "Error : invalid block checksum detected";
+                    else if (pb[b].result < 0)              msg = "Decoding Failed ! Corrupted input detected !";
+                    else if (fwrite(out_buf + pb[b].dst_off, 1, (size_t)pb[b].result, fout) != (size_t)pb[b].result)
+                        { code = 3; msg = pb[b].src_len == pb[b].dst_cap ? "Write error : cannot write data block" : "Write error : cannot write decoded block\n"; }
+                    if (msg) { if (nb) job_wait(&jobs[k]); DIE(code, "%s", msg); }
+                    filesize += (unsigned long long)pb[b].result;
+                }
             }
+            have_prev = nb > 0;
+            if (!(done || pending_msg) || !have_prev) break;
+            if (job_wait(&jobs[k]) != FOURMC_OK) DIE(1, "GPU engine error %d : %s", jobs[k].rc, jobs[k].err);
+            k ^= 1; nb = 0;                                   /* write it as "the previous batch", nothing runs meanwhile */
         }
         if (pending_msg) DIE(pending_code, "%s", pending_msg);
+        if (done) break;
     }
     /* footer (native/4mc.c:670-688) */
     {
@@ -312,7 +330,7 @@ static unsigned long long decode_stream(int displayLevel, FILE* fin, FILE* fout,
         (void)r;
         free(foot);
     }
-    hbuf_free(hin); hbuf_free(hout); free(blk);
+    for (k = 0; k < 2; k++) { hbuf_free(hin[k]); hbuf_free(hout[k]); free(blks[k]); }
     return filesize;
 }
 
