@@ -97,8 +97,7 @@ struct ZLds {
     uint32_t rank_last[16];
     uint16_t per_rank[16], val[16];
     uint32_t score[1024];
-    uint32_t stage[200];
-};
+};                                       // 19 984 B: eight blocks per CU (160 KiB of LDS); the bit packers stage their output in `count` (free by then)
 
 // ------------------------------------------------------------------------------------------------ bit writer
 // serial writer (wave-uniform state, lane 0 stores); overflow rule of BIT_CStream_t (bitstream.h:153-240):
@@ -515,6 +514,7 @@ __device__ __forceinline__ uint32_t huf_stream(ZLds& L, const uint32_t* tab, uin
                                                const uint8_t* lit, uint32_t a, uint32_t b, int lane)
 {
     if (cap <= 8) return 0;
+    uint32_t* const stage = L.count;                                // (the histogram has served: every estimate is made before the first stream)
     uint32_t total = 0, pos = 0, carry = 0, carry_nb = 0;
     for (uint32_t hi = b; hi > a; ) {
         const int32_t top = int32_t(hi) - 1 - 8 * lane;
@@ -535,24 +535,24 @@ __device__ __forceinline__ uint32_t huf_stream(ZLds& L, const uint32_t* tab, uin
         const uint32_t incl = scan_add(len);
         const uint32_t round_bits = rl(incl, 63);
         const uint32_t off = incl - len + carry_nb;
-        for (int i = lane; i < 200; i += 64) L.stage[i] = (i == 0) ? carry : 0u;
+        for (int i = lane; i < 200; i += 64) stage[i] = (i == 0) ? carry : 0u;
         if (len) {
             const uint32_t w0 = off >> 5, sh = off & 31;
             const uint64_t lo = v0 << sh;
             const uint64_t mid = (sh ? (v0 >> (64 - sh)) : 0ull) | (v1 << sh);
-            if (uint32_t(lo)) atomicOr(&L.stage[w0], uint32_t(lo));
-            if (uint32_t(lo >> 32)) atomicOr(&L.stage[w0 + 1], uint32_t(lo >> 32));
-            if (uint32_t(mid)) atomicOr(&L.stage[w0 + 2], uint32_t(mid));
-            if (uint32_t(mid >> 32)) atomicOr(&L.stage[w0 + 3], uint32_t(mid >> 32));
+            if (uint32_t(lo)) atomicOr(&stage[w0], uint32_t(lo));
+            if (uint32_t(lo >> 32)) atomicOr(&stage[w0 + 1], uint32_t(lo >> 32));
+            if (uint32_t(mid)) atomicOr(&stage[w0 + 2], uint32_t(mid));
+            if (uint32_t(mid >> 32)) atomicOr(&stage[w0 + 3], uint32_t(mid >> 32));
         }
         const uint32_t bits = carry_nb + round_bits, nbytes = bits >> 3;
         for (uint32_t wi = lane; 4 * wi < nbytes; wi += 64) {
-            const uint32_t v = L.stage[wi];
+            const uint32_t v = stage[wi];
             if (4 * wi + 4 <= nbytes && pos + 4 * wi + 4 <= cap) st4(dst + pos + 4 * wi, v);
             else for (uint32_t k = 0; k < 4; k++) if (4 * wi + k < nbytes && pos + 4 * wi + k < cap) dst[pos + 4 * wi + k] = uint8_t(v >> (8 * k));
         }
         carry_nb = bits & 7;
-        carry = (L.stage[nbytes >> 2] >> (8 * (nbytes & 3))) & ((1u << carry_nb) - 1);
+        carry = (stage[nbytes >> 2] >> (8 * (nbytes & 3))) & ((1u << carry_nb) - 1);
         pos += nbytes; total += round_bits;
         hi = hi - a > 512 ? hi - 512 : a;
     }
@@ -873,6 +873,7 @@ __device__ __forceinline__ int encode_sequences(ZLds& L, uint8_t* dst, uint32_t 
         struct SeqStage { uint32_t d[3][64]; int32_t f[3][64]; uint32_t o[3][64]; };                 // 2304 B over the Huffman builder's scratch (idle here)
         static_assert(sizeof(SeqStage) <= sizeof(L.ncount) + sizeof(L.nparent), "stage fits");
         SeqStage& st = *reinterpret_cast<SeqStage*>(&L.ncount[0]);
+        uint32_t* const stage = L.count;                                 // (the three tables are built: the histogram has served)
         const FseCt& cll = L.ct[0]; const FseCt& cof = L.ct[1]; const FseCt& cml = L.ct[2];
         const FseCt* const myct = &L.ct[lane == 0 ? 1 : lane == 1 ? 2 : 0];                         // lane 0: of, 1: ml, 2: ll
         const int me = lane < 3 ? lane : 0;
@@ -924,24 +925,24 @@ __device__ __forceinline__ int encode_sequences(ZLds& L, uint8_t* dst, uint32_t 
             const uint32_t incl = scan_add(len);
             const uint32_t round_bits = rl(incl, 63);
             const uint32_t off = incl - len + carry_nb;
-            for (int w = lane; w < 200; w += 64) L.stage[w] = (w == 0) ? carry : 0u;
+            for (int w = lane; w < 200; w += 64) stage[w] = (w == 0) ? carry : 0u;
             if (len) {
                 const uint32_t w0 = off >> 5, sh = off & 31;
                 const uint64_t lo = v0 << sh;
                 const uint64_t mid = (sh ? (v0 >> (64 - sh)) : 0ull) | (v1 << sh);
-                if (uint32_t(lo)) atomicOr(&L.stage[w0], uint32_t(lo));
-                if (uint32_t(lo >> 32)) atomicOr(&L.stage[w0 + 1], uint32_t(lo >> 32));
-                if (uint32_t(mid)) atomicOr(&L.stage[w0 + 2], uint32_t(mid));
-                if (uint32_t(mid >> 32)) atomicOr(&L.stage[w0 + 3], uint32_t(mid >> 32));
+                if (uint32_t(lo)) atomicOr(&stage[w0], uint32_t(lo));
+                if (uint32_t(lo >> 32)) atomicOr(&stage[w0 + 1], uint32_t(lo >> 32));
+                if (uint32_t(mid)) atomicOr(&stage[w0 + 2], uint32_t(mid));
+                if (uint32_t(mid >> 32)) atomicOr(&stage[w0 + 3], uint32_t(mid >> 32));
             }
             const uint32_t bits = carry_nb + round_bits, nbytes = bits >> 3;
             for (uint32_t wi = lane; 4 * wi < nbytes; wi += 64) {
-                const uint32_t v = L.stage[wi];
+                const uint32_t v = stage[wi];
                 if (4 * wi + 4 <= nbytes && pos + 4 * wi + 4 <= ocap) st4(out + pos + 4 * wi, v);
                 else for (uint32_t k = 0; k < 4; k++) if (4 * wi + k < nbytes && pos + 4 * wi + k < ocap) out[pos + 4 * wi + k] = uint8_t(v >> (8 * k));
             }
             carry_nb = bits & 7;
-            carry = (L.stage[nbytes >> 2] >> (8 * (nbytes & 3))) & ((1u << carry_nb) - 1);
+            carry = (stage[nbytes >> 2] >> (8 * (nbytes & 3))) & ((1u << carry_nb) - 1);
             pos += nbytes; total += round_bits;
         }
         {   // FSE_flushCState of ml, of, ll, then the end mark (BIT_closeCStream)

@@ -48,5 +48,18 @@ if os.path.exists(o + "summary_par_stats.md"):
                 x["SQ_INSTS_SALU"] / x["SQ_INSTS_VALU"], 4 * x["SQ_ACTIVE_INST_ANY"] / n, x["SQ_INSTS_LDS"], y.get("SQ_LDS_BANK_CONFLICT", 0) / max(y.get("SQ_LDS_IDX_ACTIVE", 1), 1))
     txt += "\n" + open(o + "summary_par_sq.md").read() + "\n" + open(o + "summary_par_sq2.md").read()
     open(f"profiles/{name}_block_parallel_decode.md", "w").write(txt)
+# 4mz Fast: tools/zstd_timing.py at 2048 blocks
+if os.path.exists(o + "summary_z1_stats.md"):
+    za, zb = rows(o + "summary_z1_sq.md"), rows(o + "summary_z1_sq2.md")
+    txt = "# rocprofv3 ... -- python tools/zstd_timing.py   (FOURMC_BENCH_BLOCKS=2048: 4mz Fast encode + decode of 2048 blocks of S-mix; three passes: kernel trace, two SQ groups)\n\n"
+    txt += open(o + "summary_z1_stats.md").read() + "\n"
+    txt += "| kernel | waves' time parked (s_waitcnt) | issuing | issue stalls | VALU busy (of 1024 SIMDs) | SALU : VALU instructions | cycles per issued instruction | LDS instr | VMEM rd / wr instr |\n|---|---|---|---|---|---|---|---|---|\n"
+    for k in za:
+        if not k.startswith("zstd_"): continue
+        x, y = za[k], zb.get(k, {}); wc = x["SQ_WAVE_CYCLES"]; cyc = y.get("GRBM_GUI_ACTIVE", 8) / 8
+        n = x["SQ_INSTS_VALU"] + x["SQ_INSTS_SALU"] + y.get("SQ_INSTS_LDS", 0) + y.get("SQ_INSTS_VMEM_RD", 0) + y.get("SQ_INSTS_VMEM_WR", 0)
+        txt += "| %s | %.0f %% | %.0f %% | %.0f %% | %.0f %% | %.2f | %.1f | %.2e | %.2e / %.2e |\n" % (k, 100 * x["SQ_WAIT_ANY"] / wc, 100 * x["SQ_ACTIVE_INST_ANY"] / wc, 100 * x["SQ_WAIT_INST_ANY"] / wc, 100 * 4 * x["SQ_ACTIVE_INST_VALU"] / (1024 * cyc), x["SQ_INSTS_SALU"] / x["SQ_INSTS_VALU"], 4 * x["SQ_ACTIVE_INST_ANY"] / n, y.get("SQ_INSTS_LDS", 0), y.get("SQ_INSTS_VMEM_RD", 0), y.get("SQ_INSTS_VMEM_WR", 0))
+    txt += "\n" + open(o + "summary_z1_sq.md").read() + "\n" + open(o + "summary_z1_sq2.md").read()
+    open(f"profiles/{name}_4mz_fast.md", "w").write(txt)
 d = json.load(open(o + "bench_stats.json"))
 print(d["value"], d["ms_per_step"], d["kernel_ms"], d["compress_GBps"], d["decompress_GBps"])

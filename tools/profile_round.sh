@@ -24,3 +24,11 @@ for p in par_stats par_sq par_sq2; do
     db=$(find $raw/$p -name "*_results.db" | head -1)
     [ -n "$db" ] && python tools/rocpd_summary.py $db > $out/summary_$p.md
 done
+# 4mz Fast (zstd level 1: zstd_encode_fast_kernel, zstd_decode_kernel): kernel stats and SQ counters of tools/zstd_timing.py at 2048 blocks
+FOURMC_BENCH_BLOCKS=2048 rocprofv3 --kernel-trace --stats -d $raw/z1_stats -o z1_stats -- python tools/zstd_timing.py > $out/z1_stats.log 2>&1
+FOURMC_BENCH_BLOCKS=2048 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU -d $raw/z1_sq -o z1_sq -- python tools/zstd_timing.py > $out/z1_sq.log 2>&1
+FOURMC_BENCH_BLOCKS=2048 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d $raw/z1_sq2 -o z1_sq2 -- python tools/zstd_timing.py > $out/z1_sq2.log 2>&1
+for p in z1_stats z1_sq z1_sq2; do
+    db=$(find $raw/$p -name "*_results.db" | head -1)
+    [ -n "$db" ] && python tools/rocpd_summary.py $db > $out/summary_$p.md
+done
