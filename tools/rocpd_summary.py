@@ -16,7 +16,7 @@ for f in sys.argv[1:]:
     try:
         q = ("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) from counters_collection "
              "group by kernel_name, counter_name")
-        rows = [r for r in cur.execute(q) if "lz4" in r[0] or "xxh32" in r[0] or "pack" in r[0]]
+        rows = [r for r in cur.execute(q) if "lz4" in r[0] or "xxh32" in r[0] or "pack" in r[0] or "zstd" in r[0]]
         if rows:
             print("| kernel | counter | sum over dispatches | dispatches | per dispatch |\n|---|---|---|---|---|")
             for k, c, v, n in rows:
