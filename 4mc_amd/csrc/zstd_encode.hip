@@ -1066,7 +1066,7 @@ __device__ __forceinline__ uint32_t tld(const uint32_t* t, uint32_t h) { return 
 // after a match ending at ip0: table refills and the repcode-2 loop (zstd_fast.c:263-281).  `fill_cur` = false when the
 // refill of current0 + 2 has been made already (dense window: it was one of the window's lanes).
 __device__ __forceinline__ void after_match(SeqStore& S, uint32_t* tab, const Params& P, const uint8_t* s, uint32_t& ip0, uint32_t& anchor,
-                                            uint32_t cur0_idx, uint32_t& rep1, uint32_t& rep2, uint32_t end, int64_t ilimit, int lane, bool fill_cur = true)
+                                            uint32_t cur0_idx, uint32_t& rep1, uint32_t& rep2, uint32_t end, int64_t ilimit, int lane, bool fill_cur = true, bool fill_end = true)
 {
     if (int64_t(ip0) > ilimit) return;
     // the four reads of this step in one round trip, ahead of the table stores
@@ -1074,7 +1074,7 @@ __device__ __forceinline__ void after_match(SeqStore& S, uint32_t* tab, const Pa
     uint32_t r_cur = ld4(s + ip0), r_rep = ld4(s + ip0 - rep2);         // (rep2 == 0 reads ip0 itself: not used then)
     {
         const uint32_t h_a = zhash(w_a, P.hlog, P.mml), h_b = zhash(w_b, P.hlog, P.mml);
-        if (lane == 0) { if (fill_cur) tab[h_a] = cur0_idx + 2; tab[h_b] = ip0; }
+        if (lane == 0) { if (fill_cur) tab[h_a] = cur0_idx + 2; if (fill_end) tab[h_b] = ip0; }
     }
     if (rep2 > 0)
         for (bool first = true; int64_t(ip0) <= ilimit; first = false) {
@@ -1130,15 +1130,16 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
     // Walk state: ip0 is the start of the running search, sp its next pair (sp - ip0 even; sp > ip0 only while the step is still
     // 2).  `owed`: a match has just ended at ip0 == sp and the refill of ip0 - 2 and the repcode-2 loop are still to do.
     uint32_t sp = ip0;
-    bool owed = false, gen_tail = false, gen_search = false;
+    bool owed = false, owed_fill = false, gen_tail = false, gen_search = false;        // owed_fill: the refill of ip0 - 2 is part of what is owed (not behind an immediate repcode-2 match)
     // the next window's input and repeat-offset bytes, read while this window's sequences and table writes are produced
     bool pf_ok = false; uint32_t pf_sp = 0; Q16 pf_q0 = {0, 0, 0, 0}, pf_q1 = {0, 0, 0, 0}; uint64_t pf_ra = 0, pf_rb = 0;
     for (;;) {
         if (owed && (gen_tail || serial || step0 != 2 || sp < max(rep1, rep2) + 4 || int64_t(sp) + 200 > ilimit)) {
-            after_match(S, tab, P, s, ip0, anchor, 0, rep1, rep2, end, ilimit, lane, false);
+            after_match(S, tab, P, s, ip0, anchor, 0, rep1, rep2, end, ilimit, lane, false, owed_fill);
             sp = ip0; owed = false;
         }
         gen_tail = false;
+        if (!owed) owed_fill = false;
         if (!serial && !gen_search && step0 == 2 && sp - ip0 <= 60 && sp >= max(rep1, rep2) + 4 && sp >= 4 && int64_t(sp) + 200 <= ilimit) {
             // ------------------------------------------------------------------------------------------ dense window
             ZPT(16);                                                                    // (everything outside the dense window)
@@ -1158,7 +1159,7 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
             const uint32_t h = zhash(u64(q0.d1, q0.d2), hlog, mls);
             uint32_t ent = tld(tab, h);
             uint32_t hfill = 0;
-            if (owed) {                                                                 // the owed refill of sp - 2 comes before every read of this window (written with the window's own)
+            if (owed_fill) {                                                            // the owed refill of sp - 2 comes before every read of this window (written with the window's own)
                 const uint32_t lo = __builtin_amdgcn_alignbit(q0.d1, q0.d0, 16), hi = __builtin_amdgcn_alignbit(q0.d2, q0.d1, 16);
                 hfill = rl(zhash(u64(lo, hi), hlog, mls), 0);
                 if (h == hfill) ent = sp0;
@@ -1223,10 +1224,10 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
             const uint64_t own = u64(q0.d0, q0.d1);
             // MR: the 4 bytes repeat; EQB: the byte repeats; EQM1: the byte before repeats.  H4 / HB: last lane for which MR / EQB
             // is known (63 when read from memory; a chosen match knows 28 bytes behind its position)
-            unsigned long long MR1 = 0, EQB1 = 0, EQM1 = 0, MR2 = 0;
-            int H41 = 63, HB1 = 63, H42 = 63;
+            unsigned long long MR1 = 0, EQB1 = 0, EQM1 = 0, MR2 = 0, EQB2 = 0, EQM2 = 0;
+            int H41 = 63, HB1 = 63, H42 = 63, HB2 = 63;
             if (rep1) { const uint64_t x = ra ^ own; MR1 = __ballot(uint32_t(x >> 32) == 0); EQB1 = __ballot((uint32_t(x >> 32) & 0xFFu) == 0); EQM1 = __ballot((uint32_t(x) >> 24) == 0); }
-            if (rep2) { const uint64_t x = rb ^ own; MR2 = __ballot(uint32_t(x >> 32) == 0); }
+            if (rep2) { const uint64_t x = rb ^ own; MR2 = __ballot(uint32_t(x >> 32) == 0); EQB2 = __ballot((uint32_t(x >> 32) & 0xFFu) == 0); EQM2 = __ballot((uint32_t(x) >> 24) == 0); }
             auto read_rep = [&](uint32_t off, int lo, unsigned long long& mr, unsigned long long& eqb, unsigned long long& eqm1) {
                 uint64_t x = ~0ull;                                                     // (lanes >= lo lie behind a match at that offset: the read stays inside the input)
                 if (lane >= lo) x = ld8(s + pos - off - 4) ^ own;
@@ -1261,8 +1262,8 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
             ZPT(13);
             int s_l = -int(sp0 - ip0), cur = 0, anc = -int(sp0 - anchor);
             const int anc0 = anc;
-            bool pend = owed;                                                           // the repcode-2 test at lane cur == s_l comes first
-            unsigned long long selH = 0, selR = 0;
+            bool pend = owed, lastI = false;                                            // pend: the repcode-2 test at lane cur == s_l comes first; lastI: the last match was an immediate repcode-2 match
+            unsigned long long selH = 0, selR = 0, selI = 0;                            // chosen: hash hits, repcode hits, immediate repcode-2 matches
             uint32_t endv = uint32_t(lane) + 4 + fw, brep = 0;                          // per lane: end of the match starting here; rep lanes: the byte before repeats
             uint32_t r1 = rep1, r2 = rep2;
             int k1 = 0, k2 = 0, m1 = 0, m2 = 0; uint64_t E1 = 0, E2 = 0;
@@ -1270,17 +1271,32 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
             const unsigned long long m_ev = m_hit | m_stop;
             // (all of the walk's state is wave-uniform: pinned to scalar registers on every way into the loop head, or the loop runs on the vector unit)
 #define WPIN() do { cur = Ui(cur); s_l = Ui(s_l); anc = Ui(anc); r1 = U(r1); r2 = U(r2); k1 = Ui(k1); k2 = Ui(k2); m1 = Ui(m1); m2 = Ui(m2); E1 = U64(E1); E2 = U64(E2); \
-                    H41 = Ui(H41); HB1 = Ui(HB1); H42 = Ui(H42); pend = Ui(int(pend)) != 0; selH = U64(selH); selR = U64(selR); MR1 = U64(MR1); EQB1 = U64(EQB1); EQM1 = U64(EQM1); MR2 = U64(MR2); } while (0)
+                    H41 = Ui(H41); HB1 = Ui(HB1); H42 = Ui(H42); HB2 = Ui(HB2); pend = Ui(int(pend)) != 0; lastI = Ui(int(lastI)) != 0; selH = U64(selH); selR = U64(selR); selI = U64(selI); MR1 = U64(MR1); EQB1 = U64(EQB1); EQM1 = U64(EQM1); MR2 = U64(MR2); EQB2 = U64(EQB2); EQM2 = U64(EQM2); } while (0)
             WPIN();
             for (;;) {
                 // ---- general step
                 if (k1) { EQB1 = ((E1 >> 4) & ((1ull << (kFwHeld + 4)) - 1)) << m1; EQM1 = EQB1 << 1; MR1 = EQB1 & (EQB1 >> 1) & (EQB1 >> 2) & (EQB1 >> 3); HB1 = min(63, m1 + kFwHeld + 3); H41 = HB1 - 3; k1 = 0; }
-                if (k2) { const unsigned long long q = ((E2 >> 4) & ((1ull << (kFwHeld + 4)) - 1)) << m2; MR2 = q & (q >> 1) & (q >> 2) & (q >> 3); H42 = min(63, m2 + kFwHeld + 3) - 3; k2 = 0; }
+                if (k2) { EQB2 = ((E2 >> 4) & ((1ull << (kFwHeld + 4)) - 1)) << m2; EQM2 = EQB2 << 1; MR2 = EQB2 & (EQB2 >> 1) & (EQB2 >> 2) & (EQB2 >> 3); HB2 = min(63, m2 + kFwHeld + 3); H42 = HB2 - 3; k2 = 0; }
                 if (pend) {
                     if (cur >= 62) { endk = 1; break; }
                     if (r2) {
-                        if (cur > H42) { unsigned long long t0, t1; read_rep(r2, cur, MR2, t0, t1); H42 = 63; }
-                        if ((MR2 >> cur) & 1) { endk = 3; break; }
+                        if (cur > H42) { read_rep(r2, cur, MR2, EQB2, EQM2); H42 = HB2 = 63; }
+                        if ((MR2 >> cur) & 1) {                                         // an immediate repcode-2 match (zstd_fast.c:270-281): offsets swap, only its first position enters the table
+                            const int q = cur;
+                            const unsigned long long t = q + 4 < 64 ? ~(EQB2 >> (q + 4)) : 1ull;
+                            const int fwv = t ? __builtin_ctzll(t) : 64;
+                            if (q + 4 + fwv > HB2 && HB2 < 63) { read_rep(r2, cur, MR2, EQB2, EQM2); H42 = HB2 = 63; { WPIN(); continue; } }
+                            if (q + 4 + fwv >= 64) { endk = 3; break; }                 // it runs to the end of the window: the serial loop takes it
+                            const int e = q + 4 + fwv;
+                            selI |= 1ull << q; lastI = true;
+                            if (lane == q) { endv = uint32_t(e); brep = 0; }
+                            ZCNT(1);
+                            { const uint32_t tr = r1; r1 = r2; r2 = tr; }
+                            { unsigned long long tq; tq = MR1; MR1 = MR2; MR2 = tq; tq = EQB1; EQB1 = EQB2; EQB2 = tq; tq = EQM1; EQM1 = EQM2; EQM2 = tq; }
+                            { int ti; ti = H41; H41 = H42; H42 = ti; ti = HB1; HB1 = HB2; HB2 = ti; }
+                            anc = s_l = cur = e;
+                            { WPIN(); continue; }
+                        }
                     }
                     pend = false;
                 }
@@ -1308,7 +1324,7 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
                         break;
                     }
                     const int e = q + 4 + fwv;
-                    selR |= 1ull << q;
+                    selR |= 1ull << q; lastI = false;
                     if (lane == q) { endv = uint32_t(e); brep = uint32_t(EQM1 >> q) & 1u; }
                     ZCNT(1);
                     anc = s_l = cur = e; pend = true;
@@ -1329,7 +1345,7 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
                 uint32_t fwm = inf & 63;
                 if (fwm == kFwHeld) fwm = kFwHeld + count_fwd(s, sp0 + uint32_t(m) + 4 + kFwHeld, cm + 4 + kFwHeld, end, lane);   // the match runs past the bytes held
                 const int e = m + 4 + int(fwm);
-                selH |= 1ull << m;
+                selH |= 1ull << m; lastI = false;
                 if (lane == m) endv = uint32_t(e);
                 ZCNT(2);
                 // repcode-2 test behind this match (offset: the previous repeat offset), as far as it is known here
@@ -1338,7 +1354,7 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
                     if (k1) { const int d = e - m1; bad0 = d > int(kFwHeld) || ((E1 >> ((d + 4) & 63)) & 15u) == 15u; }
                     else bad0 = e > H41 || ((MR1 >> (e & 63)) & 1);
                 }
-                r2 = r1; r1 = sp0 + uint32_t(m) - cm; MR2 = MR1; H42 = H41; k2 = 0;
+                r2 = r1; r1 = sp0 + uint32_t(m) - cm; MR2 = MR1; EQB2 = EQB1; EQM2 = EQM1; H42 = H41; HB2 = HB1; k2 = 0;
                 k1 = 1; m1 = m; E1 = rl64(E, uint32_t(m));
                 anc = s_l = cur = e; pend = true;
                 // ---- the chain of plain hash hits behind it: one readlane per sequence
@@ -1388,15 +1404,16 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
             }
             // ---- behind the walk, all lanes at once: the sequences (ZSTD_storeSeq) and the table writes of the chosen matches
             {
-                const unsigned long long chosen = selH | selR;
-                const bool isH = (selH >> lane) & 1, isR = (selR >> lane) & 1;
+                const unsigned long long chosen = selH | selR | selI;
+                const bool isH = (selH >> lane) & 1, isR = ((selR | selI) >> lane) & 1, isC = isH || isR;
+                const uint32_t kind = isH ? 1u : ((selI >> lane) & 1) ? 2u : 0u;        // 1: hash hit, 0: repcode hit, 2: immediate repcode-2 match
                 const uint32_t nbelow = __builtin_amdgcn_mbcnt_hi(uint32_t(chosen >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(chosen), 0));
                 const unsigned long long below = chosen & ((1ull << lane) - 1);
                 const int P = below ? 63 - __builtin_clzll(below) : 0;
-                const uint32_t endP = __shfl(endv, P), kindP = __shfl(uint32_t(isH), P);
+                const uint32_t endP = __shfl(endv, P), kindP = __shfl(kind, P);
                 const int ancl = below ? int(endP) : anc0;                              // my anchor: the end of the match chosen before me
                 uint32_t ll = 0;
-                if (isH || isR) {
+                if (isC) {
                     const uint32_t b = isH ? min(bk, min(uint32_t(lane - ancl), c - prefix)) : brep;
                     ll = uint32_t(lane - ancl) - b;
                     const uint32_t at = S.nseq + nbelow;
@@ -1405,26 +1422,30 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
                 S.nseq += uint32_t(__builtin_popcountll(chosen));
                 S.nlit += rl(scan_add(ll), 63);
                 // lanes the reference writes into the table: every lane the walk passed as a probe; of a match starting at lane
-                // P and ending at e: P (+1, +2 behind a hash hit) and e - 2
-                const int Pl = (isH || isR) ? lane : P;
-                const bool any = (isH || isR) || below != 0;
-                const int eP = (isH || isR) ? int(endv) : int(endP);
-                const bool hP = (isH || isR) ? isH : kindP != 0;
+                // P and ending at e: P (+1, +2 behind a hash hit) and e - 2 (not behind an immediate repcode-2 match)
+                const int Pl = isC ? lane : P;
+                const bool any = isC || below != 0;
+                const int eP = isC ? int(endv) : int(endP);
+                const uint32_t kP = isC ? kind : kindP;
                 const int d = lane - Pl;
-                const bool visited = lane < cur && (!any || lane >= eP || d == 0 || (hP && d <= 2) || lane == eP - 2);
+                const bool visited = lane < cur && (!any || lane >= eP || d == 0 || (kP == 1 && d <= 2) || (kP != 2 && lane == eP - 2));
                 // plain stores; of the lanes of one slot the last one writes (and the owed refill only if no lane has its slot)
                 const unsigned long long vism = __ballot(visited);
+#ifdef Z1_TRACE
+                { const unsigned long long stm = __ballot(visited && !(grp & vism & ~((2ull << lane) - 1))); if (lane == 0) printf("vis sp0 %u vism %llx storem %llx selI %llx cur %d h46 %u h62 %u ent30 %u\n", sp0, vism, stm, selI, cur, rl(h, 46), rl(h, 62), rl(ent, 30)); }
+#endif
                 if (visited && !(grp & vism & ~((2ull << lane) - 1))) tab[h] = pos + 2;
 #ifdef Z1_DOUBLECOMMIT
                 asm volatile("" ::: "memory");
                 if (visited && !(grp & vism & ~((2ull << lane) - 1))) __builtin_nontemporal_store(pos + 2, &tab[h]);
 #endif
                 const unsigned long long fillm = __ballot(visited && h == hfill);
-                if (owed && lane == 0 && !fillm) tab[hfill] = sp0;
+                if (owed_fill && lane == 0 && !fillm) tab[hfill] = sp0;
             }
             anchor = uint32_t(int(sp0) + anc); ip0 = uint32_t(int(sp0) + s_l); sp = sp0 + uint32_t(cur);
             rep1 = r1; rep2 = r2;
             owed = (endk == 1 && pend) || endk == 3;
+            owed_fill = owed && ((selH | selR | selI) ? !lastI : owed_fill);            // (no match in this window: what was owed on the way in)
             gen_tail = endk == 3; gen_search = endk == 2;
             ZCNT(5 + endk); ZPT(15);
 #ifdef Z1_TRACE

@@ -9,6 +9,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers
 p = importlib.import_module("4mc_amd"); p.gpu_init(0)
 SEQCAP = 32768 + 64
+TABLES = []
 
 def seqs(src, serial):
     os.environ["FOURMC_ZSTD_SERIAL"] = "1" if serial else "0"
@@ -22,9 +23,23 @@ def seqs(src, serial):
     raw = (C.c_uint32 * (3 * SEQCAP))()
     assert p.lib().fourmc_gpu_debug_read_workspace(raw, 0, 12 * SEQCAP) == 0
     a = np.frombuffer(raw, np.uint32).reshape(3, SEQCAP).copy()
+    global TABLES
+    traw = (C.c_uint32 * (1 << 15))()
+    assert p.lib().fourmc_gpu_debug_read_workspace(traw, 629312, 4 << 15) == 0    # zstd_encode.hip: kStoreBytes, the level-1 hash table behind it
+    TABLES.append(np.frombuffer(traw, np.uint32).copy())
     return r, a, out[:max(r, 0)].cpu().numpy()
 
-if sys.argv[1] == "sizes":                                   # the inputs of tests/test_gpu_zstd_enc.py::test_zstd_size_classes_and_tails
+if sys.argv[1] == "edge":                                    # tests/helpers.py: edge_inputs() - lists the mismatching ones, or takes one by name (cut to 128 KiB)
+    ed = helpers.edge_inputs()
+    if len(sys.argv) == 2:
+        for k, d in ed.items():
+            d = np.ascontiguousarray(d)
+            r1, _, o1 = seqs(d, False) if len(d) else (0, None, None)
+            wr, w = helpers.orc_zstd_compress(d, 1, len(d) + 1024)
+            if len(d) and not (r1 == wr and np.array_equal(o1, w)): print(k, len(d), "MISMATCH", r1, wr)
+        sys.exit(0)
+    src = np.ascontiguousarray(ed[sys.argv[2]])[: int(sys.argv[3]) if len(sys.argv) > 3 else 128 * 1024]
+elif sys.argv[1] == "sizes":                                   # the inputs of tests/test_gpu_zstd_enc.py::test_zstd_size_classes_and_tails
     rng = np.random.default_rng(5)
     big = helpers.corpus(3 * (4 << 20), first_block=5)
     sizes = [7, 8, 18, 19, 20, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 16383, 16384, 16385, 65791, 65792,
@@ -71,3 +86,9 @@ if os.environ.get("POS"):                                    # both sequence lis
             if pos + ll + ml > P - 80 and pos < P + 40: print(name, i, "at", pos, "ll", ll, "match", pos + ll, "ml", ml, "of", of, "end", pos + ll + ml)
             pos += ll + ml
             if pos > P + 40: break
+
+if os.environ.get("TABLE"):                                  # hash table at the end of the block: slots that differ (value - 2 = position)
+    t0, t1 = TABLES[-2], TABLES[-1]                          # (serial, product)
+    d = np.nonzero(t0 != t1)[0]
+    print(len(d), "slots differ; lowest positions first:")
+    for i in sorted(d, key=lambda i: min(int(t0[i]), int(t1[i])))[:12]: print("slot", i, "serial pos", int(t0[i]) - 2, "product pos", int(t1[i]) - 2)
