@@ -74,6 +74,56 @@ static void job_start(job_t* j)
 }
 static int job_wait(job_t* j) { if (j->running) { pthread_join(j->th, NULL); j->running = 0; } return j->rc; }
 
+/* The output side of a batch on a thread of its own: the calling thread is already reading the next batch while the one
+ * before this is on the GPU.  Compress: 12-byte block header + payload per block, offsets recorded for the footer;
+ * decompress: the decoded blocks.  An error is kept (code, message) and raised by the caller once nothing else runs. */
+typedef struct {
+    pthread_t th; int running;
+    int compress; FILE* fout; const uint8_t* out_buf; fourmc_block* blk; uint32_t n; int displayLevel;   /* blk: the writer's own copy (the caller reuses its array for the batch it is reading) */
+    unsigned long long *filesize, *outsize; uint64_t** offsets; size_t *noff, *capoff;
+    int code; const char* msg;
+} wjob_t;
+static void* wjob_main(void* arg)
+{
+    wjob_t* w = (wjob_t*)arg;
+    const int displayLevel = w->displayLevel;
+    uint32_t b; uint8_t hdr[12];
+    for (b = 0; b < w->n && !w->msg; b++) {
+        const fourmc_block* pb = w->blk + b;
+        if (w->compress) {
+            const uint32_t usize = pb->src_len, csize = (uint32_t)pb->result;
+            if (*w->noff == *w->capoff) {
+                *w->capoff = *w->capoff ? *w->capoff * 2 : 1024;
+                *w->offsets = (uint64_t*)realloc(*w->offsets, *w->capoff * sizeof **w->offsets);
+                if (!*w->offsets) { w->code = 1; w->msg = "Allocation error : not enough memory"; break; }
+            }
+            (*w->offsets)[(*w->noff)++] = *w->outsize;
+            *w->filesize += usize;
+            PRINT_LEVEL(3, "\rRead : %i MB   ", (int)(*w->filesize >> 20));
+            fourmc_frame_block_header(hdr, usize, csize, pb->xxh32);
+            if (fwrite(hdr, 1, 12, w->fout) != 12) { w->code = 3; w->msg = "Write error : cannot write block header"; break; }
+            if (fwrite(w->out_buf + pb->dst_off, 1, csize, w->fout) != csize)
+                { w->code = 3; w->msg = csize == usize ? "Write error : cannot write block" : "Write error : cannot write compressed block"; break; }
+            *w->outsize += 12ull + csize;
+            PRINT_LEVEL(3, "==> %.2f%%   ", (double)*w->outsize / *w->filesize * 100);
+        } else {
+            if (pb->result == FOURMC_BLK_BADSUM)  { w->code = 4; w->msg = "Error : invalid block checksum detected"; break; }
+            if (pb->result < 0)                   { w->code = 4; w->msg = "Decoding Failed ! Corrupted input detected !"; break; }
+            if (fwrite(w->out_buf + pb->dst_off, 1, (size_t)pb->result, w->fout) != (size_t)pb->result)
+                { w->code = 3; w->msg = pb->src_len == pb->dst_cap ? "Write error : cannot write data block" : "Write error : cannot write decoded block\n"; break; }
+            *w->filesize += (unsigned long long)pb->result;
+        }
+    }
+    return NULL;
+}
+static void wjob_start(wjob_t* w)
+{
+    w->code = 0; w->msg = NULL;
+    if (pthread_create(&w->th, NULL, wjob_main, w) == 0) w->running = 1;
+    else { w->running = 0; wjob_main(w); }
+}
+static void wjob_wait(wjob_t* w) { if (w->running) { pthread_join(w->th, NULL); w->running = 0; } }
+
 /* native/4mc.c:164-209 */
 static void open_io(int displayLevel, int overwrite, const char* in_name, const char* out_name, FILE** fin, FILE** fout)
 {
@@ -108,9 +158,9 @@ static int compress_file(int displayLevel, int overwrite, char* in_name, char* o
     const unsigned nbatch = batch_blocks();
     unsigned long long filesize = 0, outsize = 0;
     uint64_t* offsets = NULL; size_t noff = 0, capoff = 0;
-    uint8_t *in_buf, *out_buf, hdr[12];
+    uint8_t *in_buf, hdr[12];
     fourmc_block* blk;
-    hbuf hin[2], hout[2]; fourmc_block* blks[2]; job_t jobs[2];
+    hbuf hin[2], hout[2]; fourmc_block* blks[2]; job_t jobs[2]; wjob_t wj;
     FILE *fin, *fout;
     int codec, codec_level = 0, k, have_prev = 0;
     clock_t t0 = clock(), t1;
@@ -138,7 +188,13 @@ static int compress_file(int displayLevel, int overwrite, char* in_name, char* o
     if (fwrite(hdr, 1, 12, fout) != 12) DIE(3, "Write error : cannot write header");
     outsize = 12;
 
-    /* batch i is read while batch i - 1 is on the GPU; its results are written while batch i + 1 is */
+    /* batch i is read while batch i - 1 is on the GPU and batch i - 2 is written (three threads, two buffer sets: the output
+     * buffer of batch i is the one batch i - 2 was written from, so its writer is joined before batch i starts) */
+    memset(&wj, 0, sizeof wj);
+    wj.compress = 1; wj.fout = fout; wj.displayLevel = displayLevel;
+    wj.blk = (fourmc_block*)calloc(nbatch, sizeof *wj.blk);
+    if (!wj.blk) DIE(1, "Allocation error : not enough memory");
+    wj.filesize = &filesize; wj.outsize = &outsize; wj.offsets = &offsets; wj.noff = &noff; wj.capoff = &capoff;
     for (k = 0;; k ^= 1) {
         unsigned nb = 0, b;
         in_buf = (uint8_t*)hin[k].p; blk = blks[k];
@@ -155,8 +211,10 @@ static int compress_file(int displayLevel, int overwrite, char* in_name, char* o
         }
         if (have_prev) {                                  /* results of the previous batch */
             const int p = k ^ 1;
-            if (job_wait(&jobs[p]) != FOURMC_OK) DIE(1, "GPU engine error %d : %s", jobs[p].rc, jobs[p].err);
+            if (job_wait(&jobs[p]) != FOURMC_OK) { wjob_wait(&wj); DIE(1, "GPU engine error %d : %s", jobs[p].rc, jobs[p].err); }
         }
+        wjob_wait(&wj);                                   /* the batch before that is on disk */
+        if (wj.msg) DIE(wj.code, "%s", wj.msg);
         if (got > 0) {
             jobs[k].encode = 1; jobs[k].src = in_buf; jobs[k].src_bytes = got; jobs[k].dst = hout[k].p; jobs[k].dst_bytes = (size_t)nb * BLOCKSIZE;
             jobs[k].blk = blk; jobs[k].n = nb; jobs[k].codec = codec; jobs[k].level = codec_level;
@@ -164,28 +222,14 @@ static int compress_file(int displayLevel, int overwrite, char* in_name, char* o
         }
         if (have_prev) {
             const int p = k ^ 1;
-            out_buf = (uint8_t*)hout[p].p; blk = blks[p];
-            for (b = 0; b < jobs[p].n; b++) {
-                const uint32_t usize = blk[b].src_len, csize = (uint32_t)blk[b].result;
-                if (noff == capoff) {
-                    capoff = capoff ? capoff * 2 : 1024;
-                    offsets = (uint64_t*)realloc(offsets, capoff * sizeof *offsets);
-                    if (!offsets) DIE(1, "Allocation error : not enough memory");
-                }
-                offsets[noff++] = outsize;
-                filesize += usize;
-                PRINT_LEVEL(3, "\rRead : %i MB   ", (int)(filesize >> 20));
-                fourmc_frame_block_header(hdr, usize, csize, blk[b].xxh32);
-                if (fwrite(hdr, 1, 12, fout) != 12) DIE(3, "Write error : cannot write block header");
-                if (fwrite(out_buf + blk[b].dst_off, 1, csize, fout) != csize)
-                    DIE(3, csize == usize ? "Write error : cannot write block" : "Write error : cannot write compressed block");
-                outsize += 12ull + csize;
-                PRINT_LEVEL(3, "==> %.2f%%   ", (double)outsize / filesize * 100);
-            }
+            wj.out_buf = (const uint8_t*)hout[p].p; wj.n = jobs[p].n; memcpy(wj.blk, blks[p], (size_t)wj.n * sizeof *wj.blk);
+            wjob_start(&wj);
         }
         have_prev = got > 0;
         if (!have_prev) break;
     }
+    wjob_wait(&wj);
+    if (wj.msg) DIE(wj.code, "%s", wj.msg);
     memset(hdr, 0, 12);                                               /* end of stream mark     */
     if (fwrite(hdr, 1, 12, fout) != 12) DIE(3, "Write error : cannot write end of stream");
     outsize += 12;
@@ -199,6 +243,7 @@ static int compress_file(int displayLevel, int overwrite, char* in_name, char* o
         free(foot);
     }
     for (k = 0; k < 2; k++) { hbuf_free(hin[k]); hbuf_free(hout[k]); free(blks[k]); }
+    free(wj.blk);
     free(offsets);
     fclose(fin); fclose(fout);
 
@@ -220,8 +265,8 @@ static unsigned long long decode_stream(int displayLevel, FILE* fin, FILE* fout,
 {
     const unsigned nbatch = batch_blocks();
     unsigned long long filesize = 0;
-    uint8_t hdr[12], *in_buf, *out_buf;
-    hbuf hin[2], hout[2]; fourmc_block* blks[2]; job_t jobs[2];
+    uint8_t hdr[12], *in_buf;
+    hbuf hin[2], hout[2]; fourmc_block* blks[2]; job_t jobs[2]; wjob_t wj;
     fourmc_block* blk;
     size_t n;
     int done = 0, k, have_prev = 0;
@@ -245,11 +290,15 @@ static unsigned long long decode_stream(int displayLevel, FILE* fin, FILE* fout,
         memset(&jobs[k], 0, sizeof jobs[k]);
     }
 
-    /* batch i is gathered while batch i - 1 is on the GPU; the output of batch i - 1 is written while batch i is.  A framing
-     * error found while gathering is raised only after the blocks before it have been decoded and written, as the serial
-     * reference would; nothing exits while an engine call is still running on the helper thread. */
+    /* batch i is gathered while batch i - 1 is on the GPU and batch i - 2 is written (three threads, two buffer sets).  A
+     * framing error found while gathering is raised only after the blocks before it have been decoded and written, as the
+     * serial reference would; nothing exits while an engine call or a writer is still running. */
+    memset(&wj, 0, sizeof wj);
+    wj.compress = 0; wj.fout = fout; wj.displayLevel = displayLevel; wj.filesize = &filesize;
+    wj.blk = (fourmc_block*)calloc(nbatch, sizeof *wj.blk);
+    if (!wj.blk) DIE(1, "Allocation error : not enough memory");
     for (k = 0;; k ^= 1) {
-        unsigned nb = 0, b;
+        unsigned nb = 0;
         size_t in_used = 0;
         int pending_code = 0; const char* pending_msg = NULL;
         in_buf = (uint8_t*)hin[k].p; blk = blks[k];
@@ -273,35 +322,33 @@ static unsigned long long decode_stream(int displayLevel, FILE* fin, FILE* fout,
         }
         if (have_prev) {
             const int p = k ^ 1;
-            if (job_wait(&jobs[p]) != FOURMC_OK) DIE(1, "GPU engine error %d : %s", jobs[p].rc, jobs[p].err);
+            if (job_wait(&jobs[p]) != FOURMC_OK) { wjob_wait(&wj); DIE(1, "GPU engine error %d : %s", jobs[p].rc, jobs[p].err); }
         }
+        wjob_wait(&wj);                                       /* the batch before that is written (its buffer is this batch's) */
+        if (wj.msg) DIE(wj.code, "%s", wj.msg);
         if (nb) {
             jobs[k].encode = 0; jobs[k].src = in_buf; jobs[k].src_bytes = in_used; jobs[k].dst = hout[k].p; jobs[k].dst_bytes = (size_t)nb * BLOCKSIZE;
             jobs[k].blk = blk; jobs[k].n = nb; jobs[k].codec = codec; jobs[k].level = 0;
             job_start(&jobs[k]);
         }
-        for (;;) {                                            /* the previous batch; then, at the end of the stream, this one too */
-            if (have_prev) {
-                const int p = k ^ 1;
-                const fourmc_block* pb = blks[p];
-                out_buf = (uint8_t*)hout[p].p;
-                for (b = 0; b < jobs[p].n; b++) {
-                    const char* msg = NULL; int code = 4;
-                    if (pb[b].result == FOURMC_BLK_BADSUM)  msg = "Error : invalid block checksum detected";
-                    else if (pb[b].result < 0)              msg = "Decoding Failed ! Corrupted input detected !";
-                    else if (fwrite(out_buf + pb[b].dst_off, 1, (size_t)pb[b].result, fout) != (size_t)pb[b].result)
-                        { code = 3; msg = pb[b].src_len == pb[b].dst_cap ? "Write error : cannot write data block" : "Write error : cannot write decoded block\n"; }
-                    if (msg) { if (nb) job_wait(&jobs[k]); DIE(code, "%s", msg); }
-                    filesize += (unsigned long long)pb[b].result;
-                }
-            }
-            have_prev = nb > 0;
-            if (!(done || pending_msg) || !have_prev) break;
-            if (job_wait(&jobs[k]) != FOURMC_OK) DIE(1, "GPU engine error %d : %s", jobs[k].rc, jobs[k].err);
-            k ^= 1; nb = 0;                                   /* write it as "the previous batch", nothing runs meanwhile */
+        if (have_prev) {
+            const int p = k ^ 1;
+            wj.out_buf = (const uint8_t*)hout[p].p; wj.n = jobs[p].n; memcpy(wj.blk, blks[p], (size_t)wj.n * sizeof *wj.blk);
+            wjob_start(&wj);
         }
-        if (pending_msg) DIE(pending_code, "%s", pending_msg);
-        if (done) break;
+        have_prev = nb > 0;
+        if (done || pending_msg) {                            /* end of the stream: everything in flight, in order */
+            wjob_wait(&wj);
+            if (wj.msg) { if (have_prev) job_wait(&jobs[k]); DIE(wj.code, "%s", wj.msg); }
+            if (have_prev) {
+                if (job_wait(&jobs[k]) != FOURMC_OK) DIE(1, "GPU engine error %d : %s", jobs[k].rc, jobs[k].err);
+                wj.out_buf = (const uint8_t*)hout[k].p; wj.n = jobs[k].n; memcpy(wj.blk, blks[k], (size_t)wj.n * sizeof *wj.blk);
+                wjob_start(&wj); wjob_wait(&wj);
+                if (wj.msg) DIE(wj.code, "%s", wj.msg);
+            }
+            if (pending_msg) DIE(pending_code, "%s", pending_msg);
+            break;
+        }
     }
     /* footer (native/4mc.c:670-688) */
     {
@@ -331,6 +378,7 @@ static unsigned long long decode_stream(int displayLevel, FILE* fin, FILE* fout,
         free(foot);
     }
     for (k = 0; k < 2; k++) { hbuf_free(hin[k]); hbuf_free(hout[k]); free(blks[k]); }
+    free(wj.blk);
     return filesize;
 }
 
