@@ -1410,7 +1410,8 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
                 const uint32_t nbelow = __builtin_amdgcn_mbcnt_hi(uint32_t(chosen >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(chosen), 0));
                 const unsigned long long below = chosen & ((1ull << lane) - 1);
                 const int P = below ? 63 - __builtin_clzll(below) : 0;
-                const uint32_t endP = __shfl(endv, P), kindP = __shfl(kind, P);
+                const bool tail = isC && int64_t(sp0) + int64_t(endv) > ilimit;       // the match ends behind ilimit: no refills follow it (zstd_fast.c:263)
+                const uint32_t endP = __shfl(endv, P), kindP = __shfl(kind | (uint32_t(tail) << 3), P);
                 const int ancl = below ? int(endP) : anc0;                              // my anchor: the end of the match chosen before me
                 uint32_t ll = 0;
                 if (isC) {
@@ -1426,9 +1427,10 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
                 const int Pl = isC ? lane : P;
                 const bool any = isC || below != 0;
                 const int eP = isC ? int(endv) : int(endP);
-                const uint32_t kP = isC ? kind : kindP;
+                const uint32_t kPt = isC ? (kind | (uint32_t(tail) << 3)) : kindP, kP = kPt & 7;
+                const bool fills = !(kPt & 8);                                         // (kind 1: P is a probe, P + 1 the pair's second write, P + 2 the refill of current0 + 2; kind 0: P is that refill)
                 const int d = lane - Pl;
-                const bool visited = lane < cur && (!any || lane >= eP || d == 0 || (kP == 1 && d <= 2) || (kP != 2 && lane == eP - 2));
+                const bool visited = lane < cur && (!any || lane >= eP || (d == 0 && (kP != 0 || fills)) || (kP == 1 && (d == 1 || (d == 2 && fills))) || (kP != 2 && fills && lane == eP - 2));
                 // plain stores; of the lanes of one slot the last one writes (and the owed refill only if no lane has its slot)
                 const unsigned long long vism = __ballot(visited);
 #ifdef Z1_TRACE
@@ -1631,7 +1633,7 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
 // Lane j speculates position j of the current search: long (8-byte) and short hash probes, the repcode test at
 // ip+1 and the "next long" probe at ip1; same first-event / commit / scoreboard-cut rules as fast_block.
 __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* tl, uint32_t* ts, const Params& P, uint32_t rep[3],
-                                                const uint8_t* s, uint32_t start, uint32_t end, int lane)
+                                                const uint8_t* s, uint32_t start, uint32_t end, bool serial, int lane)
 {
     const uint32_t hl_log = P.hlog, hs_log = P.clog, wsize = 1u << P.wlog, mls = P.mml;
     const uint32_t prefix_idx = end > wsize ? end + 2 - wsize : 2;
@@ -1649,9 +1651,243 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
         if (rep2 > max_rep) { saved2 = rep2; rep2 = 0; }
         if (rep1 > max_rep) { saved1 = rep1; rep1 = 0; }
     }
-    for (;;) {                                                   // one search per iteration
-        if (int64_t(ip) + 1 > ilimit) break;
-        uint32_t IP = ip, SJ = 1, NS = ip + 256, width = 16;
+    // Walk state as in fast_block: ip is the start of the running search, sp its next position (the step is 1 while
+    // sp - ip < 192).  `owed`: a match has just ended at ip == sp and its two end refills (long: ip - 2, short: ip - 1) and the
+    // repcode-2 loop are still to do.
+    uint32_t sp = ip;
+    bool owed = false, gen_tail = false, gen_search = false;
+    // refills behind a match that ended at `at` and the repcode-2 loop (zstd_double_fast.c:262-293); the refill of curr + 2 only
+    // when it has not been made (dense window: it is one of the window's lanes)
+    auto after_match = [&](uint32_t cur0, bool fill_cur) {
+        if (int64_t(ip) > ilimit) return;
+        const uint64_t wa = fill_cur ? ld8(s + cur0) : 0, wb = ld8(s + ip - 2), wc = ld8(s + ip - 1);
+        uint32_t r_cur = ld4(s + ip), r_rep = ld4(s + ip - rep2);     // (the reads of this step in one round trip; rep2 == 0: not used)
+        if (lane == 0) {
+            if (fill_cur) { tl[HL(wa)] = cur0 + 2; ts[zhash(wa, hs_log, mls)] = cur0 + 2; }
+            tl[HL(wb)] = ip; ts[zhash(wc, hs_log, mls)] = ip + 1;
+        }
+        for (bool first = true; int64_t(ip) <= ilimit && rep2 > 0; first = false) {
+            if (!first) { r_cur = ld4(s + ip); r_rep = ld4(s + ip - rep2); }
+            if (r_cur != r_rep) break;
+            const uint32_t rlen = count_fwd(s, ip + 4, ip + 4 - rep2, end, lane) + 4;
+            const uint32_t t = rep2; rep2 = rep1; rep1 = t;
+            const uint64_t wi = ld8(s + ip);
+            if (lane == 0) { ts[zhash(wi, hs_log, mls)] = ip + 2; tl[HL(wi)] = ip + 2; }
+            store_seq(S, s, anchor, 0, 1, rlen, lane);
+            ip += rlen; anchor = ip;
+        }
+    };
+    for (;;) {                                                   // one dense window, or one search of the batched path, per iteration
+        if (owed && (gen_tail || serial || sp < max(rep1, rep2) + 4 || int64_t(sp) + 200 > ilimit)) { after_match(0, false); sp = ip; owed = false; }
+        gen_tail = false;
+        if (!serial && !gen_search && sp - ip <= 128 && sp >= max(rep1, rep2) + 4 && sp >= 4 && int64_t(sp) + 200 <= ilimit) {     // (serial: the batched search only - cross-check path)
+            // ------------------------------------------------------------------------------------------ dense window
+            // As in fast_block (see there), for two tables: lane l takes position sp + l and prepares, against both tables as they
+            // stand, its long candidate (8-byte test) and its short one (4-byte test) with 48 bytes of each: byte-equality masks
+            // EL / ES give the tests, the lengths, the catch-up and - for the candidate a chosen match used - the repcode tests
+            // behind it.  The reference examines position p as: repcode at p+1, long at p, short at p (then long at p+1 decides
+            // between p+1 and p).  A scalar walk chooses; sequences and both tables' writes follow from the chosen lanes.
+            const uint32_t sp0 = U(sp);
+            ip = U(ip); anchor = U(anchor); rep1 = U(rep1); rep2 = U(rep2);
+            const uint32_t pos = sp0 + uint32_t(lane);
+            const Q16 q0 = ld16(s + pos - 4), q1 = ld16(s + pos + 12), q2 = ld16(s + pos + 28);          // [pos - 4, pos + 44)
+            uint64_t ra = 0, rb = 0;
+            if (rep1) ra = ld8(s + pos - rep1 - 4);
+            if (rep2) rb = ld8(s + pos - rep2 - 4);
+            const uint64_t w8 = u64(q0.d1, q0.d2);
+            const uint32_t hl = HL(w8), hs = zhash(w8, hs_log, mls);
+            uint32_t entL = tld(tl, hl), entS = tld(ts, hs);
+            uint32_t hfL = 0, hfS = 0;
+            if (owed) {                                          // the owed refills (long: sp - 2, short: sp - 1) come before every read of this window
+                const uint64_t v2 = u64(__builtin_amdgcn_alignbit(q0.d1, q0.d0, 16), __builtin_amdgcn_alignbit(q0.d2, q0.d1, 16));
+                const uint64_t v1 = u64(__builtin_amdgcn_alignbit(q0.d1, q0.d0, 24), __builtin_amdgcn_alignbit(q0.d2, q0.d1, 24));
+                hfL = rl(HL(v2), 0); hfS = rl(zhash(v1, hs_log, mls), 0);
+                if (hl == hfL) entL = sp0;
+                if (hs == hfS) entS = sp0 + 1;
+            }
+            // lanes sharing a slot, per table (folded scoreboard for candidates, one ballot per group makes it exact)
+            bool secL = false, dirL = false, secS = false, dirS = false; uint32_t predL = 0, predS = 0;
+            unsigned long long grpL = 0, grpS = 0;
+            auto groups = [&](uint32_t h, uint32_t* sc, bool& second, bool& dirty, uint32_t& pred, unsigned long long& grp) {
+                atomicMin(sc, uint32_t(lane));
+                const bool poss = *sc != uint32_t(lane);
+                *sc = 0xFFFFFFFFu;
+                unsigned long long mp = __ballot(poss);
+                while (mp) {
+                    const uint32_t he = rl(h, uint32_t(__builtin_ctzll(mp)));
+                    const unsigned long long g = __ballot(h == he);
+                    mp &= ~g;
+                    if (g & (g - 1)) {
+                        if (h == he) grp = g;
+                        const uint32_t below = __builtin_amdgcn_mbcnt_hi(uint32_t(g >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(g), 0));
+                        if (h == he && below) {
+                            const unsigned long long gb = g & ((1ull << lane) - 1);
+                            pred = 63u - uint32_t(__builtin_clzll(gb));
+                            second = below == 1; dirty = below > 1;
+                        }
+                    }
+                }
+            };
+            groups(hl, &L.score[hl & 511], secL, dirL, predL, grpL);
+            groups(hs, &L.score[512 + (hs & 511)], secS, dirS, predS, grpS);
+            // candidates: 48 bytes each, byte-equality masks (bit i: byte pos - 4 + i equals the candidate's)
+            auto zb = [](uint32_t x) -> uint32_t { return ~((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x)) & 0x80808080u; };
+            auto two = [&](uint32_t xa, uint32_t xb) -> uint32_t { return ((((zb(xa) >> 7) | (zb(xb) >> 3)) * 0x00204081u) >> 21) & 0xFFu; };
+            auto emask = [&](uint32_t c) -> uint64_t {
+                const Q16 c0 = ld16(s + c - 4), c1 = ld16(s + c + 12), c2 = ld16(s + c + 28);
+                const uint32_t lo = two(q0.d0 ^ c0.d0, q0.d1 ^ c0.d1) | (two(q0.d2 ^ c0.d2, q0.d3 ^ c0.d3) << 8) | (two(q1.d0 ^ c1.d0, q1.d1 ^ c1.d1) << 16) | (two(q1.d2 ^ c1.d2, q1.d3 ^ c1.d3) << 24);
+                return u64(lo, two(q2.d0 ^ c2.d0, q2.d1 ^ c2.d1) | (two(q2.d2 ^ c2.d2, q2.d3 ^ c2.d3) << 8));
+            };
+            const uint32_t cL = entL - 2, cS = entS - 2;
+            const bool vL = entL > prefix_idx, vS = entS > prefix_idx;
+            uint64_t EL = 0, ES = 0; bool slowL = false, slowS = false;                 // slow: a hit on a candidate too close to the start to be read with its 4 bytes in front
+            if (vL) { if (cL >= 4) EL = emask(cL); else slowL = ld8(s + cL) == w8; }
+            if (vS) { if (cS >= 4) ES = emask(cS); else slowS = ld4(s + cS) == uint32_t(w8); }
+            const bool hitL = ((EL >> 4) & 0xFFu) == 0xFFu, hitS = ((ES >> 4) & 0xFu) == 0xFu;
+            const uint32_t flL = uint32_t(__builtin_ctzll(~(EL >> 4))), flS = uint32_t(__builtin_ctzll(~(ES >> 4)));   // equal bytes from pos on (at most 44)
+            const uint32_t nbL = ~uint32_t(EL) & 15u, nbS = ~uint32_t(ES) & 15u;
+            const uint32_t bkL = nbL ? uint32_t(__builtin_clz(nbL)) - 28u : 4u, bkS = nbS ? uint32_t(__builtin_clz(nbS)) - 28u : 4u;
+            // info: flL | flS << 6 | bkL << 12 | bkS << 15 | (catch-up may go beyond 4: long) << 18 | (short) << 19
+            const uint32_t info = flL | (flS << 6) | (bkL << 12) | (bkS << 15) | (uint32_t(bkL == 4 && cL - prefix > 4) << 18) | (uint32_t(bkS == 4 && cS - prefix > 4) << 19);
+            const uint32_t wpL = __shfl(q0.d1, int(predL)), wpL2 = __shfl(q0.d2, int(predL)), wpS = __shfl(q0.d1, int(predS));   // (every lane takes part)
+            const bool hitAL = secL && wpL == q0.d1 && wpL2 == q0.d2, hitAS = secS && wpS == q0.d1;
+            const unsigned long long m_dirty = __ballot(dirL || dirS),
+                                     m_cond = __ballot((secL && (hitAL || hitL)) || (secS && (hitAS || hitS))),
+                                     m_unL = __ballot(dirL || (secL && (hitAL || hitL)) || slowL),   // the long test of the lane is not known here
+                                     m_Lraw = __ballot(hitL && !secL && !dirL),                      // ... is known and positive
+                                     m_slow = __ballot(slowL || slowS);
+            const unsigned long long m_stop = m_dirty | m_cond | m_slow;
+            const unsigned long long m_L = __ballot(hitL && !secL && !dirL) & ~m_stop, m_S = __ballot(hitS && !secS && !dirS) & ~m_stop & ~m_L;
+            // repcode tests of every position, for both repeat offsets (as in fast_block)
+            const uint64_t own = u64(q0.d0, q0.d1);
+            unsigned long long MR1 = 0, EQB1 = 0, MR2 = 0;
+            int H41 = 63, HB1 = 63, H42 = 63;
+            if (rep1) { const uint64_t x = ra ^ own; MR1 = __ballot(uint32_t(x >> 32) == 0); EQB1 = __ballot((uint32_t(x >> 32) & 0xFFu) == 0); }
+            if (rep2) { const uint64_t x = rb ^ own; MR2 = __ballot(uint32_t(x >> 32) == 0); }
+            auto read_rep = [&](uint32_t off, int lo, unsigned long long& mr, unsigned long long& eqb) {
+                uint64_t x = ~0ull;
+                if (lane >= lo) x = ld8(s + pos - off - 4) ^ own;
+                mr = __ballot(uint32_t(x >> 32) == 0); eqb = __ballot((uint32_t(x >> 32) & 0xFFu) == 0);
+            };
+            // ---- the walk (scalar)
+            int s_l = -int(sp0 - ip), cur = 0, anc = -int(sp0 - anchor);
+            const int anc0 = anc;
+            bool pend = owed;
+            unsigned long long sel = 0;                                                  // lanes where a match starts
+            uint32_t kindv = 0, endv = 0;                                               // per lane: 1 long, 2 short, 3 long at p+1 (found from p), 4 repcode; end of the match
+            uint32_t r1 = rep1, r2 = rep2;
+            int k1 = 0, k2 = 0, m1 = 0, m2 = 0; uint64_t E1 = 0, E2 = 0;
+            int endk;                                                                   // 0: search goes on at cur, 1: fresh search at cur, 2: batched search at cur, 3: repcode-2 loop at cur
+#define DPIN() do { cur = Ui(cur); s_l = Ui(s_l); anc = Ui(anc); r1 = U(r1); r2 = U(r2); k1 = Ui(k1); k2 = Ui(k2); m1 = Ui(m1); m2 = Ui(m2); E1 = U64(E1); E2 = U64(E2); \
+                    H41 = Ui(H41); HB1 = Ui(HB1); H42 = Ui(H42); pend = Ui(int(pend)) != 0; sel = U64(sel); MR1 = U64(MR1); EQB1 = U64(EQB1); MR2 = U64(MR2); } while (0)
+            DPIN();
+            for (;;) {
+                if (k1) { EQB1 = ((E1 >> 4) & ((1ull << (kFwHeld + 4)) - 1)) << m1; MR1 = EQB1 & (EQB1 >> 1) & (EQB1 >> 2) & (EQB1 >> 3); HB1 = min(63, m1 + int(kFwHeld) + 3); H41 = HB1 - 3; k1 = 0; }
+                if (k2) { const unsigned long long q = ((E2 >> 4) & ((1ull << (kFwHeld + 4)) - 1)) << m2; MR2 = q & (q >> 1) & (q >> 2) & (q >> 3); H42 = min(63, m2 + int(kFwHeld) + 3) - 3; k2 = 0; }
+                if (pend) {
+                    if (cur >= 62) { endk = 1; break; }
+                    if (r2) {
+                        if (cur > H42) { unsigned long long t0; read_rep(r2, cur, MR2, t0); H42 = 63; }
+                        if ((MR2 >> cur) & 1) { endk = 3; break; }
+                    }
+                    pend = false;
+                }
+                const int pmax = 61;                                                    // last position examined here: its refills (p + 2) stay inside the window
+                if (cur > pmax) { endk = cur == s_l ? 1 : 0; break; }
+                const unsigned long long from = ~0ull << cur;
+                const unsigned long long k4 = H41 >= 63 ? ~0ull : (2ull << H41) - 1;
+                const unsigned long long evt = (m_L | m_S | m_stop) & from, evr = MR1 & (from << 1) & k4, unk = (from << 1) & ~k4;
+                const int lt = evt ? __builtin_ctzll(evt) : 64, lr = evr ? __builtin_ctzll(evr) : 999, lu = unk ? __builtin_ctzll(unk) : 999;
+                if (r1 && lr > lt + 1 && lu <= lt + 1 && lu - 1 <= pmax) { read_rep(r1, cur, MR1, EQB1); H41 = HB1 = 63; { DPIN(); continue; } }
+                if (lr <= lt + 1) {                                                     // the repcode test at lr = p + 1 comes before the table tests of p
+                    const int q = lr, p = q - 1;
+                    if (p > pmax) { cur = pmax + 1; endk = 0; break; }
+                    const unsigned long long t = q + 4 < 64 ? ~(EQB1 >> (q + 4)) : 1ull;
+                    const int fwv = t ? __builtin_ctzll(t) : 64;
+                    if (q + 4 + fwv > HB1 && HB1 < 63) { read_rep(r1, cur, MR1, EQB1); H41 = HB1 = 63; { DPIN(); continue; } }
+                    if (q + 4 + fwv >= 64) {                                            // runs to the end of the window
+                        cur = p;
+                        if (p > 0) endk = p == s_l ? 1 : 0; else endk = 2;
+                        break;
+                    }
+                    const int e = q + 4 + fwv;
+                    sel |= 1ull << q;
+                    if (lane == q) { kindv = 4; endv = uint32_t(e); }
+                    anc = s_l = cur = e; pend = true;
+                    { DPIN(); continue; }
+                }
+                if (lt >= 64 || lt > pmax) { cur = pmax + 1; endk = 0; break; }
+                const int p = lt;
+                if ((m_stop >> p) & 1) { cur = p; endk = ((m_dirty >> p) & 1) ? (p == s_l ? 1 : 0) : 2; break; }
+                int m, kd;
+                if ((m_L >> p) & 1) { m = p; kd = 1; }
+                else {                                                                  // short hit at p: a long hit at p + 1 is preferred
+                    if ((m_unL >> (p + 1)) & 1) { cur = p; endk = 2; break; }
+                    if ((m_Lraw >> (p + 1)) & 1) { m = p + 1; kd = 3; }
+                    else { m = p; kd = 2; }
+                }
+                const uint32_t inf = rl(info, uint32_t(m));
+                const bool lng = kd != 2;
+                if (((inf >> (lng ? 18 : 19)) & 1) && m - anc > 4) { cur = p; endk = 2; break; }     // the catch-up goes on in memory
+                const uint32_t cm = lng ? rl(cL, uint32_t(m)) : rl(cS, uint32_t(m));
+                uint32_t fl = lng ? inf & 63 : (inf >> 6) & 63;
+                if (fl == kFwHeld + 4) fl += count_fwd(s, sp0 + uint32_t(m) + fl, cm + fl, end, lane);
+                const int e = m + int(fl);
+                sel |= 1ull << m;
+                if (lane == m) { kindv = uint32_t(kd); endv = uint32_t(e); }
+                r2 = r1; r1 = sp0 + uint32_t(m) - cm; MR2 = MR1; H42 = H41; k2 = 0;
+                k1 = 1; m1 = m; E1 = lng ? rl64(EL, uint32_t(m)) : rl64(ES, uint32_t(m));
+                anc = s_l = cur = e; pend = true;
+                { DPIN(); }
+            }
+            // ---- behind the walk: sequences and the writes of both tables, all lanes at once
+            {
+                const bool isC = (sel >> lane) & 1;
+                const uint32_t nbelow = __builtin_amdgcn_mbcnt_hi(uint32_t(sel >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(sel), 0));
+                const unsigned long long below = sel & ((1ull << lane) - 1);
+                const int P = below ? 63 - __builtin_clzll(below) : 0;
+                const bool tail = isC && int64_t(sp0) + int64_t(endv) > ilimit;       // the match ends behind ilimit: no refills follow it (zstd_double_fast.c:262)
+                const uint32_t endP = __shfl(endv, P), kindP = __shfl(kindv | (uint32_t(tail) << 3), P);
+                const int ancl = below ? int(endP) : anc0;
+                uint32_t ll = 0;
+                if (isC) {
+                    const bool lng = kindv == 1 || kindv == 3;
+                    const uint32_t cand = lng ? cL : cS;
+                    const uint32_t b = kindv == 4 ? 0u : min(lng ? bkL : bkS, min(uint32_t(lane - ancl), cand - prefix));
+                    ll = uint32_t(lane - ancl) - b;
+                    const uint32_t at = S.nseq + nbelow;
+                    S.ll[at] = ll; S.ml[at] = (endv - uint32_t(lane)) + b - 3; S.off[at] = kindv == 4 ? 1u : pos - cand + 3;
+                }
+                S.nseq += uint32_t(__builtin_popcountll(sel));
+                S.nlit += rl(scan_add(ll), 63);
+                // table writes (zstd_double_fast.c:140,227-229,262-270): every position examined enters both tables; of a match
+                // starting at lane P (kind K) and ending at e: long P+1 (the hl1 write; K = 3: P itself) and curr+2, e-2; short curr+2, e-1
+                const int Pl = isC ? lane : P;
+                const bool any = isC || below != 0;
+                const int eP = isC ? int(endv) : int(endP);
+                const uint32_t kPt = isC ? (kindv | (uint32_t(tail) << 3)) : kindP, kP = kPt & 7;
+                const bool fills = !(kPt & 8);
+                const int d = lane - Pl;
+                const bool probe = !any || lane >= eP;
+                const bool inL = (kP <= 2 && (d <= 1 || (d == 2 && fills))) || (kP == 3 && (d == 0 || (d == 1 && fills))) || (kP == 4 && d == 1 && fills) || (fills && lane == eP - 2);
+                const bool inS = (kP <= 2 && (d == 0 || (d == 2 && fills))) || (kP >= 3 && d == 1 && fills) || (fills && lane == eP - 1);
+                const bool visL = lane < cur && (probe || inL), visS = lane < cur && (probe || inS);
+                const unsigned long long vmL = __ballot(visL), vmS = __ballot(visS);
+                if (visL && !(grpL & vmL & ~((2ull << lane) - 1))) tl[hl] = pos + 2;
+                if (visS && !(grpS & vmS & ~((2ull << lane) - 1))) ts[hs] = pos + 2;
+                const unsigned long long fmL = __ballot(visL && hl == hfL), fmS = __ballot(visS && hs == hfS);
+                if (owed && lane == 0) { if (!fmL) tl[hfL] = sp0; if (!fmS) ts[hfS] = sp0 + 1; }
+            }
+            anchor = uint32_t(int(sp0) + anc); ip = uint32_t(int(sp0) + s_l); sp = sp0 + uint32_t(cur);
+            rep1 = r1; rep2 = r2;
+            owed = (endk == 1 && pend) || endk == 3;
+            gen_tail = endk == 3; gen_search = endk == 2;
+            anchor = U(anchor); ip = U(ip); sp = U(sp); rep1 = U(rep1); rep2 = U(rep2);
+            continue;
+        }
+        gen_search = false;
+        if (sp == ip && int64_t(ip) + 1 > ilimit) break;
+        uint32_t IP = sp, SJ = 1, NS = ip + 256, width = 16;
         int ev_kind = 0;                                         // 1 rep at ip+1, 2 long at ip, 3 long at ip1, 4 short at ip, 5 end of block
         uint32_t ev_ip = 0, ev_s = 0, ev_idx = 0, ev_hl1 = 0;
         for (;;) {
@@ -1675,7 +1911,7 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
             const uint32_t cur = p + 2;
             uint32_t il0 = 0, il1 = 0, is0 = 0; bool shared = false;
             if (act && inb) {
-                il0 = tl[hl0]; is0 = ts[hs0]; il1 = (hl1 == hl0) ? cur : tl[hl1];
+                il0 = tld(tl, hl0); is0 = tld(ts, hs0); il1 = (hl1 == hl0) ? cur : tld(tl, hl1);
                 uint32_t* const a = &L.score[hl0 & 511]; uint32_t* const b = &L.score[512 + (hs0 & 511)];
                 atomicMin(a, uint32_t(lane)); atomicMin(b, uint32_t(lane));
                 shared = (*a != uint32_t(lane)) || (*b != uint32_t(lane)) || (L.score[hl1 & 511] < uint32_t(lane));
@@ -1755,24 +1991,8 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
         }
         store_seq(S, s, anchor, ip - anchor, off_base, mlen, lane);
         ip += mlen; anchor = ip;
-        if (int64_t(ip) <= ilimit) {
-            const uint64_t wa = ld8(s + cur0), wb = ld8(s + ip - 2), wc = ld8(s + ip - 1);
-            uint32_t r_cur = ld4(s + ip), r_rep = ld4(s + ip - rep2);     // (the reads of this step in one round trip; rep2 == 0: not used)
-            if (lane == 0) {
-                tl[HL(wa)] = cur0 + 2; tl[HL(wb)] = ip;
-                ts[zhash(wa, hs_log, mls)] = cur0 + 2; ts[zhash(wc, hs_log, mls)] = ip + 1;
-            }
-            for (bool first = true; int64_t(ip) <= ilimit && rep2 > 0; first = false) {
-                if (!first) { r_cur = ld4(s + ip); r_rep = ld4(s + ip - rep2); }
-                if (r_cur != r_rep) break;
-                const uint32_t rlen = count_fwd(s, ip + 4, ip + 4 - rep2, end, lane) + 4;
-                const uint32_t t = rep2; rep2 = rep1; rep1 = t;
-                const uint64_t wi = ld8(s + ip);
-                if (lane == 0) { ts[zhash(wi, hs_log, mls)] = ip + 2; tl[HL(wi)] = ip + 2; }
-                store_seq(S, s, anchor, 0, 1, rlen, lane);
-                ip += rlen; anchor = ip;
-            }
-        }
+        after_match(cur0, true);
+        sp = ip;
     }
     saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;
     rep[0] = rep1 ? rep1 : saved1;
@@ -2607,7 +2827,7 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
             else if constexpr (kTree) tail = P.strat == 7 ? opt_block(L, S, Z, P, ne.rep, Z.chain + (size_t(1) << P.clog), src, pos, pos + len, lane)
                                                      : lazy_block<true>(L, S, Z, P, ne.rep, src, pos, pos + len, n, lane);
             else if (P.strat >= 4) tail = lazy_block<false>(L, S, Z, P, ne.rep, src, pos, pos + len, n, lane);
-            else if (P.strat == 2) tail = dfast_block(L, S, tab, tab_s, P, ne.rep, src, pos, pos + len, lane);
+            else if (P.strat == 2) tail = dfast_block(L, S, tab, tab_s, P, ne.rep, src, pos, pos + len, serial, lane);
             else return kErrGeneric;                               // level 1 is the other kernel's (zstd_encode_fast_kernel)
             gather_literals(S, src, pos, lane);
             copy_bytes(S.lit + S.nlit, src + pos + len - tail, tail, lane);

@@ -57,10 +57,11 @@ def test_8gib_roundtrip_and_replica_consistency(gpu):
     assert r[victim] == gpu.BLK_BADSUM and int((r != B).sum()) == 1
 
 
-def test_zstd1_full_launch_equals_the_oracle_on_every_replica(gpu):
-    """4mz Fast at the bench's size: 2048 blocks in one launch (every CU holds its 8 blocks, the level-1 finder's table
-    reads and writes of all of them in flight together); every replica of a base block gives the same frame, and the 48
-    distinct frames are the oracle's (zstd_enc_port.c, pinned to the reference's ZSTD_compress)."""
+@pytest.mark.parametrize("level", [1, 3])
+def test_zstd_full_launch_equals_the_oracle_on_every_replica(gpu, level):
+    """4mz Fast / Medium at the bench's size: 2048 blocks in one launch (every CU holds its 8 blocks, the dense-window finders'
+    table reads and writes of all of them in flight together); every replica of a base block gives the same frame, and the
+    48 distinct frames are the oracle's (zstd_enc_port.c, pinned to the reference's ZSTD_compress)."""
     base_n, nb = 48, 2048
     base = helpers.corpus(base_n * B)
     d_src = torch.from_numpy(base).cuda().repeat(-(-nb // base_n))[: nb * B].contiguous()
@@ -68,14 +69,14 @@ def test_zstd1_full_launch_equals_the_oracle_on_every_replica(gpu):
     lens = np.full(nb, B, dtype=np.uint32)
     enc = gpu.DeviceBatch(gpu.make_blocks(offs, offs, lens, lens))
     d_stage = torch.empty(nb * B, dtype=torch.uint8, device="cuda")
-    gpu.encode_blocks(d_src, d_stage, enc, codec=gpu.CODEC_ZSTD, level=1)
+    gpu.encode_blocks(d_src, d_stage, enc, codec=gpu.CODEC_ZSTD, level=level)
     e = enc.download()
     for b in range(nb):
         assert (e["result"][b], e["xxh32"][b]) == (e["result"][b % base_n], e["xxh32"][b % base_n]), b
     stage = d_stage[: base_n * B].cpu().numpy()
     for b in range(base_n):
         src = base[b * B:(b + 1) * B]
-        r, comp = helpers.orc_zstd_compress(src, 1, B - 1)
+        r, comp = helpers.orc_zstd_compress(src, level, B - 1)
         want = comp if r > 0 else src
         assert e["result"][b] == len(want) and e["xxh32"][b] == helpers.orc_xxh32(want), b
         if b % 6 == 0:

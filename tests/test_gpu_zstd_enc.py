@@ -83,6 +83,26 @@ def test_zstd_size_classes_and_tails(gpu, level):
     _check(gpu, names, srcs, [helpers.zstd_bound(n) for n in sizes], "bound", level)
 
 
+@pytest.mark.parametrize("level", [1, 3])
+def test_zstd_matches_running_to_block_ends(gpu, level):
+    """A match that runs to the end of a 128 KiB inner block (or of the input) ends behind ilimit: the reference makes none of
+    the refills that follow a match there (zstd_fast.c:263, zstd_double_fast.c:262).  Zero runs placed on those ends, reached
+    from inside the dense window of the level-1 / level-3 finders."""
+    rng = np.random.default_rng(11)
+    words = [bytes(rng.integers(97, 123, int(rng.integers(2, 9))).astype(np.uint8)) for _ in range(300)]
+    text = np.frombuffer(b" ".join(words[int(i)] for i in rng.integers(0, 300, 120000)), np.uint8)
+    srcs, names = [], []
+    for n in (131072, 262144 + 5000, 400000):
+        for run in (40, 230, 700, 5000):
+            d = text[:n].copy()
+            for edge in list(range(131072, n + 1, 131072)) + [n]:
+                d[max(edge - run, 0):edge] = 0
+                if edge + 16 <= n: d[edge:edge + 3] = 0                      # ... and a little of the run on the other side
+            srcs.append(d); names.append("n=%d run=%d" % (n, run))
+    _check(gpu, names, srcs, [helpers.zstd_bound(len(s)) for s in srcs], "ends", level)
+    _check(gpu, names, srcs, [len(s) - 1 for s in srcs], "ends n-1", level)
+
+
 @pytest.mark.parametrize("level", [1, 3, 6])
 def test_zstd_capacity_sweep(gpu, level):
     """Capacities around the real frame size: every overflow rule of the bit and byte writers."""

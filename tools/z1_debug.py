@@ -10,6 +10,7 @@ import helpers
 p = importlib.import_module("4mc_amd"); p.gpu_init(0)
 SEQCAP = 32768 + 64
 TABLES = []
+LEVEL = int(os.environ.get("ZL", "1"))          # 1 or 3 (FOURMC_ZSTD_SERIAL=1: the wave-uniform transcription at level 1, the batched search alone at level 3)
 
 def seqs(src, serial):
     os.environ["FOURMC_ZSTD_SERIAL"] = "1" if serial else "0"
@@ -17,19 +18,36 @@ def seqs(src, serial):
     batch = p.DeviceBatch(p.make_blocks([0], [0], [n], [n + 1024]))
     out = torch.zeros(n + 2048, dtype=torch.uint8, device="cuda")
     buf = np.zeros(n + 64, np.uint8); buf[:n] = src
-    p.zstd_compress(torch.from_numpy(buf).cuda(), out, batch, 1)
+    p.zstd_compress(torch.from_numpy(buf).cuda(), out, batch, LEVEL)
     torch.cuda.synchronize()
     r = int(batch.download()["result"][0])
     raw = (C.c_uint32 * (3 * SEQCAP))()
     assert p.lib().fourmc_gpu_debug_read_workspace(raw, 0, 12 * SEQCAP) == 0
     a = np.frombuffer(raw, np.uint32).reshape(3, SEQCAP).copy()
     global TABLES
-    traw = (C.c_uint32 * (1 << 15))()
-    assert p.lib().fourmc_gpu_debug_read_workspace(traw, 629312, 4 << 15) == 0    # zstd_encode.hip: kStoreBytes, the level-1 hash table behind it
+    nt = (1 << 15) if LEVEL == 1 else (1 << 17) + (1 << 16)     # level 3: long table (2^17) then short table (2^16)
+    traw = (C.c_uint32 * nt)()
+    assert p.lib().fourmc_gpu_debug_read_workspace(traw, 629312, 4 * nt) == 0    # zstd_encode.hip: kStoreBytes, the hash table(s) behind it
     TABLES.append(np.frombuffer(traw, np.uint32).copy())
     return r, a, out[:max(r, 0)].cpu().numpy()
 
-if sys.argv[1] == "edge":                                    # tests/helpers.py: edge_inputs() - lists the mismatching ones, or takes one by name (cut to 128 KiB)
+if sys.argv[1] == "corpus":                                  # block B of the S-mix corpus: the first 128 KiB inner block whose output differs, cut there
+    bi = int(sys.argv[2])
+    full = helpers.corpus((bi + 1) * (4 << 20))[bi * (4 << 20):].copy()
+    def frame(d, serial):
+        os.environ["FOURMC_ZSTD_SERIAL"] = "1" if serial else "0"
+        n = len(d); batch = p.DeviceBatch(p.make_blocks([0], [0], [n], [n + 4096]))
+        out = torch.zeros(n + 8192, dtype=torch.uint8, device="cuda")
+        p.zstd_compress(torch.from_numpy(d).cuda(), out, batch, LEVEL); torch.cuda.synchronize()
+        r = int(batch.download()["result"][0]); return out[:r].cpu().numpy()
+    cut = None
+    for k in range(1, 33):
+        a, b = frame(full[: k * 131072], True), frame(full[: k * 131072], False)
+        if len(a) != len(b) or not np.array_equal(a, b): cut = k; break
+    print("first differing inner block:", cut)
+    if cut is None: sys.exit(0)
+    src = full[: cut * 131072]
+elif sys.argv[1] == "edge":                                    # tests/helpers.py: edge_inputs() - lists the mismatching ones, or takes one by name (cut to 128 KiB)
     ed = helpers.edge_inputs()
     if len(sys.argv) == 2:
         for k, d in ed.items():
@@ -59,12 +77,11 @@ elif len(sys.argv) == 2:
 else:
     n, cls, seed = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     src = helpers.corpus(4 << 20, first_block=cls, seed=seed)[:n].copy()
-assert len(src) <= 128 * 1024
 r0, a0, o0 = seqs(src, True)
 r1, a1, o1 = seqs(src, False)
-want_r, want = helpers.orc_zstd_compress(src, 1, len(src) + 1024)
+want_r, want = helpers.orc_zstd_compress(src, LEVEL, len(src) + 1024)
 print("serial", r0, "product", r1, "oracle", want_r, "serial==oracle", r0 == want_r and np.array_equal(o0, want))
-pos0 = pos1 = 0
+pos0 = pos1 = ((len(src) - 1) // 131072) * 131072           # (the sequence store holds the last inner block)
 for i in range(SEQCAP):
     t0, t1 = a0[:, i], a1[:, i]
     if (t0 != t1).any():
