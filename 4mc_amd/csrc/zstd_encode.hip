@@ -1769,6 +1769,42 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
                 if (lane >= lo) x = ld8(s + pos - off - 4) ^ own;
                 mr = __ballot(uint32_t(x >> 32) == 0); eqb = __ballot((uint32_t(x >> 32) & 0xFFu) == 0);
             };
+            // Where the walk goes from a match that starts at this lane (found with its long candidate: nxtL, with its short one: nxtS)
+            // if nothing but another plain table hit follows: every repcode test of the search behind it is known from the
+            // candidate's bytes and fails, the next event is a clean hit whose length and catch-up the lanes hold.  lane | kind << 8, or 64.
+            uint32_t nxtL = 64, nxtS = 64;
+            {
+                const unsigned long long m_ev = m_L | m_S | m_stop;
+                auto next_of = [&](uint32_t fl, uint64_t E) -> uint32_t {
+                    const int e = lane + int(fl);
+                    const unsigned long long sh = e < 64 ? m_ev >> e : 0ull;
+                    const int nx = e + (sh ? __builtin_ctzll(sh) : 64);
+                    if (e > 60 || nx > 61 || ((m_stop >> (nx & 63)) & 1) || nx + 4 - lane > int(kFwHeld) + 3) return 64u;
+                    int tm = nx, tk = 1;
+                    if (!((m_L >> nx) & 1)) {                                           // a short hit: a long hit at nx + 1 is preferred
+                        if ((m_unL >> (nx + 1)) & 1) return 64u;
+                        if ((m_Lraw >> (nx + 1)) & 1) { tm = nx + 1; tk = 3; } else tk = 2;
+                    }
+                    const uint64_t Es = E >> 4, M4 = Es & (Es >> 1) & (Es >> 2) & (Es >> 3);
+                    const uint64_t T = ((2ull << (nx + 1 - lane)) - 1) & ~((1ull << (e + 1 - lane)) - 1);   // the repcode tests of that search: e+1 .. nx+1
+                    if (M4 & T) return 64u;
+                    return uint32_t(tm) | (uint32_t(tk) << 8) | (uint32_t(e) << 16);
+                };
+                uint32_t tL = 64, tS = 64;
+                if (((m_Lraw >> lane) & 1) && !((m_unL >> lane) & 1) && flL < kFwHeld + 4) tL = next_of(flL, EL);
+                if (hitS && !secS && !dirS && !slowS && flS < kFwHeld + 4) tS = next_of(flS, ES);
+                // the target's own conditions (its catch-up may not go beyond the 4 bytes held, its length is held)
+                auto target_ok = [&](uint32_t t) -> uint32_t {
+                    const uint32_t tm = t & 63, tk = (t >> 8) & 7, e = t >> 16;
+                    const uint32_t it = __shfl(info, int(tm));                          // (every lane takes part)
+                    if ((t & 255) >= 64) return 64u;
+                    const bool lng = tk != 2;
+                    if (((it >> (lng ? 18 : 19)) & 1) && tm - e > 4) return 64u;
+                    if ((lng ? it & 63 : (it >> 6) & 63) == kFwHeld + 4) return 64u;
+                    return t & 0xFFFFu;
+                };
+                nxtL = target_ok(tL); nxtS = target_ok(tS);
+            }
             // ---- the walk (scalar)
             int s_l = -int(sp0 - ip), cur = 0, anc = -int(sp0 - anchor);
             const int anc0 = anc;
@@ -1835,9 +1871,51 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
                 const int e = m + int(fl);
                 sel |= 1ull << m;
                 if (lane == m) { kindv = uint32_t(kd); endv = uint32_t(e); }
+                // repcode-2 test behind this match (offset: the previous repeat offset), as far as it is known here
+                bool bad0 = false;
+                if (r1) bad0 = e > H41 || ((MR1 >> (e & 63)) & 1);
                 r2 = r1; r1 = sp0 + uint32_t(m) - cm; MR2 = MR1; H42 = H41; k2 = 0;
                 k1 = 1; m1 = m; E1 = lng ? rl64(EL, uint32_t(m)) : rl64(ES, uint32_t(m));
                 anc = s_l = cur = e; pend = true;
+                // ---- the chain of plain table hits behind it: one readlane per sequence
+                unsigned long long selc = 0, chS = 0, ch3 = 0;                          // chained lanes; those found with their short candidate; those found from the position before
+                if (fl < kFwHeld + 4)
+                    for (int t = m, kk = kd;;) {
+                        const uint32_t nx = kk == 2 ? rl(nxtS, uint32_t(t)) : rl(nxtL, uint32_t(t));
+                        if ((nx & 255) >= 64) break;
+                        t = int(nx & 63); kk = int(nx >> 8);
+                        selc |= 1ull << t;
+                        if (kk == 2) chS |= 1ull << t; else if (kk == 3) ch3 |= 1ull << t;
+                    }
+                if (selc) {
+                    // every link took the repcode-2 test behind its predecessor p for granted (offset: that of p's predecessor pp,
+                    // whose candidate bytes know it up to 40 bytes behind pp): check them all at once, cut at the first that fails
+                    const unsigned long long C = selc | (1ull << m);
+                    const bool usesS = ((chS >> lane) & 1) || (lane == m && kd == 2);
+                    const uint64_t Ech = usesS ? ES : EL;
+                    const uint32_t ech = uint32_t(lane) + (usesS ? flS : flL);
+                    const unsigned long long bl = C & ((1ull << lane) - 1);
+                    const int P = bl ? 63 - __builtin_clzll(bl) : 0;
+                    const uint32_t packP = __shfl(uint32_t(P) | (uint32_t(bl != 0) << 8), P);
+                    const int PP = int(packP & 63);
+                    const int eP = int(__shfl(ech, P));
+                    const uint64_t Epp = u64(__shfl(uint32_t(Ech), PP), __shfl(uint32_t(Ech >> 32), PP));
+                    const int d = eP - PP;
+                    const bool bad = ((selc >> lane) & 1) && (((packP >> 8) & 1) ? (d > int(kFwHeld) || ((Epp >> ((d + 4) & 63)) & 15u) == 15u) : bad0);
+                    const unsigned long long badm = __ballot(bad);
+                    if (badm) selc &= (1ull << __builtin_ctzll(badm)) - 1;
+                    if (selc) {
+                        const int Lst = 63 - __builtin_clzll(selc);
+                        const unsigned long long bL = (selc | (1ull << m)) & ((1ull << Lst) - 1);
+                        const int Lp = 63 - __builtin_clzll(bL);
+                        sel |= selc;
+                        if ((selc >> lane) & 1) { kindv = ((chS >> lane) & 1) ? 2u : ((ch3 >> lane) & 1) ? 3u : 1u; endv = ech; }
+                        const uint32_t candch = usesS ? cS : cL;
+                        r2 = sp0 + uint32_t(Lp) - rl(candch, uint32_t(Lp)); r1 = sp0 + uint32_t(Lst) - rl(candch, uint32_t(Lst));
+                        k2 = 1; m2 = Lp; E2 = rl64(Ech, uint32_t(Lp)); m1 = Lst; E1 = rl64(Ech, uint32_t(Lst));
+                        anc = s_l = cur = int(rl(ech, uint32_t(Lst)));
+                    }
+                }
                 { DPIN(); }
             }
             // ---- behind the walk: sequences and the writes of both tables, all lanes at once
