@@ -1691,6 +1691,7 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
             ip = U(ip); anchor = U(anchor); rep1 = U(rep1); rep2 = U(rep2);
             const uint32_t pos = sp0 + uint32_t(lane);
             const Q16 q0 = ld16(s + pos - 4), q1 = ld16(s + pos + 12), q2 = ld16(s + pos + 28);          // [pos - 4, pos + 44)
+            ZCNT(0);
             uint64_t ra = 0, rb = 0;
             if (rep1) ra = ld8(s + pos - rep1 - 4);
             if (rep2) rb = ld8(s + pos - rep2 - 4);
@@ -1847,7 +1848,7 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
                         break;
                     }
                     const int e = q + 4 + fwv;
-                    sel |= 1ull << q;
+                    sel |= 1ull << q; ZCNT(1);
                     if (lane == q) { kindv = 4; endv = uint32_t(e); }
                     anc = s_l = cur = e; pend = true;
                     { DPIN(); continue; }
@@ -1869,7 +1870,7 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
                 uint32_t fl = lng ? inf & 63 : (inf >> 6) & 63;
                 if (fl == kFwHeld + 4) fl += count_fwd(s, sp0 + uint32_t(m) + fl, cm + fl, end, lane);
                 const int e = m + int(fl);
-                sel |= 1ull << m;
+                sel |= 1ull << m; ZCNT(2);
                 if (lane == m) { kindv = uint32_t(kd); endv = uint32_t(e); }
                 // repcode-2 test behind this match (offset: the previous repeat offset), as far as it is known here
                 bool bad0 = false;
@@ -1904,6 +1905,7 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
                     const bool bad = ((selc >> lane) & 1) && (((packP >> 8) & 1) ? (d > int(kFwHeld) || ((Epp >> ((d + 4) & 63)) & 15u) == 15u) : bad0);
                     const unsigned long long badm = __ballot(bad);
                     if (badm) selc &= (1ull << __builtin_ctzll(badm)) - 1;
+                    ZADD(10, uint32_t(__builtin_popcountll(selc)));
                     if (selc) {
                         const int Lst = 63 - __builtin_clzll(selc);
                         const unsigned long long bL = (selc | (1ull << m)) & ((1ull << Lst) - 1);
@@ -1960,6 +1962,7 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
             rep1 = r1; rep2 = r2;
             owed = (endk == 1 && pend) || endk == 3;
             gen_tail = endk == 3; gen_search = endk == 2;
+            ZCNT(5 + endk);
             anchor = U(anchor); ip = U(ip); sp = U(sp); rep1 = U(rep1); rep2 = U(rep2);
             continue;
         }
@@ -2021,6 +2024,7 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
             width = min(64u, width * 2);
         }
         if (ev_kind == 5) break;                                 // _cleanup
+        ZCNT(3);
         const uint32_t cur0 = ev_ip + 2;                          // index of the probed position (`curr`)
         uint32_t mlen, off_base;
         if (ev_kind == 1) {
