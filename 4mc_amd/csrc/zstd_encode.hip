@@ -1,5 +1,5 @@
 // 4mc_amd/csrc/zstd_encode.hip — K6: batched ZSTD frame encode on gfx950, BYTE-IDENTICAL to the
-// reference's ZSTD_compress(dst, cap, src, n, 1) (zstd 1.5.3, strategy "fast"), the call 4mz makes per
+// reference's ZSTD_compress(dst, cap, src, n, level) (zstd 1.5.3; levels 1 / 3 / 6 / 12), the call 4mz makes per
 // 4 MiB block at its "fast" level (native/4mc.c:411-412,:467) and Java makes through
 // ZstdCompressor.compressBytesDirect (native/jniZstdCompressor.c:93).
 //
@@ -12,14 +12,17 @@
 //
 // One wavefront owns one 4mc block (one zstd frame of up to 32 blocks of 128 KiB).  Per 128 KiB
 // block it (1) runs the greedy match finder, (2) entropy-codes literals and sequences.
-//   * Match finder: the reference walks positions in pairs (ip0, ip0+1) with a repcode test at
-//     ip0+step; every tested position reads then overwrites its hash slot.  Lane j speculatively
-//     executes pair j of the current search (64 pairs per batch), a ballot picks the first event in
-//     serial order (repcode hit, hash hit, end of block); only lanes up to it commit their table
-//     writes.  Two pairs of one batch that touch the same slot are ordered by cutting the batch at
-//     the later lane (LDS atomic-min scoreboard), exactly as the LZ4 kernel does.  Extension and
-//     literal copies are wave-wide.  The hash table (<= 2^15 x u32) lives in the block's HBM
-//     workspace slot so that 8+ blocks stay resident per CU.
+//   * Match finder (levels 1 and 3): the reference walks positions one or two at a time with a repcode test ahead; every
+//     tested position reads then overwrites its hash slot(s).  Two shapes reproduce that walk exactly.  The DENSE WINDOW (see
+//     fast_block / dfast_block): lane l takes position sp + l whatever role the walk will give it; one table round trip and
+//     one candidate round trip serve 64 positions; byte-equality masks of 48 candidate bytes give the tests, the lengths and
+//     the repcode tests behind a chosen match; a scalar walk (a readlane chain for runs of plain hash hits) only chooses,
+//     sequences and table writes follow from the chosen lanes for all lanes at once.  The BATCHED SEARCH: lane j
+//     speculatively executes pair / position j of the current search, a ballot picks the first event in serial order, only
+//     lanes up to it commit their table writes, lanes that touch the same slot are ordered by cutting the batch (LDS
+//     atomic-min scoreboard) - one sequence per batch; it takes what the window hands over (steps > 2, block ends, long
+//     catch-ups, slots written twice inside a window) and is the cross-check path (FOURMC_ZSTD_SERIAL=1).  The hash tables
+//     (<= 2^17 x u32) live in the block's HBM workspace slot; LDS per block is 19 984 bytes so that eight blocks share a CU.
 //   * Entropy stage: histograms are wave-parallel (LDS atomics); Huffman bit packing is wave-parallel
 //     (8 symbols per lane, DPP prefix sum of code lengths, LDS atomic-or staging); table construction
 //     (Huffman tree, FSE normalisation/spread) and the three interleaved FSE state chains are serial
