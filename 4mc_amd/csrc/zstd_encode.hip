@@ -1658,16 +1658,16 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
     // sp - ip < 192).  `owed`: a match has just ended at ip == sp and its two end refills (long: ip - 2, short: ip - 1) and the
     // repcode-2 loop are still to do.
     uint32_t sp = ip;
-    bool owed = false, gen_tail = false, gen_search = false;
+    bool owed = false, owed_fill = false, gen_tail = false, gen_search = false;   // owed_fill: the two end refills are part of what is owed (not behind an immediate repcode-2 match)
     // refills behind a match that ended at `at` and the repcode-2 loop (zstd_double_fast.c:262-293); the refill of curr + 2 only
     // when it has not been made (dense window: it is one of the window's lanes)
-    auto after_match = [&](uint32_t cur0, bool fill_cur) {
+    auto after_match = [&](uint32_t cur0, bool fill_cur, bool fill_end) {
         if (int64_t(ip) > ilimit) return;
         const uint64_t wa = fill_cur ? ld8(s + cur0) : 0, wb = ld8(s + ip - 2), wc = ld8(s + ip - 1);
         uint32_t r_cur = ld4(s + ip), r_rep = ld4(s + ip - rep2);     // (the reads of this step in one round trip; rep2 == 0: not used)
         if (lane == 0) {
             if (fill_cur) { tl[HL(wa)] = cur0 + 2; ts[zhash(wa, hs_log, mls)] = cur0 + 2; }
-            tl[HL(wb)] = ip; ts[zhash(wc, hs_log, mls)] = ip + 1;
+            if (fill_end) { tl[HL(wb)] = ip; ts[zhash(wc, hs_log, mls)] = ip + 1; }
         }
         for (bool first = true; int64_t(ip) <= ilimit && rep2 > 0; first = false) {
             if (!first) { r_cur = ld4(s + ip); r_rep = ld4(s + ip - rep2); }
@@ -1681,8 +1681,9 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
         }
     };
     for (;;) {                                                   // one dense window, or one search of the batched path, per iteration
-        if (owed && (gen_tail || serial || sp < max(rep1, rep2) + 4 || int64_t(sp) + 200 > ilimit)) { after_match(0, false); sp = ip; owed = false; }
+        if (owed && (gen_tail || serial || sp < max(rep1, rep2) + 4 || int64_t(sp) + 200 > ilimit)) { after_match(0, false, owed_fill); sp = ip; owed = false; }
         gen_tail = false;
+        if (!owed) owed_fill = false;
         if (!serial && !gen_search && sp - ip <= 128 && sp >= max(rep1, rep2) + 4 && sp >= 4 && int64_t(sp) + 200 <= ilimit) {     // (serial: the batched search only - cross-check path)
             // ------------------------------------------------------------------------------------------ dense window
             // As in fast_block (see there), for two tables: lane l takes position sp + l and prepares, against both tables as they
@@ -1702,7 +1703,7 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
             const uint32_t hl = HL(w8), hs = zhash(w8, hs_log, mls);
             uint32_t entL = tld(tl, hl), entS = tld(ts, hs);
             uint32_t hfL = 0, hfS = 0;
-            if (owed) {                                          // the owed refills (long: sp - 2, short: sp - 1) come before every read of this window
+            if (owed_fill) {                                     // the owed refills (long: sp - 2, short: sp - 1) come before every read of this window
                 const uint64_t v2 = u64(__builtin_amdgcn_alignbit(q0.d1, q0.d0, 16), __builtin_amdgcn_alignbit(q0.d2, q0.d1, 16));
                 const uint64_t v1 = u64(__builtin_amdgcn_alignbit(q0.d1, q0.d0, 24), __builtin_amdgcn_alignbit(q0.d2, q0.d1, 24));
                 hfL = rl(HL(v2), 0); hfS = rl(zhash(v1, hs_log, mls), 0);
@@ -1764,10 +1765,10 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
             const unsigned long long m_L = __ballot(hitL && !secL && !dirL) & ~m_stop, m_S = __ballot(hitS && !secS && !dirS) & ~m_stop & ~m_L;
             // repcode tests of every position, for both repeat offsets (as in fast_block)
             const uint64_t own = u64(q0.d0, q0.d1);
-            unsigned long long MR1 = 0, EQB1 = 0, MR2 = 0;
-            int H41 = 63, HB1 = 63, H42 = 63;
+            unsigned long long MR1 = 0, EQB1 = 0, MR2 = 0, EQB2 = 0;
+            int H41 = 63, HB1 = 63, H42 = 63, HB2 = 63;
             if (rep1) { const uint64_t x = ra ^ own; MR1 = __ballot(uint32_t(x >> 32) == 0); EQB1 = __ballot((uint32_t(x >> 32) & 0xFFu) == 0); }
-            if (rep2) { const uint64_t x = rb ^ own; MR2 = __ballot(uint32_t(x >> 32) == 0); }
+            if (rep2) { const uint64_t x = rb ^ own; MR2 = __ballot(uint32_t(x >> 32) == 0); EQB2 = __ballot((uint32_t(x >> 32) & 0xFFu) == 0); }
             auto read_rep = [&](uint32_t off, int lo, unsigned long long& mr, unsigned long long& eqb) {
                 uint64_t x = ~0ull;
                 if (lane >= lo) x = ld8(s + pos - off - 4) ^ own;
@@ -1812,23 +1813,37 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
             // ---- the walk (scalar)
             int s_l = -int(sp0 - ip), cur = 0, anc = -int(sp0 - anchor);
             const int anc0 = anc;
-            bool pend = owed;
+            bool pend = owed, lastI = false;
             unsigned long long sel = 0;                                                  // lanes where a match starts
-            uint32_t kindv = 0, endv = 0;                                               // per lane: 1 long, 2 short, 3 long at p+1 (found from p), 4 repcode; end of the match
+            uint32_t kindv = 0, endv = 0;                                               // per lane: 1 long, 2 short, 3 long at p+1 (found from p), 4 repcode, 5 immediate repcode-2; end of the match
             uint32_t r1 = rep1, r2 = rep2;
             int k1 = 0, k2 = 0, m1 = 0, m2 = 0; uint64_t E1 = 0, E2 = 0;
             int endk;                                                                   // 0: search goes on at cur, 1: fresh search at cur, 2: batched search at cur, 3: repcode-2 loop at cur
 #define DPIN() do { cur = Ui(cur); s_l = Ui(s_l); anc = Ui(anc); r1 = U(r1); r2 = U(r2); k1 = Ui(k1); k2 = Ui(k2); m1 = Ui(m1); m2 = Ui(m2); E1 = U64(E1); E2 = U64(E2); \
-                    H41 = Ui(H41); HB1 = Ui(HB1); H42 = Ui(H42); pend = Ui(int(pend)) != 0; sel = U64(sel); MR1 = U64(MR1); EQB1 = U64(EQB1); MR2 = U64(MR2); } while (0)
+                    H41 = Ui(H41); HB1 = Ui(HB1); H42 = Ui(H42); HB2 = Ui(HB2); pend = Ui(int(pend)) != 0; lastI = Ui(int(lastI)) != 0; sel = U64(sel); MR1 = U64(MR1); EQB1 = U64(EQB1); MR2 = U64(MR2); EQB2 = U64(EQB2); } while (0)
             DPIN();
             for (;;) {
                 if (k1) { EQB1 = ((E1 >> 4) & ((1ull << (kFwHeld + 4)) - 1)) << m1; MR1 = EQB1 & (EQB1 >> 1) & (EQB1 >> 2) & (EQB1 >> 3); HB1 = min(63, m1 + int(kFwHeld) + 3); H41 = HB1 - 3; k1 = 0; }
-                if (k2) { const unsigned long long q = ((E2 >> 4) & ((1ull << (kFwHeld + 4)) - 1)) << m2; MR2 = q & (q >> 1) & (q >> 2) & (q >> 3); H42 = min(63, m2 + int(kFwHeld) + 3) - 3; k2 = 0; }
+                if (k2) { EQB2 = ((E2 >> 4) & ((1ull << (kFwHeld + 4)) - 1)) << m2; MR2 = EQB2 & (EQB2 >> 1) & (EQB2 >> 2) & (EQB2 >> 3); HB2 = min(63, m2 + int(kFwHeld) + 3); H42 = HB2 - 3; k2 = 0; }
                 if (pend) {
                     if (cur >= 62) { endk = 1; break; }
                     if (r2) {
-                        if (cur > H42) { unsigned long long t0; read_rep(r2, cur, MR2, t0); H42 = 63; }
-                        if ((MR2 >> cur) & 1) { endk = 3; break; }
+                        if (cur > H42) { read_rep(r2, cur, MR2, EQB2); H42 = HB2 = 63; }
+                        if ((MR2 >> cur) & 1) {                                         // an immediate repcode-2 match (zstd_double_fast.c:274-290): offsets swap, only its first position enters the tables
+                            const int q = cur;
+                            const unsigned long long t = q + 4 < 64 ? ~(EQB2 >> (q + 4)) : 1ull;
+                            const int fwv = t ? __builtin_ctzll(t) : 64;
+                            if (q + 4 + fwv > HB2 && HB2 < 63) { read_rep(r2, cur, MR2, EQB2); H42 = HB2 = 63; { DPIN(); continue; } }
+                            if (q + 4 + fwv >= 64) { endk = 3; break; }                 // it runs to the end of the window: the serial loop takes it
+                            const int e = q + 4 + fwv;
+                            sel |= 1ull << q; lastI = true;
+                            if (lane == q) { kindv = 5; endv = uint32_t(e); }
+                            { const uint32_t tr = r1; r1 = r2; r2 = tr; }
+                            { unsigned long long tq; tq = MR1; MR1 = MR2; MR2 = tq; tq = EQB1; EQB1 = EQB2; EQB2 = tq; }
+                            { int ti; ti = H41; H41 = H42; H42 = ti; ti = HB1; HB1 = HB2; HB2 = ti; }
+                            anc = s_l = cur = e;
+                            { DPIN(); continue; }
+                        }
                     }
                     pend = false;
                 }
@@ -1851,7 +1866,7 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
                         break;
                     }
                     const int e = q + 4 + fwv;
-                    sel |= 1ull << q; ZCNT(1);
+                    sel |= 1ull << q; lastI = false; ZCNT(1);
                     if (lane == q) { kindv = 4; endv = uint32_t(e); }
                     anc = s_l = cur = e; pend = true;
                     { DPIN(); continue; }
@@ -1873,12 +1888,12 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
                 uint32_t fl = lng ? inf & 63 : (inf >> 6) & 63;
                 if (fl == kFwHeld + 4) fl += count_fwd(s, sp0 + uint32_t(m) + fl, cm + fl, end, lane);
                 const int e = m + int(fl);
-                sel |= 1ull << m; ZCNT(2);
+                sel |= 1ull << m; lastI = false; ZCNT(2);
                 if (lane == m) { kindv = uint32_t(kd); endv = uint32_t(e); }
                 // repcode-2 test behind this match (offset: the previous repeat offset), as far as it is known here
                 bool bad0 = false;
                 if (r1) bad0 = e > H41 || ((MR1 >> (e & 63)) & 1);
-                r2 = r1; r1 = sp0 + uint32_t(m) - cm; MR2 = MR1; H42 = H41; k2 = 0;
+                r2 = r1; r1 = sp0 + uint32_t(m) - cm; MR2 = MR1; EQB2 = EQB1; H42 = H41; HB2 = HB1; k2 = 0;
                 k1 = 1; m1 = m; E1 = lng ? rl64(EL, uint32_t(m)) : rl64(ES, uint32_t(m));
                 anc = s_l = cur = e; pend = true;
                 // ---- the chain of plain table hits behind it: one readlane per sequence
@@ -1936,10 +1951,10 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
                 if (isC) {
                     const bool lng = kindv == 1 || kindv == 3;
                     const uint32_t cand = lng ? cL : cS;
-                    const uint32_t b = kindv == 4 ? 0u : min(lng ? bkL : bkS, min(uint32_t(lane - ancl), cand - prefix));
+                    const uint32_t b = kindv >= 4 ? 0u : min(lng ? bkL : bkS, min(uint32_t(lane - ancl), cand - prefix));
                     ll = uint32_t(lane - ancl) - b;
                     const uint32_t at = S.nseq + nbelow;
-                    S.ll[at] = ll; S.ml[at] = (endv - uint32_t(lane)) + b - 3; S.off[at] = kindv == 4 ? 1u : pos - cand + 3;
+                    S.ll[at] = ll; S.ml[at] = (endv - uint32_t(lane)) + b - 3; S.off[at] = kindv >= 4 ? 1u : pos - cand + 3;
                 }
                 S.nseq += uint32_t(__builtin_popcountll(sel));
                 S.nlit += rl(scan_add(ll), 63);
@@ -1952,18 +1967,19 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
                 const bool fills = !(kPt & 8);
                 const int d = lane - Pl;
                 const bool probe = !any || lane >= eP;
-                const bool inL = (kP <= 2 && (d <= 1 || (d == 2 && fills))) || (kP == 3 && (d == 0 || (d == 1 && fills))) || (kP == 4 && d == 1 && fills) || (fills && lane == eP - 2);
-                const bool inS = (kP <= 2 && (d == 0 || (d == 2 && fills))) || (kP >= 3 && d == 1 && fills) || (fills && lane == eP - 1);
+                const bool inL = (kP <= 2 && (d <= 1 || (d == 2 && fills))) || (kP == 3 && (d == 0 || (d == 1 && fills))) || (kP == 4 && d == 1 && fills) || (kP == 5 && d == 0) || (kP != 5 && fills && lane == eP - 2);
+                const bool inS = (kP <= 2 && (d == 0 || (d == 2 && fills))) || ((kP == 3 || kP == 4) && d == 1 && fills) || (kP == 5 && d == 0) || (kP != 5 && fills && lane == eP - 1);
                 const bool visL = lane < cur && (probe || inL), visS = lane < cur && (probe || inS);
                 const unsigned long long vmL = __ballot(visL), vmS = __ballot(visS);
                 if (visL && !(grpL & vmL & ~((2ull << lane) - 1))) tl[hl] = pos + 2;
                 if (visS && !(grpS & vmS & ~((2ull << lane) - 1))) ts[hs] = pos + 2;
                 const unsigned long long fmL = __ballot(visL && hl == hfL), fmS = __ballot(visS && hs == hfS);
-                if (owed && lane == 0) { if (!fmL) tl[hfL] = sp0; if (!fmS) ts[hfS] = sp0 + 1; }
+                if (owed_fill && lane == 0) { if (!fmL) tl[hfL] = sp0; if (!fmS) ts[hfS] = sp0 + 1; }
             }
             anchor = uint32_t(int(sp0) + anc); ip = uint32_t(int(sp0) + s_l); sp = sp0 + uint32_t(cur);
             rep1 = r1; rep2 = r2;
             owed = (endk == 1 && pend) || endk == 3;
+            owed_fill = owed && (sel ? !lastI : owed_fill);                             // (no match in this window: what was owed on the way in)
             gen_tail = endk == 3; gen_search = endk == 2;
             ZCNT(5 + endk);
             anchor = U(anchor); ip = U(ip); sp = U(sp); rep1 = U(rep1); rep2 = U(rep2);
@@ -2076,7 +2092,7 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
         }
         store_seq(S, s, anchor, ip - anchor, off_base, mlen, lane);
         ip += mlen; anchor = ip;
-        after_match(cur0, true);
+        after_match(cur0, true, true);
         sp = ip;
     }
     saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;

@@ -277,7 +277,10 @@ def main():
                                        ("4mc_high_lz4hc4", p.CODEC_LZ4_HC, 4, "hc4")):
             out[name] = config_leg(name, d_src, nb, codec, level, hc, base, base_blocks, 4.0)
         # BASELINE configs[4]'s workload at a single-GPU size: 4mz Ultra (zstd 12) on the synthetic log corpus
-        nlog = min(256, nb)
+        # (every CU holds 8 blocks as in the other legs when the 49 MiB of level-12 tables per block fit: 2048 blocks take 97 GiB)
+        nlog = nb
+        free = torch.cuda.mem_get_info(dev)[0] if hasattr(torch.cuda, "mem_get_info") else 0
+        while nlog > 256 and nlog * (49 + 14) * (1 << 20) > 0.8 * free: nlog //= 2
         logs = helpers.corpus(min(nlog, 24) * B, first_block=0, logs=True)
         d_logs = torch.from_numpy(logs).to(dev).repeat(-(-nlog // min(nlog, 24)))[: nlog * B].contiguous()
         out["4mz_ultra_zstd12_logs"] = config_leg("4mz_ultra_zstd12_logs", d_logs, nlog, p.CODEC_ZSTD, 12, "zstd12", logs, min(nlog, 24), 6.0)

@@ -53,7 +53,7 @@ elif sys.argv[1] == "edge":                                    # tests/helpers.p
         for k, d in ed.items():
             d = np.ascontiguousarray(d)
             r1, _, o1 = seqs(d, False) if len(d) else (0, None, None)
-            wr, w = helpers.orc_zstd_compress(d, 1, len(d) + 1024)
+            wr, w = helpers.orc_zstd_compress(d, LEVEL, len(d) + 1024)
             if len(d) and not (r1 == wr and np.array_equal(o1, w)): print(k, len(d), "MISMATCH", r1, wr)
         sys.exit(0)
     src = np.ascontiguousarray(ed[sys.argv[2]])[: int(sys.argv[3]) if len(sys.argv) > 3 else 128 * 1024]
@@ -68,7 +68,7 @@ elif sys.argv[1] == "sizes":                                   # the inputs of t
         for n, o in zip(sizes, offs):
             if n > 128 * 1024: continue
             d = big[int(o): int(o) + n].copy()
-            r1, _, o1 = seqs(d, False); wr, w = helpers.orc_zstd_compress(d, 1, n + 1024)
+            r1, _, o1 = seqs(d, False); wr, w = helpers.orc_zstd_compress(d, LEVEL, n + 1024)
             print(n, "ok" if r1 == wr and np.array_equal(o1, w) else "MISMATCH %d %d" % (r1, wr))
         sys.exit(0)
     i = sizes.index(int(sys.argv[2])); src = big[int(offs[i]): int(offs[i]) + sizes[i]].copy()
