@@ -1395,6 +1395,7 @@ __device__ __forceinline__ uint32_t fast_block(ZLds& L, SeqStore& S, uint32_t* t
                 }
                 { WPIN(); }
             }
+#undef WPIN
             ZPT(14);
             {   // where the next window starts is known: its reads go out now
                 const uint32_t nsp = sp0 + uint32_t(cur), nip = uint32_t(int(sp0) + s_l);
@@ -1938,6 +1939,7 @@ __device__ __forceinline__ uint32_t dfast_block(ZLds& L, SeqStore& S, uint32_t* 
                 }
                 { DPIN(); }
             }
+#undef DPIN
             // ---- behind the walk: sequences and the writes of both tables, all lanes at once
             {
                 const bool isC = (sel >> lane) & 1;
