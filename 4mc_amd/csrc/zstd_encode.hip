@@ -2836,13 +2836,14 @@ __device__ __forceinline__ bool is_rle(const uint8_t* s, uint32_t n, int lane)
 // kTree: the instance for the binary-tree strategies of level 12 (btlazy2 up to 256 KiB, btopt up to 16 KiB: a file's short last
 // block), compiled into a kernel of its own so that their code does not weigh on the register allocation of the fast /
 // dfast / lazy paths every full block takes (with the tree finder inlined next to it, dfast ran 7 % slower)
-// kFast: the level-1 kernel's instance (strategy "fast" only: the other match finders are not compiled into it, so its
+// kFast: 1 = the level-1 kernel's instance (strategy "fast" only), 2 = the level-3 kernel's ("dfast" only), 0 = the lazy levels: the
+// other match finders are not compiled into an instance, so its
 // registers are allocated for the dense window alone)
-template <bool kTree, bool kFast>
+template <bool kTree, int kFast>
 __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* work, int level, bool serial, int lane)
 {
-    Params P = level_params(n, kFast ? 1 : level);
-    if (kFast) P.strat = 1;
+    Params P = level_params(n, kFast == 1 ? 1 : kFast == 2 ? 3 : level);
+    if (kFast) P.strat = uint32_t(kFast);
     uint32_t* const tab = reinterpret_cast<uint32_t*>(work + kStoreBytes);
     uint32_t* const tab_s = reinterpret_cast<uint32_t*>(work + kStoreBytes + (size_t(4) << 17));      // level 3: short-hash table
     SeqStore S;
@@ -2926,12 +2927,12 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
             ZPH(t_out);
             if (pos + 2 > Z.ntu + 384) { const uint32_t gap = pos + 2 - Z.ntu - 384; Z.ntu = pos + 2 - min(gap, 192u); }   // ZSTD_buildSeqStore :2890-2896
             uint32_t tail;
-            if constexpr (kFast) tail = fast_block(L, S, tab, P, ne.rep, src, pos, pos + len, n, serial, lane);
+            if constexpr (kFast == 1) tail = fast_block(L, S, tab, P, ne.rep, src, pos, pos + len, n, serial, lane);
+            else if constexpr (kFast == 2) tail = dfast_block(L, S, tab, tab_s, P, ne.rep, src, pos, pos + len, serial, lane);
             else if constexpr (kTree) tail = P.strat == 7 ? opt_block(L, S, Z, P, ne.rep, Z.chain + (size_t(1) << P.clog), src, pos, pos + len, lane)
                                                      : lazy_block<true>(L, S, Z, P, ne.rep, src, pos, pos + len, n, lane);
             else if (P.strat >= 4) tail = lazy_block<false>(L, S, Z, P, ne.rep, src, pos, pos + len, n, lane);
-            else if (P.strat == 2) tail = dfast_block(L, S, tab, tab_s, P, ne.rep, src, pos, pos + len, serial, lane);
-            else return kErrGeneric;                               // level 1 is the other kernel's (zstd_encode_fast_kernel)
+            else return kErrGeneric;                               // levels 1 and 3 are the other kernels' (zstd_encode_fast_kernel, zstd_encode_dfast_kernel)
             gather_literals(S, src, pos, lane);
             copy_bytes(S.lit + S.nlit, src + pos + len - tail, tail, lane);
             S.nlit += tail;
@@ -2984,7 +2985,7 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
 // container_mode 1: native/4mc.c:467-489 (capacity n-1; an error stores the block raw)
 __device__ __forceinline__ bool tree_sized(int level, uint32_t n) { return level == 12 && n <= 256 * 1024; }   // clevels.h:66,92,118: btlazy2, btopt
 
-template <bool kTree, bool kFast>
+template <bool kTree, int kFast>
 __device__ __forceinline__ void zstd_encode_one(ZLds& L, const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks, uint32_t nblocks,
                                                 uint8_t* work_base, int container_mode, int level, int serial)
 {
@@ -3009,7 +3010,7 @@ void zstd_encode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
                         uint8_t* work_base, int container_mode, int level, int serial)
 {
     __shared__ ZLds L;
-    zstd_encode_one<false, false>(L, src_base, dst_base, blocks, nblocks, work_base, container_mode, level, serial);
+    zstd_encode_one<false, 0>(L, src_base, dst_base, blocks, nblocks, work_base, container_mode, level, serial);
 }
 
 // level 1 (4mz "fast", the configuration the bench quotes)
@@ -3018,7 +3019,16 @@ void zstd_encode_fast_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
                              uint8_t* work_base, int container_mode, int level, int serial)
 {
     __shared__ ZLds L;
-    zstd_encode_one<false, true>(L, src_base, dst_base, blocks, nblocks, work_base, container_mode, level, serial);
+    zstd_encode_one<false, 1>(L, src_base, dst_base, blocks, nblocks, work_base, container_mode, level, serial);
+}
+
+// level 3 (4mz "medium")
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void zstd_encode_dfast_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks, uint32_t nblocks,
+                              uint8_t* work_base, int container_mode, int level, int serial)
+{
+    __shared__ ZLds L;
+    zstd_encode_one<false, 2>(L, src_base, dst_base, blocks, nblocks, work_base, container_mode, level, serial);
 }
 
 // level 12, blocks of 256 KiB and less (a file's short last block): binary-tree finder, optimal parser below 16 KiB
@@ -3027,7 +3037,7 @@ void zstd_encode_tree_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
                             uint8_t* work_base, int container_mode, int level, int serial)
 {
     __shared__ ZLds L;
-    zstd_encode_one<true, false>(L, src_base, dst_base, blocks, nblocks, work_base, container_mode, level, serial);
+    zstd_encode_one<true, 0>(L, src_base, dst_base, blocks, nblocks, work_base, container_mode, level, serial);
 }
 
 } // namespace
@@ -3038,7 +3048,7 @@ extern "C" hipError_t fourmc_launch_zstd_encode(const void* d_src, void* d_dst, 
                                                 void* d_work, int container_mode, int level, int serial, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(level == 1 ? zstd_encode_fast_kernel : zstd_encode_kernel, dim3(n), dim3(64), 0, stream,
+    hipLaunchKernelGGL(level == 1 ? zstd_encode_fast_kernel : level == 3 ? zstd_encode_dfast_kernel : zstd_encode_kernel, dim3(n), dim3(64), 0, stream,
                        static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n,
                        static_cast<uint8_t*>(d_work), container_mode, level, serial);
     if (level == 12)
