@@ -267,3 +267,19 @@ def test_zstd12_log_corpus_blocks(gpu):
         r = ref.ZSTD_compress(out.ctypes.data, B - 1, srcs[0].ctypes.data, B, 12)
         res, outs = _encode(gpu, [srcs[0]], [B - 1], 12)
         assert int(res[0]) == int(r) and np.array_equal(outs[0], out[:r])
+
+
+@pytest.mark.parametrize("level", [1, 3])
+def test_zstd_dense_window_equals_the_batched_search(gpu, level, monkeypatch):
+    """The two shapes of the level-1 / level-3 match finders (dense window; batched search alone, FOURMC_ZSTD_SERIAL=1: at
+    level 1 the wave-uniform transcription of the reference loop) write the same frames: six 4 MiB blocks of different classes."""
+    data = helpers.corpus(12 * B)
+    picks = [0, 1, 2, 3, 5, 7]
+    srcs = [data[b * B:(b + 1) * B] for b in picks]
+    caps = [B - 1] * len(srcs)
+    monkeypatch.setenv("FOURMC_ZSTD_SERIAL", "0")
+    res_a, outs_a = _encode(gpu, srcs, caps, level)
+    monkeypatch.setenv("FOURMC_ZSTD_SERIAL", "1")
+    res_b, outs_b = _encode(gpu, srcs, caps, level)
+    for b, ra, oa, rb, ob in zip(picks, res_a, outs_a, res_b, outs_b):
+        assert int(ra) == int(rb) and np.array_equal(oa, ob), b
