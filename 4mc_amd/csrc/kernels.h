@@ -21,6 +21,8 @@ size_t     fourmc_lz4_decode_work_bytes(uint32_t n);
 size_t     fourmc_lz4_decode_tok_offset(void);
 hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                                     uint32_t n, int container_mode, void* d_work, hipStream_t stream);
+hipError_t fourmc_launch_lz4_rows(const void* d_src, void* d_dst, fourmc_block* d_blocks,
+                                  uint32_t n, int container_mode, hipStream_t stream);
 hipError_t fourmc_launch_lz4_parse(const void* d_src, const void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                    int container_mode, void* d_work, hipStream_t stream);
 hipError_t fourmc_launch_lz4_exec(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,

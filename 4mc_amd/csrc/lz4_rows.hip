@@ -1,0 +1,685 @@
+// 4mc_amd/csrc/lz4_rows.hip — K1r: row-parallel LZ4 block decode on gfx950 (wave64), the default fast path of
+// fourmc_launch_lz4_decode since round 3.
+//
+// Replaces LZ4_decompress_safe(in, out, csize, usize) (native/4mc.c:661, native/jniDecompressor.c:88 ->
+// native/lz4/lz4.c:2345-2350 -> :1936-2339) for every block whose stream is regular; anything else (rule
+// violations, odd end-of-block shapes, sizes beyond 4 MiB) is handed to the exact walker of lz4_decode.hip
+// (result = kRetry), which reproduces the reference's accept / reject set and negative return codes.
+//
+// What is serial in an LZ4 block is only WHERE the tokens are.  The compressed stream is cut into aligned rows of 64
+// bytes and four waves per block work as a pipeline through LDS:
+//   PRE   every byte of a row is decoded as if a token started there (literal count, match length, offset, next
+//         token); five rounds of pointer doubling over ds_bpermute give, for each of the 64 possible entry points of
+//         the row, where the token chain leaves the row and how many literal / match bytes it produces on the way
+//         (one packed dword per entry: the row's TABLE).  No dependence on other rows: rows are processed four at a
+//         time, straight from global memory (unaligned dword loads).
+//   WALK  the only serial chain left: one LDS look-up per row (entry -> exit, output position, match-space position).
+//         Tokens the tables do not cover (length continuations beyond one byte, the end of the block) are decoded
+//         here one at a time under the strict rules of the reference's safe loop (lz4.c:2120-2330).
+//   POST  once a row's entry point is known: marks the row's true tokens (a v_readlane chain), prefix-sums their
+//         sizes (DPP), stores the row's LITERALS straight from the stream bytes the lanes hold (a byte scatter: the
+//         output position of a literal is its stream position plus a per-token constant, carried to the lanes by one
+//         max-scan), and publishes one record per token for the copier: {offset, where its match goes}.
+//   COPY  executes the matches in MATCH SPACE: the match bytes of all sequences laid end to end.  Lane l of a step
+//         produces match byte g + l; its owner token is found by a max-scan over a ring of start marks, source and
+//         destination follow from the token's record.  Lanes whose source is already stored go first, the others
+//         follow in passes (overlapping matches read the period instead: no dependence inside a match).
+// Literal stores (POST) and match loads (COPY) meet in the CU's L1; a record is published to the copier only after
+// the stores of its literals have completed.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fourmc_gpu.h"
+#include "kernels.h"
+#include "devcopy.h"
+#include "lz4par.h"
+
+namespace {
+
+constexpr int kRetry = lz4par::kRetryCode;
+constexpr int kNR  = 8;            // rows in the table / field ring
+constexpr int kNQ  = 8;            // records in flight between POST / WALK and COPY
+constexpr int kOwn = 2048;         // match-space ring of start marks (entries)
+constexpr int kSpan = 512;         // output bytes one copier window may span
+constexpr uint32_t kMaxRowLits = 2047, kMaxRowMatch = 511;    // a row beyond these goes token by token (four rows of marks fit the ring)
+constexpr int kTailGuard = 16 + 337 + 64;   // rows whose tokens may touch the last 16 stream bytes are never batched
+constexpr uint32_t kSpinLimit = 1u << 19;
+#ifndef K1R_STEPS
+#define K1R_STEPS 4                 // 64-lane sub-steps the copier keeps in flight per iteration
+#endif
+
+struct RowSlot { uint32_t tab[64]; uint2 fld[64]; };
+struct Shared {
+    uint32_t own[kOwn];            // own[m & (kOwn-1)] = key of the token whose match starts at match-space position m
+    RowSlot  rows[kNR];
+    uint2    rec[kNQ][64];         // per record and token lane: {offset | mpos << 16, D | (mpos >> 16) << 22 | overlap << 31}
+    uint4    res[kNR];             // WALK -> POST, per visited row: {row + 1, entry | q << 6, output position, match-space position}
+    uint2    pub[kNQ];             // POST / WALK -> COPY, per record: {q + 1 once ready, end of the record in match space}
+    uint16_t scr[kSpan + 8];         // COPY: the output bytes [bound0, bound0 + kSpan) of the window being executed: 0 literal /
+                                   // older data (in memory), 0x200 match byte still to come, 0x100 | byte once produced
+    // progress words; pairs that one reader wants together sit in one 8-byte word
+    uint2    pw;                   // x: PRE, rows [0, x) have tables and fields in the ring;  y: WALK, rows [0, y) are decided
+    uint2    cc;                   // COPY: x records consumed, y match-space bytes consumed
+    uint32_t post_rows;            // POST: rows [0, post_rows) are done with their ring slots
+    uint32_t total_q;              // WALK: number of records of the block once known, else 0xFFFFFFFF
+    uint32_t failed;
+    int      end_value;
+};
+static_assert(sizeof(Shared) <= 20480, "eight blocks per CU need <= 20 KiB of LDS each");
+
+__device__ __forceinline__ uint32_t ldv(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void stv(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
+__device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l) { return uint32_t(__builtin_amdgcn_readlane(int(v), int(l))); }
+// LDS operations of one wave execute in order; what has to be stopped is the compiler moving them
+#define LDS_ORDER() asm volatile("" ::: "memory")
+
+// per-role cycle counters of the profiling side build (make rprof; tools/k1r_prof.py): slot 7 = the role's whole time,
+// slots 0..6 = time spent in its wait sites / counts
+#ifdef K1R_PROF
+struct Prof {
+    unsigned long long t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    __device__ __forceinline__ unsigned long long now() const { return __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void add(int i, unsigned long long since) { t[i] += __builtin_amdgcn_s_memtime() - since; }
+    __device__ __forceinline__ void count(int i, unsigned long long n = 1) { t[i] += n; }
+};
+#else
+struct Prof {
+    __device__ __forceinline__ unsigned long long now() const { return 0; }
+    __device__ __forceinline__ void add(int, unsigned long long) {}
+    __device__ __forceinline__ void count(int, unsigned long long = 1) {}
+};
+#endif
+
+__device__ __forceinline__ uint2 ldv2(const uint2* p)
+{
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return make_uint2(rfl(uint32_t(v)), rfl(uint32_t(v >> 32)));
+}
+// bounded wait on LDS words: `poll` re-reads what `cond` looks at; false = somebody failed (or the wait ran out): the
+// role leaves and the exact kernel decides
+template <class P, class F> __device__ __forceinline__ bool wait_until(Shared* S, Prof& pf, int site, P poll, F cond)
+{
+    if (cond()) return true;
+    poll();
+    if (cond()) { LDS_ORDER(); return true; }
+    const unsigned long long t0 = pf.now();
+    for (uint32_t spins = 0;;) {
+        if (rfl(ldv(&S->failed))) return false;
+        __builtin_amdgcn_s_sleep(1);
+        poll();
+        if (cond()) break;
+        if (++spins > kSpinLimit) { stv(&S->failed, 1); return false; }
+    }
+    pf.add(site, t0);
+    LDS_ORDER();
+    return true;
+}
+
+// every byte the roles touch in memory is GLOBAL memory: say so in the pointer types (a generic pointer costs FLAT
+// instructions, which also count on lgkmcnt and make every later wait a full one)
+typedef __attribute__((address_space(1))) uint8_t gbyte;
+typedef __attribute__((address_space(1))) const uint8_t cgbyte;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32_u __attribute__((aligned(1)));
+typedef u32x4 u32x4_u __attribute__((aligned(1)));
+__device__ __forceinline__ uint32_t ld4u(cgbyte* p) { return *reinterpret_cast<__attribute__((address_space(1))) const u32_u*>(p); }
+__device__ __forceinline__ u32x4 ld16g(cgbyte* p) { return *reinterpret_cast<__attribute__((address_space(1))) const u32x4_u*>(p); }
+__device__ __forceinline__ void st16g(gbyte* p, u32x4 v) { *reinterpret_cast<__attribute__((address_space(1))) u32x4*>(p) = v; }
+
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v)
+{ return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, ROWMASK, 0xf, false)); }
+__device__ __forceinline__ uint32_t scan_add(uint32_t v)
+{
+    v += dpp0<0x111, 0xf>(v); v += dpp0<0x112, 0xf>(v); v += dpp0<0x114, 0xf>(v); v += dpp0<0x118, 0xf>(v);
+    v += dpp0<0x142, 0xa>(v); v += dpp0<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t scan_max(uint32_t v)
+{
+    v = max(v, dpp0<0x111, 0xf>(v)); v = max(v, dpp0<0x112, 0xf>(v)); v = max(v, dpp0<0x114, 0xf>(v)); v = max(v, dpp0<0x118, 0xf>(v));
+    v = max(v, dpp0<0x142, 0xa>(v)); v = max(v, dpp0<0x143, 0xc>(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t bperm(uint32_t addr4, uint32_t v) { return uint32_t(__builtin_amdgcn_ds_bpermute(int(addr4), int(v))); }
+
+// ---------------------------------------------------------------------------------------------------------- PRE
+// field word x: offset | hop << 16 | stream byte << 24;   y: match | overlap << 9 | regular << 10 | lit-ext << 11 | literals << 16
+__device__ void role_pre(Shared* S, Prof& pf, cgbyte* src, int csize, int lane)
+{
+    const int nrows = (csize + 63) >> 6;
+    const int lastpos = csize - 4;
+    int post_seen = 0;
+    auto request = [&](int r0, uint32_t (&w)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) w[u] = ld4u(src + min((r0 + u) * 64 + lane, lastpos));
+    };
+    auto group = [&](int r0, const uint32_t (&w)[4]) -> bool {
+        post_seen = int(rfl(uint32_t(post_seen)));
+        if (!wait_until(S, pf, 0, [&] { post_seen = int(rfl(ldv(&S->post_rows))); }, [&] { return post_seen + kNR >= r0 + 4; })) return false;
+        uint32_t offpos[4], L[4], lext[4], wo[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t b = w[u] & 0xff, b1 = (w[u] >> 8) & 0xff, L0 = b >> 4;
+            lext[u] = L0 == 15 ? 1u : 0u;
+            L[u] = L0 + (lext[u] ? b1 : 0u);
+            offpos[u] = uint32_t(lane) + 1 + lext[u] + L[u];
+            wo[u] = ld4u(src + min((r0 + u) * 64 + int(offpos[u]), lastpos));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t b = w[u] & 0xff, b1 = (w[u] >> 8) & 0xff, M0 = b & 15;
+            const uint32_t off = wo[u] & 0xffff, e1 = (wo[u] >> 16) & 0xff;
+            const bool mext = M0 == 15;
+            const uint32_t ml = M0 + 4 + (mext ? e1 : 0u);
+            const bool reg = !(lext[u] && b1 == 255) && !(mext && e1 == 255);
+            const uint32_t nxt = reg ? offpos[u] + 2 + (mext ? 1u : 0u) : uint32_t(lane);
+            const uint32_t pz = reg ? (L[u] << 16 | ml) : 0u;
+            const bool nonterm = reg && nxt < 64;
+            const uint32_t h0 = nonterm ? nxt : uint32_t(lane);
+            uint32_t h4 = h0 << 2, sum = nonterm ? pz : 0u;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {               // <= 21 tokens in 64 bytes: 2^5 hops reach the terminal
+                sum += bperm(h4, sum);
+                h4 = bperm(h4, h4);
+            }
+            const uint32_t tot = sum + bperm(h4, pz);
+            uint32_t X = bperm(h4, nxt);
+            uint32_t lits = tot >> 16, mls = tot & 0xffff;
+            if (lits > kMaxRowLits || mls > kMaxRowMatch) { X = uint32_t(lane); lits = 0; mls = 0; }
+            RowSlot& rs = S->rows[(r0 + u) & (kNR - 1)];
+            rs.tab[lane] = X << 21 | lits << 10 | mls;
+            const uint32_t ovl = (reg && off < ml) ? 1u : 0u;
+            rs.fld[lane] = make_uint2(off | h0 << 16 | b << 24, pz | ovl << 9 | (reg ? 1u : 0u) << 10 | lext[u] << 11);
+        }
+        LDS_ORDER();
+        if (lane == 0) stv(&S->pw.x, uint32_t(r0 + 4));
+        return true;
+    };
+    uint32_t wa[4], wb[4];
+    request(0, wa);
+    for (int r0 = 0; r0 < nrows; r0 += 8) {
+        request(r0 + 4, wb);
+        if (!group(r0, wa)) return;
+        if (r0 + 4 >= nrows) break;
+        request(r0 + 8, wa);
+        if (!group(r0 + 4, wb)) return;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------- WALK
+// literal runs the walk copies itself (general sequences): 16 bytes per lane, two granules in flight; a small register
+// footprint matters more here than the last GB/s (all four roles share one register allocation: 64 VGPRs for 8 waves / SIMD)
+__device__ __attribute__((noinline)) void lean_copy(gbyte* dst, cgbyte* src, int n, int lane)
+{
+    const int head = min(n, int((16 - (uintptr_t(dst) & 15)) & 15));
+    if (lane < head) dst[lane] = src[lane];
+    int k = head;
+    for (; k + 2048 <= n; k += 2048) {
+        const u32x4 v0 = ld16g(src + k + 16 * lane), v1 = ld16g(src + k + 1024 + 16 * lane);
+        st16g(dst + k + 16 * lane, v0);
+        st16g(dst + k + 1024 + 16 * lane, v1);
+    }
+    for (; k + 1024 <= n; k += 1024) { const u32x4 v = ld16g(src + k + 16 * lane); st16g(dst + k + 16 * lane, v); }
+    for (; k < n; k += 64) { const int i = k + lane; if (i < n) dst[i] = src[i]; }
+}
+struct Win {                       // 64 stream bytes around the position the walk decodes token by token
+    cgbyte* src; int csize; int la_pos; uint32_t la; int lane;
+    __device__ __forceinline__ void reload(int p) { la_pos = p; const int a = p + lane; la = a < csize ? uint32_t(src[a]) : 0u; }
+    __device__ __forceinline__ uint32_t get(int p) { if (p < la_pos || p >= la_pos + 64) reload(p); return rdl(la, uint32_t(p - la_pos)); }
+};
+// length continuation bytes (lz4.c:1903-1928): whole runs of 255 per step via a ballot over the window
+__device__ __forceinline__ bool more_len(Win& s, int& ip, int lim, bool check_first, int& len)
+{
+    if (check_first && ip >= lim) return false;
+    for (;;) {
+        if (ip < s.la_pos || ip >= s.la_pos + 64) s.reload(ip);
+        const int l0 = ip - s.la_pos;
+        const unsigned long long not255 = __ballot(s.la != 255u) >> l0;
+        const int avail = 64 - l0;
+        int n, add; bool done;
+        if (not255 == 0) { n = avail; add = 255 * avail; done = false; }
+        else { const int t = __builtin_ctzll(not255); n = t + 1; add = 255 * t + int(rdl(s.la, uint32_t(l0 + t))); done = true; }
+        if (ip + n > lim) return false;
+        ip += n;
+        len = len > 0x40000000 - add ? 0x40000000 : len + add;
+        if (done) return true;
+    }
+}
+
+__device__ void role_walk(Shared* S, Prof& pf, cgbyte* src, gbyte* dst, int csize, int cap, int lane)
+{
+    const int iend = csize, oend = cap;
+    const int rlast = (csize - kTailGuard) >> 6;            // negative: no row is batched
+    Win win; win.src = src; win.csize = csize; win.lane = lane; win.la = 0; win.la_pos = -(1 << 30);
+    int p = 0, op = 0;
+    uint32_t mb = 0, q = 0, wpos = 0;
+    int row_general = -1, pre_seen = 0, post_seen = 0;
+    uint32_t cq_seen = 0, cg_seen = 0;
+    auto fail = [&]() { if (lane == 0) stv(&S->failed, 1); };
+    auto decided = [&](uint32_t upto) { if (upto > wpos) { wpos = upto; LDS_ORDER(); if (lane == 0) stv(&S->pw.y, wpos); } };
+    for (;;) {
+        p = int(rfl(uint32_t(p))); op = int(rfl(uint32_t(op))); mb = rfl(mb); q = rfl(q); wpos = rfl(wpos);
+        pre_seen = int(rfl(uint32_t(pre_seen))); post_seen = int(rfl(uint32_t(post_seen))); cq_seen = rfl(cq_seen); cg_seen = rfl(cg_seen);
+        const int r = p >> 6; const uint32_t e = uint32_t(p) & 63;
+        decided(uint32_t(r));
+        if (r <= rlast && r != row_general) {
+            if (!wait_until(S, pf, 0, [&] { pre_seen = int(rfl(ldv(&S->pw.x))); }, [&] { return pre_seen > r; })) return;
+            const uint32_t t = rfl(S->rows[r & (kNR - 1)].tab[e]);
+            const uint32_t X = t >> 21, lits = (t >> 10) & 0x7ff, mls = t & 0x3ff;
+            if (X != e && op + int(lits + mls) + 80 <= oend) {
+                if (!wait_until(S, pf, 1, [&] { post_seen = int(rfl(ldv(&S->post_rows))); }, [&] { return post_seen + kNR > r; })) return;
+                if (lane == 0) S->res[r & (kNR - 1)] = make_uint4(uint32_t(r + 1), e | q << 6, uint32_t(op), mb);
+                decided(uint32_t(r + 1));
+                op += int(lits + mls); mb += mls; p = r * 64 + int(X); q++;
+                continue;
+            }
+        }
+        // ------------------------------------------------------------ one sequence under the strict rules
+        row_general = r;
+        pf.count(4);
+        const unsigned long long tg = pf.now();
+        int ip = p;
+        if (ip >= iend) { fail(); return; }
+        const uint32_t token = win.get(ip); ip++;
+        int lit = int(token >> 4), mlen = int(token & 15);
+        if (lit == 15) { if (!more_len(win, ip, iend - 15, true, lit)) { fail(); return; } }
+        if (op + lit > oend - 12 || ip + lit > iend - 8) {
+            if (ip + lit != iend || op + lit > oend) { fail(); return; }
+            lean_copy(dst + op, src + ip, lit, lane);                  // the block's last sequence: literals only
+            if (lane == 0) S->end_value = op + lit;
+            break;
+        }
+        const int lit_ip = ip;
+        ip += lit;
+        const int op2 = op + lit;
+        const int off = int(win.get(ip)) | (int(win.get(ip + 1)) << 8);
+        ip += 2;
+        if (mlen == 15) { if (!more_len(win, ip, iend - 4, false, mlen)) { fail(); return; } }
+        mlen += 4;
+        if (off == 0 || off > op2 || op2 + mlen > oend - 5) { fail(); return; }
+        lean_copy(dst + op, src + lit_ip, lit, lane);
+        if (!wait_until(S, pf, 2, [&] { const uint2 c = ldv2(&S->cc); cq_seen = c.x; cg_seen = c.y; },
+                        [&] { return cq_seen + kNQ > q && mb < cg_seen + kOwn; })) return;
+        if (lane == 0) {
+            S->own[mb & (kOwn - 1)] = (q << 6) << 3;
+            S->rec[q & (kNQ - 1)][0] = make_uint2(uint32_t(off) | mb << 16,
+                                                  uint32_t(op2 - int(mb)) | (mb >> 16) << 22 | (off < mlen ? 1u : 0u) << 31);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // the literals are in memory before the record is seen
+        if (lane == 0) S->pub[q & (kNQ - 1)] = make_uint2(q + 1, mb + uint32_t(mlen));
+        op = op2 + mlen; mb += uint32_t(mlen); p = ip; q++;
+        pf.add(3, tg);
+    }
+    LDS_ORDER();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) { stv(&S->total_q, q); stv(&S->pw.y, 0xFFFFFFFFu); }
+}
+
+// ---------------------------------------------------------------------------------------------------------- POST
+// Four rows per iteration, each complete in itself (a literal run that leaves its row is fetched from the stream by the
+// row that owns the token), so that the four dependent chains of a row - the token walk, two DPP scans, the LDS round
+// trips - overlap with those of its neighbours instead of adding up.
+__device__ void role_post(Shared* S, Prof& pf, cgbyte* src, gbyte* dst, int csize, int lane)
+{
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    const int nrows = (csize + 63) >> 6;
+    uint32_t pend_q = kNone, pend_m = 0;             // lanes 0..3: the records of the previous group, their literal stores issued
+    uint32_t pre_seen = 0, wpos_seen = 0, cq_seen = 0, cg_seen = 0;      // progress of the other roles as last read
+    (void)pre_seen;
+    auto fail = [&]() { if (lane == 0) stv(&S->failed, 1); };
+    auto publish = [&]() {
+        LDS_ORDER();
+        if (lane < 4 && pend_q != kNone) S->pub[pend_q & (kNQ - 1)] = make_uint2(pend_q + 1, pend_m);
+        pend_q = kNone;
+    };
+    auto poll_pw = [&] { const uint2 v = ldv2(&S->pw); pre_seen = v.x; wpos_seen = v.y; };
+    for (int R = 0, n = 0; R < nrows; R += n) {
+        wpos_seen = rfl(wpos_seen); cq_seen = rfl(cq_seen); cg_seen = rfl(cg_seen);
+        unsigned long long tp = pf.now();
+        // the group: the rows the walk has decided, four at most (waiting for a full group could wait for the walk while the
+        // walk waits for the copier and the copier for this group's records)
+        if (wpos_seen < uint32_t(R + 4)) {
+            poll_pw();
+            if (wpos_seen <= uint32_t(R)) {          // nothing decided yet: nothing to overlap the drain with
+                if (__ballot(pend_q != kNone)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); publish(); }
+                if (!wait_until(S, pf, 7, poll_pw, [&] { return wpos_seen > uint32_t(R); })) return;
+            }
+        }
+        n = int(min(wpos_seen - uint32_t(R), 4u));
+        LDS_ORDER();
+        pf.add(0, tp); tp = pf.now();
+        // one round trip: the walk's words and the fields of the four rows
+        uint4 rs[4]; uint2 f[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { rs[u] = S->res[(R + u) & (kNR - 1)]; f[u] = S->rows[(R + u) & (kNR - 1)].fld[lane]; }
+        bool vis[4]; uint32_t e[4], q[4], mb[4]; int op[4];
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            vis[u] = u < n && rfl(rs[u].x) == uint32_t(R + u + 1);
+            const uint32_t eq = rfl(rs[u].y);
+            e[u] = vis[u] ? eq & 63 : 0u; q[u] = eq >> 6; op[u] = int(rfl(rs[u].z)); mb[u] = rfl(rs[u].w);
+            any |= vis[u];
+        }
+        pf.add(1, tp); tp = pf.now();
+        if (any) {
+            // ---- the true tokens of each row: four v_readlane chains side by side, marks dropped by v_writelane (the chain
+            // stays on the vector unit: a scalar bit-set between two hops would put a VALU -> SGPR -> SALU round trip into it)
+            uint32_t pos[4], hop[4], tokv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { pos[u] = e[u]; hop[u] = vis[u] ? (f[u].x >> 16) & 63 : uint32_t(lane); tokv[u] = 0; }
+            for (int round = 0; round < 3; round++) {
+#pragma unroll
+                for (int i = 0; i < 7; i++) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        asm volatile("s_nop 3\n\tv_writelane_b32 %0, 1, %1" : "+v"(tokv[u]) : "s"(pos[u]));
+                        pos[u] = rdl(hop[u], pos[u]);
+                    }
+                }
+                bool done = true;
+#pragma unroll
+                for (int u = 0; u < 4; u++) done &= rdl(hop[u], pos[u]) == pos[u];
+                if (done) break;
+            }
+            pf.add(2, tp); tp = pf.now();
+            uint32_t pz[4], incl[4], excl[4], mls_t[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                asm volatile("s_nop 3\n\tv_writelane_b32 %0, 1, %1" : "+v"(tokv[u]) : "s"(pos[u]));
+                const bool is_tok = vis[u] && tokv[u] != 0 && ((f[u].y >> 10) & 1);       // on the chain, and a regular token
+                pz[u] = is_tok ? (f[u].y & 0x01FF01FFu) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) incl[u] = scan_add(pz[u]);
+            uint32_t q_last = 0, m_end = 0; unsigned long long bad = 0;
+            uint32_t D[4], mpos[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                excl[u] = incl[u] - pz[u];
+                mls_t[u] = rdl(incl[u], 63) & 0xffff;
+                D[u] = uint32_t(op[u]) - mb[u] + (incl[u] >> 16);        // destination of a match byte = match-space position + D
+                mpos[u] = mb[u] + (excl[u] & 0xffff);
+                const uint32_t off = f[u].x & 0xffff;
+                bad |= __ballot(pz[u] != 0 && (off == 0 || off > mpos[u] + D[u]));
+                if (vis[u]) { q_last = q[u]; m_end = mb[u] + mls_t[u]; }
+            }
+            if (bad) { fail(); return; }
+            pf.add(3, tp); tp = pf.now();
+            auto room = [&] { return cq_seen + kNQ > q_last && m_end <= cg_seen + kOwn; };
+            auto poll_cc = [&] { const uint2 c = ldv2(&S->cc); cq_seen = c.x; cg_seen = c.y; };
+            if (!room()) {
+                poll_cc();
+                if (!room()) {                       // the copier has to catch up: it may be waiting for records held back here
+                    if (__ballot(pend_q != kNone)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); publish(); }
+                    if (!wait_until(S, pf, 7, poll_cc, room)) return;
+                }
+            }
+            pf.add(4, tp); tp = pf.now();
+            // the previous group's literal stores were issued a whole group ago: complete them (normally no wait) and show its
+            // records to the copier BEFORE this group's stores go out, so that no count of issued stores is needed
+            if (__ballot(pend_q != kNone)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); publish(); }
+            // ---- records for the copier (rows that were not visited have no tokens: nothing is written for them)
+            uint32_t new_q = kNone, new_m = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (pz[u] != 0) {
+                    S->own[mpos[u] & (kOwn - 1)] = (q[u] << 6 | uint32_t(lane)) << 3;
+                    S->rec[q[u] & (kNQ - 1)][lane] = make_uint2((f[u].x & 0xffff) | mpos[u] << 16,
+                                                                D[u] | (mpos[u] >> 16) << 22 | ((f[u].y >> 9) & 1) << 31);
+                }
+                if (vis[u] && lane == u) { new_q = q[u]; new_m = mb[u] + mls_t[u]; }
+            }
+            // ---- literals: the latest token at or before a stream lane owns it (max-scan of keys ordered by literal start)
+            uint32_t km[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t litlo = uint32_t(lane) + 1 + ((f[u].y >> 11) & 1);
+                const uint32_t dl = (excl[u] >> 16) + (excl[u] & 0xffff) + 512 - litlo;   // output position of stream lane 0, relative to op - 512
+                km[u] = scan_max(pz[u] != 0 ? (litlo << 23 | (pz[u] >> 16) << 14 | dl) : 0u);
+            }
+            int sn[4]; bool spilled = false, spill_more = false;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {                               // rows without tokens: no lane passes the test
+                if (uint32_t(lane) - (km[u] >> 23) < ((km[u] >> 14) & 0x1ff)) dst[lane + int(km[u] & 0x3fff) + op[u] - 512] = uint8_t(f[u].x >> 24);
+                // the row's last token: literals beyond the row come straight from the stream
+                const uint32_t k63 = rdl(km[u], 63);
+                sn[u] = int(k63 >> 23) + int((k63 >> 14) & 0x1ff) - max(int(k63 >> 23), 64);
+                spilled |= sn[u] > 0; spill_more |= sn[u] > 64;
+            }
+            if (spilled) {                                              // the first 64 bytes of every run in one batch of loads
+                uint32_t sv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int first = max(int(rdl(km[u], 63) >> 23), 64);           // row-relative stream position of the first byte outside
+                    sv[u] = src[lane < sn[u] ? (R + u) * 64 + first + lane : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t k63 = rdl(km[u], 63);
+                    const int first = max(int(k63 >> 23), 64);
+                    if (lane < sn[u]) dst[first + int(k63 & 0x3fff) + op[u] - 512 + lane] = uint8_t(sv[u]);
+                }
+                if (spill_more) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t k63 = rdl(km[u], 63);
+                        const int first = max(int(k63 >> 23), 64);
+                        cgbyte* from = src + (R + u) * 64 + first;
+                        gbyte* to = dst + first + int(k63 & 0x3fff) + op[u] - 512;
+                        for (int k = 64 + lane; k < sn[u]; k += 64) { const uint8_t v = from[k]; to[k] = v; }
+                    }
+                }
+            }
+            pf.add(5, tp); tp = pf.now();
+            pend_q = new_q; pend_m = new_m;
+        }
+        LDS_ORDER();
+        if (lane == 0) stv(&S->post_rows, uint32_t(R + n));
+        pf.add(6, tp);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    publish();
+}
+
+// ---------------------------------------------------------------------------------------------------------- COPY
+template <int K>
+__device__ void role_copy(Shared* S, Prof& pf, gbyte* dst, int lane)
+{
+    uint32_t g = 0, qa = 0, cqv = 0, ext = 0, ck = 0;
+    for (uint32_t spins = 0;;) {
+        g = rfl(g); qa = rfl(qa); cqv = rfl(cqv); ext = rfl(ext); ck = rfl(ck);
+        // one round trip: the publication words of all record slots (lanes 0..7) and the start marks of the next K * 64
+        // match-space positions
+        unsigned long long tc = pf.now();
+        const uint2 pb = S->pub[lane & (kNQ - 1)];
+        LDS_ORDER();                                   // issued in this order: a record seen ready has its marks in place
+        uint32_t mark[K];
+#pragma unroll
+        for (int u = 0; u < K; u++) mark[u] = S->own[(g + 64u * u + uint32_t(lane)) & (kOwn - 1)];
+        {   // records consumed so far: [cqv, qa) with an end at or below g
+            const uint32_t ql = cqv + ((uint32_t(lane) - cqv) & (kNQ - 1));
+            cqv += uint32_t(__builtin_popcountll(__ballot(lane < kNQ && ql < qa && pb.y <= g)));
+            // records that became ready: slots qa, qa + 1, ... in a row
+            const uint32_t qn = qa + ((uint32_t(lane) - qa) & (kNQ - 1));
+            const uint32_t ok = uint32_t(__ballot(lane < kNQ && pb.x == qn + 1)) & 0xffu;
+            const uint32_t rot = ((ok | ok << 8) >> (qa & (kNQ - 1))) & 0xffu;
+            const uint32_t n = uint32_t(__builtin_ctz(~rot));             // 0..8
+            if (n) { ext = rdl(pb.y, (qa + n - 1) & (kNQ - 1)); qa += n; }
+        }
+        LDS_ORDER();
+        if (lane == 0) *reinterpret_cast<volatile unsigned long long*>(&S->cc) = (unsigned long long)cqv | (unsigned long long)g << 32;
+        if (ext == g) {
+            if (rfl(ldv(&S->total_q)) == qa) break;                     // every record consumed
+            if (rfl(ldv(&S->failed))) return;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit) { stv(&S->failed, 1); return; }
+            continue;
+        }
+        spins = 0;
+        pf.count(1); pf.count(2, min(ext - g, 64u * K));
+        uint32_t avail = min(ext - g, 64u * K);
+        // ---- owners.  Everything below is written as batches of K independent operations without branches in between:
+        // the compiler issues the K LDS / memory operations of a batch back to back and waits once (a branch around each
+        // would serialise them, one round trip after the other)
+        uint32_t dest[K], sp[K], km[K], nl[K];
+#pragma unroll
+        for (int u = 0; u < K; u++) { nl[u] = avail > 64u * u ? min(avail - 64u * u, 64u) : 0u; km[u] = scan_max(mark[u]); }
+#pragma unroll
+        for (int u = 0; u < K; u++) { km[u] = max(km[u], ck); const uint32_t last = rdl(km[u], nl[u] ? nl[u] - 1 : 0u); ck = nl[u] ? last : ck; }
+        uint2 rc[K];
+#pragma unroll
+        for (int u = 0; u < K; u++) rc[u] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(&S->rec[0][0]) + (km[u] & 0xFFF));
+        unsigned long long anyovl = 0;
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            const uint32_t m = g + 64u * u + uint32_t(lane);
+            dest[u] = m + (rc[u].y & 0x3FFFFF);
+            sp[u] = dest[u] - (rc[u].x & 0xffff);
+            anyovl |= __ballot(int(rc[u].y) < 0 && uint32_t(lane) < nl[u]);
+        }
+        if (anyovl) {                                                   // overlapping matches: read the period, not the match itself
+#pragma unroll
+            for (int u = 0; u < K; u++) {
+                const uint32_t m = g + 64u * u + uint32_t(lane);
+                const uint32_t off = rc[u].x & 0xffff, D = rc[u].y & 0x3FFFFF;
+                const uint32_t mpos = rc[u].x >> 16 | ((rc[u].y >> 22) & 63) << 16;
+                const uint32_t rel = m - mpos;
+                if (int(rc[u].y) < 0 && rel >= off) sp[u] = mpos + D - off + rel % max(off, 1u);
+            }
+        }
+        // the window ends where its output would leave the scratch span (literal runs between the matches count)
+        const uint32_t bound0 = rdl(dest[0], 0);
+        {
+            uint32_t keep_total = avail; bool cut = false;
+#pragma unroll
+            for (int u = 0; u < K; u++) {
+                const unsigned long long out = __ballot(uint32_t(lane) < nl[u] && dest[u] - bound0 >= uint32_t(kSpan));
+                if (out && !cut) { cut = true; keep_total = 64u * u + uint32_t(__builtin_ctzll(out)); }
+            }
+            if (cut) {                                                  // rare: long literal runs inside the window
+                avail = keep_total;                                     // >= 1: lane 0 of the first sub-step is always inside
+                const uint32_t lu = (avail - 1) >> 6, ll = (avail - 1) & 63;
+                ck = 0;
+#pragma unroll
+                for (int u = 0; u < K; u++) { nl[u] = avail > 64u * u ? min(avail - 64u * u, 64u) : 0u; if (uint32_t(u) == lu) ck = rdl(km[u], ll); }
+            }
+        }
+        pf.add(4, tc); tc = pf.now();
+        // ---- execute.  Sources inside the window: a match byte another lane of the window produces travels through the
+        // scratch; anything else (literals, older output) is in memory already - records are admitted only once their
+        // literals are
+        reinterpret_cast<uint4*>(S->scr)[lane] = make_uint4(0, 0, 0, 0);
+        LDS_ORDER();
+        bool lv[K];
+#pragma unroll
+        for (int u = 0; u < K; u++) { lv[u] = uint32_t(lane) < nl[u]; if (lv[u]) S->scr[dest[u] - bound0] = 0x200; }
+        LDS_ORDER();
+        uint32_t t[K], val[K];
+#pragma unroll
+        for (int u = 0; u < K; u++) t[u] = S->scr[(lv[u] && sp[u] >= bound0) ? sp[u] - bound0 : uint32_t(kSpan)];     // scr[kSpan] stays 0
+        bool now[K]; unsigned long long pend[K];
+#pragma unroll
+        for (int u = 0; u < K; u++) { now[u] = lv[u] && t[u] == 0; pend[u] = __ballot(lv[u] && t[u] != 0); }
+        pf.add(5, tc); tc = pf.now();
+#pragma unroll
+        for (int u = 0; u < K; u++) val[u] = dst[now[u] ? sp[u] : 0u];
+#ifdef K1R_PROF
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pf.add(6, tc); tc = pf.now();
+#endif
+#pragma unroll
+        for (int u = 0; u < K; u++) if (now[u]) { dst[dest[u]] = uint8_t(val[u]); S->scr[dest[u] - bound0] = uint16_t(0x100u | val[u]); }
+        for (uint32_t rounds = 0;; rounds++) {
+            unsigned long long any = 0;
+#pragma unroll
+            for (int u = 0; u < K; u++) any |= pend[u];
+            if (!any) break;
+            if (rounds > 64u * K) { stv(&S->failed, 1); return; }       // every round completes a lane: more means broken marks
+            pf.count(3);
+            LDS_ORDER();
+#pragma unroll
+            for (int u = 0; u < K; u++) t[u] = S->scr[((pend[u] >> lane) & 1) ? sp[u] - bound0 : uint32_t(kSpan)];
+#pragma unroll
+            for (int u = 0; u < K; u++) {
+                const bool got = (t[u] & 0x100) != 0;
+                if (got) { dst[dest[u]] = uint8_t(t[u]); S->scr[dest[u] - bound0] = uint16_t(t[u]); }
+                pend[u] &= ~__ballot(got);
+            }
+        }
+        g += avail;
+        pf.add(0, tc);
+    }
+}
+
+__global__ __launch_bounds__(256, 8)
+void lz4_decode_rows_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
+                            fourmc_block* blocks, uint32_t nblocks, int container_mode, unsigned long long* prof)
+{
+    __shared__ __attribute__((aligned(16))) Shared S;
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    const fourmc_block blk = uniform_block(blocks[b]);
+    if (container_mode && blk.result == FOURMC_BLK_BADSUM) return;
+    const uint8_t* src = src_base + blk.src_off;
+    uint8_t* dst = dst_base + blk.dst_off;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    if (container_mode && blk.src_len == blk.dst_cap) {                 // stored block (native/4mc.c:635-642)
+        if (wave == 0) { wave_copy(dst, src, int(blk.src_len), lane); if (lane == 0) blocks[b].result = int(blk.src_len); }
+        return;
+    }
+    if (blk.src_len < 8 || blk.src_len > lz4par::kSrcMax || blk.dst_cap < 64 || blk.dst_cap > lz4par::kDstMax) {
+        if (threadIdx.x == 0) blocks[b].result = kRetry;
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < uint32_t(kOwn); i += 256) S.own[i] = 0;
+    if (threadIdx.x < uint32_t(kNR)) S.res[threadIdx.x] = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < uint32_t(kNQ)) S.pub[threadIdx.x] = make_uint2(0, 0);
+    if (threadIdx.x == 0) {
+        S.scr[kSpan] = 0; S.pw = make_uint2(0, 0); S.cc = make_uint2(0, 0); S.post_rows = 0; S.total_q = 0xFFFFFFFFu; S.failed = 0; S.end_value = kRetry;
+    }
+    __syncthreads();
+    const int csize = int(blk.src_len), cap = int(blk.dst_cap);
+    Prof pf;
+    const unsigned long long t_role = pf.now();
+    cgbyte* gsrc = (cgbyte*)src; gbyte* gdst = (gbyte*)dst;
+    if (wave == 0) role_pre(&S, pf, gsrc, csize, lane);
+    else if (wave == 1) role_walk(&S, pf, gsrc, gdst, csize, cap, lane);
+    else if (wave == 2) role_post(&S, pf, gsrc, gdst, csize, lane);
+    else role_copy<K1R_STEPS>(&S, pf, gdst, lane);
+    pf.add(7, t_role);
+#ifdef K1R_PROF
+    if (prof && lane == 0) for (int i = 0; i < 8; i++) prof[(size_t(b) * 4 + wave) * 8 + i] = pf.t[i];
+#endif
+    __syncthreads();
+    if (threadIdx.x == 0) blocks[b].result = S.failed ? kRetry : S.end_value;
+}
+
+} // namespace
+
+#ifdef K1R_PROF
+static unsigned long long* g_prof = nullptr; static uint32_t g_prof_blocks = 0;
+#endif
+extern "C" hipError_t fourmc_launch_lz4_rows(const void* d_src, void* d_dst, fourmc_block* d_blocks,
+                                             uint32_t n, int container_mode, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    unsigned long long* prof = nullptr;
+#ifdef K1R_PROF
+    if (n > g_prof_blocks) { if (g_prof) (void)hipFree(g_prof); g_prof = nullptr; if (hipMalloc(&g_prof, size_t(n) * 32 * 8) == hipSuccess) g_prof_blocks = n; }
+    prof = g_prof;
+#endif
+    hipLaunchKernelGGL(lz4_decode_rows_kernel, dim3(n), dim3(256), 0, stream,
+                       static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n, container_mode, prof);
+    return hipGetLastError();
+}
+
+#ifdef K1R_PROF
+// profiling side build only: the counters of the last launch, [block][role: pre, walk, post, copy][8]
+extern "C" int fourmc_gpu_debug_rows_prof(unsigned long long* host, uint32_t nblocks)
+{
+    if (!g_prof || nblocks > g_prof_blocks) return -1;
+    return hipMemcpy(host, g_prof, size_t(nblocks) * 32 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
