@@ -37,19 +37,22 @@ namespace {
 
 constexpr int kRetry = lz4par::kRetryCode;
 constexpr int kNR  = 8;            // rows in the table / field ring
-constexpr int kNQ  = 8;            // records in flight between POST / WALK and COPY
+constexpr int kNQ  = 16;           // records in flight between POST / WALK and COPY
 constexpr int kOwn = 2048;         // match-space ring of start marks (entries)
 constexpr int kSpan = 512;         // output bytes one copier window may span
 constexpr uint32_t kMaxRowLits = 2047, kMaxRowMatch = 511;    // a row beyond these goes token by token (four rows of marks fit the ring)
 constexpr int kTailGuard = 16 + 337 + 64;   // rows whose tokens may touch the last 16 stream bytes are never batched
 constexpr uint32_t kSpinLimit = 1u << 19;
+#ifndef K1R_NAP
+#define K1R_NAP 6                   // s_sleep units (64 clk) between two looks at a progress word
+#endif
 #ifndef K1R_STEPS
 #define K1R_STEPS 4                 // 64-lane sub-steps the copier keeps in flight per iteration
 #endif
 
 struct RowSlot { uint32_t tab[64]; uint2 fld[64]; };
 struct Shared {
-    uint32_t own[kOwn];            // own[m & (kOwn-1)] = key of the token whose match starts at match-space position m
+    uint16_t own[kOwn];            // own[m & (kOwn-1)] = mark of the token whose match starts at match-space position m (see COPY)
     RowSlot  rows[kNR];
     uint2    rec[kNQ][64];         // per record and token lane: {offset | mpos << 16, D | (mpos >> 16) << 22 | overlap << 31}
     uint4    res[kNR];             // WALK -> POST, per visited row: {row + 1, entry | q << 6, output position, match-space position}
@@ -105,7 +108,7 @@ template <class P, class F> __device__ __forceinline__ bool wait_until(Shared* S
     const unsigned long long t0 = pf.now();
     for (uint32_t spins = 0;;) {
         if (rfl(ldv(&S->failed))) return false;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(K1R_NAP);
         poll();
         if (cond()) break;
         if (++spins > kSpinLimit) { stv(&S->failed, 1); return false; }
@@ -302,7 +305,7 @@ __device__ void role_walk(Shared* S, Prof& pf, cgbyte* src, gbyte* dst, int csiz
         if (!wait_until(S, pf, 2, [&] { const uint2 c = ldv2(&S->cc); cq_seen = c.x; cg_seen = c.y; },
                         [&] { return cq_seen + kNQ > q && mb < cg_seen + kOwn; })) return;
         if (lane == 0) {
-            S->own[mb & (kOwn - 1)] = (q << 6) << 3;
+            S->own[mb & (kOwn - 1)] = uint16_t(((q & 511) << 6) + 1);
             S->rec[q & (kNQ - 1)][0] = make_uint2(uint32_t(off) | mb << 16,
                                                   uint32_t(op2 - int(mb)) | (mb >> 16) << 22 | (off < mlen ? 1u : 0u) << 31);
         }
@@ -425,7 +428,7 @@ __device__ void role_post(Shared* S, Prof& pf, cgbyte* src, gbyte* dst, int csiz
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (pz[u] != 0) {
-                    S->own[mpos[u] & (kOwn - 1)] = (q[u] << 6 | uint32_t(lane)) << 3;
+                    S->own[mpos[u] & (kOwn - 1)] = uint16_t(((q[u] & 511) << 6 | uint32_t(lane)) + 1);
                     S->rec[q[u] & (kNQ - 1)][lane] = make_uint2((f[u].x & 0xffff) | mpos[u] << 16,
                                                                 D[u] | (mpos[u] >> 16) << 22 | ((f[u].y >> 9) & 1) << 31);
                 }
@@ -484,12 +487,15 @@ __device__ void role_post(Shared* S, Prof& pf, cgbyte* src, gbyte* dst, int csiz
 }
 
 // ---------------------------------------------------------------------------------------------------------- COPY
+// Start marks are 16 bits: ((q & 511) << 6 | token lane) + 1, 0 = none.  The copier clears the marks it has consumed, so
+// every mark it reads belongs to a record in flight, and compares them relative to the oldest unconsumed record (at
+// most kNQ records are in flight: the 9 bits of q never wrap inside one comparison).
 template <int K>
 __device__ void role_copy(Shared* S, Prof& pf, gbyte* dst, int lane)
 {
-    uint32_t g = 0, qa = 0, cqv = 0, ext = 0, ck = 0;
+    uint32_t g = 0, qa = 0, cqv = 0, ext = 0, ckraw = 0, idle = 0;
     for (uint32_t spins = 0;;) {
-        g = rfl(g); qa = rfl(qa); cqv = rfl(cqv); ext = rfl(ext); ck = rfl(ck);
+        g = rfl(g); qa = rfl(qa); cqv = rfl(cqv); ext = rfl(ext); ckraw = rfl(ckraw); idle = rfl(idle);
         // one round trip: the publication words of all record slots (lanes 0..7) and the start marks of the next K * 64
         // match-space positions
         unsigned long long tc = pf.now();
@@ -503,34 +509,42 @@ __device__ void role_copy(Shared* S, Prof& pf, gbyte* dst, int lane)
             cqv += uint32_t(__builtin_popcountll(__ballot(lane < kNQ && ql < qa && pb.y <= g)));
             // records that became ready: slots qa, qa + 1, ... in a row
             const uint32_t qn = qa + ((uint32_t(lane) - qa) & (kNQ - 1));
-            const uint32_t ok = uint32_t(__ballot(lane < kNQ && pb.x == qn + 1)) & 0xffu;
-            const uint32_t rot = ((ok | ok << 8) >> (qa & (kNQ - 1))) & 0xffu;
-            const uint32_t n = uint32_t(__builtin_ctz(~rot));             // 0..8
+            const uint32_t ok = uint32_t(__ballot(lane < kNQ && pb.x == qn + 1)) & ((1u << kNQ) - 1);
+            const uint32_t rot = uint32_t(((unsigned long long)ok | (unsigned long long)ok << kNQ) >> (qa & (kNQ - 1))) & ((1u << kNQ) - 1);
+            const uint32_t n = uint32_t(__builtin_ctz(~rot));             // 0..kNQ
             if (n) { ext = rdl(pb.y, (qa + n - 1) & (kNQ - 1)); qa += n; }
         }
         LDS_ORDER();
         if (lane == 0) *reinterpret_cast<volatile unsigned long long*>(&S->cc) = (unsigned long long)cqv | (unsigned long long)g << 32;
+        const bool ended = rfl(ldv(&S->total_q)) == qa;
         if (ext == g) {
-            if (rfl(ldv(&S->total_q)) == qa) break;                     // every record consumed
+            if (ended) break;                                           // every record consumed
             if (rfl(ldv(&S->failed))) return;
             __builtin_amdgcn_s_sleep(1);
             if (++spins > kSpinLimit) { stv(&S->failed, 1); return; }
             continue;
         }
-        spins = 0;
+        spins = 0; idle = 0;
         pf.count(1); pf.count(2, min(ext - g, 64u * K));
         uint32_t avail = min(ext - g, 64u * K);
         // ---- owners.  Everything below is written as batches of K independent operations without branches in between:
         // the compiler issues the K LDS / memory operations of a batch back to back and waits once (a branch around each
         // would serialise them, one round trip after the other)
+        // marks are compared relative to the record before the oldest unconsumed one: the carried owner (of the last byte
+        // consumed) may belong to it
+        const uint32_t base = ((cqv - 1) & 511) << 6;
         uint32_t dest[K], sp[K], km[K], nl[K];
 #pragma unroll
-        for (int u = 0; u < K; u++) { nl[u] = avail > 64u * u ? min(avail - 64u * u, 64u) : 0u; km[u] = scan_max(mark[u]); }
+        for (int u = 0; u < K; u++) {
+            nl[u] = avail > 64u * u ? min(avail - 64u * u, 64u) : 0u;
+            km[u] = scan_max(mark[u] ? ((mark[u] - 1 - base) & 0x7FFF) + 1 : 0u);
+        }
+        uint32_t ck = ckraw ? ((ckraw - 1 - base) & 0x7FFF) + 1 : 0u;
 #pragma unroll
         for (int u = 0; u < K; u++) { km[u] = max(km[u], ck); const uint32_t last = rdl(km[u], nl[u] ? nl[u] - 1 : 0u); ck = nl[u] ? last : ck; }
         uint2 rc[K];
 #pragma unroll
-        for (int u = 0; u < K; u++) rc[u] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(&S->rec[0][0]) + (km[u] & 0xFFF));
+        for (int u = 0; u < K; u++) rc[u] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(&S->rec[0][0]) + (((km[u] - 1 + base) & (kNQ * 64 - 1)) << 3));
         unsigned long long anyovl = 0;
 #pragma unroll
         for (int u = 0; u < K; u++) {
@@ -566,15 +580,20 @@ __device__ void role_copy(Shared* S, Prof& pf, gbyte* dst, int lane)
                 for (int u = 0; u < K; u++) { nl[u] = avail > 64u * u ? min(avail - 64u * u, 64u) : 0u; if (uint32_t(u) == lu) ck = rdl(km[u], ll); }
             }
         }
+        ckraw = ((ck - 1 + base) & 0x7FFF) + 1;                         // ck != 0: the window has at least one byte, its owner a mark
         pf.add(4, tc); tc = pf.now();
         // ---- execute.  Sources inside the window: a match byte another lane of the window produces travels through the
         // scratch; anything else (literals, older output) is in memory already - records are admitted only once their
-        // literals are
-        reinterpret_cast<uint4*>(S->scr)[lane] = make_uint4(0, 0, 0, 0);
+        // literals are.  The marks of the window are consumed: cleared.
+#pragma unroll
+        for (int i = 0; i < kSpan * 2 / 1024; i++) reinterpret_cast<uint4*>(S->scr)[lane + 64 * i] = make_uint4(0, 0, 0, 0);
         LDS_ORDER();
         bool lv[K];
 #pragma unroll
-        for (int u = 0; u < K; u++) { lv[u] = uint32_t(lane) < nl[u]; if (lv[u]) S->scr[dest[u] - bound0] = 0x200; }
+        for (int u = 0; u < K; u++) {
+            lv[u] = uint32_t(lane) < nl[u];
+            if (lv[u]) { S->scr[dest[u] - bound0] = 0x200; S->own[(g + 64u * u + uint32_t(lane)) & (kOwn - 1)] = 0; }
+        }
         LDS_ORDER();
         uint32_t t[K], val[K];
 #pragma unroll
@@ -585,12 +604,9 @@ __device__ void role_copy(Shared* S, Prof& pf, gbyte* dst, int lane)
         pf.add(5, tc); tc = pf.now();
 #pragma unroll
         for (int u = 0; u < K; u++) val[u] = dst[now[u] ? sp[u] : 0u];
-#ifdef K1R_PROF
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        pf.add(6, tc); tc = pf.now();
-#endif
 #pragma unroll
         for (int u = 0; u < K; u++) if (now[u]) { dst[dest[u]] = uint8_t(val[u]); S->scr[dest[u] - bound0] = uint16_t(0x100u | val[u]); }
+        pf.add(6, tc); tc = pf.now();
         for (uint32_t rounds = 0;; rounds++) {
             unsigned long long any = 0;
 #pragma unroll
@@ -600,11 +616,11 @@ __device__ void role_copy(Shared* S, Prof& pf, gbyte* dst, int lane)
             pf.count(3);
             LDS_ORDER();
 #pragma unroll
-            for (int u = 0; u < K; u++) t[u] = S->scr[((pend[u] >> lane) & 1) ? sp[u] - bound0 : uint32_t(kSpan)];
-#pragma unroll
             for (int u = 0; u < K; u++) {
-                const bool got = (t[u] & 0x100) != 0;
-                if (got) { dst[dest[u]] = uint8_t(t[u]); S->scr[dest[u] - bound0] = uint16_t(t[u]); }
+                if (!pend[u]) continue;                                 // (uniform) most rounds concern one or two sub-steps
+                const uint32_t tt = S->scr[((pend[u] >> lane) & 1) ? sp[u] - bound0 : uint32_t(kSpan)];
+                const bool got = (tt & 0x100) != 0;
+                if (got) { dst[dest[u]] = uint8_t(tt); S->scr[dest[u] - bound0] = uint16_t(tt); }
                 pend[u] &= ~__ballot(got);
             }
         }
@@ -633,7 +649,7 @@ void lz4_decode_rows_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_b
         if (threadIdx.x == 0) blocks[b].result = kRetry;
         return;
     }
-    for (uint32_t i = threadIdx.x; i < uint32_t(kOwn); i += 256) S.own[i] = 0;
+    for (uint32_t i = threadIdx.x; i < uint32_t(kOwn) / 2; i += 256) reinterpret_cast<uint32_t*>(S.own)[i] = 0;
     if (threadIdx.x < uint32_t(kNR)) S.res[threadIdx.x] = make_uint4(0, 0, 0, 0);
     if (threadIdx.x < uint32_t(kNQ)) S.pub[threadIdx.x] = make_uint2(0, 0);
     if (threadIdx.x == 0) {
