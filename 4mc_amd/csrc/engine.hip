@@ -30,10 +30,15 @@ int fail_hip(hipError_t e, const char* what)
 }
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail_hip(e_, #x); } while (0)
 
+// The HIP current device belongs to the THREAD: the file API runs engine calls on helper threads, which would otherwise
+// work on device 0 whatever fourmc_gpu_init / FOURMC_DEVICE selected.  Every entry point passes through here.
 int ensure_device()
 {
-    if (g_device.load(std::memory_order_acquire) >= 0) return FOURMC_OK;
-    return fourmc_gpu_init(-1);
+    int d = g_device.load(std::memory_order_acquire);
+    if (d < 0) { if (int r = fourmc_gpu_init(-1)) return r; d = g_device.load(std::memory_order_acquire); }
+    thread_local int t_device = -1;
+    if (t_device != d) { HIP_TRY(hipSetDevice(d)); t_device = d; }
+    return FOURMC_OK;
 }
 
 // Host-staging arena: device buffers reused across host-buffer calls (grown on demand).
@@ -212,13 +217,13 @@ int fourmc_gpu_debug_lz4_parse(const void* d_src, const void* d_dst, fourmc_bloc
                                void* host, size_t bytes, size_t* layout)
 {
     if (int r = ensure_device()) return r;
-    if (layout) { layout[0] = fourmc_lz4_decode_work_bytes(1); layout[1] = 64; layout[2] = fourmc_lz4_decode_tok_offset(); }
+    if (layout) { layout[0] = fourmc_lz4_parse_work_bytes(1); layout[1] = 64; layout[2] = fourmc_lz4_decode_tok_offset(); }
     if (n == 0) return FOURMC_OK;
     WsLease ws; void* work = nullptr;
-    if (int r = ws.get(nullptr, fourmc_lz4_decode_work_bytes(n), &work)) return r;
+    if (int r = ws.get(nullptr, fourmc_lz4_parse_work_bytes(n), &work)) return r;
     HIP_TRY(fourmc_launch_lz4_parse(d_src, d_dst, d_blocks, n, container_mode, work, nullptr));
     HIP_TRY(hipDeviceSynchronize());
-    const size_t have = fourmc_lz4_decode_work_bytes(n);
+    const size_t have = fourmc_lz4_parse_work_bytes(n);
     if (host && bytes) HIP_TRY(hipMemcpy(host, work, bytes < have ? bytes : have, hipMemcpyDeviceToHost));
     return FOURMC_OK;
 }
@@ -372,13 +377,16 @@ static int host_roundtrip_sharded(const void* src, void* dst, fourmc_block* bloc
     for (size_t k = 0; k < rg.size() && rc == FOURMC_OK; k++) {                      // stage + launch every range
         Arena& a = g_arenas[k]; const Range& r = rg[k];
         a.device = (dev0 + int(k)) % ndev;
-        HIP_TRY(hipSetDevice(a.device));
+        // no return from inside this loop: earlier ranges are in flight against the caller's buffers and have to be waited for
+        // below, and the thread's device has to be put back
+        auto step = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == FOURMC_OK) rc = fail_hip(e, what); return rc == FOURMC_OK; };
+        if (!step(hipSetDevice(a.device), "hipSetDevice")) break;
         if ((rc = arena_reserve(a, size_t(r.smax - r.smin), size_t(r.dmax - r.dmin), r.hi - r.lo))) break;
-        HIP_TRY(hipMemcpyAsync(a.d_src, static_cast<const char*>(src) + r.smin, size_t(r.smax - r.smin), hipMemcpyHostToDevice, a.stream));
-        HIP_TRY(hipMemcpyAsync(a.d_blk, blocks + r.lo, (r.hi - r.lo) * sizeof(fourmc_block), hipMemcpyHostToDevice, a.stream));
+        if (!step(hipMemcpyAsync(a.d_src, static_cast<const char*>(src) + r.smin, size_t(r.smax - r.smin), hipMemcpyHostToDevice, a.stream), "hipMemcpyAsync")) break;
+        if (!step(hipMemcpyAsync(a.d_blk, blocks + r.lo, (r.hi - r.lo) * sizeof(fourmc_block), hipMemcpyHostToDevice, a.stream), "hipMemcpyAsync")) break;
         rc = launch_host_op(op, codec, level, static_cast<char*>(a.d_src) - r.smin, static_cast<char*>(a.d_dst) - r.dmin, a.d_blk, r.hi - r.lo, a.stream);
         if (rc) break;
-        HIP_TRY(hipMemcpyAsync(blocks + r.lo, a.d_blk, (r.hi - r.lo) * sizeof(fourmc_block), hipMemcpyDeviceToHost, a.stream));
+        if (!step(hipMemcpyAsync(blocks + r.lo, a.d_blk, (r.hi - r.lo) * sizeof(fourmc_block), hipMemcpyDeviceToHost, a.stream), "hipMemcpyAsync")) break;
     }
     for (size_t k = 0; k < rg.size(); k++) {                                          // results, then what each block produced
         Arena& a = g_arenas[k]; const Range& r = rg[k];

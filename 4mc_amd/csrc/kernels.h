@@ -17,7 +17,8 @@ enum {
                                   // match -> result = 0
 };
 
-size_t     fourmc_lz4_decode_work_bytes(uint32_t n);
+size_t     fourmc_lz4_decode_work_bytes(uint32_t n);     /* what the selected decode path leases: 0 unless it is the block-parallel pair */
+size_t     fourmc_lz4_parse_work_bytes(uint32_t n);
 size_t     fourmc_lz4_decode_tok_offset(void);
 hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                                     uint32_t n, int container_mode, void* d_work, hipStream_t stream);

@@ -574,27 +574,37 @@ void lz4_decode_retry_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
 // Block-parallel path (lz4_parse.hip + lz4_exec.hip) for every block, then the exact walker for whatever they handed back
 // (rule violations, blocks beyond the parallel path's size limits), so results and error codes stay the reference's.
 extern "C" size_t fourmc_lz4_decode_tok_offset(void) { return lz4par::kTokOff; }
-extern "C" size_t fourmc_lz4_decode_work_bytes(uint32_t n)
+// Device workspace of the block-parallel pair (parse records): 10.8 MB per block, 21.7 GiB for a full batch.  Only launches
+// that run that pair need it; every other decode path leases nothing (tens of GiB of dead HBM per stream).
+extern "C" size_t fourmc_lz4_parse_work_bytes(uint32_t n)
 {
     const uint32_t m = n < lz4par::kMaxBatch ? n : lz4par::kMaxBatch;
     return size_t(m ? m : 1) * lz4par::kSlotBytes;
 }
+extern "C" int fourmc_gpu_get_lz4_decode_path(void);
+extern "C" size_t fourmc_lz4_decode_work_bytes(uint32_t n)
+{
+    const int path = fourmc_gpu_get_lz4_decode_path();
+    return (path == 1 || path == 3) ? fourmc_lz4_parse_work_bytes(n) : 0;
+}
 
 // Which fast path serves LZ4 decode launches.  Both produce identical results (anything irregular goes to the exact
 // walker either way); they differ in how a block is parallelised:
-//   4  "rows"            row-parallel pipeline of four waves per block (lz4_rows.hip): the default since round 3
+//   6  "auto"            4 for launches of up to 1536 blocks, 0 above: the default since round 3
+//   4  "rows"            row-parallel pipeline of four waves per block (lz4_rows.hip)
 //   0  "wave trio"       one parser wave walks the token chain, two copier waves execute (lz4_decode_fast_kernel)
 //   1  "block parallel"  parse kernel (token chain found by the whole workgroup, records in HBM) + executor kernel
 //                        (16 KiB LDS ring, literal / chain / flush waves)            lz4_parse.hip, lz4_exec.hip
 // Measured on 2048 x 4 MiB of S-mix (profiles/r02_*): 0 = 57 ms, 1 = 38 + 52 ms, so 0 stays the default; the
-// environment variable FOURMC_DECODE (rows | exact | trio | par | paronly) or fourmc_gpu_set_lz4_decode_path() select.
+// environment variable FOURMC_DECODE (auto | rows | exact | trio | par | paronly | rowsonly) or fourmc_gpu_set_lz4_decode_path() select.
 static int g_decode_path = -1;
 extern "C" void fourmc_gpu_set_lz4_decode_path(int path) { g_decode_path = path; }
 extern "C" int fourmc_gpu_get_lz4_decode_path(void)
 {
     if (g_decode_path < 0) {
         const char* mode = getenv("FOURMC_DECODE");
-        g_decode_path = 4;
+        g_decode_path = 6;
+        if (mode && !strcmp(mode, "rows")) g_decode_path = 4;
         if (mode && !strcmp(mode, "trio")) g_decode_path = 0;
         if (mode && !strcmp(mode, "rowsonly")) g_decode_path = 5;
         if (mode && !strcmp(mode, "exact")) g_decode_path = 2;
@@ -610,7 +620,11 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
     if (n == 0) return hipSuccess;
     const uint8_t* s8 = static_cast<const uint8_t*>(d_src);
     uint8_t* d8 = static_cast<uint8_t*>(d_dst);
-    const int path = fourmc_gpu_get_lz4_decode_path();
+    int path = fourmc_gpu_get_lz4_decode_path();
+    // 6 "auto": a launch that leaves wave slots free is bound by the chain of its slowest block - the row pipeline's is the
+    // shorter one (36 ms against 43 ms for 64..256 blocks of the S-mix); a launch that fills every CU with eight blocks is
+    // bound by what the CU can issue, where the wave trio needs less (57 ms against 59 ms for 2048 blocks)
+    if (path == 6) path = n <= 1536 ? 4 : 0;
     if (path == 2) {
         hipLaunchKernelGGL(lz4_decode_exact_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
         return hipGetLastError();

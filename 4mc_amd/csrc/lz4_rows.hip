@@ -50,12 +50,13 @@ constexpr uint32_t kSpinLimit = 1u << 19;
 #define K1R_STEPS 4                 // 64-lane sub-steps the copier keeps in flight per iteration
 #endif
 
-struct RowSlot { uint32_t tab[64]; uint2 fld[64]; };
+struct RowSlot { uint32_t tab[64]; uint4 fld[64]; };        // fld: {x, y, token-chain mask of the entry (lo, hi)}
+constexpr int kRecTok = 24;        // token records per row record (a row of 64 bytes holds 21 tokens at most)
 struct Shared {
     uint16_t own[kOwn];            // own[m & (kOwn-1)] = mark of the token whose match starts at match-space position m (see COPY)
     RowSlot  rows[kNR];
-    uint2    rec[kNQ][64];         // per record and token lane: {offset | mpos << 16, D | (mpos >> 16) << 22 | overlap << 31}
-    uint4    res[kNR];             // WALK -> POST, per visited row: {row + 1, entry | q << 6, output position, match-space position}
+    uint2    rec[kNQ][kRecTok];    // per record and token (by rank in its row): {offset | mpos << 16, D | (mpos >> 16) << 22 | overlap << 31}
+    uint4    res[kNR][2];          // WALK -> POST, per visited row: {row + 1, entry | q << 6, output position, match-space position}, {chain mask lo, hi, -, -}
     uint2    pub[kNQ];             // POST / WALK -> COPY, per record: {q + 1 once ready, end of the record in match space}
     uint16_t scr[kSpan + 8];         // COPY: the output bytes [bound0, bound0 + kSpan) of the window being executed: 0 literal /
                                    // older data (in memory), 0x200 match byte still to come, 0x100 | byte once produced
@@ -147,7 +148,7 @@ __device__ __forceinline__ uint32_t scan_max(uint32_t v)
 __device__ __forceinline__ uint32_t bperm(uint32_t addr4, uint32_t v) { return uint32_t(__builtin_amdgcn_ds_bpermute(int(addr4), int(v))); }
 
 // ---------------------------------------------------------------------------------------------------------- PRE
-// field word x: offset | hop << 16 | stream byte << 24;   y: match | overlap << 9 | regular << 10 | lit-ext << 11 | literals << 16
+// field word x: offset | stream byte << 24;   y: match | overlap << 9 | regular << 10 | lit-ext << 11 | literals << 16;   z, w: chain mask
 __device__ void role_pre(Shared* S, Prof& pf, cgbyte* src, int csize, int lane)
 {
     const int nrows = (csize + 63) >> 6;
@@ -180,20 +181,33 @@ __device__ void role_pre(Shared* S, Prof& pf, cgbyte* src, int csize, int lane)
             const uint32_t pz = reg ? (L[u] << 16 | ml) : 0u;
             const bool nonterm = reg && nxt < 64;
             const uint32_t h0 = nonterm ? nxt : uint32_t(lane);
-            uint32_t h4 = h0 << 2, sum = nonterm ? pz : 0u;
+            // pointer doubling over ds_bpermute.  One register carries the hop AND the sizes summed along it: literals << 19 |
+            // match bytes << 6 | hop lane (21 tokens of <= 269 / 273 bytes: 13 bits each), so a round moves both with one permute;
+            // the regular tokens on the chain that starts at each lane travel beside it as a 64-bit mask (what POST needs of a row)
+            const uint32_t pzp = (pz >> 16) << 19 | (pz & 0xffff) << 6;
+            uint32_t v = (nonterm ? pzp : 0u) | h0, h4 = h0 << 2;
+            // (the mask starts with the lane itself and the lane it hops to: k rounds cover 2^k hops, the last node included;
+            // an irregular token may get its bit - it has no sizes, which is what POST takes a token by)
+            uint32_t mlo = ((reg && lane < 32) ? 1u << lane : 0u) | (h0 < 32 ? 1u << h0 : 0u);
+            uint32_t mhi = ((reg && lane >= 32) ? 1u << (lane - 32) : 0u) | (h0 >= 32 ? 1u << (h0 - 32) : 0u);
+            auto round = [&] {
+                const uint32_t t = bperm(h4, v);
+                mlo |= bperm(h4, mlo); mhi |= bperm(h4, mhi);
+                v = (v & ~63u) + t;                     // sums add, the hop becomes the hop's hop
+                h4 = (t & 63) << 2;
+            };
 #pragma unroll
-            for (int k = 0; k < 5; k++) {               // <= 21 tokens in 64 bytes: 2^5 hops reach the terminal
-                sum += bperm(h4, sum);
-                h4 = bperm(h4, h4);
-            }
-            const uint32_t tot = sum + bperm(h4, pz);
+            for (int k = 0; k < 4; k++) round();       // 2^4 hops: chains of up to 16 tokens
+            if (__ballot(bperm(h4, h4) != h4)) round(); // (uniform) a chain of 17..21 tokens needs the fifth round
+            const uint32_t tz = bperm(h4, pzp);
+            const uint32_t tot = (v & ~63u) + (tz & ~63u);
             uint32_t X = bperm(h4, nxt);
-            uint32_t lits = tot >> 16, mls = tot & 0xffff;
+            uint32_t lits = tot >> 19, mls = (tot >> 6) & 0x1fff;
             if (lits > kMaxRowLits || mls > kMaxRowMatch) { X = uint32_t(lane); lits = 0; mls = 0; }
             RowSlot& rs = S->rows[(r0 + u) & (kNR - 1)];
             rs.tab[lane] = X << 21 | lits << 10 | mls;
             const uint32_t ovl = (reg && off < ml) ? 1u : 0u;
-            rs.fld[lane] = make_uint2(off | h0 << 16 | b << 24, pz | ovl << 9 | (reg ? 1u : 0u) << 10 | lext[u] << 11);
+            rs.fld[lane] = make_uint4(off | b << 24, pz | ovl << 9 | (reg ? 1u : 0u) << 10 | lext[u] << 11, mlo, mhi);
         }
         LDS_ORDER();
         if (lane == 0) stv(&S->pw.x, uint32_t(r0 + 4));
@@ -202,6 +216,13 @@ __device__ void role_pre(Shared* S, Prof& pf, cgbyte* src, int csize, int lane)
     uint32_t wa[4], wb[4];
     request(0, wa);
     for (int r0 = 0; r0 < nrows; r0 += 8) {
+        // rows the walk has passed already (it copies long literal runs itself) need no tables: go on where it is
+        const int walked = int(min(rfl(ldv(&S->pw.y)), uint32_t(nrows)));
+        if (walked >= r0 + 16) {
+            r0 = (walked & ~7) - 8;                                     // the loop adds 8 (nobody asks for the tables of the rows passed over)
+            request(r0 + 8, wa);
+            continue;
+        }
         request(r0 + 4, wb);
         if (!group(r0, wa)) return;
         if (r0 + 4 >= nrows) break;
@@ -269,10 +290,11 @@ __device__ void role_walk(Shared* S, Prof& pf, cgbyte* src, gbyte* dst, int csiz
         if (r <= rlast && r != row_general) {
             if (!wait_until(S, pf, 0, [&] { pre_seen = int(rfl(ldv(&S->pw.x))); }, [&] { return pre_seen > r; })) return;
             const uint32_t t = rfl(S->rows[r & (kNR - 1)].tab[e]);
+            const uint4 fe = S->rows[r & (kNR - 1)].fld[e];               // same round trip: the entry's chain mask
             const uint32_t X = t >> 21, lits = (t >> 10) & 0x7ff, mls = t & 0x3ff;
             if (X != e && op + int(lits + mls) + 80 <= oend) {
                 if (!wait_until(S, pf, 1, [&] { post_seen = int(rfl(ldv(&S->post_rows))); }, [&] { return post_seen + kNR > r; })) return;
-                if (lane == 0) S->res[r & (kNR - 1)] = make_uint4(uint32_t(r + 1), e | q << 6, uint32_t(op), mb);
+                if (lane == 0) { S->res[r & (kNR - 1)][1] = make_uint4(fe.z, fe.w, 0, 0); S->res[r & (kNR - 1)][0] = make_uint4(uint32_t(r + 1), e | q << 6, uint32_t(op), mb); }
                 decided(uint32_t(r + 1));
                 op += int(lits + mls); mb += mls; p = r * 64 + int(X); q++;
                 continue;
@@ -329,6 +351,7 @@ __device__ void role_post(Shared* S, Prof& pf, cgbyte* src, gbyte* dst, int csiz
     const int nrows = (csize + 63) >> 6;
     uint32_t pend_q = kNone, pend_m = 0;             // lanes 0..3: the records of the previous group, their literal stores issued
     uint32_t pre_seen = 0, wpos_seen = 0, cq_seen = 0, cg_seen = 0;      // progress of the other roles as last read
+    uint32_t clean_from = 0, clean_to = 0;                               // rows [clean_from, clean_to) are known not to be visited
     (void)pre_seen;
     auto fail = [&]() { if (lane == 0) stv(&S->failed, 1); };
     auto publish = [&]() {
@@ -338,7 +361,7 @@ __device__ void role_post(Shared* S, Prof& pf, cgbyte* src, gbyte* dst, int csiz
     };
     auto poll_pw = [&] { const uint2 v = ldv2(&S->pw); pre_seen = v.x; wpos_seen = v.y; };
     for (int R = 0, n = 0; R < nrows; R += n) {
-        wpos_seen = rfl(wpos_seen); cq_seen = rfl(cq_seen); cg_seen = rfl(cg_seen);
+        wpos_seen = rfl(wpos_seen); cq_seen = rfl(cq_seen); cg_seen = rfl(cg_seen); clean_from = rfl(clean_from); clean_to = rfl(clean_to);
         unsigned long long tp = pf.now();
         // the group: the rows the walk has decided, four at most (waiting for a full group could wait for the walk while the
         // walk waits for the copier and the copier for this group's records)
@@ -350,50 +373,46 @@ __device__ void role_post(Shared* S, Prof& pf, cgbyte* src, gbyte* dst, int csiz
             }
         }
         n = int(min(wpos_seen - uint32_t(R), 4u));
+        // The walk writes a row's word only while that row is less than kNR rows above post_rows: seen from row R, the decided rows
+        // from R + kNR on were not visited (the walk is past them and never returns).  Long literal runs make such stretches: pass them.
+        if (wpos_seen > clean_to && uint32_t(R + kNR) < wpos_seen) {
+            if (uint32_t(R + kNR) > clean_to) clean_from = uint32_t(R + kNR);
+            clean_to = wpos_seen;
+        }
+        if (uint32_t(R) >= clean_from && uint32_t(R) < clean_to) {
+            n = int(min(clean_to, uint32_t(nrows)) - uint32_t(R));
+            LDS_ORDER();
+            if (lane == 0) stv(&S->post_rows, uint32_t(R + n));
+            continue;
+        }
         LDS_ORDER();
         pf.add(0, tp); tp = pf.now();
         // one round trip: the walk's words and the fields of the four rows
-        uint4 rs[4]; uint2 f[4];
+        // (the progress word is read first: rows it shows as produced are in the ring when the field reads below execute)
+        const unsigned long long pwv = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&S->pw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        LDS_ORDER();
+        const uint32_t f4x = S->rows[(R + 4) & (kNR - 1)].fld[lane].x;   // stream bytes of the row behind the group (literal runs reaching into it)
+        uint4 rs[4], rm[4]; uint2 f[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { rs[u] = S->res[(R + u) & (kNR - 1)]; f[u] = S->rows[(R + u) & (kNR - 1)].fld[lane]; }
-        bool vis[4]; uint32_t e[4], q[4], mb[4]; int op[4];
+        for (int u = 0; u < 4; u++) {
+            rs[u] = S->res[(R + u) & (kNR - 1)][0]; rm[u] = S->res[(R + u) & (kNR - 1)][1];
+            f[u] = *reinterpret_cast<const uint2*>(&S->rows[(R + u) & (kNR - 1)].fld[lane]);
+        }
+        bool vis[4]; uint32_t q[4], mb[4]; int op[4]; unsigned long long tokmask[4];
         bool any = false;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             vis[u] = u < n && rfl(rs[u].x) == uint32_t(R + u + 1);
-            const uint32_t eq = rfl(rs[u].y);
-            e[u] = vis[u] ? eq & 63 : 0u; q[u] = eq >> 6; op[u] = int(rfl(rs[u].z)); mb[u] = rfl(rs[u].w);
+            q[u] = rfl(rs[u].y) >> 6; op[u] = int(rfl(rs[u].z)); mb[u] = rfl(rs[u].w);
+            tokmask[u] = vis[u] ? ((unsigned long long)rfl(rm[u].y) << 32 | rfl(rm[u].x)) : 0ull;
             any |= vis[u];
         }
         pf.add(1, tp); tp = pf.now();
         if (any) {
-            // ---- the true tokens of each row: four v_readlane chains side by side, marks dropped by v_writelane (the chain
-            // stays on the vector unit: a scalar bit-set between two hops would put a VALU -> SGPR -> SALU round trip into it)
-            uint32_t pos[4], hop[4], tokv[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { pos[u] = e[u]; hop[u] = vis[u] ? (f[u].x >> 16) & 63 : uint32_t(lane); tokv[u] = 0; }
-            for (int round = 0; round < 3; round++) {
-#pragma unroll
-                for (int i = 0; i < 7; i++) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        asm volatile("s_nop 3\n\tv_writelane_b32 %0, 1, %1" : "+v"(tokv[u]) : "s"(pos[u]));
-                        pos[u] = rdl(hop[u], pos[u]);
-                    }
-                }
-                bool done = true;
-#pragma unroll
-                for (int u = 0; u < 4; u++) done &= rdl(hop[u], pos[u]) == pos[u];
-                if (done) break;
-            }
             pf.add(2, tp); tp = pf.now();
             uint32_t pz[4], incl[4], excl[4], mls_t[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                asm volatile("s_nop 3\n\tv_writelane_b32 %0, 1, %1" : "+v"(tokv[u]) : "s"(pos[u]));
-                const bool is_tok = vis[u] && tokv[u] != 0 && ((f[u].y >> 10) & 1);       // on the chain, and a regular token
-                pz[u] = is_tok ? (f[u].y & 0x01FF01FFu) : 0u;
-            }
+            for (int u = 0; u < 4; u++) pz[u] = ((tokmask[u] >> lane) & 1) ? (f[u].y & 0x01FF01FFu) : 0u;
 #pragma unroll
             for (int u = 0; u < 4; u++) incl[u] = scan_add(pz[u]);
             uint32_t q_last = 0, m_end = 0; unsigned long long bad = 0;
@@ -428,8 +447,9 @@ __device__ void role_post(Shared* S, Prof& pf, cgbyte* src, gbyte* dst, int csiz
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (pz[u] != 0) {
-                    S->own[mpos[u] & (kOwn - 1)] = uint16_t(((q[u] & 511) << 6 | uint32_t(lane)) + 1);
-                    S->rec[q[u] & (kNQ - 1)][lane] = make_uint2((f[u].x & 0xffff) | mpos[u] << 16,
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(tokmask[u] >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(tokmask[u]), 0u));
+                    S->own[mpos[u] & (kOwn - 1)] = uint16_t(((q[u] & 511) << 6 | rank) + 1);
+                    S->rec[q[u] & (kNQ - 1)][rank] = make_uint2((f[u].x & 0xffff) | mpos[u] << 16,
                                                                 D[u] | (mpos[u] >> 16) << 22 | ((f[u].y >> 9) & 1) << 31);
                 }
                 if (vis[u] && lane == u) { new_q = q[u]; new_m = mb[u] + mls_t[u]; }
@@ -442,37 +462,28 @@ __device__ void role_post(Shared* S, Prof& pf, cgbyte* src, gbyte* dst, int csiz
                 const uint32_t dl = (excl[u] >> 16) + (excl[u] & 0xffff) + 512 - litlo;   // output position of stream lane 0, relative to op - 512
                 km[u] = scan_max(pz[u] != 0 ? (litlo << 23 | (pz[u] >> 16) << 14 | dl) : 0u);
             }
-            int sn[4]; bool spilled = false, spill_more = false;
+            const uint32_t pre_now = rfl(uint32_t(pwv));
 #pragma unroll
             for (int u = 0; u < 4; u++) {                               // rows without tokens: no lane passes the test
                 if (uint32_t(lane) - (km[u] >> 23) < ((km[u] >> 14) & 0x1ff)) dst[lane + int(km[u] & 0x3fff) + op[u] - 512] = uint8_t(f[u].x >> 24);
-                // the row's last token: literals beyond the row come straight from the stream
-                const uint32_t k63 = rdl(km[u], 63);
-                sn[u] = int(k63 >> 23) + int((k63 >> 14) & 0x1ff) - max(int(k63 >> 23), 64);
-                spilled |= sn[u] > 0; spill_more |= sn[u] > 64;
             }
-            if (spilled) {                                              // the first 64 bytes of every run in one batch of loads
-                uint32_t sv[4];
+            // the row's last token: its literals may run on into the next rows.  Their first 64 bytes are the next row's stream
+            // bytes - held by this wave (the next row of the group, or the row behind it), lane for lane
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int first = max(int(rdl(km[u], 63) >> 23), 64);           // row-relative stream position of the first byte outside
-                    sv[u] = src[lane < sn[u] ? (R + u) * 64 + first + lane : 0];
+            for (int u = 0; u < 4; u++) {
+                const uint32_t k63 = rdl(km[u], 63);
+                const uint32_t lo63 = k63 >> 23, end63 = lo63 + ((k63 >> 14) & 0x1ff);      // row-relative stream positions
+                if (end63 <= 64) continue;                              // (uniform) nothing outside the row
+                int from_pos = int(max(lo63, 64u));
+                if (pre_now > uint32_t(R + u + 1)) {
+                    const uint32_t nb = (u < 3 ? f[u < 3 ? u + 1 : 0].x : f4x) >> 24;
+                    if (uint32_t(lane + 64) - lo63 < ((k63 >> 14) & 0x1ff)) dst[lane + 64 + int(k63 & 0x3fff) + op[u] - 512] = uint8_t(nb);
+                    from_pos = 128;
                 }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t k63 = rdl(km[u], 63);
-                    const int first = max(int(k63 >> 23), 64);
-                    if (lane < sn[u]) dst[first + int(k63 & 0x3fff) + op[u] - 512 + lane] = uint8_t(sv[u]);
-                }
-                if (spill_more) {
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const uint32_t k63 = rdl(km[u], 63);
-                        const int first = max(int(k63 >> 23), 64);
-                        cgbyte* from = src + (R + u) * 64 + first;
-                        gbyte* to = dst + first + int(k63 & 0x3fff) + op[u] - 512;
-                        for (int k = 64 + lane; k < sn[u]; k += 64) { const uint8_t v = from[k]; to[k] = v; }
-                    }
+                if (end63 > uint32_t(from_pos)) {                       // rare: beyond what is at hand - straight from the stream
+                    cgbyte* from = src + (R + u) * 64;
+                    gbyte* to = dst + int(k63 & 0x3fff) + op[u] - 512;
+                    for (int k = from_pos + lane; k < int(end63); k += 64) { const uint8_t v = from[k]; to[k] = v; }
                 }
             }
             pf.add(5, tp); tp = pf.now();
@@ -499,12 +510,14 @@ __device__ void role_copy(Shared* S, Prof& pf, gbyte* dst, int lane)
         // one round trip: the publication words of all record slots (lanes 0..7) and the start marks of the next K * 64
         // match-space positions
         unsigned long long tc = pf.now();
-        const uint2 pb = S->pub[lane & (kNQ - 1)];
+        const bool look = ext - g < 64u * K;                              // a full window is there already: no need to look for records
+        uint2 pb = make_uint2(0, 0);
+        if (look) pb = S->pub[lane & (kNQ - 1)];
         LDS_ORDER();                                   // issued in this order: a record seen ready has its marks in place
         uint32_t mark[K];
 #pragma unroll
         for (int u = 0; u < K; u++) mark[u] = S->own[(g + 64u * u + uint32_t(lane)) & (kOwn - 1)];
-        {   // records consumed so far: [cqv, qa) with an end at or below g
+        if (look) {   // records consumed so far: [cqv, qa) with an end at or below g
             const uint32_t ql = cqv + ((uint32_t(lane) - cqv) & (kNQ - 1));
             cqv += uint32_t(__builtin_popcountll(__ballot(lane < kNQ && ql < qa && pb.y <= g)));
             // records that became ready: slots qa, qa + 1, ... in a row
@@ -544,7 +557,10 @@ __device__ void role_copy(Shared* S, Prof& pf, gbyte* dst, int lane)
         for (int u = 0; u < K; u++) { km[u] = max(km[u], ck); const uint32_t last = rdl(km[u], nl[u] ? nl[u] - 1 : 0u); ck = nl[u] ? last : ck; }
         uint2 rc[K];
 #pragma unroll
-        for (int u = 0; u < K; u++) rc[u] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(&S->rec[0][0]) + (((km[u] - 1 + base) & (kNQ * 64 - 1)) << 3));
+        for (int u = 0; u < K; u++) {
+            const uint32_t x = km[u] - 1 + base;                        // (q & 511) << 6 | rank
+            rc[u] = S->rec[(x >> 6) & (kNQ - 1)][min(x & 63, uint32_t(kRecTok - 1))];
+        }
         unsigned long long anyovl = 0;
 #pragma unroll
         for (int u = 0; u < K; u++) {
@@ -650,7 +666,7 @@ void lz4_decode_rows_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_b
         return;
     }
     for (uint32_t i = threadIdx.x; i < uint32_t(kOwn) / 2; i += 256) reinterpret_cast<uint32_t*>(S.own)[i] = 0;
-    if (threadIdx.x < uint32_t(kNR)) S.res[threadIdx.x] = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < uint32_t(kNR)) S.res[threadIdx.x][0] = make_uint4(0, 0, 0, 0);
     if (threadIdx.x < uint32_t(kNQ)) S.pub[threadIdx.x] = make_uint2(0, 0);
     if (threadIdx.x == 0) {
         S.scr[kSpan] = 0; S.pw = make_uint2(0, 0); S.cc = make_uint2(0, 0); S.post_rows = 0; S.total_q = 0xFFFFFFFFu; S.failed = 0; S.end_value = kRetry;

@@ -58,6 +58,11 @@ int fourmc_shard_write(int fd, uint32_t magic, int rank, uint64_t first, uint64_
     uint8_t hdr[12];
     uint64_t b;
     if (rank == 0) {
+        /* The reference opens its output with "wb" (native/4mc.c:200): an older, longer file of that name must not leave bytes
+         * behind the footer - readers find the footer from the END of the file.  After the gather every rank knows the final
+         * size; rank 0 sets it.  Cutting to the FINAL size cannot hurt what the other ranks have written already. */
+        const uint64_t final_size = (nblocks ? off_all[nblocks - 1] + 12 + csize_all[nblocks - 1] : 12) + 12 + (20 + 4 * nblocks);
+        if (ftruncate(fd, (off_t)final_size) != 0) return -1;
         fourmc_frame_header(hdr, magic);
         if (pwrite_all(fd, hdr, 12, 0)) return -1;
     }
@@ -127,7 +132,11 @@ int fourmc_file_compress_sharded(const char* in_name, const char* out_name, int 
         blk[b].dst_cap = blk[b].src_len;
     }
     if (count && fourmc_host_4mc_encode(in_buf, in_bytes, out_buf, count * FOURMC_BLOCKSIZE, blk, (uint32_t)count, codec, codec_level) != FOURMC_OK) { rc = -3; goto done; }
-    for (b = 0; b < count; b++) { cs_mine[b] = (uint32_t)blk[b].result; usz[b] = blk[b].src_len; xs[b] = blk[b].xxh32; poff[b] = blk[b].dst_off; }
+    for (b = 0; b < count; b++) {
+        /* a per-block failure code must not become a 4 GiB size that every rank then builds its offsets on */
+        if (blk[b].result <= 0 || (uint32_t)blk[b].result > blk[b].src_len) { rc = -3; goto done; }
+        cs_mine[b] = (uint32_t)blk[b].result; usz[b] = blk[b].src_len; xs[b] = blk[b].xxh32; poff[b] = blk[b].dst_off;
+    }
 
     /* the one exchange of the path: per-block compressed sizes, padded to equal counts per rank */
     if (world > 1) { if (allgather(ctx, cs_pad, per * 4, cs_all) != 0) { rc = -4; goto done; } }

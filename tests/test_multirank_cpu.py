@@ -113,6 +113,9 @@ def test_two_ranks_write_one_4mc_file(tmp_path):
     helpers.oracle(); helpers.corpus_lib()                       # build the checkers once, not in both ranks at the same time
     man = json.load(open(os.path.join(helpers.ROOT, "tests", "golden", "corpus_manifest.json")))
     path = str(tmp_path / "two_ranks.4mc")
+    # an older, LONGER file of that name: nothing of it may survive behind the footer (readers find the footer from the end)
+    with open(path, "wb") as f:
+        f.write(b"\xEE" * (man["levels"]["4mc-1"]["file_bytes"] + 12345))
     ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
     ps = [ctx.Process(target=_file_worker, args=(r, 2, port, path, q)) for r in range(2)]
     [p.start() for p in ps]
