@@ -553,6 +553,43 @@ int fourmc_host_4mc_decode(const void* src, size_t src_bytes, void* dst, size_t 
                            fourmc_block* blocks, uint32_t n, int codec)
 { return host_roundtrip(src, src_bytes, dst, dst_bytes, blocks, n, 1, codec, 0); }
 
+// Encode `n` blocks and hand back the finished piece of the .4mc / .4mz file: "12-byte header + payload" per block, back
+// to back (native/4mc.c:309-315), laid down in HBM by pack.hip and copied to `image` in ONE transfer - `image` may be the
+// file itself (a shared mapping): nothing passes through a staging buffer or stdio.  image_off[b] = where block b's header
+// sits in the piece (the footer index is built from these), *image_bytes = its length.
+int fourmc_host_4mc_encode_image(const void* src, size_t src_bytes, fourmc_block* blocks, uint32_t n, int codec, int level,
+                                 void* image, size_t image_cap, uint64_t* image_off, size_t* image_bytes)
+{
+    if (int r = ensure_device()) return r;
+    if (n == 0) { *image_bytes = 0; return FOURMC_OK; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    static void* d_img = nullptr; static size_t img_cap = 0;          // guarded by g_mu, like the arena
+    static uint64_t* d_ioff = nullptr; static size_t ioff_cap = 0;
+    size_t dst_bytes = 0;
+    for (uint32_t b = 0; b < n; b++) dst_bytes = std::max<size_t>(dst_bytes, blocks[b].dst_off + blocks[b].dst_cap);
+    if (int r = arena_reserve(g_arena, src_bytes, dst_bytes, n)) return r;
+    hipStream_t s = g_arena.stream;
+    HIP_TRY(hipMemcpyAsync(g_arena.d_src, src, src_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(g_arena.d_blk, blocks, n * sizeof(fourmc_block), hipMemcpyHostToDevice, s));
+    if (int r = launch_host_op(0, codec, level, g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s)) return r;
+    HIP_TRY(hipMemcpyAsync(blocks, g_arena.d_blk, n * sizeof(fourmc_block), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    uint64_t pos = 0;
+    for (uint32_t b = 0; b < n; b++) {
+        if (blocks[b].result <= 0 || uint32_t(blocks[b].result) > blocks[b].src_len) { snprintf(g_err, sizeof g_err, "block %u: encoder returned %d", b, blocks[b].result); return FOURMC_EINVAL; }
+        image_off[b] = pos; pos += 12ull + uint32_t(blocks[b].result);
+    }
+    if (pos > image_cap) { snprintf(g_err, sizeof g_err, "image capacity %zu below %llu", image_cap, (unsigned long long)pos); return FOURMC_EINVAL; }
+    if (pos > img_cap) { if (d_img) HIP_TRY(hipFree(d_img)); d_img = nullptr; img_cap = 0; HIP_TRY(hipMalloc(&d_img, pos + pos / 8 + 4096)); img_cap = pos + pos / 8 + 4096; }
+    if (n > ioff_cap) { if (d_ioff) HIP_TRY(hipFree(d_ioff)); d_ioff = nullptr; ioff_cap = 0; HIP_TRY(hipMalloc(&d_ioff, (size_t(n) + 64) * 8)); ioff_cap = size_t(n) + 64; }
+    HIP_TRY(hipMemcpyAsync(d_ioff, image_off, size_t(n) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(fourmc_launch_pack_image(g_arena.d_dst, d_img, g_arena.d_blk, d_ioff, n, s));
+    HIP_TRY(hipMemcpyAsync(image, d_img, pos, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *image_bytes = pos;
+    return FOURMC_OK;
+}
+
 int fourmc_LZ4_compress_default(const char* src, char* dst, int srcSize, int dstCapacity)
 {
     if (srcSize < 0 || dstCapacity < 0) return 0;

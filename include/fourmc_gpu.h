@@ -150,6 +150,11 @@ int fourmc_host_4mc_encode(const void* src, size_t src_bytes, void* dst, size_t 
                            fourmc_block* blocks, uint32_t n, int codec, int level);
 int fourmc_host_4mc_decode(const void* src, size_t src_bytes, void* dst, size_t dst_bytes,
                            fourmc_block* blocks, uint32_t n, int codec);
+/* Encode `n` blocks and return the finished piece of the file image ("12-byte block header + payload" per block, back to
+ * back: native/4mc.c:309-315, :321-327) in ONE device-to-host transfer into `image` - which may be the output file itself
+ * (a shared mapping).  image_off[b]: where block b's header sits in the piece; *image_bytes: the piece's length. */
+int fourmc_host_4mc_encode_image(const void* src, size_t src_bytes, fourmc_block* blocks, uint32_t n, int codec, int level,
+                                 void* image, size_t image_cap, uint64_t* image_off, size_t* image_bytes);
 
 #ifdef __cplusplus
 }

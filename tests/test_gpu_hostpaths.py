@@ -147,3 +147,37 @@ def test_pipe_mode_and_overwrite_refusal(gpu, tmp_path):
     assert r.returncode == 3 and b"already exists" in r.stderr
     r = subprocess.run([gpu.cli_path(), str(src), str(out)], input=b"y\n", capture_output=True)       # ... and with yes
     assert r.returncode == 0 and out.read_bytes() == want
+
+
+@pytest.mark.parametrize("mapped", ["1", "0"], ids=["mapped", "streaming"])
+def test_cli_mapped_and_streaming_paths_write_the_same_files(gpu, golden_corpus, tmp_path, mapped):
+    """regular files take the mapped path (input and output files mapped, 512-block launches, no stdio in between),
+    FOURMC_MMAP=0 and pipes the streaming one: same files, same messages, same exit codes, same bytes left behind by a
+    file that is corrupt half way through (what the reference CLI leaves: native/4mc.c:637-668)."""
+    man, data, src = golden_corpus
+    env = dict(os.environ, FOURMC_MMAP=mapped)
+    for flags, key in (([], "4mc-1"), (["-2"], "4mc-2"), (["-z", "-1"], "4mz-1")):
+        out = tmp_path / ("m%s_%s" % (mapped, key)); back = tmp_path / "back.bin"
+        r = subprocess.run([gpu.cli_path(), *flags, "-f", str(src), str(out)], capture_output=True, env=env)
+        assert r.returncode == 0, r.stderr
+        assert b"Compressed (" in r.stderr
+        assert _sha(out) == man["levels"][key]["sha256"], (mapped, key)
+        dflags = ["-z"] if key.startswith("4mz") else []
+        r = subprocess.run([gpu.cli_path(), *dflags, "-d", "-f", str(out), str(back)], capture_output=True, env=env)
+        assert r.returncode == 0, r.stderr
+        assert b"Successfully decoded %d bytes" % len(data) in r.stderr
+        assert _sha(back) == man["corpus"]["sha256"]
+        if key == "4mc-1":
+            # a payload byte of a block in the middle flipped: exit 4, the blocks before it are in the output
+            img = bytearray(out.read_bytes())
+            img[len(img) // 2] ^= 0x40
+            bad = tmp_path / "bad.4mc"; bad.write_bytes(bytes(img)); part = tmp_path / ("part%s.bin" % mapped)
+            r = subprocess.run([gpu.cli_path(), "-d", "-f", str(bad), str(part)], capture_output=True, env=env)
+            assert r.returncode == 4 and b"invalid block checksum detected" in r.stderr, r.stderr
+            got = part.read_bytes()
+            assert 0 < len(got) < len(data) and len(got) % helpers.B == 0 and got == data[: len(got)].tobytes()
+            ref = helpers.ref_cli()
+            if ref:
+                rp = tmp_path / "part_ref.bin"
+                rr = subprocess.run([ref, "-d", "-f", str(bad), str(rp)], capture_output=True)
+                assert rr.returncode == 4 and rp.read_bytes() == got
