@@ -91,13 +91,12 @@ int fourmc_file_compress_sharded(const char* in_name, const char* out_name, int 
                                  fourmc_allgather_fn allgather, void* ctx)
 {
     struct stat st;
-    uint64_t nblocks, first, count, b, per, in_bytes;
-    uint8_t *in_buf = NULL, *out_buf = NULL;
+    uint64_t nblocks, first, count, b, per;
+    uint8_t *in_buf = NULL, *out_buf = NULL, *store = NULL;
     fourmc_block* blk = NULL;
     uint32_t *cs_mine = NULL, *cs_pad = NULL, *cs_all = NULL, *usz = NULL, *xs = NULL;
     uint64_t *off_all = NULL, *poff = NULL;
     int codec, codec_level = 0, rc = 0, fd = -1;
-    FILE* fin;
 
     if (magic == FOURMC_MAGIC_4MC) {                                  /* native/4mc.c:243-253   */
         if (level <= 1) codec = FOURMC_CODEC_LZ4_FAST;
@@ -111,44 +110,74 @@ int fourmc_file_compress_sharded(const char* in_name, const char* out_name, int 
     nblocks = ((uint64_t)st.st_size + FOURMC_BLOCKSIZE - 1) / FOURMC_BLOCKSIZE;
     fourmc_shard_range(nblocks, rank, world, &first, &count);
     per = world > 0 ? (nblocks + (uint64_t)world - 1) / (uint64_t)world : nblocks;
-    in_bytes = count ? ((first + count == nblocks ? (uint64_t)st.st_size : (first + count) * FOURMC_BLOCKSIZE) - first * FOURMC_BLOCKSIZE) : 0;
 
-    in_buf = (uint8_t*)malloc(in_bytes + 1); out_buf = (uint8_t*)malloc(count * FOURMC_BLOCKSIZE + 1);
-    blk = (fourmc_block*)calloc(count + 1, sizeof *blk);
-    cs_pad = (uint32_t*)calloc(per + 1, 4); cs_all = (uint32_t*)calloc(per * (uint64_t)(world > 0 ? world : 1) + 1, 4);
-    usz = (uint32_t*)calloc(count + 1, 4); xs = (uint32_t*)calloc(count + 1, 4);
-    off_all = (uint64_t*)calloc(nblocks + 1, 8); poff = (uint64_t*)calloc(count + 1, 8);
-    cs_mine = cs_pad;
-    if (!in_buf || !out_buf || !blk || !cs_pad || !cs_all || !usz || !xs || !off_all || !poff) { rc = -5; goto done; }
-
-    fin = fopen(in_name, "rb");
-    if (!fin) { rc = -1; goto done; }
-    if (fseeko(fin, (off_t)(first * FOURMC_BLOCKSIZE), SEEK_SET) != 0 || fread(in_buf, 1, in_bytes, fin) != in_bytes) { fclose(fin); rc = -1; goto done; }
-    fclose(fin);
-    for (b = 0; b < count; b++) {
-        const uint64_t left = in_bytes - b * FOURMC_BLOCKSIZE;
-        blk[b].src_off = b * FOURMC_BLOCKSIZE; blk[b].dst_off = b * FOURMC_BLOCKSIZE;
-        blk[b].src_len = (uint32_t)(left < FOURMC_BLOCKSIZE ? left : FOURMC_BLOCKSIZE);
-        blk[b].dst_cap = blk[b].src_len;
-    }
-    if (count && fourmc_host_4mc_encode(in_buf, in_bytes, out_buf, count * FOURMC_BLOCKSIZE, blk, (uint32_t)count, codec, codec_level) != FOURMC_OK) { rc = -3; goto done; }
-    for (b = 0; b < count; b++) {
-        /* a per-block failure code must not become a 4 GiB size that every rank then builds its offsets on */
-        if (blk[b].result <= 0 || (uint32_t)blk[b].result > blk[b].src_len) { rc = -3; goto done; }
-        cs_mine[b] = (uint32_t)blk[b].result; usz[b] = blk[b].src_len; xs[b] = blk[b].xxh32; poff[b] = blk[b].dst_off;
+    /* The rank's range goes through the engine in batches of FOURMC_BATCH_BLOCKS blocks (default 512 = 2 GiB: the kernels need
+     * hundreds of blocks per launch), so that the input is never in memory as a whole (64 GiB over 8 ranks would be 8 GiB of
+     * pageable memory per rank); what has to stay until the gather is the COMPRESSED range, kept back to back in `store`. */
+    {
+        const char* e = getenv("FOURMC_BATCH_BLOCKS");
+        uint64_t nbatch = e ? (uint64_t)atol(e) : 512, store_cap = 0, store_len = 0, b0;
+        int fdin;
+        if (nbatch < 1) nbatch = 1;
+        if (nbatch > 4096) nbatch = 4096;
+        if (nbatch > count) nbatch = count ? count : 1;
+        in_buf = (uint8_t*)malloc(nbatch * FOURMC_BLOCKSIZE); out_buf = (uint8_t*)malloc(nbatch * FOURMC_BLOCKSIZE);
+        blk = (fourmc_block*)calloc(nbatch + 1, sizeof *blk);
+        cs_pad = (uint32_t*)calloc(per + 1, 4); cs_all = (uint32_t*)calloc(per * (uint64_t)(world > 0 ? world : 1) + 1, 4);
+        usz = (uint32_t*)calloc(count + 1, 4); xs = (uint32_t*)calloc(count + 1, 4);
+        off_all = (uint64_t*)calloc(nblocks + 1, 8); poff = (uint64_t*)calloc(count + 1, 8);
+        cs_mine = cs_pad;
+        if (!in_buf || !out_buf || !blk || !cs_pad || !cs_all || !usz || !xs || !off_all || !poff) { rc = -5; goto done; }
+        fdin = open(in_name, O_RDONLY);
+        if (fdin < 0) { rc = -1; goto done; }
+        for (b0 = 0; b0 < count; b0 += nbatch) {
+            const uint64_t nb = count - b0 < nbatch ? count - b0 : nbatch;
+            const uint64_t at = (first + b0) * FOURMC_BLOCKSIZE;
+            const uint64_t bytes = ((uint64_t)st.st_size - at < nb * FOURMC_BLOCKSIZE) ? (uint64_t)st.st_size - at : nb * FOURMC_BLOCKSIZE;
+            uint64_t got = 0, need = 0;
+            while (got < bytes) { ssize_t r = pread(fdin, in_buf + got, (size_t)(bytes - got), (off_t)(at + got)); if (r <= 0) break; got += (uint64_t)r; }
+            if (got != bytes) { close(fdin); rc = -1; goto done; }
+            for (b = 0; b < nb; b++) {
+                const uint64_t left = bytes - b * FOURMC_BLOCKSIZE;
+                blk[b].src_off = b * FOURMC_BLOCKSIZE; blk[b].dst_off = b * FOURMC_BLOCKSIZE;
+                blk[b].src_len = (uint32_t)(left < FOURMC_BLOCKSIZE ? left : FOURMC_BLOCKSIZE);
+                blk[b].dst_cap = blk[b].src_len; blk[b].result = 0; blk[b].xxh32 = 0;
+            }
+            if (fourmc_host_4mc_encode(in_buf, (size_t)bytes, out_buf, (size_t)(nb * FOURMC_BLOCKSIZE), blk, (uint32_t)nb, codec, codec_level) != FOURMC_OK) { close(fdin); rc = -3; goto done; }
+            for (b = 0; b < nb; b++) {
+                /* a per-block failure code must not become a 4 GiB size that every rank then builds its offsets on */
+                if (blk[b].result <= 0 || (uint32_t)blk[b].result > blk[b].src_len) { close(fdin); rc = -3; goto done; }
+                need += (uint32_t)blk[b].result;
+            }
+            if (store_len + need > store_cap) {
+                uint8_t* ns;
+                store_cap = (store_len + need) + (store_len + need) / 4 + (1u << 20);
+                ns = (uint8_t*)realloc(store, (size_t)store_cap);
+                if (!ns) { close(fdin); rc = -5; goto done; }
+                store = ns;
+            }
+            for (b = 0; b < nb; b++) {
+                const uint32_t cs = (uint32_t)blk[b].result;
+                memcpy(store + store_len, out_buf + blk[b].dst_off, cs);
+                cs_mine[b0 + b] = cs; usz[b0 + b] = blk[b].src_len; xs[b0 + b] = blk[b].xxh32; poff[b0 + b] = store_len;
+                store_len += cs;
+            }
+        }
+        close(fdin);
     }
 
     /* the one exchange of the path: per-block compressed sizes, padded to equal counts per rank */
-    if (world > 1) { if (allgather(ctx, cs_pad, per * 4, cs_all) != 0) { rc = -4; goto done; } }
-    else memcpy(cs_all, cs_pad, per * 4);
+    if (allgather) { if (allgather(ctx, cs_pad, per * 4, cs_all) != 0) { rc = -4; goto done; } }   /* also with one rank: the launcher's collective is the real one */
+    else if (world <= 1) memcpy(cs_all, cs_pad, per * 4);
+    else { rc = -4; goto done; }
     {   /* ranks' padded rows -> one array in block order (row r holds blocks [r * per, ..)) : already contiguous */
         fourmc_shard_offsets(cs_all, nblocks, off_all);
     }
     fd = open(out_name, O_WRONLY | O_CREAT, 0644);
     if (fd < 0) { rc = -2; goto done; }
-    if (fourmc_shard_write(fd, magic, rank, first, count, nblocks, off_all, cs_all, usz, xs, out_buf, poff) != 0) rc = -2;
+    if (fourmc_shard_write(fd, magic, rank, first, count, nblocks, off_all, cs_all, usz, xs, store ? store : out_buf, poff) != 0) rc = -2;
     if (close(fd) != 0 && rc == 0) rc = -2;
 done:
-    free(in_buf); free(out_buf); free(blk); free(cs_pad); free(cs_all); free(usz); free(xs); free(off_all); free(poff);
+    free(in_buf); free(out_buf); free(store); free(blk); free(cs_pad); free(cs_all); free(usz); free(xs); free(off_all); free(poff);
     return rc;
 }

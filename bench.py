@@ -68,54 +68,43 @@ def host_codecs(helpers):
     return "port", {"lz4": lz4, "hc4": hc4, "zstd1": zs(1), "zstd3": zs(3), "zstd12": zs(12)}, o.orc_xxh32
 
 
-def cpu_leg(helpers, base, nblk, codec, budget_s, B):
-    """One 4mc/4mz block loop per thread on a bounded sample of `base` (the reference's per-block work, native/4mc.c:
-    301-329 compress + checksum, :637-661 checksum + decode): GB/s of uncompressed bytes over wall time, all host cores."""
+def reference_sizes(helpers, base, nblk, codec, B):
+    """compressed size per distinct corpus block by the host comparator's code (for ratio_vs_reference), 16 threads"""
+    from concurrent.futures import ThreadPoolExecutor
     kind, codecs, xxh = host_codecs(helpers)
-    comp, dec = codecs[codec]
-    cores = max(1, os.cpu_count() or 1)
-    done = {"c": 0.0, "d": 0.0, "bytes": 0, "csize": {}}
-    lock = threading.Lock()
-    stop_at = time.perf_counter() + budget_s
+    comp, _ = codecs[codec]
+    def one(b):
+        out = np.empty(B + B // 128 + 1024, np.uint8)
+        r = comp(base[b * B:(b + 1) * B].ctypes.data, B, out.ctypes.data, B - 1)
+        return b, (int(r) if 0 < r < B else B)
+    with ThreadPoolExecutor(16) as ex:
+        return dict(ex.map(one, range(nblk)))
 
-    def work(tid):
-        out = np.empty(B + B // 128 + 1024, np.uint8); back = np.empty(B, np.uint8)
-        tc = td = 0.0; nb = 0; cs = {}
-        k = tid
-        while True:
-            b = k % nblk
-            src = base[b * B:(b + 1) * B]
-            t0 = time.perf_counter()
-            r = comp(src.ctypes.data, B, out.ctypes.data, B - 1)
-            stored = not (0 < r < B)
-            xxh(src.ctypes.data if stored else out.ctypes.data, B if stored else r, 0)
-            t1 = time.perf_counter()
-            xxh(src.ctypes.data if stored else out.ctypes.data, B if stored else r, 0)
-            if stored:
-                back[:] = src
-            else:
-                dec(out.ctypes.data, r, back.ctypes.data, B)
-            t2 = time.perf_counter()
-            tc += t1 - t0; td += t2 - t1; nb += B; cs[b] = B if stored else int(r)
-            k += cores
-            if time.perf_counter() > stop_at or k >= 4096 * nblk:
-                break
-        with lock:
-            done["c"] += tc; done["d"] += td; done["bytes"] += nb; done["csize"].update(cs)
 
-    t_start = time.perf_counter()
-    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
-    [t.start() for t in th]; [t.join() for t in th]
-    wall = time.perf_counter() - t_start
-    return {
-        "value": round(done["bytes"] / wall / 1e9, 4), "unit": "GB/s", "cores": cores, "cpu": cpu_model(), "kind": kind,
-        "sample": f"{done['bytes'] >> 20} MiB of the corpus ({nblk} distinct blocks), compress+xxh32 then xxh32+decompress per block, "
-                  f"one block loop per thread, {cores} threads, {wall:.1f} s",
-        "compress_GBps_per_core": round(done["bytes"] / done["c"] / 1e9, 4),
-        "decompress_GBps_per_core": round(done["bytes"] / done["d"] / 1e9, 4),
-        "compress_GBps_all_cores": round(done["bytes"] / (done["c"] / cores) / 1e9, 3),
-        "decompress_GBps_all_cores": round(done["bytes"] / (done["d"] / cores) / 1e9, 3),
-    }, done["csize"]
+def cpu_leg(helpers, base, nblk, codec, budget_s, B, logs=False):
+    """The reference's per-block work (native/4mc.c:301-329 compress + checksum, :637-661 checksum + decode) on the host:
+    tools/cpu_baseline (C, one pinned thread per PHYSICAL core, NUMA-local buffers, compress phase then decompress phase,
+    each >= budget_s, rate = all threads' bytes / wall time of the phase).  `value` = uncompressed bytes per second of compress +
+    decompress time, the definition of the GPU figure: 1 / (1 / compress_rate + 1 / decompress_rate)."""
+    import json as _json, subprocess
+    exe = os.path.join(ROOT, "tools", "cpu_baseline")
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libref4mc.so")
+    lib = ref_so if os.path.exists(ref_so) else os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(exe):
+        subprocess.run(["gcc", "-O2", "-pthread", "tools/cpu_baseline.c", "tools/corpus.c", "-ldl", "-o", "tools/cpu_baseline"], cwd=ROOT, check=True)
+    cmd = [exe, "--lib", lib, "--codec", codec, "--seconds", str(budget_s), "--blocks", str(nblk)] + (["--logs"] if logs else [])
+    if os.environ.get("SILESIA_DIR") and not logs:
+        tmp = os.path.join(os.environ.get("FOURMC_BENCH_TMP", "/tmp"), "bench_corpus.bin"); base[: nblk * B].tofile(tmp); cmd += ["--data", tmp]
+    r = _json.loads(subprocess.run(cmd, capture_output=True, check=True, text=True).stdout)
+    c, d = r["compress_GBps"], r["decompress_GBps"]
+    out = {"value": round(1.0 / (1.0 / c + 1.0 / d), 3), "unit": "GB/s", "cores": r["threads"], "cores_physical": r["cores_physical"], "cpus_logical": r["cpus_logical"],
+           "cpu": cpu_model(), "kind": r["kind"],
+           "sample": f"{r['blocks_per_thread']} blocks of the corpus per thread ({r['corpus_blocks']} distinct), compress+xxh32 phase {r['compress_seconds']} s then "
+                     f"xxh32+decompress phase {r['decompress_seconds']} s, one pinned thread per physical core, thread-local (NUMA-local) buffers; tools/cpu_baseline.c",
+           "compress_GBps_all_cores": c, "decompress_GBps_all_cores": d,
+           "compress_GBps_per_core": r["compress_GBps_per_thread"], "decompress_GBps_per_core": r["decompress_GBps_per_thread"],
+           "slowest_thread_GBps": [r["compress_GBps_slowest_thread"], r["decompress_GBps_slowest_thread"]], "round_trip_failures": r["round_trip_failures"]}
+    return out, reference_sizes(helpers, base, nblk, codec, B)
 
 
 def load_corpus(helpers, base_blocks, B):
@@ -263,7 +252,7 @@ def main():
         out = {"blocks": nblk, "compress_GBps": round(nblk * B / t_enc / 1e6, 3), "decompress_GBps": round(nblk * B / t_dec / 1e6, 3),
                "ratio": round(nblk * B / float((cs + 12).sum()), 4), "encode_blocks_ms": round(t_enc, 2), "decode_blocks_ms": round(t_dec, 2)}
         if not args.no_cpu:
-            cb, ref_cs = cpu_leg(helpers, host_base, host_nblk, host_codec, budget, B)
+            cb, ref_cs = cpu_leg(helpers, host_base, host_nblk, host_codec, budget, B, logs=name.endswith("_logs"))
             out["cpu_baseline"] = cb
             have = sorted(ref_cs)
             if have:                               # same blocks, reference sizes against the sizes of this run
@@ -288,75 +277,82 @@ def main():
         return out
 
     def decode_64gib():
-        """Decode-only at the size the north-star target is quoted on: 16384 blocks = 64 GiB written.  The compressed side is
-        the 8 GiB configuration's image with every payload referenced 8 times (4.4 GB of payloads read 8 times from HBM: a
-        64 GiB image would not fit next to 64 GiB of output and the source)."""
+        """Decode-only at the size the north-star target is quoted on: 16384 blocks = 64 GiB written, read from a 35 GB image of
+        physically DISTINCT payloads (the 8 GiB configuration's image copied 8 times in HBM, every block descriptor pointing into
+        its own copy: nothing is read twice).  Runs as 8 launches' worth of blocks in one call (the engine's decode entry point)."""
         nd = args.decode_blocks
+        reps = -(-nd // nb)
+        img_bytes = int((state["loc_off"][-1] + 12 + state["csz"][-1]).item())
+        img_pad = (img_bytes + 4095) & ~4095
         free, _ = torch.cuda.mem_get_info()
-        need = nd * B + (64 << 20)
-        if free < need + (12 << 30):
-            return {"skipped": "not enough free HBM for %d blocks of output" % nd}
+        need = nd * B + reps * img_pad + (64 << 20)
+        if free < need + (8 << 30):
+            return {"skipped": "not enough free HBM for %d blocks of output and %d image copies" % (nd, reps)}
         big = torch.empty(nd * B + 64, dtype=torch.uint8, device=dev)
-        dd = state["dec"].repeat(-(-nd // nb), 1)[:nd].contiguous()
-        dd.view(torch.int64)[:, 1] = torch.arange(nd, device=dev, dtype=torch.int64) * B
+        img = torch.empty(reps * img_pad + 64, dtype=torch.uint8, device=dev)
+        for k in range(reps):
+            img[k * img_pad: k * img_pad + img_bytes] = d_image[:img_bytes]
+        dd = state["dec"].repeat(reps, 1)[:nd].contiguous()
+        d64 = dd.view(torch.int64)
+        d64[:, 0] += (torch.arange(nd, device=dev, dtype=torch.int64) // nb) * img_pad
+        d64[:, 1] = torch.arange(nd, device=dev, dtype=torch.int64) * B
         dd[:, 6] = 0
-        t = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_image.data_ptr(), big.data_ptr(), dd.data_ptr(), nd, 0, sp), "decode64"))
+        t = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_decode_blocks(img.data_ptr(), big.data_ptr(), dd.data_ptr(), nd, 0, sp), "decode64"))
         ok = bool((dd[:, 6] == B).all())
         for k in range(0, nd, nb):
             m = min(nb, nd - k)
             ok = ok and bool(torch.equal(big[k * B:(k + m) * B], d_src[: m * B]))
         assert ok, "64 GiB decode: round trip failed"
         cbytes = int(state["csz"].sum().item()) * (nd // nb) if nd % nb == 0 else None
-        hash_ms = timed(lambda: p.binding.check(L.fourmc_gpu_xxh32(d_image.data_ptr(), dd.clone().data_ptr(), nd, 0, sp), "xxh32"))
+        hash_ms = timed(lambda: p.binding.check(L.fourmc_gpu_xxh32(img.data_ptr(), dd.clone().data_ptr(), nd, 0, sp), "xxh32"))
         alg = (cbytes or 0) + nd * B
-        del big
+        del big, img
         return {"blocks": nd, "uncompressed_GiB": nd * B / 2**30, "decode_blocks_ms": round(t, 2), "of_which_xxh32_verify_ms": round(hash_ms, 2),
                 "decompress_GBps": round(nd * B / t / 1e6, 2),
                 "roofline": {"bound": "hbm", "achieved": round(alg / ((t - hash_ms) * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(alg / ((t - hash_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-                "note": "payloads of the 8 GiB image referenced %d times; 64 GiB of distinct output" % (nd // nb)}
+                "note": "%d distinct copies of the 8 GiB image in HBM (%.1f GB of payloads, each read once); 64 GiB of distinct output" % (reps, reps * img_bytes / 1e9)}
 
     def decode_path_comparison():
-        """Both LZ4 decode fast paths on the same launch (identical results): the default wave trio and the block-parallel
-        parse + executor pair, HIP events around the decode_blocks call minus the hash launch."""
+        """The LZ4 decode fast paths on the same launch (identical results): the wave trio, the row pipeline (lz4_rows.hip) and the
+        block-parallel parse + executor pair; HIP events around the decode_blocks call minus the hash launch.  "auto" (the
+        default) takes the row pipeline up to 1536 blocks per launch and the trio above."""
         out = {}
         before = L.fourmc_gpu_get_lz4_decode_path()
         vb = state["dec"].clone()
         x_ver = timed(lambda: p.binding.check(L.fourmc_gpu_xxh32(d_image.data_ptr(), vb.data_ptr(), nb, 0, sp), "xxh32"))
-        for path, name in ((0, "wave_trio"), (1, "block_parallel")):
+        for path, name in ((0, "wave_trio"), (4, "row_pipeline"), (1, "block_parallel")):
             L.fourmc_gpu_set_lz4_decode_path(path)
             dd = state["dec"].clone(); dd[:, 6] = 0
             t = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_image.data_ptr(), d_out.data_ptr(), dd.data_ptr(), nb, 0, sp), name))
             ok = bool((dd[:, 6] == B).all()) and bool(torch.equal(d_out[: nb * B], d_src))
             out[name] = {"lz4_decode_ms": round(t - x_ver, 3), "round_trip": ok}
+        for m in (256, 1024):                          # launches that do not fill the chip: what the file API sends
+            if m >= nb: continue
+            xv = timed(lambda: p.binding.check(L.fourmc_gpu_xxh32(d_image.data_ptr(), state["dec"][:m].clone().data_ptr(), m, 0, sp), "xxh32"))
+            for path, name in ((0, "wave_trio"), (4, "row_pipeline")):
+                L.fourmc_gpu_set_lz4_decode_path(path)
+                dd = state["dec"][:m].clone(); dd[:, 6] = 0
+                t = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_image.data_ptr(), d_out.data_ptr(), dd.data_ptr(), m, 0, sp), name))
+                out[name]["lz4_decode_ms_%d_blocks" % m] = round(t - xv, 3)
         L.fourmc_gpu_set_lz4_decode_path(before)
         return out
 
     def cli_wallclock():
-        """The drop-in CLI end to end (file in, file out, PCIe and stdio included) next to the reference CLI built from the
-        reference's sources (oracle/_ref/4mc_ref), same 2 GiB file, page cache warm."""
-        import subprocess, tempfile
-        ref_cli = helpers.ref_cli()
-        nblk = 512
-        out = {"file_GiB": nblk * B / 2**30}
-        with tempfile.TemporaryDirectory(dir=os.environ.get("FOURMC_BENCH_TMP", "/tmp")) as d:
-            src = os.path.join(d, "in.bin")
-            with open(src, "wb") as f:
-                for k in range(0, nblk, base_blocks):
-                    f.write(base[: min(base_blocks, nblk - k) * B].tobytes())
-            for name, exe in (("gpu_cli", p.cli_path()), ("reference_cli", ref_cli)):
-                if not exe or not os.path.exists(exe):
-                    continue
-                c = os.path.join(d, name + ".4mc"); back = os.path.join(d, name + ".back")
-                t0 = time.perf_counter(); r1 = subprocess.run([exe, "-f", src, c], capture_output=True); t1 = time.perf_counter()
-                r2 = subprocess.run([exe, "-d", "-f", c, back], capture_output=True); t2 = time.perf_counter()
-                ok = r1.returncode == 0 and r2.returncode == 0 and os.path.getsize(back) == nblk * B
-                out[name] = {"compress_MBps": round(nblk * B / (t1 - t0) / 1e6, 1), "decompress_MBps": round(nblk * B / (t2 - t1) / 1e6, 1), "ok": ok,
-                             "file_bytes": os.path.getsize(c) if os.path.exists(c) else None}
-                os.remove(back)
-            if "gpu_cli" in out and "reference_cli" in out:
-                out["files_identical"] = out["gpu_cli"]["file_bytes"] == out["reference_cli"]["file_bytes"]
-        return out
+        """The drop-in CLI end to end (file in, file out, process start, PCIe and file system included) next to the reference CLI built
+        from the reference's sources (oracle/_ref/4mc_ref): the same 8 GiB file on tmpfs, both directions, files compared
+        (tools/cli_timing.py)."""
+        import json as _json, subprocess
+        d = os.environ.get("FOURMC_BENCH_TMP") or ("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+        gib = float(os.environ.get("FOURMC_BENCH_CLI_GIB", "8"))
+        try:
+            st = os.statvfs(d)
+            if st.f_bavail * st.f_frsize < (3.2 * gib + 2) * 2**30: gib = 2.0
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_timing.py"), "--gib", str(gib), "--dir", d, "--modes", "default"],
+                               capture_output=True, text=True, timeout=600)
+            return _json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:                         # never let the side measurement take the bench line down
+            return {"skipped": repr(e)[:200]}
 
     for _ in range(args.warmup):
         step(False)
@@ -419,7 +415,8 @@ def main():
             "data": data_note,
             "config": {"workload": "4mc Fast (LZ4 fast), 4 MiB blocks, corpus replicated to %.2f GiB per GPU, HBM resident" % (U / 2**30),
                        "blocks_per_gpu": nb, "block_bytes": B, "parallelism": f"block-range dp{world}", "arch": arch,
-                       "lz4_decode_path": {0: "wave trio (parser wave + 2 copier waves per block)", 1: "block parallel (parse + executor kernels)"}.get(L.fourmc_gpu_get_lz4_decode_path(), "other")},
+                       "lz4_decode_path": {0: "wave trio (parser wave + 2 copier waves per block)", 1: "block parallel (parse + executor kernels)", 4: "row pipeline (pre / walk / post / copy waves per block)",
+                                           6: "auto: row pipeline up to 1536 blocks per launch, wave trio above (this launch: %s)" % ("row pipeline" if nb <= 1536 else "wave trio")}.get(L.fourmc_gpu_get_lz4_decode_path(), "other")},
             "compress_GBps": round(world * U / (comp_ms * 1e-3) / 1e9, 3),
             "decompress_GBps": round(world * U / (dec_ms * 1e-3) / 1e9, 3),
             "ratio": round(U / (12 + Cbytes + 12 + 20 + 4 * nb), 4),

@@ -85,3 +85,75 @@ def test_zstd_full_launch_equals_the_oracle_on_every_replica(gpu, level):
     late = 2040
     want_r = int(e["result"][late % base_n])
     assert torch.equal(d_stage[late * B: late * B + want_r], d_stage[(late % base_n) * B: (late % base_n) * B + want_r])
+
+
+def _full_launch_against_the_oracle(gpu, base, base_n, nb, codec, level, oracle_fn, sample_every):
+    """`nb` blocks (replicas of `base_n` distinct ones) in ONE launch: every replica equals its base block's result, the base
+    blocks equal the oracle's (size + XXH32 for all, bytes for a sample), and the batch decodes back to the input."""
+    d_src = torch.from_numpy(base).cuda().repeat(-(-nb // base_n))[: nb * B].contiguous()
+    offs = np.arange(nb, dtype=np.uint64) * B
+    lens = np.full(nb, B, dtype=np.uint32)
+    enc = gpu.DeviceBatch(gpu.make_blocks(offs, offs, lens, lens))
+    d_stage = torch.empty(nb * B, dtype=torch.uint8, device="cuda")
+    gpu.encode_blocks(d_src, d_stage, enc, codec=codec, level=level)
+    e = enc.download()
+    for b in range(nb):
+        assert (e["result"][b], e["xxh32"][b]) == (e["result"][b % base_n], e["xxh32"][b % base_n]), b
+    stage = d_stage[: base_n * B].cpu().numpy()
+    for b in range(base_n):
+        src = base[b * B:(b + 1) * B]
+        r, comp = oracle_fn(src)
+        want = comp if 0 < r < B else src
+        assert e["result"][b] == len(want) and e["xxh32"][b] == helpers.orc_xxh32(want), b
+        if b % sample_every == 0:
+            assert np.array_equal(stage[b * B: b * B + len(want)], want), b
+    late = nb - 8
+    want_r = int(e["result"][late % base_n])
+    assert torch.equal(d_stage[late * B: late * B + want_r], d_stage[(late % base_n) * B: (late % base_n) * B + want_r])
+    dec = gpu.DeviceBatch(gpu.make_blocks(offs, offs, e["result"].astype(np.uint32), lens, e["xxh32"]))
+    d_out = torch.empty(nb * B + 64, dtype=torch.uint8, device="cuda")
+    gpu.decode_blocks(d_stage, d_out, dec, codec=codec)
+    assert bool((torch.from_numpy(dec.download()["result"].astype(np.int64)) == B).all())
+    assert torch.equal(d_out[: nb * B], d_src)
+
+
+def test_hc4_full_launch_equals_the_oracle_on_every_replica(gpu):
+    """BASELINE configs[3] (4mc High, LZ4 HC level 4) at the bench's size: 2048 blocks in one launch (builder + parser waves of
+    eight blocks per CU, 768 MiB of hash / chain tables in flight)."""
+    base = helpers.corpus(48 * B)
+    _full_launch_against_the_oracle(gpu, base, 48, 2048, gpu.CODEC_LZ4_HC, 4, lambda s: helpers.orc_compress_hc(s, 4, B - 1), 8)
+
+
+def test_zstd12_logs_full_launch_equals_the_oracle_on_every_replica(gpu):
+    """BASELINE configs[4]'s codec and corpus (4mz Ultra, zstd level 12, synthetic logs) in one launch as large as the level's 49 MiB
+    of tables per block allow (2048 blocks = 97 GiB on a 288 GB part)."""
+    nb = 2048
+    free = torch.cuda.mem_get_info()[0]
+    while nb > 256 and nb * (49 + 14) * (1 << 20) > 0.8 * free:
+        nb //= 2
+    logs = helpers.corpus(24 * B, logs=True)
+    _full_launch_against_the_oracle(gpu, logs, 24, nb, gpu.CODEC_ZSTD, 12, lambda s: helpers.orc_zstd_compress(s, 12, B - 1), 6)
+
+
+@pytest.mark.parametrize("path", [0, 4], ids=["trio", "rows"])
+def test_both_lz4_decode_paths_at_full_size(gpu, path):
+    """2048 blocks in one launch through each fast path (the default picks by launch size): all 8 GiB equal the input"""
+    base_n, nb = 48, 2048
+    base = helpers.corpus(base_n * B)
+    d_src = torch.from_numpy(base).cuda().repeat(-(-nb // base_n))[: nb * B].contiguous()
+    offs = np.arange(nb, dtype=np.uint64) * B
+    lens = np.full(nb, B, dtype=np.uint32)
+    enc = gpu.DeviceBatch(gpu.make_blocks(offs, offs, lens, lens))
+    d_stage = torch.empty(nb * B, dtype=torch.uint8, device="cuda")
+    gpu.encode_blocks(d_src, d_stage, enc)
+    e = enc.download()
+    before = gpu.lib().fourmc_gpu_get_lz4_decode_path()
+    gpu.lib().fourmc_gpu_set_lz4_decode_path(path)
+    try:
+        dec = gpu.DeviceBatch(gpu.make_blocks(offs, offs, e["result"].astype(np.uint32), lens, e["xxh32"]))
+        d_out = torch.zeros(nb * B + 64, dtype=torch.uint8, device="cuda")
+        gpu.decode_blocks(d_stage, d_out, dec)
+        assert bool((torch.from_numpy(dec.download()["result"].astype(np.int64)) == B).all())
+        assert torch.equal(d_out[: nb * B], d_src)
+    finally:
+        gpu.lib().fourmc_gpu_set_lz4_decode_path(before)

@@ -181,3 +181,20 @@ def test_cli_mapped_and_streaming_paths_write_the_same_files(gpu, golden_corpus,
                 rp = tmp_path / "part_ref.bin"
                 rr = subprocess.run([ref, "-d", "-f", str(bad), str(rp)], capture_output=True)
                 assert rr.returncode == 4 and rp.read_bytes() == got
+
+
+def test_c_launcher_gathers_the_index_through_rccl(gpu, golden_corpus, tmp_path):
+    """tools/shard_rccl: the C host of the several-ranks writer with ncclAllGather (librccl.so, loaded at run time) as its one
+    collective.  RCCL refuses two ranks on one device, so a one-GPU box runs WORLD_SIZE=1: communicator, stream and call are
+    the real ones, the file equals the reference CLI's (more ranks: the same code, byte layout in test_multirank_cpu.py)."""
+    exe = os.path.join(helpers.ROOT, "tools", "shard_rccl")
+    if not os.path.exists(exe):
+        pytest.skip("tools/shard_rccl not built (__graft_entry__.build())")
+    man, data, src = golden_corpus
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", FOURMC_BATCH_BLOCKS="5")
+    for flags, key in (([], "4mc-1"), (["-z", "-1"], "4mz-1")):
+        out = tmp_path / ("rccl_" + key)
+        out.write_bytes(b"\xEE" * (man["levels"][key]["file_bytes"] + 999))       # an older, longer file of that name
+        r = subprocess.run([exe, *flags, str(src), str(out)], capture_output=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert _sha(out) == man["levels"][key]["sha256"], key

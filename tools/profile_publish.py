@@ -34,20 +34,27 @@ for k in ("lz4_encode_fast_kernel", "lz4_decode_fast_kernel", [k for k in a if k
     out += "| %s | %.0f %% | %.0f %% | %.0f %% | %.0f %% | %.2f | %.1f | %.2e | %.2e / %.2e |\n" % (k, 100 * x["SQ_WAIT_ANY"] / wc, 100 * x["SQ_ACTIVE_INST_ANY"] / wc, 100 * x["SQ_WAIT_INST_ANY"] / wc, 100 * 4 * x["SQ_ACTIVE_INST_VALU"] / (1024 * cyc), x["SQ_INSTS_SALU"] / x["SQ_INSTS_VALU"], 4 * x["SQ_ACTIVE_INST_ANY"] / n, y["SQ_INSTS_LDS"], y["SQ_INSTS_VMEM_RD"], y["SQ_INSTS_VMEM_WR"])
 out += "\n" + open(o + "summary_sq.md").read() + "\n" + open(o + "summary_sq2.md").read()
 open(f"profiles/{name}_sq_counters.md", "w").write(out)
-# the opt-in block-parallel LZ4 decode path (tools/k1_timing.py under FOURMC_DECODE=par)
-if os.path.exists(o + "summary_par_stats.md"):
-    pa, pb = rows(o + "summary_par_sq.md"), rows(o + "summary_par_sq2.md")
-    txt = "# FOURMC_DECODE=par rocprofv3 ... -- python tools/k1_timing.py   (2048 blocks of S-mix, decode only; three passes: kernel trace, two SQ groups)\n\n"
-    txt += open(o + "summary_par_stats.md").read() + "\n"
-    txt += "| kernel | waves' time parked (s_waitcnt) | issuing | issue stalls | SALU : VALU | cycles per issued instruction | LDS instr | LDS bank-conflict cycles / LDS active cycles |\n|---|---|---|---|---|---|---|---|\n"
-    for k in pa:
-        if not (k.startswith("lz4_exec") or k.startswith("lz4_parse")): continue
-        x, y = pa[k], pb.get(k, {})
-        wc = x["SQ_WAVE_CYCLES"]; n = x["SQ_INSTS_VALU"] + x["SQ_INSTS_SALU"] + x["SQ_INSTS_LDS"] + y.get("SQ_INSTS_VMEM_RD", 0) + y.get("SQ_INSTS_VMEM_WR", 0)
-        txt += "| %s | %.0f %% | %.0f %% | %.0f %% | %.2f | %.1f | %.2e | %.2f |\n" % (k, 100 * x["SQ_WAIT_ANY"] / wc, 100 * x["SQ_ACTIVE_INST_ANY"] / wc, 100 * x["SQ_WAIT_INST_ANY"] / wc,
-                x["SQ_INSTS_SALU"] / x["SQ_INSTS_VALU"], 4 * x["SQ_ACTIVE_INST_ANY"] / n, x["SQ_INSTS_LDS"], y.get("SQ_LDS_BANK_CONFLICT", 0) / max(y.get("SQ_LDS_IDX_ACTIVE", 1), 1))
-    txt += "\n" + open(o + "summary_par_sq.md").read() + "\n" + open(o + "summary_par_sq2.md").read()
-    open(f"profiles/{name}_block_parallel_decode.md", "w").write(txt)
+# the LZ4 decode paths side by side (tools/k1_timing.py under FOURMC_DECODE=rows / trio)
+if os.path.exists(o + "summary_rows_stats.md"):
+    txt = "# FOURMC_DECODE=rows | trio  rocprofv3 ... -- python tools/k1_timing.py   (2048 and 256 blocks of S-mix, decode only; per mode: two kernel traces, two SQ groups)\n\n"
+    txt += "| path | kernel | waves' time parked (s_waitcnt) | issuing | issue stalls | VALU busy (of 1024 SIMDs) | SALU : VALU | instructions per output byte (VALU+SALU+LDS+VMEM) | LDS instr | LDS busy (of 256 CUs) | LDS bank-conflict / LDS active |\n|---|---|---|---|---|---|---|---|---|---|---|\n"
+    for mode, kern in (("rows", "lz4_decode_rows_kernel"), ("trio", "lz4_decode_fast_kernel")):
+        pa, pb = rows(o + f"summary_{mode}_sq.md"), rows(o + f"summary_{mode}_sq2.md")
+        if kern not in pa: continue
+        x, y = pa[kern], pb.get(kern, {})
+        wc = x["SQ_WAVE_CYCLES"]; cyc = y.get("GRBM_GUI_ACTIVE", 8) / 8
+        n = x["SQ_INSTS_VALU"] + x["SQ_INSTS_SALU"] + x["SQ_INSTS_LDS"] + y.get("SQ_INSTS_VMEM_RD", 0) + y.get("SQ_INSTS_VMEM_WR", 0)
+        txt += "| %s | %s | %.0f %% | %.0f %% | %.0f %% | %.0f %% | %.2f | %.2f | %.2e | %.0f %% | %.2f |\n" % (mode, kern, 100 * x["SQ_WAIT_ANY"] / wc, 100 * x["SQ_ACTIVE_INST_ANY"] / wc, 100 * x["SQ_WAIT_INST_ANY"] / wc,
+                100 * 4 * y.get("SQ_ACTIVE_INST_VALU", 0) / (1024 * cyc), x["SQ_INSTS_SALU"] / x["SQ_INSTS_VALU"], n / (2048 * 4194304.0), x["SQ_INSTS_LDS"],
+                100 * 4 * y.get("SQ_ACTIVE_INST_LDS", 0) / (256 * cyc), y.get("SQ_LDS_BANK_CONFLICT", 0) / max(y.get("SQ_LDS_IDX_ACTIVE", 1), 1))
+    for mode in ("rows", "trio"):
+        for sfx in ("_stats", "256_stats", "_sq", "_sq2"):
+            f = o + f"summary_{mode}{sfx}.md"
+            if os.path.exists(f): txt += f"\n## {mode}{sfx}\n\n" + open(f).read()
+        for sfx in ("_stats", "256_stats"):
+            f = o + f"{mode}{sfx}.log"
+            if os.path.exists(f): txt += "\n```\n" + "".join(l for l in open(f) if "S-mix" in l) + "```\n"
+    open(f"profiles/{name}_lz4_decode_paths.md", "w").write(txt)
 # 4mz Fast: tools/zstd_timing.py at 2048 blocks
 if os.path.exists(o + "summary_z1_stats.md"):
     za, zb = rows(o + "summary_z1_sq.md"), rows(o + "summary_z1_sq2.md")

@@ -16,13 +16,17 @@ for p in stats fetch write sq sq2; do
     [ -n "$db" ] && python tools/rocpd_summary.py $db > $out/summary_$p.md
     grep "^{\"metric\"" $out/$p.log | tail -1 > $out/bench_$p.json
 done
-# the block-parallel LZ4 decode path (opt-in): kernel stats and SQ counters of the decode-only timing tool
-FOURMC_DECODE=par rocprofv3 --kernel-trace --stats -d $raw/par_stats -o par_stats -- python tools/k1_timing.py > $out/par_stats.log 2>&1
-FOURMC_DECODE=par rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $raw/par_sq -o par_sq -- python tools/k1_timing.py > $out/par_sq.log 2>&1
-FOURMC_DECODE=par rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE -d $raw/par_sq2 -o par_sq2 -- python tools/k1_timing.py > $out/par_sq2.log 2>&1
-for p in par_stats par_sq par_sq2; do
+# the row-parallel LZ4 decode pipeline (lz4_rows.hip; default up to 1536 blocks per launch): kernel stats and SQ counters of the
+# decode-only timing tool at 2048 blocks (a full chip) and 256 blocks (what the file API sends), the wave trio beside it
+for mode in rows trio; do
+  FOURMC_DECODE=$mode rocprofv3 --kernel-trace --stats -d $raw/${mode}_stats -o ${mode}_stats -- python tools/k1_timing.py > $out/${mode}_stats.log 2>&1
+  FOURMC_BENCH_BLOCKS=256 FOURMC_DECODE=$mode rocprofv3 --kernel-trace --stats -d $raw/${mode}256_stats -o ${mode}256_stats -- python tools/k1_timing.py > $out/${mode}256_stats.log 2>&1
+  FOURMC_DECODE=$mode rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $raw/${mode}_sq -o ${mode}_sq -- python tools/k1_timing.py > $out/${mode}_sq.log 2>&1
+  FOURMC_DECODE=$mode rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $raw/${mode}_sq2 -o ${mode}_sq2 -- python tools/k1_timing.py > $out/${mode}_sq2.log 2>&1
+  for p in ${mode}_stats ${mode}256_stats ${mode}_sq ${mode}_sq2; do
     db=$(find $raw/$p -name "*_results.db" | head -1)
     [ -n "$db" ] && python tools/rocpd_summary.py $db > $out/summary_$p.md
+  done
 done
 # 4mz Fast (zstd level 1: zstd_encode_fast_kernel, zstd_decode_kernel): kernel stats and SQ counters of tools/zstd_timing.py at 2048 blocks
 FOURMC_BENCH_BLOCKS=2048 rocprofv3 --kernel-trace --stats -d $raw/z1_stats -o z1_stats -- python tools/zstd_timing.py > $out/z1_stats.log 2>&1
