@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_JSON = os.path.join("profiles", "r02_traffic.json")
+TRAFFIC_JSON = os.path.join("profiles", "r03_traffic.json")
 
 
 def cpu_model():
@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configs and the 64 GiB decode leg timed after the headline")
     ap.add_argument("--decode-blocks", type=int, default=16384, help="blocks of the decode-only leg (16384 = 64 GiB)")
+    ap.add_argument("--config", choices=["fast", "ultra_logs"], default="fast",
+                    help="fast: BASELINE configs[1], 4mc Fast on the S-mix (the headline).  ultra_logs: configs[4]'s codec and corpus - 4mz Ultra (zstd 12) on the "
+                         "synthetic log corpus, block ranges per rank, the footer index gathered over RCCL, then decoded rank by rank (no collective)")
     args = ap.parse_args()
 
     import torch
@@ -149,7 +152,17 @@ def main():
     nb = args.blocks
 
     # ---- corpus: generated / loaded once, replicated in HBM to nb blocks (physically distinct copies)
-    base, base_blocks, data_note = load_corpus(helpers, 48, B)
+    ULTRA = args.config == "ultra_logs"
+    CODEC, LEVEL = (p.CODEC_ZSTD, 12) if ULTRA else (0, 0)
+    ENC, DEC = ("zstd_encode", "zstd_decode") if ULTRA else ("lz4_encode", "lz4_decode")
+    if ULTRA:
+        free = torch.cuda.mem_get_info(dev)[0]
+        while nb > 256 and nb * (49 + 14 + 17) * (1 << 20) > 0.8 * free: nb //= 2          # level-12 tables, decode scratch, the four 4 MiB-per-block buffers
+        base, base_blocks = helpers.corpus(24 * B, first_block=0, logs=True), 24
+        data_note = "synthetic log corpus (tools/corpus.c corpus_fill_logs, seed 0x4D43, 24 distinct blocks replicated in HBM)"
+        args.no_extras = True
+    else:
+        base, base_blocks, data_note = load_corpus(helpers, 48, B)
     d_base = torch.from_numpy(base).to(dev)
     reps = -(-nb // base_blocks)
     d_src = d_base.repeat(reps)[: nb * B].contiguous()
@@ -173,7 +186,7 @@ def main():
         e = [ev() for _ in range(8)]
         # ------------------------------------------------------------------ compress
         e[0].record()
-        p.binding.check(L.fourmc_gpu_4mc_encode_blocks(d_src.data_ptr(), d_stage.data_ptr(), enc.ptr, nb, 0, 0, sp), "encode")
+        p.binding.check(L.fourmc_gpu_4mc_encode_blocks(d_src.data_ptr(), d_stage.data_ptr(), enc.ptr, nb, CODEC, LEVEL, sp), "encode")
         e[2].record()
         desc = enc.d.view(torch.int32).view(nb, 8)
         csz = desc[:, 6].to(torch.int64)                         # result = stored payload size
@@ -198,7 +211,7 @@ def main():
         dec_desc[:, 6] = 0
         dec_desc[:, 7] = desc[:, 7]                              # expected checksum
         e[5].record()
-        p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_image.data_ptr(), d_out.data_ptr(), dec_desc.data_ptr(), nb, 0, sp), "decode")
+        p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_image.data_ptr(), d_out.data_ptr(), dec_desc.data_ptr(), nb, CODEC, sp), "decode")
         e[7].record()
         state["csz"], state["dec"], state["img_off"], state["loc_off"] = csz, dec_desc, img_off, loc_off
         if record:
@@ -211,13 +224,13 @@ def main():
         loc_off = state["loc_off"]
         t0 = ev(); t1 = ev(); t2 = ev()
         t0.record()
-        p.binding.check(L.fourmc_gpu_4mc_encode_blocks(d_src.data_ptr(), d_stage.data_ptr(), enc.ptr, nb, 0, 0, sp), "encode")
+        p.binding.check(L.fourmc_gpu_4mc_encode_blocks(d_src.data_ptr(), d_stage.data_ptr(), enc.ptr, nb, CODEC, LEVEL, sp), "encode")
         t1.record()
         p.binding.check(L.fourmc_gpu_4mc_pack_image(d_stage.data_ptr(), d_image.data_ptr(), enc.ptr, loc_off.data_ptr(), nb, sp), "pack")
         t2.record()
         d0 = ev(); d1 = ev()
         d0.record()
-        p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_image.data_ptr(), d_out.data_ptr(), state["dec"].data_ptr(), nb, 0, sp), "decode")
+        p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_image.data_ptr(), d_out.data_ptr(), state["dec"].data_ptr(), nb, CODEC, sp), "decode")
         d1.record()
         h0 = ev(); h1 = ev()
         hb = p.DeviceBatch(p.make_blocks(offs, offs, state["csz"].cpu().numpy().astype(np.uint32), lens), dev)
@@ -229,8 +242,8 @@ def main():
         torch.cuda.synchronize()
         enc_total, pack, dec_total = t0.elapsed_time(t1), t1.elapsed_time(t2), d0.elapsed_time(d1)
         x_out, x_ver = h0.elapsed_time(h1), v0.elapsed_time(v1)
-        return {"lz4_encode": enc_total - x_out, "xxh32_out": x_out, "pack": pack,
-                "xxh32_verify": x_ver, "lz4_decode": dec_total - x_ver}
+        return {ENC: enc_total - x_out, "xxh32_out": x_out, "pack": pack,
+                "xxh32_verify": x_ver, DEC: dec_total - x_ver}
 
     def timed(fn):
         fn()                                       # untimed first call: workspace allocation happens here
@@ -386,34 +399,51 @@ def main():
     comp_ms = float(np.mean(phase["compress"])); dec_ms = float(np.mean(phase["decompress"]))
     alg_enc = U + int(csz.sum().item())          # encode launch: reads U, writes payloads
     alg_dec = int(csz.sum().item()) + U          # decode launch: reads payloads, writes U
-    dom = "lz4_encode" if kts["lz4_encode"] >= kts["lz4_decode"] else "lz4_decode"
-    alg = alg_enc if dom == "lz4_encode" else alg_dec
+    dom = ENC if kts[ENC] >= kts[DEC] else DEC
+    alg = alg_enc if dom == ENC else alg_dec
 
     # HBM bytes per launch from the PMC passes (rocprofv3 FETCH_SIZE + WRITE_SIZE, separate runs of this same script at
     # --blocks 512; summary and calibration note in profiles/), scaled to this launch: NOT measured in this run
     traffic = {}
-    try:
-        tj = json.load(open(os.path.join(ROOT, TRAFFIC_JSON)))
-        for k in ("lz4_encode", "lz4_decode"):
-            traffic[k] = int((tj[k]["fetch_KiB"] + tj[k]["write_KiB"]) * 1024 * nb / tj["blocks"])
-    except Exception:
-        pass
+    # HBM traffic of the two headline kernels: measured INSIDE this run when rocprofv3 is on the box (tools/traffic_probe.py: two PMC
+    # passes around the same launches at this launch size), else taken from the committed passes of the round
+    traffic_src = {}
+    probe = None
+    if rank == 0 and world == 1 and not args.no_extras and not os.environ.get("FOURMC_BENCH_NO_PMC"):
+        try:
+            import shutil, subprocess
+            if shutil.which("rocprofv3"):
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "traffic_probe.py"), "--blocks", str(nb)], capture_output=True, text=True, timeout=900)
+                probe = json.loads(r.stdout.strip().splitlines()[-1])
+                for k in ("lz4_encode", "lz4_decode"):
+                    traffic[k] = probe[k]["traffic"]; traffic_src[k] = probe["source"]
+        except Exception as e:
+            probe = {"error": repr(e)[:300]}
+    if not traffic:
+        try:
+            tj = json.load(open(os.path.join(ROOT, TRAFFIC_JSON)))
+            for k in ("lz4_encode", "lz4_decode"):
+                traffic[k] = int((tj[k]["fetch_KiB"] + tj[k]["write_KiB"]) * 1024 * nb / tj["blocks"])
+                traffic_src[k] = TRAFFIC_JSON + " (rocprofv3 PMC passes of the round, scaled by blocks; not measured in this run)"
+        except Exception:
+            pass
 
     def roof(name, algb):
         a = algb / (kts[name] * 1e-3) / 1e9
         return {"kernel": name, "bound": "hbm", "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(a / HBM_PEAK_GBS, 5), "traffic": traffic.get(name),
-                "traffic_source": (TRAFFIC_JSON + " (rocprofv3 PMC passes of this script at --blocks 512, scaled by blocks; not measured in this run)") if name in traffic else None,
+                "traffic_source": traffic_src.get(name),
                 "algorithmic_bytes_per_launch": algb, "avg_launch_ms": round(kts[name], 3)}
 
     if rank == 0:
         line = {
-            "metric": "GB/s compress+decompress (silesia-like S-mix, 4mc-Fast)",
+            "metric": "GB/s compress+decompress (synthetic logs, 4mz-Ultra zstd 12)" if ULTRA else "GB/s compress+decompress (silesia-like S-mix, 4mc-Fast)",
             "value": round(world * U / (wall / args.steps) / 1e9, 3), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": data_note,
-            "config": {"workload": "4mc Fast (LZ4 fast), 4 MiB blocks, corpus replicated to %.2f GiB per GPU, HBM resident" % (U / 2**30),
+            "config": {"workload": ("4mz Ultra (zstd level 12), 4 MiB blocks, log corpus replicated to %.2f GiB per GPU, HBM resident; block ranges per rank, footer index gathered over RCCL" if ULTRA else
+                                    "4mc Fast (LZ4 fast), 4 MiB blocks, corpus replicated to %.2f GiB per GPU, HBM resident") % (U / 2**30),
                        "blocks_per_gpu": nb, "block_bytes": B, "parallelism": f"block-range dp{world}", "arch": arch,
                        "lz4_decode_path": {0: "wave trio (parser wave + 2 copier waves per block)", 1: "block parallel (parse + executor kernels)", 4: "row pipeline (pre / walk / post / copy waves per block)",
                                            6: "auto: row pipeline up to 1536 blocks per launch, wave trio above (this launch: %s)" % ("row pipeline" if nb <= 1536 else "wave trio")}.get(L.fourmc_gpu_get_lz4_decode_path(), "other")},
@@ -423,15 +453,17 @@ def main():
             "kernel_ms": {k: round(v, 3) for k, v in kts.items()},
             "kernel_ms_note": "HIP events on the launch stream in an extra pass after the timed steps; the hash launches are timed alone and subtracted from the fused calls, so the parts need not add up to ms_per_step",
             "roofline": roof(dom, alg),
-            "roofline_decode": roof("lz4_decode", alg_dec),
+            "roofline_decode": roof(DEC, alg_dec),
         }
+        if probe is not None:
+            line["traffic_probe"] = probe
         if world == 1 and not args.no_cpu:             # the host-core baseline is measured at N = 1 only
-            cb, ref_cs = cpu_leg(helpers, base, base_blocks, "lz4", 12.0, B)
+            cb, ref_cs = cpu_leg(helpers, base, base_blocks, "zstd12" if ULTRA else "lz4", 12.0, B, logs=ULTRA)
             line["cpu_baseline"] = cb
             mine = csz[:base_blocks].cpu().numpy()
             have = sorted(b for b in ref_cs if b < len(mine))
             line["ratio_vs_reference"] = round(float(sum(12 + ref_cs[b] for b in have)) / float(sum(12 + int(mine[b]) for b in have)), 6) if have else None
-            line["ratio_vs_reference_note"] = "container bytes of the reference's LZ4_compress_default on the host over this run's, same %d blocks (1.0 = identical sizes; payloads are byte-identical by the parity tests)" % len(have)
+            line["ratio_vs_reference_note"] = "container bytes of the reference's codec on the host over this run's, same %d blocks (1.0 = identical sizes; payloads are byte-identical by the parity tests)" % len(have)
         else:
             line["cpu_baseline"] = None
             line["ratio_vs_reference"] = None

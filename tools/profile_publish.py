@@ -22,7 +22,7 @@ t["xxh32"] = {"fetch_KiB": fe[xk]["FETCH_SIZE"], "write_KiB": wr[xk]["WRITE_SIZE
 t["pack"] = {"fetch_KiB": fe["pack_image_kernel"]["FETCH_SIZE"], "write_KiB": wr["pack_image_kernel"]["WRITE_SIZE"]}
 json.dump(t, open(traffic_json, "w"), indent=1)
 open(f"profiles/{name}_kernel_stats.md", "w").write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1   (tools/profile_round.sh)\n\n" + open(o + "summary_stats.md").read())
-open(f"profiles/{name}_hbm_traffic.md", "w").write("# rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) -- python bench.py --blocks 512 --no-extras --no-cpu --steps 2 --warmup 1\n# per-dispatch values are KiB (see the calibration note in the round's *_traffic.json)\n\n" + open(o + "summary_fetch.md").read() + "\n" + open(o + "summary_write.md").read())
+open(f"profiles/{name}_hbm_traffic.md", "w").write("# rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) -- python bench.py --no-extras --no-cpu --steps 2 --warmup 1   (2048 blocks: the kernels of the headline launch)\n# per-dispatch values are KiB (see the calibration note in the round's *_traffic.json)\n\n" + open(o + "summary_fetch.md").read() + "\n" + open(o + "summary_write.md").read())
 open(f"profiles/{name}_bench_under_rocprof.json", "w").write(open(o + "bench_stats.json").read())
 open(f"profiles/{name}_bench.json", "w").write(open(o + "bench_stats.json").read())
 a, b = rows(o + "summary_sq.md"), rows(o + "summary_sq2.md")
