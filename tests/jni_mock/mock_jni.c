@@ -82,6 +82,43 @@ int main(int argc, char** argv)
     JNIEnv env = &tab;
 
     const char* codecs[2] = {"Lz4", "Zstd"};
+    if (argc > 5) {
+        /* BlockCompressorStream's call pattern (Lz4Codec.java:95-104 / ZstdCodec, the raw block codecs): a stream of small
+         * buffers - `chunk` bytes per compressBytesDirect call on buffers of directBufferSize = chunk + overhead, far from
+         * 4 MiB -, each framed with its length by the caller; here the compressed chunks are written back to back with
+         * their sizes so that the test can compare every one with the oracle, then each is decompressed again. */
+        const int chunk = atoi(argv[5]);
+        for (int c = 0; c < 2; c++) {
+            char ccls[32], dcls[32], name[96];
+            snprintf(ccls, sizeof ccls, "%sCompressor", codecs[c]);
+            snprintf(dcls, sizeof dcls, "%sDecompressor", codecs[c]);
+            ((init_fn)sym(lib, ccls, "initIDs"))(&env, (jclass)ccls);
+            ((init_fn)sym(lib, dcls, "initIDs"))(&env, (jclass)dcls);
+            const int dbs = chunk + chunk / 6 + 32 + 1024;                    /* "bufferSize + compressionOverhead" of the Java side */
+            snprintf(name, sizeof name, "%s/%s_stream.bin", dir, codecs[c]);
+            FILE* fo = fopen(name, "wb");
+            snprintf(name, sizeof name, "%s/%s_stream.sizes", dir, codecs[c]);
+            FILE* fs = fopen(name, "w");
+            int calls = 0, bad = 0, thrown = 0;
+            for (int at = 0; at < n; at += chunk, calls++) {
+                const int len = n - at < chunk ? n - at : chunk;
+                obj_t co = {{{"finish", 0, 0, 0}, {"finished", 0, 0, 0}, {"uncompressedDirectBuf", 1, 0, raw + at}, {"uncompressedDirectBufLen", 0, len, 0},
+                             {"compressedDirectBuf", 1, 0, comp}, {"directBufferSize", 0, dbs, 0}}, 6};
+                g_thrown[0] = 0;
+                jint r = ((call0_fn)sym(lib, ccls, "compressBytesDirect"))(&env, &co);
+                if (g_thrown[0] || r <= 0 || co.f[3].ival != 0) { thrown++; continue; }
+                fwrite(comp, 1, (size_t)r, fo); fprintf(fs, "%d\n", r);
+                obj_t dob = {{{"finished", 0, 0, 0}, {"compressedDirectBuf", 1, 0, comp}, {"compressedDirectBufLen", 0, r, 0},
+                              {"uncompressedDirectBuf", 1, 0, back}, {"directBufferSize", 0, dbs, 0}}, 5};
+                g_thrown[0] = 0;
+                jint d = ((call0_fn)sym(lib, dcls, "decompressBytesDirect"))(&env, &dob);
+                if (g_thrown[0] || d != len || memcmp(back, raw + at, (size_t)len) || dob.f[2].ival != 0) bad++;
+            }
+            fclose(fo); fclose(fs);
+            printf("%s_stream %d - | bad=%d thrown=%d\n", codecs[c], calls, bad, thrown);
+        }
+        return 0;
+    }
     for (int c = 0; c < 2; c++) {
         char ccls[32], dcls[32], tag[64];
         snprintf(ccls, sizeof ccls, "%sCompressor", codecs[c]);

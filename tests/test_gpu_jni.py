@@ -22,8 +22,15 @@ def test_jni_entry_points_through_mock_env(gpu, tmp_path):
     src = tmp_path / "in.bin"; src.write_bytes(data.tobytes())
     r = subprocess.run([str(exe), gpu.lib_path(), str(src), str(n), str(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    check_jni_protocol(r.stdout, data, tmp_path, level9_on_device=False)
+
+
+def check_jni_protocol(stdout, data, out_dir, level9_on_device):
+    """What the mock driver's output has to show, whichever library it drove: this repository's (on the GPU) or the reference's
+    shipped artefact (tests/test_jni_reference_artifact.py, on the CPU) - the same expectations for both."""
+    n = len(data)
     out = {}
-    for line in r.stdout.splitlines():
+    for line in stdout.splitlines():
         name, val, rest = line.split(" ", 2)
         out[name] = (int(val), rest)
     bound = helpers.oracle().orc_lz4_compress_bound(n)
@@ -40,15 +47,52 @@ def test_jni_entry_points_through_mock_env(gpu, tmp_path):
     for name, (wr, wbytes) in want.items():
         got_r, rest = out[name]
         assert got_r == wr and rest.startswith("- ") and "ulen_after=0" in rest, (name, got_r, wr, rest)
-        assert np.array_equal(np.fromfile(tmp_path / (name + ".bin"), dtype=np.uint8), wbytes), name
+        assert np.array_equal(np.fromfile(os.path.join(str(out_dir), name + ".bin"), dtype=np.uint8), wbytes), name
         d, rest = out[name + "_roundtrip"]
         assert d == n and "same=1" in rest and "clen_after=0" in rest, (name, d, rest)
-    # a zstd level that is not on the device: error code returned AND InternalError thrown, buffer length untouched
-    r6, rest = out["Zstd_compressBytesDirectHC_level9"]
-    assert "java/lang/InternalError: ZSTD_compress returned: " in rest and ("ulen_after=%d" % n) in rest
+    r9, rest = out["Zstd_compressBytesDirectHC_level9"]
+    if level9_on_device:
+        # the reference serves every zstd level: a frame, no exception, the buffer length reset
+        assert r9 > 0 and "InternalError" not in rest and "ulen_after=0" in rest, (r9, rest)
+    else:
+        # a zstd level that is not on the device: error code returned AND InternalError thrown, buffer length untouched
+        assert "java/lang/InternalError: ZSTD_compress returned: " in rest and ("ulen_after=%d" % n) in rest
     for codec, fn in (("Lz4", "LZ4_decompress_safe"), ("Zstd", "LZ4_decompress_safe")):   # zstd reuses the text (jniZstdDecompressor.c:96)
         d, rest = out[codec + "_decompress_garbage"]
         assert d < 0 and ("java/lang/InternalError: %s returned: %d" % (fn, d)) in rest, (codec, d, rest)
+
+
+def check_block_stream(stdout, data, out_dir, chunk):
+    """BlockCompressorStream-shaped use of the raw codecs (Lz4Codec.java:95-104): every small buffer's compressed bytes equal the
+    oracle's for that buffer, every one decompresses back, nothing is thrown, the length fields are reset after every call."""
+    n = len(data)
+    calls = -(-n // chunk)
+    for codec, orc in (("Lz4", lambda s: helpers.orc_compress(s, helpers.oracle().orc_lz4_compress_bound(len(s)))),
+                       ("Zstd", lambda s: helpers.orc_zstd_compress(s, 1))):
+        line = [l for l in stdout.splitlines() if l.startswith(codec + "_stream ")][0]
+        assert line.split()[1] == str(calls) and "bad=0 thrown=0" in line, line
+        sizes = [int(x) for x in open(os.path.join(str(out_dir), codec + "_stream.sizes")).read().split()]
+        blob = np.fromfile(os.path.join(str(out_dir), codec + "_stream.bin"), dtype=np.uint8)
+        assert len(sizes) == calls and sum(sizes) == len(blob)
+        at = 0
+        for k, sz in enumerate(sizes):
+            r, want = orc(data[k * chunk: min(n, (k + 1) * chunk)])
+            assert sz == r and np.array_equal(blob[at: at + sz], want), (codec, k, sz, r)
+            at += sz
+
+
+def test_raw_codecs_in_block_compressor_stream_shape(gpu, tmp_path):
+    """many small blocks through the JNI entry points (64 KiB-class buffers, directBufferSize far from 4 MiB): the call pattern of
+    Hadoop's BlockCompressorStream around Lz4Codec / ZstdCodec"""
+    exe = tmp_path / "mock_jni"
+    subprocess.run(["gcc", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "jni_mock", "mock_jni.c"),
+                    "-ldl", "-o", str(exe)], check=True)
+    n, chunk = 1_000_000, 65536 - 65536 // 255 - 16
+    data = helpers.corpus(n, first_block=9)
+    src = tmp_path / "in.bin"; src.write_bytes(data.tobytes())
+    r = subprocess.run([str(exe), gpu.lib_path(), str(src), str(n), str(tmp_path), str(chunk)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    check_block_stream(r.stdout, data, tmp_path, chunk)
 
 
 def test_concurrent_one_block_calls_share_launches(gpu):
