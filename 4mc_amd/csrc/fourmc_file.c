@@ -45,11 +45,15 @@ static unsigned batch_blocks(void)
     return (unsigned)v;
 }
 
-/* Staging buffers: page-locked when the engine can provide them (H2D / D2H at PCIe rate), malloc otherwise. */
+/* Staging buffers of the streaming path: plain memory.  On the bench host a copy from or into pageable memory runs at
+ * 50 GB/s (tools/ubench/host_io.cpp) while page-locking the four 256 MiB buffers costs 0.35 s of every process
+ * (tools/startup_timing.py: `4mc -d` of one block 0.64 s with, 0.3 s without); FOURMC_PINNED=1 brings them back. */
 typedef struct { void* p; int pinned; } hbuf;
 static hbuf hbuf_alloc(size_t n)
 {
-    hbuf b; b.p = fourmc_host_alloc(n); b.pinned = b.p != NULL;
+    const char* e = getenv("FOURMC_PINNED");
+    hbuf b; b.p = NULL; b.pinned = 0;
+    if (e && !strcmp(e, "1")) { b.p = fourmc_host_alloc(n); b.pinned = b.p != NULL; }
     if (!b.p) b.p = malloc(n);
     return b;
 }

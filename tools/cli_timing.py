@@ -2,7 +2,7 @@
 """Wall clock of the drop-in CLI next to the reference CLI (oracle/_ref/4mc_ref, built from the reference's sources) on the
 same file, both directions, files compared.  usage: python tools/cli_timing.py [--gib 8] [--dir /dev/shm] [--zstd]
 Prints one JSON object.  The process start (HIP runtime + device, ~0.1-0.2 s) is inside the GPU CLI's wall clock; it is
-also reported alone (`gpu_cli_startup_s`: the CLI compressing an empty file)."""
+also reported alone (`gpu_cli_one_block_s`: the CLI compressing one 4 MiB block - process start, HIP runtime, device, one launch)."""
 import argparse, hashlib, json, os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -33,8 +33,8 @@ def main():
         with open(src, "wb") as f:
             for k in range(0, nblk, 48):
                 f.write(base[: min(48, nblk - k) * B].tobytes())
-        empty = os.path.join(d, "empty"); open(empty, "wb").close()
-        t0 = time.perf_counter(); subprocess.run([p.cli_path(), "-f", empty, os.path.join(d, "e.4mc")], capture_output=True); out["gpu_cli_startup_s"] = round(time.perf_counter() - t0, 3)
+        one = os.path.join(d, "one"); open(one, "wb").write(base[:B].tobytes())
+        t0 = time.perf_counter(); subprocess.run([p.cli_path(), "-f", one, os.path.join(d, "one.4mc")], capture_output=True); out["gpu_cli_one_block_s"] = round(time.perf_counter() - t0, 3)
         runs = [("reference_cli", helpers.ref_cli(), {})]
         for m in a.modes.split(","):
             runs.append(("gpu_cli" if m == "default" else "gpu_cli_" + m, p.cli_path(), {} if m == "default" else {"FOURMC_MMAP": "1" if m == "mapped" else "0"}))
