@@ -46,6 +46,12 @@ constexpr uint32_t kSpinLimit = 1u << 19;
 #ifndef K1R_NAP
 #define K1R_NAP 6                   // s_sleep units (64 clk) between two looks at a progress word
 #endif
+#ifndef K1R_NAP_PRE
+#define K1R_NAP_PRE 32              // PRE waiting for ring space, WALK waiting for tables: the roles that run ahead of the others
+#endif
+#ifndef K1R_NAP_WALK
+#define K1R_NAP_WALK 16
+#endif
 #ifndef K1R_STEPS
 #define K1R_STEPS 4                 // 64-lane sub-steps the copier keeps in flight per iteration
 #endif
@@ -101,15 +107,17 @@ __device__ __forceinline__ uint2 ldv2(const uint2* p)
 }
 // bounded wait on LDS words: `poll` re-reads what `cond` looks at; false = somebody failed (or the wait ran out): the
 // role leaves and the exact kernel decides
-template <class P, class F> __device__ __forceinline__ bool wait_until(Shared* S, Prof& pf, int site, P poll, F cond)
+template <int NAP = K1R_NAP, class P, class F> __device__ __forceinline__ bool wait_until(Shared* S, Prof& pf, int site, P poll, F cond)
 {
     if (cond()) return true;
     poll();
     if (cond()) { LDS_ORDER(); return true; }
     const unsigned long long t0 = pf.now();
     for (uint32_t spins = 0;;) {
-        if (rfl(ldv(&S->failed))) return false;
-        __builtin_amdgcn_s_sleep(K1R_NAP);
+        // a waiting wave costs the working ones issue slots and LDS reads: nap between looks (the roles that run ahead nap longer),
+        // look at the failure word only now and then
+        if ((spins & 7) == 0 && rfl(ldv(&S->failed))) return false;
+        __builtin_amdgcn_s_sleep(NAP);
         poll();
         if (cond()) break;
         if (++spins > kSpinLimit) { stv(&S->failed, 1); return false; }
@@ -160,7 +168,7 @@ __device__ void role_pre(Shared* S, Prof& pf, cgbyte* src, int csize, int lane)
     };
     auto group = [&](int r0, const uint32_t (&w)[4]) -> bool {
         post_seen = int(rfl(uint32_t(post_seen)));
-        if (!wait_until(S, pf, 0, [&] { post_seen = int(rfl(ldv(&S->post_rows))); }, [&] { return post_seen + kNR >= r0 + 4; })) return false;
+        if (!wait_until<K1R_NAP_PRE>(S, pf, 0, [&] { post_seen = int(rfl(ldv(&S->post_rows))); }, [&] { return post_seen + kNR >= r0 + 4; })) return false;
         uint32_t offpos[4], L[4], lext[4], wo[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -288,7 +296,7 @@ __device__ void role_walk(Shared* S, Prof& pf, cgbyte* src, gbyte* dst, int csiz
         const int r = p >> 6; const uint32_t e = uint32_t(p) & 63;
         decided(uint32_t(r));
         if (r <= rlast && r != row_general) {
-            if (!wait_until(S, pf, 0, [&] { pre_seen = int(rfl(ldv(&S->pw.x))); }, [&] { return pre_seen > r; })) return;
+            if (!wait_until<K1R_NAP_WALK>(S, pf, 0, [&] { pre_seen = int(rfl(ldv(&S->pw.x))); }, [&] { return pre_seen > r; })) return;
             const uint32_t t = rfl(S->rows[r & (kNR - 1)].tab[e]);
             const uint4 fe = S->rows[r & (kNR - 1)].fld[e];               // same round trip: the entry's chain mask
             const uint32_t X = t >> 21, lits = (t >> 10) & 0x7ff, mls = t & 0x3ff;
