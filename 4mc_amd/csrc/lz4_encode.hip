@@ -87,7 +87,7 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
 {
     uint16_t* tab16 = reinterpret_cast<uint16_t*>(tab32);
 #ifdef K2_PROF   // one-off phase profile (tools/k2_phases.py builds a side library with -DK2_PROF): cycles per phase
-    uint64_t pt_search = 0, pt_ext = 0, pt_match = 0, pt_cur = 0, pt_tab = 0, pt_gather = 0, pt_emit = 0, pt_nwin = 0, pt_nseq = 0, pt_nslow = 0, pt_none = 0, pt_cross = 0, pt_dcut = 0, pt_scut = 0, pt0 = __builtin_readcyclecounter(), pt1;
+    uint64_t pt_search = 0, pt_ext = 0, pt_match = 0, pt_cur = 0, pt_tab = 0, pt_gather = 0, pt_emit = 0, pt_nwin = 0, pt_nseq = 0, pt_nslow = 0, pt_none = 0, pt_cross = 0, pt_dcut = 0, pt_scut = 0, pt_prep = 0, pt_gen = 0, pt_nit = 0, pt0 = __builtin_readcyclecounter(), pt1;
 #define K2PH(acc) do { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); pt1 = __builtin_readcyclecounter(); acc += pt1 - pt0; pt0 = pt1; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define K2CNT(c) do { c++; } while (0)
 #else
@@ -329,8 +329,10 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                     const bool term = !shm || ((infE >> 17) & 1) || (((infE >> 8) & 7) == 5 && E - lane >= 5);
                     nxt = term ? (0x8000u | (shm ? uint32_t(E) : 64u)) : ((infE & 255) | (uint32_t(E) << 8));
                 }
+                K2PH(pt_prep);
                 for (;;) {
                     unsigned long long sel = 0;
+                    K2CNT(pt_nit);
                     int reason = -1, e = 0;                             // 0: no event left, 1: stop at lane e, 2: match leaves the window
                     const int anc0 = anc;
                     if (gen || anc != cur || hd != hd2) {
@@ -350,7 +352,9 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                             }
                         }
                     }
+                    K2PH(pt_gen);
                     while (reason < 0) {
+                        K2CNT(pt_nseq);
                         const uint32_t t = rl(nxt, cur);
                         if (t & 0x8000u) { e = int(t & 127); reason = e == 64 ? 0 : 1; break; }
                         sel |= 1ull << ((t >> 8) & 63);
@@ -587,7 +591,7 @@ last_literals:
         op += run;
     }
 #ifdef K2_PROF
-    if (lane == 0 && n == (4 << 20)) { uint64_t* c = reinterpret_cast<uint64_t*>(dst + n - 32); c[0] = pt_search; c[1] = pt_ext; c[2] = pt_match; uint64_t* d = reinterpret_cast<uint64_t*>(dst + n - 128); d[0] = pt_cur; d[1] = pt_tab; d[2] = pt_gather; d[3] = pt_emit; d[4] = pt_nwin; d[5] = pt_nseq; d[6] = pt_nslow; uint64_t* f = reinterpret_cast<uint64_t*>(dst + n - 192); f[0] = pt_none; f[1] = pt_cross; f[2] = pt_dcut; f[3] = pt_scut; }
+    if (lane == 0 && n == (4 << 20)) { uint64_t* c = reinterpret_cast<uint64_t*>(dst + n - 32); c[0] = pt_search; c[1] = pt_ext; c[2] = pt_match; uint64_t* d = reinterpret_cast<uint64_t*>(dst + n - 128); d[0] = pt_cur; d[1] = pt_tab; d[2] = pt_gather; d[3] = pt_emit; d[4] = pt_nwin; d[5] = pt_nseq; d[6] = pt_nslow; uint64_t* f = reinterpret_cast<uint64_t*>(dst + n - 192); f[0] = pt_none; f[1] = pt_cross; f[2] = pt_dcut; f[3] = pt_scut; f[4] = pt_prep; f[5] = pt_gen; f[6] = pt_nit; }
 #endif
     return int(op);
 }

@@ -22,12 +22,12 @@ for b in range(12):
     r = int(enc.download()["result"][0])
     c = stage[B - 32: B - 8].cpu().numpy().view(np.uint64) if r < B - 256 else np.zeros(3, np.uint64)
     d = stage[B - 128: B - 72].cpu().numpy().view(np.uint64) if r < B - 256 else np.zeros(7, np.uint64)
-    f = stage[B - 192: B - 160].cpu().numpy().view(np.uint64) if r < B - 256 else np.zeros(4, np.uint64)
-    tot = float(c.sum() + d[:4].sum()) or 1.0
+    f = stage[B - 192: B - 136].cpu().numpy().view(np.uint64) if r < B - 256 else np.zeros(7, np.uint64)
+    tot = float(c.sum() + d[:4].sum() + f[4] + f[5]) or 1.0
     dec = p.DeviceBatch(p.make_blocks([0], [0], [r], [B], enc.download()["xxh32"]))
     out = torch.zeros(B + 64, dtype=torch.uint8, device="cuda")
     ds = torch.cuda.Event(enable_timing=True); de = torch.cuda.Event(enable_timing=True)
     p.decode_blocks(stage, out, dec); torch.cuda.synchronize()
     ds.record(); p.decode_blocks(stage, out, dec); de.record(); torch.cuda.synchronize()
     print(f"        K1 dec {ds.elapsed_time(de):7.2f} ms")
-    print(f"{names[b]:7s} csize {r:8d} enc {s.elapsed_time(e):8.2f} ms   dense: cursor {100*d[0]/tot:4.1f}% table {100*d[1]/tot:4.1f}% gather {100*d[2]/tot:4.1f}% parse {100*c[1]/tot:4.1f}% emit {100*d[3]/tot:4.1f}% commit {100*c[2]/tot:4.1f}% | sparse {100*c[0]/tot:4.1f}%  windows {int(d[4])} seq {int(d[5])} slow-seq {int(d[6])} | window ends: none {int(f[0])} cross {int(f[1])} dirty-cut {int(f[2])} stride-cut {int(f[3])}")
+    print(f"{names[b]:7s} csize {r:8d} enc {s.elapsed_time(e):8.2f} ms   dense: cursor {100*d[0]/tot:4.1f}% table {100*d[1]/tot:4.1f}% gather {100*d[2]/tot:4.1f}% prep {100*f[4]/tot:4.1f}% general {100*f[5]/tot:4.1f}% walk {100*c[1]/tot:4.1f}% emit {100*d[3]/tot:4.1f}% commit {100*c[2]/tot:4.1f}% | sparse {100*c[0]/tot:4.1f}%  windows {int(d[4])} seq {int(d[5])} slow-seq {int(d[6])} | window ends: none {int(f[0])} cross {int(f[1])} dirty-cut {int(f[2])} stride-cut {int(f[3])} inner-iterations {int(f[6])} total-clk {tot:.3g}")
