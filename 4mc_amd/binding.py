@@ -48,6 +48,9 @@ _GPU_API = {
     "fourmc_gpu_debug_read_workspace": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t]),
     "fourmc_gpu_set_lz4_decode_path": (None, [C.c_int]),
     "fourmc_gpu_get_lz4_decode_path": (C.c_int, []),
+    "fourmc_gpu_set_zstd_decode_split": (None, [C.c_int]),
+    "fourmc_gpu_get_zstd_decode_split": (C.c_int, []),
+    "fourmc_gpu_debug_zstd_exec_counts": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fourmc_gpu_debug_lz4_parse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "fourmc_debug_one_block_counters": (None, [C.c_void_p, C.c_void_p]),
     "fourmc_gpu_xxh32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),

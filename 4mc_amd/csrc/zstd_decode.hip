@@ -22,6 +22,8 @@
 #include "fourmc_gpu.h"
 #include "kernels.h"
 #include "devcopy.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -703,8 +705,13 @@ struct V2Info {                                               // LDS, aliases ZS
     uint32_t lit_off[kMaxInner], lit_size[kMaxInner];        // regenerated literals: where (src offset or literal area) / how many
     uint32_t nseq[kMaxInner], seq_off[kMaxInner];
     uint8_t  type[kMaxInner], lit_kind[kMaxInner], lit_rle[kMaxInner], bad[kMaxInner];   // lit_kind: 0 in place, 1 rle, 2 literal area
+    uint32_t nblk, pad[3];                                   // (for the helper wave of a two-wave launch)
 };
 static_assert(sizeof(V2Info) <= sizeof(uint16_t) * 4096, "V2Info must fit the aliased table");
+constexpr int kPendingExec = -1000000011;                     // block result between the two kernels: entropy stage done, execution owed
+constexpr int kRetryZ      = -1000000013;                     // the execute kernel declined: the one-wave kernel decodes the block from scratch
+struct V2Pending { uint32_t nblk, pad; uint64_t fcs; V2Info info; };
+static_assert(sizeof(V2Pending) <= size_t(kBlockMax), "the pending header lives in the serial path's literal buffer");
 
 struct LitHdr { int ltype; uint32_t lh, lsize, lcsize; bool one; };
 __device__ __forceinline__ bool parse_lit_hdr(const uint8_t* bp, int bend, LitHdr& h)
@@ -785,8 +792,111 @@ __device__ __forceinline__ bool skip_seq_table(ZState* zl, const uint8_t* bp, in
     return true;
 }
 
-__device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csize, uint8_t* dst, int cap, uint8_t* work, ZState* z, int lane)
+// step 1c/1d of the lane-parallel path for ONE lane: the three FSE tables of the lane's block (its own descriptions, or those of the
+// block it repeats) in the lane's workspace slot `zl`, then the block's sequences as (ll, ml, Offset_Value) triples into the
+// sequence area.  Returns false on corrupt input.
+__device__ __forceinline__ bool v2_sequences_lane(ZState* zl, const ZState* z, const V2Info* I, const uint8_t* src, const uint8_t* bp, const int bend,
+                                                  const int spos, const int nseq, const uint32_t modes, const uint32_t soff, uint32_t* seqarea, const int lane)
 {
+    bool bad = false;
+    if (nseq > 0) {
+        uint32_t* const logs = zl->rank + 12;                      // table logs of LL / OF / ML (rank[] is free after the Huffman build)
+        logs[0] = logs[1] = logs[2] = 0;
+        int pos = spos;
+        for (int t = 0; t < 3 && !bad; t++) {
+            int mode = int((modes >> (6 - 2 * t)) & 3);
+            if (mode != 3) { const int lg = build_seq_table_lane(zl, bp, bend, pos, t, mode); if (lg < 0) bad = true; else logs[t] = uint32_t(lg); continue; }
+            // repeat: the most recent earlier block with sequences defines it (possibly itself by repeating)
+            int j = lane - 1; bool found = false;
+            for (; j >= 0 && !bad; j--) {
+                if (I->type[j] != 2 || I->nseq[j] == 0) continue;
+                const uint8_t* bj = src + I->off[j]; const int be = int(I->size[j]);
+                LitHdr hj; int pj, nj; uint32_t mj;
+                if (!parse_lit_hdr(bj, be, hj)) { bad = true; break; }
+                pj = int(hj.lh + hj.lcsize);
+                if (!parse_seq_hdr(bj, be, pj, nj, mj)) { bad = true; break; }
+                const int mt = int((mj >> (6 - 2 * t)) & 3);
+                if (mt == 3) continue;
+                for (int u = 0; u < t && !bad; u++) if (!skip_seq_table(zl, bj, be, pj, u, int((mj >> (6 - 2 * u)) & 3))) bad = true;
+                if (!bad) { const int lg = build_seq_table_lane(zl, bj, be, pj, t, mt); if (lg < 0) bad = true; else logs[t] = uint32_t(lg); }
+                found = true;
+                break;
+            }
+            if (!found) bad = true;
+        }
+        if (!bad) {
+            const int ll_log = int(logs[0]), of_log = int(logs[1]), ml_log = int(logs[2]);
+            // one 8-byte entry per LL / ML state: {FSE entry, baseline | extra bits << 20}, in the slot's Huffman table space (free
+            // here): a sequence costs three table reads instead of five - at 2048 frames x 32 lanes every one of them goes to memory
+            uint2* const cl = reinterpret_cast<uint2*>(zl->huf);
+            uint2* const cm = cl + 512;
+            for (int u = 0; u < (1 << ll_log); u++) { const uint32_t e = zl->ll[u], c = e & 0xff; cl[u] = make_uint2(e, z->llb[c] | (uint32_t(z->llx[c]) << 20)); }
+            for (int u = 0; u < (1 << ml_log); u++) { const uint32_t e = zl->ml[u], c = e & 0xff; cm[u] = make_uint2(e, z->mlb[c] | (uint32_t(z->mlx[c]) << 20)); }
+            BitsBack bs;
+            if (!bs.init(bp + pos, bend - pos)) bad = true;
+            else {
+                uint32_t sl = bs.read(ll_log), so = bs.read(of_log), sm = bs.read(ml_log);
+                uint32_t* out = seqarea + size_t(soff) * 2;
+                for (int n = 0; n < nseq; n++) {
+                    const uint2 cle = cl[sl], cme = cm[sm];
+                    const uint32_t el = cle.x, eo = zl->of[so], em = cme.x;
+                    const uint32_t lv = cle.y, mv = cme.y;
+                    const uint32_t ocode = eo & 0xff;
+                    if (ocode > 31) { bad = true; break; }
+                    const uint32_t ov = (1u << ocode) + bs.read(int(ocode));                 // Offset_Value: 1..3 repeat codes, else offset + 3
+                    const uint32_t mlen = (mv & 0xFFFFF) + bs.read(int(mv >> 20));
+                    const uint32_t llen = (lv & 0xFFFFF) + bs.read(int(lv >> 20));
+                    sl = (el >> 16) + bs.read(int((el >> 8) & 0xff));
+                    sm = (em >> 16) + bs.read(int((em >> 8) & 0xff));
+                    so = (eo >> 16) + bs.read(int((eo >> 8) & 0xff));
+                    if (ov >> 28) { bad = true; break; }                                   // no such distance inside one 4mc block
+                    *reinterpret_cast<uint2*>(out + 2 * n) = make_uint2(llen | (mlen << 18), ov | ((mlen >> 14) << 28));
+                }
+                if (bs.pos > 0) bad = true;                        // bits left over: corruption
+            }
+        }
+    }
+    return !bad;
+}
+
+
+// The helper wave of a two-wave launch (mode 1): waits for the first wave's go (block table complete), decodes the sequences of
+// every inner block - lane i block i, in the upper half of the workspace slots - and reports.
+// flags[0]: 0 wait, 1 go (block table complete), 2 nothing to do;  flags[1]: 0 running, 1 done, 2 corrupt input
+__device__ __forceinline__ void v2_helper_wave(const uint8_t* src, uint8_t* work, ZState* z, uint32_t* flags, int lane)
+{
+    V2Info* const I = reinterpret_cast<V2Info*>(z->huf);
+    for (uint32_t spins = 0;; spins++) {
+        const uint32_t g = __hip_atomic_load(&flags[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (g == 1) break;
+        if (g == 2) return;
+        __builtin_amdgcn_s_sleep(8);
+        if (spins > (1u << 22)) return;                                // (the first wave gives up on seq_done the same way)
+    }
+    const int nblk = int(I->nblk);
+    ZState* const zl = reinterpret_cast<ZState*>(work + size_t(lane + 32) * kV2State);
+    uint8_t* const litarea = work + kMaxInner * kV2State;
+    uint32_t* const seqarea = reinterpret_cast<uint32_t*>(litarea + kV2Lit);
+    bool bad = false;
+    if (lane < nblk && I->type[lane] == 2 && I->nseq[lane] > 0) {
+        const uint8_t* const bp = src + I->off[lane];
+        const int bend = int(I->size[lane]);
+        LitHdr lh; int spos, nseq; uint32_t modes;
+        if (!parse_lit_hdr(bp, bend, lh)) bad = true;                  // (validated by the first wave already)
+        else {
+            spos = int(lh.lh + lh.lcsize);
+            if (!parse_seq_hdr(bp, bend, spos, nseq, modes)) bad = true;
+            else bad = !v2_sequences_lane(zl, z, I, src, bp, bend, spos, nseq, modes, I->seq_off[lane], seqarea, lane);
+        }
+    }
+    const bool anybad = __ballot(bad) != 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                  // the triples are in memory before the report is seen
+    if (lane == 0) __hip_atomic_store(&flags[1], anybad ? 2u : 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csize, uint8_t* dst, int cap, uint8_t* work, ZState* z, int lane, const bool split, uint32_t* flags)
+{
+    const bool two_wave = flags != nullptr;
     V2Info* const I = reinterpret_cast<V2Info*>(z->huf);
     ZState* const zl = reinterpret_cast<ZState*>(work + size_t(lane) * kV2State);
     uint8_t* const litarea = work + kMaxInner * kV2State;
@@ -847,12 +957,17 @@ __device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csiz
             I->lit_off[lane] = lh.ltype >= 2 ? loff : I->off[lane] + lh.lh;
             I->lit_rle[lane] = (mine && lh.ltype == 1) ? bp[lh.lh] : uint8_t(0);
         }
+        const bool helper_go = two_wave && nblk <= 32;
+        if (helper_go) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) { I->nblk = uint32_t(nblk); __hip_atomic_store(&flags[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        }
         ZPH(t_hdr);
         // ------------------------------------------------------------ step 1b: Huffman literals (table of this block or of the block it repeats)
         // With <= 32 inner blocks the upper half-wave would idle: lane L works on block L & 31 and decodes the stream
         // pair L >> 5 of its four Huffman streams (each half builds its own copy of the table in its own slot).
         // Only when the launch leaves the CUs under-filled: at 8 waves per CU the extra table builds cost more than they save.
-        const bool split = nblk <= 32 && gridDim.x < 1024u;
+        const bool split = nblk <= 32 && gridDim.x < 1024u && !helper_go;        // (the helper wave owns the upper workspace slots)
         const int hb = split ? (lane & 31) : lane, half = split ? (lane >> 5) : 0;
         LitHdr hh = lh; const uint8_t* hbp = bp; uint32_t hloff = loff; bool hmine = mine;
         if (split && lane >= 32) {
@@ -861,24 +976,49 @@ __device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csiz
             hh.ltype = 0;
             if (hmine) { parse_lit_hdr(hbp, int(I->size[hb]), hh); hloff = I->lit_off[hb]; }      // already validated by lane hb
         }
+        // Huffman tables.  Built once per DEFINING block (literal type 2, by its own lane, in its workspace slot); a block of type 3
+        // ("treeless") reads the table of the nearest defining block before it - text-like frames have one table for all 32 blocks.
+        // The first three tables are copied into LDS (the FSE table space of the one-wave path, idle here): a symbol is a chain of
+        // table read -> bits -> next read, 130 clk per link from LDS against a trip to memory (2048 frames x 32 lanes x 4 KiB of
+        // tables do not stay in any cache).
+        int huf_log = 0, used = 0;
+        const bool definer = hmine && hh.ltype == 2 && half == 0;
+        if (definer) { used = read_huf_table(zl, hbp + hh.lh, int(hh.lcsize), &huf_log); if (used < 0) bad = true; }
+        if (__ballot(bad)) return kErr;
+        const unsigned long long defmask = __ballot(definer);
+        int defj = -1;
         if (hmine && hh.ltype >= 2) {
-            int huf_log = 0, used = 0;
-            if (hh.ltype == 2) used = read_huf_table(zl, hbp + hh.lh, int(hh.lcsize), &huf_log);
-            else {
-                int j = hb - 1, ok = 0;
-                for (; j >= 0; j--) {
-                    if (I->type[j] != 2) continue;
-                    LitHdr hj;
-                    const uint8_t* bj = src + I->off[j];
-                    if (!parse_lit_hdr(bj, int(I->size[j]), hj)) break;
-                    if (hj.ltype == 2) { ok = read_huf_table(zl, bj + hj.lh, int(hj.lcsize), &huf_log) >= 0; break; }
-                }
-                if (!ok) used = -1;
+            const unsigned long long cand = hh.ltype == 2 ? (1ull << hb) : (defmask & ((1ull << hb) - 1));
+            if (cand) defj = 63 - __builtin_clzll(cand); else bad = true;
+        }
+        if (__ballot(bad)) return kErr;
+        const int dj = defj < 0 ? 0 : defj;
+        const int my_log = __shfl(huf_log, dj);
+        const int used_dj = __shfl(used, dj);
+        const int my_used = hh.ltype == 2 ? used_dj : 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");             // the tables are in memory before other lanes read them
+        const uint16_t* tab = reinterpret_cast<const ZState*>(work + size_t(dj) * kV2State)->huf;
+        {
+            uint16_t* const slot[3] = {reinterpret_cast<uint16_t*>(z->ll), reinterpret_cast<uint16_t*>(z->llv), z->huf + 1024};
+            int ns = 0;
+            for (unsigned long long dm = defmask; dm && ns < 3; dm &= dm - 1) {
+                const int j = __builtin_ctzll(dm);
+                const int lg = __builtin_amdgcn_readlane(huf_log, j);
+                if (lg > 11) continue;                                 // 8 KiB: stays in memory
+                const uint8_t* from = reinterpret_cast<const uint8_t*>(reinterpret_cast<const ZState*>(work + size_t(j) * kV2State)->huf);
+                const int bytes = max(2 << lg, 16);
+                for (int k = 16 * lane; k < bytes; k += 1024)
+                    *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(slot[ns]) + k) = *reinterpret_cast<const uint4*>(from + k);
+                if (defj == j) tab = slot[ns];
+                ns++;
             }
-            if (used < 0) bad = true;
-            else {
-                const uint8_t* hp8 = hbp + hh.lh + used;
-                const int hlen = int(hh.lcsize) - used;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        const int huf_log_mine = my_log;
+        if (hmine && hh.ltype >= 2) {
+            {
+                const uint8_t* hp8 = hbp + hh.lh + my_used;
+                const int hlen = int(hh.lcsize) - my_used;
                 uint8_t* const out = litarea + hloff;
                 int nstreams = 1, l1 = 0, l2 = 0, l3 = 0, seg = int(hh.lsize);
                 if (!hh.one) {
@@ -896,13 +1036,22 @@ __device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csiz
                     const int o_off = nstreams == 1 ? 0 : seg * j, o_len = nstreams == 1 ? int(hh.lsize) : ((j == 3) ? int(hh.lsize) - 3 * seg : seg);
                     BitsBack bs;
                     if (!bs.init(hp8 + s_off, s_len)) { bad = true; break; }
-                    for (int i = 0; i < o_len; i++) {
-                        const uint32_t idx = (bs.pos >= huf_log) ? bs.peek_at(bs.pos - huf_log, huf_log)
-                                                                 : (bs.peek_at(0, bs.pos > 0 ? bs.pos : 0) << (huf_log - (bs.pos > 0 ? bs.pos : 0)));
-                        const uint32_t e = zl->huf[idx];
+                    auto symbol = [&]() -> uint32_t {
+                        const uint32_t idx = (bs.pos >= huf_log_mine) ? bs.peek_at(bs.pos - huf_log_mine, huf_log_mine)
+                                                                 : (bs.peek_at(0, bs.pos > 0 ? bs.pos : 0) << (huf_log_mine - (bs.pos > 0 ? bs.pos : 0)));
+                        const uint32_t e = tab[idx];
                         bs.pos -= int(e >> 8);
-                        out[o_off + i] = uint8_t(e);
+                        return e & 0xff;
+                    };
+                    // four symbols per store: a byte store per symbol and lane is a partial-sector write each (2048 frames x 32
+                    // lanes of them at a time)
+                    struct __attribute__((packed, aligned(1))) U4 { uint32_t v; };
+                    int i = 0;
+                    for (; i + 4 <= o_len; i += 4) {
+                        uint32_t w4 = symbol(); w4 |= symbol() << 8; w4 |= symbol() << 16; w4 |= symbol() << 24;
+                        reinterpret_cast<U4*>(out + o_off + i)->v = w4;
                     }
+                    for (; i < o_len; i++) out[o_off + i] = uint8_t(symbol());
                     if (bs.pos != 0) bad = true;
                 }
             }
@@ -910,61 +1059,28 @@ __device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csiz
         if (__ballot(bad)) return kErr;
         ZPH(t_lit);
         // ------------------------------------------------------------ step 1c/1d: sequence tables, then the sequences themselves
-        if (mine && nseq > 0) {
-            uint32_t* const logs = zl->rank + 12;                      // table logs of LL / OF / ML (rank[] is free after the Huffman build)
-            logs[0] = logs[1] = logs[2] = 0;
-            int pos = spos;
-            for (int t = 0; t < 3 && !bad; t++) {
-                int mode = int((modes >> (6 - 2 * t)) & 3);
-                if (mode != 3) { const int lg = build_seq_table_lane(zl, bp, bend, pos, t, mode); if (lg < 0) bad = true; else logs[t] = uint32_t(lg); continue; }
-                // repeat: the most recent earlier block with sequences defines it (possibly itself by repeating)
-                int j = lane - 1; bool found = false;
-                for (; j >= 0 && !bad; j--) {
-                    if (I->type[j] != 2 || I->nseq[j] == 0) continue;
-                    const uint8_t* bj = src + I->off[j]; const int be = int(I->size[j]);
-                    LitHdr hj; int pj, nj; uint32_t mj;
-                    if (!parse_lit_hdr(bj, be, hj)) { bad = true; break; }
-                    pj = int(hj.lh + hj.lcsize);
-                    if (!parse_seq_hdr(bj, be, pj, nj, mj)) { bad = true; break; }
-                    const int mt = int((mj >> (6 - 2 * t)) & 3);
-                    if (mt == 3) continue;
-                    for (int u = 0; u < t && !bad; u++) if (!skip_seq_table(zl, bj, be, pj, u, int((mj >> (6 - 2 * u)) & 3))) bad = true;
-                    if (!bad) { const int lg = build_seq_table_lane(zl, bj, be, pj, t, mt); if (lg < 0) bad = true; else logs[t] = uint32_t(lg); }
-                    found = true;
-                    break;
-                }
-                if (!found) bad = true;
+        // (two-wave launches: the helper wave has been decoding the sequences of every block while this one decoded the literals)
+        if (helper_go) {
+            for (uint32_t spins = 0;; spins++) {
+                const uint32_t d = __hip_atomic_load(&flags[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (d) { if (d == 2) bad = true; break; }
+                __builtin_amdgcn_s_sleep(16);
+                if (spins > (1u << 22)) { bad = true; break; }
             }
-            if (!bad) {
-                const int ll_log = int(logs[0]), of_log = int(logs[1]), ml_log = int(logs[2]);
-                for (int u = 0; u < (1 << ll_log); u++) { const uint32_t c = zl->ll[u] & 0xff; zl->llv[u] = z->llb[c] | (uint32_t(z->llx[c]) << 20); }
-                for (int u = 0; u < (1 << ml_log); u++) { const uint32_t c = zl->ml[u] & 0xff; zl->mlv[u] = z->mlb[c] | (uint32_t(z->mlx[c]) << 20); }
-                BitsBack bs;
-                if (!bs.init(bp + pos, bend - pos)) bad = true;
-                else {
-                    uint32_t sl = bs.read(ll_log), so = bs.read(of_log), sm = bs.read(ml_log);
-                    uint32_t* out = seqarea + size_t(soff) * 2;
-                    for (int n = 0; n < nseq; n++) {
-                        const uint32_t el = zl->ll[sl], eo = zl->of[so], em = zl->ml[sm];
-                        const uint32_t lv = zl->llv[sl], mv = zl->mlv[sm];
-                        const uint32_t ocode = eo & 0xff;
-                        if (ocode > 31) { bad = true; break; }
-                        const uint32_t ov = (1u << ocode) + bs.read(int(ocode));                 // Offset_Value: 1..3 repeat codes, else offset + 3
-                        const uint32_t mlen = (mv & 0xFFFFF) + bs.read(int(mv >> 20));
-                        const uint32_t llen = (lv & 0xFFFFF) + bs.read(int(lv >> 20));
-                        sl = (el >> 16) + bs.read(int((el >> 8) & 0xff));
-                        sm = (em >> 16) + bs.read(int((em >> 8) & 0xff));
-                        so = (eo >> 16) + bs.read(int((eo >> 8) & 0xff));
-                        if (ov >> 28) { bad = true; break; }                                   // no such distance inside one 4mc block
-                        out[2 * n] = llen | (mlen << 18); out[2 * n + 1] = ov | ((mlen >> 14) << 28);
-                    }
-                    if (bs.pos > 0) bad = true;                        // bits left over: corruption
-                }
-            }
-        }
+        } else if (mine && nseq > 0) bad = !v2_sequences_lane(zl, z, I, src, bp, bend, spos, nseq, modes, soff, seqarea, lane);
         if (__ballot(bad)) return kErr;
     }
     ZPH(t_seq);
+    if (split && cap <= (4 << 20)) {
+        // the execution belongs to the second kernel (zstd_exec_kernel): leave what it needs - the block table - next to the
+        // literal and sequence areas (in the slot's tail, which only the serial path uses)
+        V2Pending* const P = reinterpret_cast<V2Pending*>(work + kV2Bytes - (kBlockMax + 64));
+        const uint32_t* from = reinterpret_cast<const uint32_t*>(I);
+        uint32_t* to = reinterpret_cast<uint32_t*>(&P->info);
+        for (uint32_t i = lane; i < sizeof(V2Info) / 4; i += 64) to[i] = from[i];
+        if (lane == 0) { P->nblk = uint32_t(nblk); P->fcs = fcs; uint64_t* c = reinterpret_cast<uint64_t*>(work + kV2Bytes - 64); c[0] = t_lit; c[1] = t_hdr; c[2] = t_seq; c[3] = 0; }
+        return kPendingExec;
+    }
     // ---------------------------------------------------------------- step 2: execute the blocks in order
     int op = 0;
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
@@ -1113,45 +1229,92 @@ __device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csiz
 }
 
 // container_mode as in lz4_decode.hip (BADSUM skip, stored copy, negative -> CORRUPT)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+// mode 0: the whole decode in this kernel; 1: entropy stage here, execution in zstd_exec_kernel (result = kPendingExec) unless the
+// frame is of a shape only the serial path takes; 2: only the blocks the execute kernel handed back (result == kRetryZ), whole decode
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2)))
 void zstd_decode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks,
-                        uint32_t nblocks, uint8_t* scratch, int container_mode)
+                        uint32_t nblocks, uint8_t* scratch, int container_mode, int mode)
 {
     __shared__ ZState zs;
+    __shared__ uint32_t flags[2];
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
     const fourmc_block blk = uniform_block(blocks[b]);
+    if (mode == 2 && blk.result != kRetryZ) return;
     const uint8_t* src = src_base + blk.src_off;
     uint8_t* dst = dst_base + blk.dst_off;
     uint8_t* const work = scratch + size_t(b) * kV2Bytes;
     uint8_t* litbuf = work + kV2Bytes - (kBlockMax + 64);              // the serial path's literal buffer: the tail of the slot
-    int r;
-    if (container_mode) {
-        if (blk.result == FOURMC_BLK_BADSUM) return;
-        if (blk.src_len == blk.dst_cap) { wave_copy(dst, src, int(blk.src_len), threadIdx.x); r = int(blk.src_len); }
-        else {
-            r = zstd_decode_frame_v2(src, int(blk.src_len), dst, int(blk.dst_cap), work, &zs, threadIdx.x);
-            if (r == kDecline) r = zstd_decode_frames(src, int(blk.src_len), dst, int(blk.dst_cap), litbuf, &zs, threadIdx.x);
-            if (r < 0) r = FOURMC_BLK_CORRUPT;
-        }
-    } else {
-        r = zstd_decode_frame_v2(src, int(blk.src_len), dst, int(blk.dst_cap), work, &zs, threadIdx.x);
-        if (r == kDecline) r = zstd_decode_frames(src, int(blk.src_len), dst, int(blk.dst_cap), litbuf, &zs, threadIdx.x);
+    const bool split = mode == 1;
+    const bool two_wave = blockDim.x > 64;                              // mode 1 launches: a helper wave for the sequences
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    if (container_mode && blk.result == FOURMC_BLK_BADSUM) return;
+    if (two_wave) {
+        if (threadIdx.x == 0) { flags[0] = 0; flags[1] = 0; }
+        __syncthreads();
+        if (wave == 1) { v2_helper_wave(src, work, &zs, flags, lane); return; }
     }
-    if (threadIdx.x == 0) blocks[b].result = r;
+    uint32_t* const fl = two_wave ? flags : nullptr;
+    auto release_helper = [&] {   // whatever made the first wave leave before its go: the helper wave has nothing to do
+        if (two_wave && lane == 0 && __hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
+            __hip_atomic_store(&flags[0], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    int r;
+    if (container_mode && blk.src_len == blk.dst_cap) { release_helper(); wave_copy(dst, src, int(blk.src_len), lane); r = int(blk.src_len); }
+    else {
+        r = zstd_decode_frame_v2(src, int(blk.src_len), dst, int(blk.dst_cap), work, &zs, lane, split, fl);
+        release_helper();
+        if (r == kDecline) r = zstd_decode_frames(src, int(blk.src_len), dst, int(blk.dst_cap), litbuf, &zs, lane);
+        if (container_mode && r < 0 && r != kPendingExec) r = FOURMC_BLK_CORRUPT;
+    }
+    if (lane == 0) blocks[b].result = r;
 }
+
+#include "zstd_exec.inc"
 
 } // namespace
 
 extern "C" size_t fourmc_zstd_scratch_bytes(uint32_t n) { return size_t(n) * kV2Bytes; }
 extern "C" size_t fourmc_zstd_dec_counter_offset(void) { return kV2Bytes - 64; }   // phase counters of block 0 (profiling aid)
 
+// test aid: blocks the execute kernel completed / handed back to the one-wave kernel since the last call (this device)
+extern "C" int fourmc_gpu_debug_zstd_exec_counts(unsigned long long* executed, unsigned long long* handed_back)
+{
+    unsigned long long c[2] = {0, 0}, z[2] = {0, 0};
+    if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_x_counts), sizeof c) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_x_counts), z, sizeof z) != hipSuccess) return -1;
+    if (executed) *executed = c[0];
+    if (handed_back) *handed_back = c[1];
+    return 0;
+}
+
+// FOURMC_ZDECODE = split (default: entropy kernel + execute kernel + hand-backs) | single (everything in the one-wave kernel)
+static int g_zdecode_split = -1;
+extern "C" void fourmc_gpu_set_zstd_decode_split(int on) { g_zdecode_split = on ? 1 : 0; }
+extern "C" int fourmc_gpu_get_zstd_decode_split(void)
+{
+    if (g_zdecode_split < 0) { const char* e = getenv("FOURMC_ZDECODE"); g_zdecode_split = (e && !strcmp(e, "single")) ? 0 : 1; }
+    return g_zdecode_split;
+}
+
 extern "C" hipError_t fourmc_launch_zstd_decode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                                 void* d_scratch, int container_mode, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(zstd_decode_kernel, dim3(n), dim3(64), 0, stream,
+    const int split = fourmc_gpu_get_zstd_decode_split();
+    static const int helper = [] { const char* e = getenv("FOURMC_ZHELPER"); return e ? atoi(e) : -1; }();
+    // the helper wave pays while the frames' chains are what a launch waits for; a full chip is bound by the table reads instead
+    const bool two_wave = split && (helper < 0 ? n <= 1024u : helper != 0);
+    hipLaunchKernelGGL(zstd_decode_kernel, dim3(n), dim3(two_wave ? 128 : 64), 0, stream,
                        static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n,
-                       static_cast<uint8_t*>(d_scratch), container_mode);
+                       static_cast<uint8_t*>(d_scratch), container_mode, split ? 1 : 0);
+    if (split) {
+        hipLaunchKernelGGL(zstd_exec_kernel, dim3(n), dim3(256), 0, stream,
+                           static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n,
+                           static_cast<uint8_t*>(d_scratch), container_mode);
+        hipLaunchKernelGGL(zstd_decode_kernel, dim3(n), dim3(64), 0, stream,
+                           static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n,
+                           static_cast<uint8_t*>(d_scratch), container_mode, 2);
+    }
     return hipGetLastError();
 }

@@ -83,6 +83,12 @@ int fourmc_gpu_debug_read_workspace(void* host, size_t offset, size_t bytes);
  * copier waves per block (default), 1 = block-parallel parse kernel + executor kernel; results are identical. */
 void fourmc_gpu_set_lz4_decode_path(int path);
 int  fourmc_gpu_get_lz4_decode_path(void);
+/* Tuning knob: 4mz decode as entropy kernel + execute kernel (1, default; FOURMC_ZDECODE=split) or all in the one-wave kernel
+ * (0; FOURMC_ZDECODE=single); results are identical. */
+void fourmc_gpu_set_zstd_decode_split(int on);
+int  fourmc_gpu_get_zstd_decode_split(void);
+/* Test aid: blocks the 4mz execute kernel completed / handed back to the one-wave kernel since the last call. */
+int  fourmc_gpu_debug_zstd_exec_counts(unsigned long long* executed, unsigned long long* handed_back);
 /* Test aid: runs only the parser kernel of the block-parallel LZ4 decoder on `n` blocks and copies the first `bytes` of
  * the workspace (block 0's slot first: header, window descriptors, token positions) to `host`; layout[0..2] = slot bytes,
  * descriptor offset, token offset. */

@@ -154,3 +154,82 @@ def test_cli_decodes_4mz_files(gpu, tmp_path):
         (tmp_path / "bad.4mz").write_bytes(bytes(bad))
         r = subprocess.run([cli, "-d", "-z", "-f", str(tmp_path / "bad.4mz"), str(tmp_path / "x")], capture_output=True)
         assert r.returncode == 4 and b"invalid block checksum detected" in r.stderr
+
+
+def _shaped_blocks():
+    """Inputs chosen for the execute kernel (zstd_exec.inc): bulk records (stored and RLE inner blocks, literal runs above 1 KiB,
+    literals behind the last sequence), matches above 1 KiB and at distances up to the whole block, overlapping matches of
+    small periods, groups cut by the literal / match caps, ragged sizes."""
+    rng = np.random.default_rng(2024)
+    text = helpers.corpus(B)[: B]
+    out = []
+    out.append(np.zeros(B, np.uint8))                                                     # RLE blocks
+    out.append(rng.integers(0, 256, B, dtype=np.uint8))                                   # stored (the container keeps it raw)
+    a = rng.integers(0, 256, 300 << 10, dtype=np.uint8)
+    out.append(np.concatenate([a, text[: 200 << 10], a, a[: 100 << 10], text[: 200 << 10], a])[: B].copy())   # long matches, far away
+    b = text[: B].copy()
+    for i in range(0, B - 8192, 8192): b[i:i + 3000] = rng.integers(0, 256, 3000, dtype=np.uint8)              # literal runs above 1 KiB
+    out.append(b)
+    c = np.zeros(B, np.uint8)
+    pos = 0
+    for k, per in enumerate([1, 2, 3, 5, 7, 13, 31, 64, 100, 257, 1000] * 40):          # overlapping matches of many periods
+        n = 2000 + 137 * (k % 11)
+        if pos + n > B: break
+        c[pos:pos + per] = rng.integers(0, 256, per, dtype=np.uint8)
+        for i in range(pos + per, pos + n): c[i] = c[i - per]
+        pos += n
+    c[pos:] = text[: B - pos]
+    out.append(c)
+    d = np.concatenate([text[: 1 << 20], np.zeros(1 << 20, np.uint8), rng.integers(0, 256, 1 << 20, dtype=np.uint8), text[: 1 << 20]])
+    out.append(d)                                                                         # compressed, RLE and stored inner blocks in one frame
+    for n in (1, 100, 16384, (128 << 10) + 1, (1 << 20) + 12345):
+        out.append(text[5000: 5000 + n].copy())
+    return out
+
+
+def test_zstd_execute_kernel_shapes_both_paths(gpu):
+    """The two-kernel decode (entropy stage + execute kernel, zstd_exec.inc) and the one-wave kernel give the input back, on frames
+    of every shape the execute kernel treats specially, at levels 1 and 3; on damaged frames they give the same verdicts and bytes."""
+    srcs = _shaped_blocks()
+    lib = gpu.lib()
+    before = lib.fourmc_gpu_get_zstd_decode_split()
+    try:
+        for level in (1, 3):
+            frames = []
+            for s in srcs:
+                r, comp = helpers.orc_zstd_compress(s, level, len(s) + 1024)
+                assert r > 0
+                frames.append(bytes(comp[:r]))
+            caps = [len(s) for s in srcs]
+            got = {}
+            import ctypes as C
+            done, back = C.c_ulonglong(0), C.c_ulonglong(0)
+            for split in (1, 0):
+                lib.fourmc_gpu_set_zstd_decode_split(split)
+                lib.fourmc_gpu_debug_zstd_exec_counts(C.byref(done), C.byref(back))     # (reset)
+                res, outs, _, _ = _decode(gpu, frames, caps)
+                for i, (r, o, s) in enumerate(zip(res, outs, srcs)):
+                    assert r == len(s), (level, split, i, r)
+                    assert np.array_equal(o, s), (level, split, i)
+                assert lib.fourmc_gpu_debug_zstd_exec_counts(C.byref(done), C.byref(back)) == 0
+                # every frame is one the execute kernel takes, and none comes back (valid input)
+                assert (done.value, back.value) == ((len(frames), 0) if split else (0, 0)), (split, done.value, back.value)
+            # damaged copies of the big frames: the verdict of the two paths is the same, and so are accepted bytes
+            rng = np.random.default_rng(5 + level)
+            bad, bcaps = [], []
+            for i in (2, 3, 4, 5):
+                base = np.frombuffer(frames[i], np.uint8)
+                for t in range(6):
+                    m = base.copy()
+                    if t % 2 == 0: m[rng.integers(16, len(m))] ^= 1 << rng.integers(0, 8)
+                    else: j = rng.integers(16, len(m) - 4); m[j:j + 3] = rng.integers(0, 256, 3, dtype=np.uint8)
+                    bad.append(m.tobytes()); bcaps.append(caps[i])
+            for split in (1, 0):
+                lib.fourmc_gpu_set_zstd_decode_split(split)
+                res, outs, _, _ = _decode(gpu, bad, bcaps)
+                got[split] = (res.copy(), [o.copy() for o in outs])
+            assert np.array_equal(got[0][0], got[1][0]), (got[0][0], got[1][0])
+            for a, b2, r in zip(got[0][1], got[1][1], got[0][0]):
+                if r >= 0: assert np.array_equal(a, b2)
+    finally:
+        lib.fourmc_gpu_set_zstd_decode_split(before)

@@ -43,11 +43,12 @@ def run(src, nb, tag):
     td = t(lambda: p.decode_blocks(stage, out, dec, codec=p.CODEC_ZSTD))
     import ctypes as C
     p.lib().fourmc_zstd_dec_counter_offset.restype = C.c_size_t
-    dc = counters(0, p.lib().fourmc_zstd_dec_counter_offset(), ("literals", "headers", "sequences", "execute")) if nb == 1 else ""
+    dc = counters(0, p.lib().fourmc_zstd_dec_counter_offset(), ("literals", "headers", "sequences", "execute")) if (nb == 1 or os.environ.get("FOURMC_ZDECODE") == "single") else ""
     ok = torch.equal(out[: nb * B], src[: nb * B])
     cs = int(r["result"].astype(np.int64).sum())
     print(f"{tag:12s} blocks {nb:5d} ratio {nb * B / cs:6.3f}  enc {te:9.2f} ms ({nb * B / te / 1e6:7.2f} GB/s)  dec {td:9.2f} ms ({nb * B / td / 1e6:7.2f} GB/s) roundtrip {'ok' if ok else 'BAD'}", flush=True)
     if nb == 1: print(f"             enc phases: {ec}\n             dec phases: {dc}", flush=True)
+    elif dc: print(f"             dec phases of block 0 (one-wave kernel): {dc}", flush=True)
     if dn: print(dn, flush=True)
 if "--classes" in sys.argv:
     data = helpers.corpus(12 * B)
