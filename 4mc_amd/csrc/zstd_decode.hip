@@ -965,9 +965,8 @@ __device__ __forceinline__ int zstd_decode_frame_v2(const uint8_t* src, int csiz
         ZPH(t_hdr);
         // ------------------------------------------------------------ step 1b: Huffman literals (table of this block or of the block it repeats)
         // With <= 32 inner blocks the upper half-wave would idle: lane L works on block L & 31 and decodes the stream
-        // pair L >> 5 of its four Huffman streams (each half builds its own copy of the table in its own slot).
-        // Only when the launch leaves the CUs under-filled: at 8 waves per CU the extra table builds cost more than they save.
-        const bool split = nblk <= 32 && gridDim.x < 1024u && !helper_go;        // (the helper wave owns the upper workspace slots)
+        // pair L >> 5 of its four Huffman streams (both halves read the same table: see below).
+        const bool split = nblk <= 32 && !helper_go;                             // (the helper wave owns the upper workspace slots)
         const int hb = split ? (lane & 31) : lane, half = split ? (lane >> 5) : 0;
         LitHdr hh = lh; const uint8_t* hbp = bp; uint32_t hloff = loff; bool hmine = mine;
         if (split && lane >= 32) {
@@ -1304,7 +1303,7 @@ extern "C" hipError_t fourmc_launch_zstd_decode(const void* d_src, void* d_dst, 
     const int split = fourmc_gpu_get_zstd_decode_split();
     static const int helper = [] { const char* e = getenv("FOURMC_ZHELPER"); return e ? atoi(e) : -1; }();
     // the helper wave pays while the frames' chains are what a launch waits for; a full chip is bound by the table reads instead
-    const bool two_wave = split && (helper < 0 ? n <= 1024u : helper != 0);
+    const bool two_wave = split && (helper < 0 ? n <= 256u : helper != 0);
     hipLaunchKernelGGL(zstd_decode_kernel, dim3(n), dim3(two_wave ? 128 : 64), 0, stream,
                        static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n,
                        static_cast<uint8_t*>(d_scratch), container_mode, split ? 1 : 0);
