@@ -592,11 +592,12 @@ extern "C" size_t fourmc_lz4_decode_work_bytes(uint32_t n)
 // walker either way); they differ in how a block is parallelised:
 //   6  "auto"            4 for launches of up to 1536 blocks, 0 above: the default since round 3
 //   4  "rows"            row-parallel pipeline of four waves per block (lz4_rows.hip)
+//   7  "lanes"           one lane per sequence, wide pieces (lz4_rows.hip, K1w): 84 ms on the S-mix, opt-in
 //   0  "wave trio"       one parser wave walks the token chain, two copier waves execute (lz4_decode_fast_kernel)
 //   1  "block parallel"  parse kernel (token chain found by the whole workgroup, records in HBM) + executor kernel
 //                        (16 KiB LDS ring, literal / chain / flush waves)            lz4_parse.hip, lz4_exec.hip
 // Measured on 2048 x 4 MiB of S-mix (profiles/r02_*): 0 = 57 ms, 1 = 38 + 52 ms, so 0 stays the default; the
-// environment variable FOURMC_DECODE (auto | rows | exact | trio | par | paronly | rowsonly) or fourmc_gpu_set_lz4_decode_path() select.
+// environment variable FOURMC_DECODE (auto | rows | lanes | exact | trio | par | paronly | rowsonly | lanesonly) or fourmc_gpu_set_lz4_decode_path() select.
 static int g_decode_path = -1;
 extern "C" void fourmc_gpu_set_lz4_decode_path(int path) { g_decode_path = path; }
 extern "C" int fourmc_gpu_get_lz4_decode_path(void)
@@ -607,6 +608,8 @@ extern "C" int fourmc_gpu_get_lz4_decode_path(void)
         if (mode && !strcmp(mode, "rows")) g_decode_path = 4;
         if (mode && !strcmp(mode, "trio")) g_decode_path = 0;
         if (mode && !strcmp(mode, "rowsonly")) g_decode_path = 5;
+        if (mode && !strcmp(mode, "lanes")) g_decode_path = 7;
+        if (mode && !strcmp(mode, "lanesonly")) g_decode_path = 8;
         if (mode && !strcmp(mode, "exact")) g_decode_path = 2;
         if (mode && !strcmp(mode, "par")) g_decode_path = 1;
         if (mode && !strcmp(mode, "paronly")) g_decode_path = 3;
@@ -632,6 +635,12 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
     if (path == 4 || path == 5) {
         hipError_t e = fourmc_launch_lz4_rows(d_src, d_dst, d_blocks, n, container_mode, stream);
         if (e != hipSuccess || path == 5) return e;       // 5: test aid, shows what the row pipeline alone did
+        hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
+        return hipGetLastError();
+    }
+    if (path == 7 || path == 8) {
+        hipError_t e = fourmc_launch_lz4_lanes(d_src, d_dst, d_blocks, n, container_mode, stream);
+        if (e != hipSuccess || path == 8) return e;       // 8: test aid, shows what the lane-per-sequence path alone did
         hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
         return hipGetLastError();
     }

@@ -696,6 +696,346 @@ void lz4_decode_rows_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_b
     if (threadIdx.x == 0) blocks[b].result = S.failed ? kRetry : S.end_value;
 }
 
+
+// ================================================================================================ K1w: one lane per sequence
+// The third shape of the LZ4 fast path (FOURMC_DECODE=lanes).  The row pipeline and the wave trio move one byte per lane and
+// step, which costs 3.4 - 4.7 wave instructions per output byte; here a lane owns a whole SEQUENCE and moves it in pieces of
+// 16 / 8 / 4 / 2 / 1 bytes, so that 64 sequences (some 600 bytes of text) cost about 200 instructions.  Two waves per block:
+//   WALK  the serial part and nothing else: per window of 64 stream bytes every lane decodes the token that would start at its
+//         byte (where the next one starts), a v_readlane chain marks the true tokens, and their stream POSITIONS go into a queue
+//         in LDS.  Tokens the window rules do not cover (length continuations beyond one byte, long literal runs, the end of the
+//         block) are decoded one at a time under the strict rules of the reference's safe loop (lz4.c:2120-2330) and queued with
+//         their lengths.  The walk never needs an output position.
+//   EXEC  takes up to 64 queued tokens: every lane reads its token and offset from the stream, a prefix sum of the sizes gives
+//         each sequence its place, literals go out first (stream -> output), then the matches in passes: a match is copied once
+//         everything in front of the first unfinished match of the batch covers its source (one pass for most batches of text).
+//         Output-side rules (room behind a sequence, offsets) are checked here.  General tokens are executed by the whole wave.
+// Irregular input of any kind ends in kRetry: the exact walker of lz4_decode.hip decides.
+constexpr int kTQ = 2048;                // token queue (entries)
+constexpr int kLaneMatchMax = 80;        // longer matches / literal runs are general tokens (executed by the whole wave)
+constexpr int kLRing = 4096, kLChunk = 1024, kLAhead = 2048;   // WALK's stream ring: bytes, refill granule (64 lanes x 16 B), staged ahead of the cursor
+struct LShared {
+    uint8_t  ring[kLRing];               // the compressed stream around WALK's cursor (aligned 16-byte granules, one KiB ahead of use)
+    uint32_t tq[kTQ];                    // stream position of a token; a general token takes four entries: 1 << 31 | literal start, literals, offset, match length (0: last literals)
+    uint32_t head, tail, total, failed;  // WALK: entries [0, head) written, their number once the block ends; EXEC: entries [0, tail) consumed
+    int      end_value;
+};
+
+template <class P, class F> __device__ __forceinline__ bool lwait(LShared* S, Prof& pf, int nap, P poll, F cond)
+{
+    if (cond()) return true;
+    poll();
+    if (cond()) { LDS_ORDER(); return true; }
+    const unsigned long long t0 = pf.now();
+    for (uint32_t spins = 0;;) {
+        if ((spins & 7) == 0 && rfl(ldv(&S->failed))) return false;
+        if (nap <= 2) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(8);
+        poll();
+        if (cond()) break;
+        if (++spins > kSpinLimit) { stv(&S->failed, 1); return false; }
+    }
+    pf.add(0, t0);
+    LDS_ORDER();
+    return true;
+}
+
+__device__ void lanes_walk(LShared* S, Prof& pf, cgbyte* src, const int csize, const int lane)
+{
+    const int iend = csize;
+    Win win; win.src = src; win.csize = csize; win.lane = lane; win.la = 0; win.la_pos = -(1 << 30);
+    int ip = 0;
+    uint32_t head = 0, tail_seen = 0;
+    // aligned 16-byte granules are safe to read whenever they hold at least one stream byte
+    const int delta = int(uintptr_t(src) & 15), qend = delta + csize;
+    cgbyte* const abase = src - delta;
+    auto fetch = [&](int q) -> u32x4 { const int g = q + 16 * lane; u32x4 v = {0, 0, 0, 0}; if (g < qend) v = *reinterpret_cast<__attribute__((address_space(1))) const u32x4*>(abase + g); return v; };
+    int fill_hi = 0;
+    u32x4 pend = fetch(0);
+    auto fail = [&]() { if (lane == 0) stv(&S->failed, 1); };
+    auto room = [&](uint32_t n) -> bool {
+        return lwait(S, pf, 8, [&] { tail_seen = rfl(ldv(&S->tail)); }, [&] { return head + n <= tail_seen + uint32_t(kTQ); });
+    };
+    for (;;) {
+        ip = int(rfl(uint32_t(ip))); head = rfl(head); tail_seen = rfl(tail_seen); fill_hi = int(rfl(uint32_t(fill_hi)));
+        if (ip + 64 + 16 <= iend) {
+            // ---- a window: lane j = the token that would start at stream byte ip + j (four bytes per lane, from the ring: the
+            // stream is staged a KiB ahead, a window costs LDS reads instead of a trip to memory in the middle of the chain)
+            {
+                const int q = ip + delta;
+                if (q >= fill_hi + kLChunk) { fill_hi = q & ~(kLChunk - 1); pend = fetch(fill_hi); }
+                while (fill_hi < q + kLAhead && fill_hi < qend) {
+                    *reinterpret_cast<u32x4*>(S->ring + ((fill_hi + 16 * lane) & (kLRing - 1))) = pend;
+                    fill_hi += kLChunk;
+                    pend = fetch(fill_hi);
+                }
+            }
+            const int q0 = ip + delta + lane;
+            LDS_ORDER();
+            const uint32_t w = uint32_t(S->ring[q0 & (kLRing - 1)]) | uint32_t(S->ring[(q0 + 1) & (kLRing - 1)]) << 8 |
+                               uint32_t(S->ring[(q0 + 2) & (kLRing - 1)]) << 16 | uint32_t(S->ring[(q0 + 3) & (kLRing - 1)]) << 24;
+            const uint32_t b = w & 0xff, b1 = (w >> 8) & 0xff, L0 = b >> 4, M0 = b & 15;
+            const bool lext = L0 == 15, mext = M0 == 15;
+            const uint32_t L = L0 + (lext ? b1 : 0u);
+            const uint32_t offpos = uint32_t(lane) + 1 + (lext ? 1u : 0u) + L;
+            const uint32_t wo = uint32_t(__shfl(int(w), int(offpos & 63)));
+            const uint32_t e1 = (wo >> 16) & 0xff;
+            const uint32_t ml = M0 + 4 + (mext ? e1 : 0u);
+            const uint32_t nxt = offpos + 2 + (mext ? 1u : 0u);
+            const bool ok = !(lext && b1 == 255) && !(mext && e1 == 255) && nxt <= 64 && ml <= uint32_t(kLaneMatchMax);
+            const uint32_t jump = ok ? nxt : 128u + uint32_t(lane);     // 64: the window ends behind this token; >= 128: no window token
+            const uint32_t hop = lane == 63 ? 63u : min(jump, 63u);
+            unsigned long long tokmask = 0;
+            uint32_t pos = 0;
+            for (int round = 0; round < 3 && pos != 63; round++) {
+#pragma unroll
+                for (int i = 0; i < 7; i++) {
+                    asm volatile("s_bitset1_b64 %0, %1" : "+s"(tokmask) : "s"(pos));
+                    pos = rdl(hop, pos);
+                }
+            }
+            tokmask &= ~(1ull << 63);
+            {   // where the chain left the window: behind its last token (64), or at a byte that is no window token
+                const uint32_t last = 63u - uint32_t(__builtin_clzll(tokmask | 1ull));
+                const uint32_t j = rdl(jump, last);
+                if (j >= 128) { tokmask &= ~(1ull << last); pos = last; } else pos = j;
+            }
+            if (tokmask) {
+                const uint32_t cnt = uint32_t(__builtin_popcountll(tokmask));
+                pf.count(1); pf.count(2, cnt);
+                if (!room(cnt)) return;
+                if ((tokmask >> lane) & 1) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(tokmask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(tokmask), 0u));
+                    S->tq[(head + rank) & (kTQ - 1)] = uint32_t(ip) + uint32_t(lane);
+                }
+                head += cnt;
+                LDS_ORDER();
+                if (lane == 0) stv(&S->head, head);
+                ip += int(pos);
+                continue;
+            }
+        }
+        // ---- one sequence under the strict rules (stream side; EXEC checks the output side)
+        pf.count(3);
+        if (ip >= iend) { fail(); return; }
+        const uint32_t token = win.get(ip); ip++;
+        int lit = int(token >> 4), mlen = int(token & 15);
+        if (lit == 15) { if (!more_len(win, ip, iend - 15, true, lit)) { fail(); return; } }
+        const bool last = ip + lit > iend - 8;
+        if (last && ip + lit != iend) { fail(); return; }
+        const int lit_ip = ip;
+        int off = 0;
+        if (!last) {
+            ip += lit;
+            off = int(win.get(ip)) | (int(win.get(ip + 1)) << 8);
+            ip += 2;
+            if (mlen == 15) { if (!more_len(win, ip, iend - 4, false, mlen)) { fail(); return; } }
+            mlen += 4;
+            if (off == 0) { fail(); return; }
+        } else mlen = 0;
+        if (!room(4)) return;
+        if (lane < 4) S->tq[(head + uint32_t(lane)) & (kTQ - 1)] = lane == 0 ? (0x80000000u | uint32_t(lit_ip)) : (lane == 1 ? uint32_t(lit) : (lane == 2 ? uint32_t(off) : uint32_t(mlen)));
+        head += 4;
+        LDS_ORDER();
+        if (lane == 0) stv(&S->head, head);
+        if (last) break;
+    }
+    LDS_ORDER();
+    if (lane == 0) stv(&S->total, head);
+}
+
+// dst[d .. d+n) = dst[d-off ..], byte-serial semantics, by the whole wave: 16 bytes per lane where the distance allows
+__device__ __attribute__((noinline)) void lanes_big_match(gbyte* dst, int d, int off, int n, int lane)
+{
+    if (off < 16) {
+        // the output is periodic: the first 64 bytes straight from the period, then the distance is the largest multiple of
+        // the period that fits 64 (>= 50)
+        const int r = lane % off;
+        if (lane < min(n, 64)) { const uint8_t v = dst[d - off + r]; dst[d + lane] = v; }
+        if (n <= 64) return;
+        const int D = (64 / off) * off;
+        d += 64; n -= 64; off = D;
+    }
+    // a step moves `step` bytes, a multiple of 16 not larger than the distance: no step reads what it writes
+    const int step = min(off & ~15, 1024);
+    int k = 0;
+    for (; k + step <= n; k += step) {
+        if (16 * lane < step) { const u32x4 v = ld16g(dst + d - off + k + 16 * lane); *reinterpret_cast<__attribute__((address_space(1))) u32x4_u*>(dst + d + k + 16 * lane) = v; }
+    }
+    while (k < n) {                                                     // what is left (less than a step): bytes
+        const int lim = min(n - k, min(off, 64));
+        if (lane < lim) { const uint8_t v = dst[d - off + k + lane]; dst[d + k + lane] = v; }
+        k += lim;
+    }
+}
+
+__device__ void lanes_exec(LShared* S, Prof& pf, cgbyte* src, gbyte* dst, const int cap, const int lane)
+{
+    const int oend = cap;
+    uint32_t tail = 0, head_seen = 0, total = 0xFFFFFFFFu;
+    int op = 0;
+    auto fail = [&]() { if (lane == 0) stv(&S->failed, 1); };
+    for (;;) {
+        tail = rfl(tail); head_seen = rfl(head_seen); op = int(rfl(uint32_t(op)));
+        if (head_seen == tail) {
+            auto poll = [&] { total = rfl(ldv(&S->total)); LDS_ORDER(); head_seen = rfl(ldv(&S->head)); };
+            if (!lwait(S, pf, 2, poll, [&] { return head_seen != tail || total == tail; })) return;
+            if (head_seen == tail) break;                               // total == tail: every token executed
+        }
+        const uint32_t n = min(head_seen - tail, 64u);
+        const uint32_t e = uint32_t(lane) < n ? S->tq[(tail + uint32_t(lane)) & (kTQ - 1)] : 0u;
+        const unsigned long long gm = __ballot(uint32_t(lane) < n && (e >> 31));
+        const uint32_t g = gm ? uint32_t(__builtin_ctzll(gm)) : n;
+        if (g == 0) {
+            // ---- a general token, by the whole wave
+            pf.count(5);
+            const int lit_ip = int(rdl(e, 0) & 0x7FFFFFFFu), lit = int(rdl(e, 1)), off = int(rdl(e, 2)), mlen = int(rdl(e, 3));
+            tail += 4;
+            LDS_ORDER();
+            if (lane == 0) stv(&S->tail, tail);
+            if (mlen == 0) {                                            // the block's last sequence: literals only
+                if (op + lit > oend) { fail(); return; }
+                lean_copy(dst + op, src + lit_ip, lit, lane);
+                op += lit;
+                continue;
+            }
+            if (op + lit > oend - 12) { fail(); return; }
+            const int op2 = op + lit;
+            if (off > op2 || op2 + mlen > oend - 5) { fail(); return; }
+            lean_copy(dst + op, src + lit_ip, lit, lane);
+            lanes_big_match(dst, op2, off, mlen, lane);
+            op = op2 + mlen;
+            continue;
+        }
+        // ---- up to 64 window tokens, one per lane
+        pf.count(1); pf.count(2, g);
+        const bool act = uint32_t(lane) < g;
+        const uint32_t pos = act ? e : 0u;
+        const uint32_t w = ld4u(src + pos);
+        const uint32_t b = w & 0xff, b1 = (w >> 8) & 0xff, L0 = b >> 4, M0 = b & 15;
+        const uint32_t lextn = L0 == 15 ? 1u : 0u;
+        const uint32_t L = act ? L0 + (lextn ? b1 : 0u) : 0u;
+        const uint32_t wo = ld4u(src + pos + 1 + lextn + L);
+        const uint32_t off = wo & 0xffff;
+        const uint32_t ml = act ? M0 + 4 + (M0 == 15 ? (wo >> 16) & 0xff : 0u) : 0u;
+        tail += g;
+        LDS_ORDER();
+        if (lane == 0) stv(&S->tail, tail);
+        const uint32_t sz = L + ml;
+        const uint32_t incl = scan_add(sz);
+        const uint32_t ostart = uint32_t(op) + incl - sz, mdest = ostart + L;
+        const uint32_t T = rdl(incl, 63);
+        if (__ballot(act && (off == 0 || off > mdest || ostart + L > uint32_t(oend - 12) || mdest + ml > uint32_t(oend - 5))) || oend < 12) { fail(); return; }
+        // pieces of a run of n bytes (n < 32 after the 16-byte loop): all loads, then all stores - one round trip
+        auto copy_run = [&](const bool on, cgbyte* from, gbyte* to, uint32_t nb) {
+            uint32_t k = 0;
+            while (__ballot(on && nb - k >= 32)) { if (on && nb - k >= 32) { const u32x4 v = ld16g(from + k); *reinterpret_cast<__attribute__((address_space(1))) u32x4_u*>(to + k) = v; k += 16; } }
+            const uint32_t r = on ? nb - k : 0u;                         // < 32
+            typedef uint64_t u64_u __attribute__((aligned(1)));
+            typedef uint16_t u16_u __attribute__((aligned(1)));
+            u32x4 v16 = {0, 0, 0, 0}; uint64_t v8 = 0; uint32_t v4 = 0, v2 = 0, v1 = 0;
+            const uint32_t o16 = k, o8 = k + (r & 16), o4 = o8 + (r & 8), o2 = o4 + (r & 4), o1 = o2 + (r & 2);
+            if (r & 16) v16 = ld16g(from + o16);
+            if (r & 8) v8 = *reinterpret_cast<__attribute__((address_space(1))) const u64_u*>(from + o8);
+            if (r & 4) v4 = ld4u(from + o4);
+            if (r & 2) v2 = *reinterpret_cast<__attribute__((address_space(1))) const u16_u*>(from + o2);
+            if (r & 1) v1 = from[o1];
+            if (r & 16) *reinterpret_cast<__attribute__((address_space(1))) u32x4_u*>(to + o16) = v16;
+            if (r & 8) *reinterpret_cast<__attribute__((address_space(1))) u64_u*>(to + o8) = v8;
+            if (r & 4) *reinterpret_cast<__attribute__((address_space(1))) u32_u*>(to + o4) = v4;
+            if (r & 2) *reinterpret_cast<__attribute__((address_space(1))) u16_u*>(to + o2) = uint16_t(v2);
+            if (r & 1) to[o1] = uint8_t(v1);
+        };
+        copy_run(act && L != 0, src + pos + 1 + lextn, dst + ostart, L);
+        // ---- matches.  Which earlier matches of the batch a source touches is fixed: destinations ascend with the lane, so they are
+        // the lanes [u0, u1) found by two binary searches over the wave (ends <= source start, starts < source end); a match goes
+        // in the first pass in which none of those is unfinished.  What a match reads of ITSELF (offset < length) is no dependence
+        // on others: such a lane copies piece by piece, each piece behind its own stores (pieces of 16 or 8 bytes; below 8 the
+        // whole wave expands the period).
+        const bool overlap = act && off < ml;
+        const uint32_t s0 = mdest - off, s1 = overlap ? mdest : s0 + ml;
+        const uint32_t mend = act ? mdest + ml : 0xFFFFFFFFu, mdst = act ? mdest : 0xFFFFFFFFu;
+        unsigned long long dep = 0;
+        if (__ballot(act && s1 > uint32_t(op))) {                        // (uniform) some source reaches into this batch
+            uint32_t u0 = 0, u1 = 0;
+#pragma unroll
+            for (int step = 32; step; step >>= 1) {
+                const uint32_t e0 = bperm((u0 + uint32_t(step) - 1) << 2, mend), e1 = bperm((u1 + uint32_t(step) - 1) << 2, mdst);
+                if (e0 <= s0) u0 += uint32_t(step);
+                if (e1 < s1) u1 += uint32_t(step);
+            }
+            u0 = min(u0, 63u); u1 = min(u1, 64u);
+            const unsigned long long below1 = u1 >= 64 ? ~0ull : ~(~0ull << u1), below0 = ~(~0ull << u0);
+            dep = act && u1 > u0 ? below1 & ~below0 : 0ull;
+        }
+        unsigned long long done = ~__ballot(act);
+        const unsigned long long tpass = pf.now();
+        for (uint32_t pass = 0; ~done; pass++) {
+            if (pass > 64) { fail(); return; }
+            pf.count(3);
+            const bool go = !((done >> lane) & 1) && (dep & ~done) == 0;
+            const unsigned long long gomask = __ballot(go);
+            copy_run(go && !overlap, (cgbyte*)(dst + s0), dst + mdest, ml);
+            const unsigned long long ov = __ballot(go && overlap);
+            if (ov) {
+                pf.count(4, uint64_t(__builtin_popcountll(ov)));
+                // offsets of 8 and more: in the lane, sequentially (a piece never reads what it writes itself)
+                const bool seq = go && overlap && off >= 8;
+                if (__ballot(seq)) {
+                    typedef uint64_t u64_u __attribute__((aligned(1)));
+                    uint32_t k = 0;
+                    while (__ballot(seq && off >= 16 && ml - k >= 16)) { if (seq && off >= 16 && ml - k >= 16) { const u32x4 v = ld16g((cgbyte*)(dst + s0 + k)); *reinterpret_cast<__attribute__((address_space(1))) u32x4_u*>(dst + mdest + k) = v; k += 16; } }
+                    while (__ballot(seq && ml - k >= 8)) { if (seq && ml - k >= 8) { const uint64_t v = *reinterpret_cast<__attribute__((address_space(1))) const u64_u*>(dst + s0 + k); *reinterpret_cast<__attribute__((address_space(1))) u64_u*>(dst + mdest + k) = v; k += 8; } }
+                    if (seq && ((ml - k) & 4)) { const uint32_t v = ld4u((cgbyte*)(dst + s0 + k)); *reinterpret_cast<__attribute__((address_space(1))) u32_u*>(dst + mdest + k) = v; k += 4; }
+                    if (seq && ((ml - k) & 2)) { typedef uint16_t u16_u __attribute__((aligned(1))); const uint16_t v = *reinterpret_cast<__attribute__((address_space(1))) const u16_u*>(dst + s0 + k); *reinterpret_cast<__attribute__((address_space(1))) u16_u*>(dst + mdest + k) = v; k += 2; }
+                    if (seq && ((ml - k) & 1)) { const uint8_t v = dst[s0 + k]; dst[mdest + k] = v; }
+                }
+                for (unsigned long long m = __ballot(go && overlap && off < 8); m; m &= m - 1) {   // short periods: by the whole wave, one at a time
+                    const uint32_t f = uint32_t(__builtin_ctzll(m));
+                    lanes_big_match(dst, int(rdl(mdest, f)), int(rdl(off, f)), int(rdl(ml, f)), lane);
+                }
+            }
+            done |= gomask;
+        }
+        pf.add(6, tpass);
+        op += int(T);
+    }
+    if (lane == 0) S->end_value = op;
+}
+
+__global__ __launch_bounds__(128)
+void lz4_decode_lanes_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
+                             fourmc_block* blocks, uint32_t nblocks, int container_mode, unsigned long long* prof)
+{
+    __shared__ __attribute__((aligned(16))) LShared S;
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    const fourmc_block blk = uniform_block(blocks[b]);
+    if (container_mode && blk.result == FOURMC_BLK_BADSUM) return;
+    const uint8_t* src = src_base + blk.src_off;
+    uint8_t* dst = dst_base + blk.dst_off;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    if (container_mode && blk.src_len == blk.dst_cap) {                 // stored block (native/4mc.c:635-642)
+        if (wave == 0) { wave_copy(dst, src, int(blk.src_len), lane); if (lane == 0) blocks[b].result = int(blk.src_len); }
+        return;
+    }
+    if (blk.src_len < 8 || blk.src_len > lz4par::kSrcMax || blk.dst_cap < 64 || blk.dst_cap > lz4par::kDstMax) {
+        if (threadIdx.x == 0) blocks[b].result = kRetry;
+        return;
+    }
+    if (threadIdx.x == 0) { S.head = 0; S.tail = 0; S.total = 0xFFFFFFFFu; S.failed = 0; S.end_value = kRetry; }
+    __syncthreads();
+    Prof pf;
+    const unsigned long long t_role = pf.now();
+    if (wave == 0) lanes_walk(&S, pf, (cgbyte*)src, int(blk.src_len), lane);
+    else lanes_exec(&S, pf, (cgbyte*)src, (gbyte*)dst, int(blk.dst_cap), lane);
+    pf.add(7, t_role);
+#ifdef K1R_PROF
+    if (prof && lane == 0) for (int i = 0; i < 8; i++) prof[(size_t(b) * 4 + wave) * 8 + i] = pf.t[i];
+#endif
+    __syncthreads();
+    if (threadIdx.x == 0) blocks[b].result = S.failed ? kRetry : S.end_value;
+}
+
 } // namespace
 
 #ifdef K1R_PROF
@@ -723,3 +1063,17 @@ extern "C" int fourmc_gpu_debug_rows_prof(unsigned long long* host, uint32_t nbl
     return hipMemcpy(host, g_prof, size_t(nblocks) * 32 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
 }
 #endif
+
+extern "C" hipError_t fourmc_launch_lz4_lanes(const void* d_src, void* d_dst, fourmc_block* d_blocks,
+                                              uint32_t n, int container_mode, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    unsigned long long* prof = nullptr;
+#ifdef K1R_PROF
+    if (n > g_prof_blocks) { if (g_prof) (void)hipFree(g_prof); g_prof = nullptr; if (hipMalloc(&g_prof, size_t(n) * 32 * 8) == hipSuccess) g_prof_blocks = n; }
+    prof = g_prof;
+#endif
+    hipLaunchKernelGGL(lz4_decode_lanes_kernel, dim3(n), dim3(128), 0, stream,
+                       static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n, container_mode, prof);
+    return hipGetLastError();
+}

@@ -8,7 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers
 p = importlib.import_module("4mc_amd"); p.gpu_init(0)
-p.lib().fourmc_gpu_set_lz4_decode_path(5)
+LANES = os.environ.get("LANES") == "1"                                  # the lane-per-sequence path (two roles) instead of the row pipeline
+p.lib().fourmc_gpu_set_lz4_decode_path(8 if LANES else 5)
 L = C.CDLL(os.environ["FOURMC_LIB"])
 L.fourmc_gpu_debug_rows_prof.argtypes = [C.c_void_p, C.c_uint32]; L.fourmc_gpu_debug_rows_prof.restype = C.c_int
 B = p.BLOCKSIZE
@@ -17,6 +18,11 @@ ROLE = {0: ("pre ", ["wait ring", "", "", "", "", "", ""]),
         1: ("walk", ["wait pre", "wait res slot", "wait copier", "general tokens", "#general", "", ""]),
         2: ("post", ["walk wait", "row reads", "marking", "sizes", "copier room", "records+literals", "publish"]),
         3: ("copy", ["stores+rounds", "#iterations", "#match bytes", "#passes", "admit+owners", "scratch phase", "loads"])}
+
+if LANES:
+    ROLE = {0: ("walk", ["wait queue room", "#windows", "#window tokens", "#general tokens", "", "", ""]),
+            1: ("exec", ["wait tokens", "#batches", "#batch tokens", "#passes", "#overlapping (whole wave)", "#general", "matches"]),
+            2: ("-", [""] * 7), 3: ("-", [""] * 7)}
 
 def show(t, ms, tag):
     print(f"== {tag}: {ms:.2f} ms; Mclk (counts plain)")
