@@ -36,9 +36,9 @@ out += "\n" + open(o + "summary_sq.md").read() + "\n" + open(o + "summary_sq2.md
 open(f"profiles/{name}_sq_counters.md", "w").write(out)
 # the LZ4 decode paths side by side (tools/k1_timing.py under FOURMC_DECODE=rows / trio)
 if os.path.exists(o + "summary_rows_stats.md"):
-    txt = "# FOURMC_DECODE=rows | trio  rocprofv3 ... -- python tools/k1_timing.py   (2048 and 256 blocks of S-mix, decode only; per mode: two kernel traces, two SQ groups)\n\n"
+    txt = "# FOURMC_DECODE=rows | trio | lanes  rocprofv3 ... -- python tools/k1_timing.py   (2048 and 256 blocks of S-mix, decode only; per mode: two kernel traces, two SQ groups)\n\n"
     txt += "| path | kernel | waves' time parked (s_waitcnt) | issuing | issue stalls | VALU busy (of 1024 SIMDs) | SALU : VALU | instructions per output byte (VALU+SALU+LDS+VMEM) | LDS instr | LDS busy (of 256 CUs) | LDS bank-conflict / LDS active |\n|---|---|---|---|---|---|---|---|---|---|---|\n"
-    for mode, kern in (("rows", "lz4_decode_rows_kernel"), ("trio", "lz4_decode_fast_kernel")):
+    for mode, kern in (("rows", "lz4_decode_rows_kernel"), ("trio", "lz4_decode_fast_kernel"), ("lanes", "lz4_decode_lanes_kernel")):
         pa, pb = rows(o + f"summary_{mode}_sq.md"), rows(o + f"summary_{mode}_sq2.md")
         if kern not in pa: continue
         x, y = pa[kern], pb.get(kern, {})
@@ -47,7 +47,7 @@ if os.path.exists(o + "summary_rows_stats.md"):
         txt += "| %s | %s | %.0f %% | %.0f %% | %.0f %% | %.0f %% | %.2f | %.2f | %.2e | %.0f %% | %.2f |\n" % (mode, kern, 100 * x["SQ_WAIT_ANY"] / wc, 100 * x["SQ_ACTIVE_INST_ANY"] / wc, 100 * x["SQ_WAIT_INST_ANY"] / wc,
                 100 * 4 * y.get("SQ_ACTIVE_INST_VALU", 0) / (1024 * cyc), x["SQ_INSTS_SALU"] / x["SQ_INSTS_VALU"], n / (2048 * 4194304.0), x["SQ_INSTS_LDS"],
                 100 * 4 * y.get("SQ_ACTIVE_INST_LDS", 0) / (256 * cyc), y.get("SQ_LDS_BANK_CONFLICT", 0) / max(y.get("SQ_LDS_IDX_ACTIVE", 1), 1))
-    for mode in ("rows", "trio"):
+    for mode in ("rows", "trio", "lanes"):
         for sfx in ("_stats", "256_stats", "_sq", "_sq2"):
             f = o + f"summary_{mode}{sfx}.md"
             if os.path.exists(f): txt += f"\n## {mode}{sfx}\n\n" + open(f).read()
