@@ -329,6 +329,15 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                     const bool term = !shm || ((infE >> 17) & 1) || (((infE >> 8) & 7) == 5 && E - lane >= 5);
                     nxt = term ? (0x8000u | (shm ? uint32_t(E) : 64u)) : ((infE & 255) | (uint32_t(E) << 8));
                 }
+                // the same for a lane as a chosen HIT: where the walk lands behind its match, and what it does there
+                uint32_t nextE, fin;
+                {
+                    const uint32_t land = info & 255;
+                    const uint32_t nl = __shfl(nxt, int(land & 63));
+                    const bool endn = land >= 64 || (nl & 0x8000u);
+                    nextE = endn ? uint32_t(lane) : (nl >> 8) & 63;
+                    fin = land >= 64 ? 0x4000u : nl;
+                }
                 K2PH(pt_prep);
                 for (;;) {
                     unsigned long long sel = 0;
@@ -353,13 +362,27 @@ __device__ int lz4_encode_block(const uint8_t* src, uint8_t* dst, const int n, c
                         }
                     }
                     K2PH(pt_gen);
-                    while (reason < 0) {
+                    if (reason < 0) {
+                        // The walk proper, over the HIT lanes: nextE is the next chosen hit behind a hit (itself when taking it ends
+                        // the walk), so the chain is a straight run of s_bitset1 + v_readlane pairs without a branch per sequence
+                        // (re-marking the last hit is harmless), tested for its end every six; `fin` says what ended it.
                         K2CNT(pt_nseq);
                         const uint32_t t = rl(nxt, cur);
-                        if (t & 0x8000u) { e = int(t & 127); reason = e == 64 ? 0 : 1; break; }
-                        sel |= 1ull << ((t >> 8) & 63);
-                        cur = anc = int(t & 255);
-                        if (cur >= 64) reason = 2;
+                        if (t & 0x8000u) { e = int(t & 127); reason = e == 64 ? 0 : 1; }
+                        else {
+                            uint32_t E = (t >> 8) & 63;
+                            for (;;) {
+                                asm volatile("s_bitset1_b64 %0, %1" : "+s"(sel) : "s"(E));
+                                const uint32_t n1 = rl(nextE, int(E));
+                                if (n1 == E) break;
+                                E = n1;
+                            }
+                            asm volatile("s_bitset1_b64 %0, %1" : "+s"(sel) : "s"(E));
+                            const uint32_t f = rl(fin, int(E));
+                            cur = anc = int(rl(info, int(E)) & 255);
+                            if (f & 0x4000u) reason = 2;
+                            else { e = int(f & 127); reason = e == 64 ? 0 : 1; }
+                        }
                     }
                     K2PH(pt_ext);
                     if (sel) {
