@@ -26,6 +26,8 @@ hipError_t fourmc_launch_lz4_rows(const void* d_src, void* d_dst, fourmc_block* 
                                   uint32_t n, int container_mode, hipStream_t stream);
 hipError_t fourmc_launch_lz4_lanes(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                                   uint32_t n, int container_mode, hipStream_t stream);
+hipError_t fourmc_launch_lz4_wx(const void* d_src, void* d_dst, fourmc_block* d_blocks,
+                                  uint32_t n, int container_mode, hipStream_t stream);
 hipError_t fourmc_launch_lz4_parse(const void* d_src, const void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                    int container_mode, void* d_work, hipStream_t stream);
 hipError_t fourmc_launch_lz4_exec(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,

@@ -590,14 +590,15 @@ extern "C" size_t fourmc_lz4_decode_work_bytes(uint32_t n)
 
 // Which fast path serves LZ4 decode launches.  Both produce identical results (anything irregular goes to the exact
 // walker either way); they differ in how a block is parallelised:
-//   6  "auto"            4 for launches of up to 1536 blocks, 0 above: the default since round 3
+//   6  "auto"            9: the default since the end of round 3
+//   9  "wx"              walk wave + sequence / literal wave + window copier (plan and execute waves), lz4_rows.hip (K1x)
 //   4  "rows"            row-parallel pipeline of four waves per block (lz4_rows.hip)
 //   7  "lanes"           one lane per sequence, wide pieces (lz4_rows.hip, K1w): 84 ms on the S-mix, opt-in
 //   0  "wave trio"       one parser wave walks the token chain, two copier waves execute (lz4_decode_fast_kernel)
 //   1  "block parallel"  parse kernel (token chain found by the whole workgroup, records in HBM) + executor kernel
 //                        (16 KiB LDS ring, literal / chain / flush waves)            lz4_parse.hip, lz4_exec.hip
 // Measured on 2048 x 4 MiB of S-mix (profiles/r02_*): 0 = 57 ms, 1 = 38 + 52 ms, so 0 stays the default; the
-// environment variable FOURMC_DECODE (auto | rows | lanes | exact | trio | par | paronly | rowsonly | lanesonly) or fourmc_gpu_set_lz4_decode_path() select.
+// environment variable FOURMC_DECODE (auto | wx | rows | lanes | exact | trio | par | paronly | rowsonly | lanesonly | wxonly) or fourmc_gpu_set_lz4_decode_path() select.
 static int g_decode_path = -1;
 extern "C" void fourmc_gpu_set_lz4_decode_path(int path) { g_decode_path = path; }
 extern "C" int fourmc_gpu_get_lz4_decode_path(void)
@@ -610,6 +611,8 @@ extern "C" int fourmc_gpu_get_lz4_decode_path(void)
         if (mode && !strcmp(mode, "rowsonly")) g_decode_path = 5;
         if (mode && !strcmp(mode, "lanes")) g_decode_path = 7;
         if (mode && !strcmp(mode, "lanesonly")) g_decode_path = 8;
+        if (mode && !strcmp(mode, "wx")) g_decode_path = 9;
+        if (mode && !strcmp(mode, "wxonly")) g_decode_path = 10;
         if (mode && !strcmp(mode, "exact")) g_decode_path = 2;
         if (mode && !strcmp(mode, "par")) g_decode_path = 1;
         if (mode && !strcmp(mode, "paronly")) g_decode_path = 3;
@@ -624,10 +627,9 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
     const uint8_t* s8 = static_cast<const uint8_t*>(d_src);
     uint8_t* d8 = static_cast<uint8_t*>(d_dst);
     int path = fourmc_gpu_get_lz4_decode_path();
-    // 6 "auto": a launch that leaves wave slots free is bound by the chain of its slowest block - the row pipeline's is the
-    // shorter one (36 ms against 43 ms for 64..256 blocks of the S-mix); a launch that fills every CU with eight blocks is
-    // bound by what the CU can issue, where the wave trio needs less (57 ms against 59 ms for 2048 blocks)
-    if (path == 6) path = n <= 1536 ? 4 : 0;
+    // 6 "auto": the walk + window copier (lz4_rows.hip, K1x) has the shortest chain per block at every launch size (29 ms against
+    // 36 / 43 ms for the row pipeline / the wave trio at 64..256 blocks, 38 / 44 / 49 at 1024, 55.5 / 59 / 57 at 2048)
+    if (path == 6) path = 9;
     if (path == 2) {
         hipLaunchKernelGGL(lz4_decode_exact_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
         return hipGetLastError();
@@ -635,6 +637,12 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
     if (path == 4 || path == 5) {
         hipError_t e = fourmc_launch_lz4_rows(d_src, d_dst, d_blocks, n, container_mode, stream);
         if (e != hipSuccess || path == 5) return e;       // 5: test aid, shows what the row pipeline alone did
+        hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
+        return hipGetLastError();
+    }
+    if (path == 9 || path == 10) {
+        hipError_t e = fourmc_launch_lz4_wx(d_src, d_dst, d_blocks, n, container_mode, stream);
+        if (e != hipSuccess || path == 10) return e;      // 10: test aid, shows what the path alone did
         hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
         return hipGetLastError();
     }

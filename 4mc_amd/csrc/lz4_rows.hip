@@ -711,6 +711,15 @@ void lz4_decode_rows_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_b
 //         everything in front of the first unfinished match of the batch covers its source (one pass for most batches of text).
 //         Output-side rules (room behind a sequence, offsets) are checked here.  General tokens are executed by the whole wave.
 // Irregular input of any kind ends in kRetry: the exact walker of lz4_decode.hip decides.
+#ifndef K1X_NAP_ROOM
+#define K1X_NAP_ROOM 16
+#endif
+#ifndef K1X_NAP_PLAN
+#define K1X_NAP_PLAN 4
+#endif
+#ifndef K1X_NAP_WALK
+#define K1X_NAP_WALK 32
+#endif
 constexpr int kTQ = 2048;                // token queue (entries)
 constexpr int kLaneMatchMax = 80;        // longer matches / literal runs are general tokens (executed by the whole wave)
 constexpr int kLRing = 4096, kLChunk = 1024, kLAhead = 2048;   // WALK's stream ring: bytes, refill granule (64 lanes x 16 B), staged ahead of the cursor
@@ -721,7 +730,7 @@ struct LShared {
     int      end_value;
 };
 
-template <class P, class F> __device__ __forceinline__ bool lwait(LShared* S, Prof& pf, int nap, P poll, F cond)
+template <class SH, class P, class F> __device__ __forceinline__ bool lwait(SH* S, Prof& pf, int nap, P poll, F cond)
 {
     if (cond()) return true;
     poll();
@@ -729,7 +738,7 @@ template <class P, class F> __device__ __forceinline__ bool lwait(LShared* S, Pr
     const unsigned long long t0 = pf.now();
     for (uint32_t spins = 0;;) {
         if ((spins & 7) == 0 && rfl(ldv(&S->failed))) return false;
-        if (nap <= 2) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(8);
+        if (nap <= 2) __builtin_amdgcn_s_sleep(2); else if (nap <= 8) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(32);
         poll();
         if (cond()) break;
         if (++spins > kSpinLimit) { stv(&S->failed, 1); return false; }
@@ -739,8 +748,11 @@ template <class P, class F> __device__ __forceinline__ bool lwait(LShared* S, Pr
     return true;
 }
 
-__device__ void lanes_walk(LShared* S, Prof& pf, cgbyte* src, const int csize, const int lane)
+template <class SH, int TQ, int RING, int AHEAD>
+__device__ void lanes_walk(SH* S, Prof& pf, cgbyte* src, const int csize, const int lane)
 {
+    constexpr int kTQ = TQ, kLRing = RING, kLAhead = AHEAD;
+
     const int iend = csize;
     Win win; win.src = src; win.csize = csize; win.lane = lane; win.la = 0; win.la_pos = -(1 << 30);
     int ip = 0;
@@ -753,7 +765,7 @@ __device__ void lanes_walk(LShared* S, Prof& pf, cgbyte* src, const int csize, c
     u32x4 pend = fetch(0);
     auto fail = [&]() { if (lane == 0) stv(&S->failed, 1); };
     auto room = [&](uint32_t n) -> bool {
-        return lwait(S, pf, 8, [&] { tail_seen = rfl(ldv(&S->tail)); }, [&] { return head + n <= tail_seen + uint32_t(kTQ); });
+        return lwait(S, pf, K1X_NAP_WALK, [&] { tail_seen = rfl(ldv(&S->tail)); }, [&] { return head + n <= tail_seen + uint32_t(kTQ); });
     };
     for (;;) {
         ip = int(rfl(uint32_t(ip))); head = rfl(head); tail_seen = rfl(tail_seen); fill_hi = int(rfl(uint32_t(fill_hi)));
@@ -1026,9 +1038,430 @@ void lz4_decode_lanes_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
     __syncthreads();
     Prof pf;
     const unsigned long long t_role = pf.now();
-    if (wave == 0) lanes_walk(&S, pf, (cgbyte*)src, int(blk.src_len), lane);
+    if (wave == 0) lanes_walk<LShared, kTQ, kLRing, kLAhead>(&S, pf, (cgbyte*)src, int(blk.src_len), lane);
     else lanes_exec(&S, pf, (cgbyte*)src, (gbyte*)dst, int(blk.dst_cap), lane);
     pf.add(7, t_role);
+#ifdef K1R_PROF
+    if (prof && lane == 0) for (int i = 0; i < 8; i++) prof[(size_t(b) * 4 + wave) * 8 + i] = pf.t[i];
+#endif
+    __syncthreads();
+    if (threadIdx.x == 0) blocks[b].result = S.failed ? kRetry : S.end_value;
+}
+
+
+// ================================================================================================ K1x: the walk in front of the window copier
+// FOURMC_DECODE=wx.  Four waves per block: WALK as in K1w (token positions into a queue; the serial part and nothing else), then the
+// execute pipeline of the 4mz decoder (zstd_exec.inc) fed from that queue:
+//   SL    up to 64 queued tokens, one per lane: token and offset from the stream, prefix sums place every sequence in the output,
+//         in the group's literal bytes and in MATCH SPACE; one record per sequence for PLAN, then the group's literals - one byte
+//         per lane, owner by max-scan over a byte map of literal starts, read from where the token's literals lie in the stream.
+//         A group reaches PLAN only after its literal stores have completed.  General tokens: literals by the whole wave, the match
+//         as a group of one.
+//   PLAN / EXEC   the window copier (256 match-space positions per window, stores one window late), as in zstd_exec.inc.
+constexpr int kYQ = 4, kYOwn = 1024, kYSpan = 512, kYSteps = 4, kYTQ = 512, kYRing = 2048, kYAhead = 1024;
+constexpr uint32_t kYLitCap = 1023, kYMatCap = 511;
+struct YShared {
+    uint16_t own[kYOwn];                 // start marks in match space: ((q & 511) << 6 | lane) + 1
+    uint2    rec[kYQ][64];               // {offset | mpos[9:0] << 22, D | mpos[18:10] << 22 | overlap << 31}
+    uint2    plan[2][kYSteps * 64];      // PLAN -> EXEC
+    uint8_t  ring[kYRing];               // WALK: the compressed stream around its cursor
+    uint32_t tq[kYTQ];                   // WALK -> SL: token positions (general tokens: four entries, see K1w)
+    uint16_t scr[2][kYSpan + 8];         // EXEC: two windows' worth of produced bytes
+    uint8_t  lmark[1024 + 64];           // SL: lane + 1 at the literal-stream start of each sequence of the group
+    uint2    pub[kYQ];                   // SL -> PLAN: {q + 1 once the group's literals are in memory, end of the group in match space}
+    uint2    phdr[2];
+    uint2    cc;                         // PLAN: x groups consumed, y match-space bytes consumed
+    uint32_t head, tail, total;          // the token queue
+    uint32_t plan_ready, plan_total, exec_done;
+    uint32_t total_q, failed;
+    int      end_value;
+};
+static_assert(sizeof(YShared) <= 20480, "eight blocks per CU need <= 20 KiB of LDS each");
+
+template <class P, class F> __device__ __forceinline__ bool ywait(YShared* S, int nap, P poll, F cond, unsigned long long& waited)
+{
+    if (cond()) return true;
+    poll();
+    if (cond()) { LDS_ORDER(); return true; }
+    for (uint32_t spins = 0;;) {
+        if ((spins & 7) == 0 && rfl(ldv(&S->failed))) return false;
+        if (nap <= 2) __builtin_amdgcn_s_sleep(2); else if (nap <= 4) __builtin_amdgcn_s_sleep(4); else if (nap <= 8) __builtin_amdgcn_s_sleep(8); else if (nap <= 16) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(32);
+        poll();
+        waited++;
+        if (cond()) break;
+        if (++spins > kSpinLimit) { stv(&S->failed, 1); return false; }
+    }
+    LDS_ORDER();
+    return true;
+}
+
+template <int K>
+__device__ void y_plan(YShared* S, const int lane, unsigned long long& waited)
+{
+    uint32_t g = 0, qa = 0, cqv = 0, ext = 0, ckraw = 0, wi = 0, xdone = 0;
+    for (uint32_t spins = 0;;) {
+        g = rfl(g); qa = rfl(qa); cqv = rfl(cqv); ext = rfl(ext); ckraw = rfl(ckraw); wi = rfl(wi); xdone = rfl(xdone);
+        const bool look = ext - g < 64u * K;
+        uint2 pb = make_uint2(0, 0);
+        if (look) pb = S->pub[lane & (kYQ - 1)];
+        LDS_ORDER();
+        uint32_t mark[K];
+#pragma unroll
+        for (int u = 0; u < K; u++) mark[u] = S->own[(g + 64u * u + uint32_t(lane)) & (kYOwn - 1)];
+        if (look) {
+            const uint32_t ql = cqv + ((uint32_t(lane) - cqv) & (kYQ - 1));
+            cqv += uint32_t(__builtin_popcountll(__ballot(lane < kYQ && ql < qa && pb.y <= g)));
+            const uint32_t qn = qa + ((uint32_t(lane) - qa) & (kYQ - 1));
+            const uint32_t ok = uint32_t(__ballot(lane < kYQ && pb.x == qn + 1)) & ((1u << kYQ) - 1);
+            const uint32_t rot = uint32_t(((unsigned long long)ok | (unsigned long long)ok << kYQ) >> (qa & (kYQ - 1))) & ((1u << kYQ) - 1);
+            const uint32_t n = uint32_t(__builtin_ctz(~rot));
+            if (n) { ext = rdl(pb.y, (qa + n - 1) & (kYQ - 1)); qa += n; }
+        }
+        LDS_ORDER();
+        if (lane == 0) *reinterpret_cast<volatile unsigned long long*>(&S->cc) = (unsigned long long)cqv | (unsigned long long)g << 32;
+        const bool ended = rfl(ldv(&S->total_q)) == qa;
+        if (ext == g) {
+            // records without match bytes (bulk records) are consumed by the look above; nothing to execute
+            if (ended && cqv == qa) break;
+            if (rfl(ldv(&S->failed))) return;
+            __builtin_amdgcn_s_sleep(K1X_NAP_PLAN);
+            waited++;
+            if (++spins > kSpinLimit) { stv(&S->failed, 1); return; }
+            continue;
+        }
+        spins = 0;
+        uint32_t avail = min(ext - g, 64u * K);
+        const uint32_t base = ((cqv - 1) & 511) << 6;
+        uint32_t dest[K], sp[K], km[K], nl[K];
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            nl[u] = avail > 64u * u ? min(avail - 64u * u, 64u) : 0u;
+            km[u] = scan_max(mark[u] ? ((mark[u] - 1 - base) & 0x7FFF) + 1 : 0u);
+        }
+        // (the carried owner may belong to a record consumed long ago when records without match bytes lie in between: it is
+        // not needed then - the window starts with a mark of its own - and must not win the comparison)
+        uint32_t ck = ckraw ? ((ckraw - 1 - base) & 0x7FFF) + 1 : 0u;
+        if (ck > uint32_t(kYQ + 2) * 64u) ck = 0;
+#pragma unroll
+        for (int u = 0; u < K; u++) { km[u] = max(km[u], ck); const uint32_t last = rdl(km[u], nl[u] ? nl[u] - 1 : 0u); ck = nl[u] ? last : ck; }
+        uint2 rc[K];
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            const uint32_t x = km[u] - 1 + base;                        // (q & 511) << 6 | lane of the sequence
+            rc[u] = S->rec[(x >> 6) & (kYQ - 1)][x & 63];
+        }
+        unsigned long long anyovl = 0;
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            const uint32_t m = g + 64u * u + uint32_t(lane);
+            dest[u] = m + (rc[u].y & 0x3FFFFF);
+            sp[u] = dest[u] - (rc[u].x & 0x3FFFFF);
+            anyovl |= __ballot(int(rc[u].y) < 0 && uint32_t(lane) < nl[u]);
+        }
+        if (anyovl) {                                                   // overlapping matches: read the period, not the match itself
+#pragma unroll
+            for (int u = 0; u < K; u++) {
+                const uint32_t m = g + 64u * u + uint32_t(lane);
+                const uint32_t off = rc[u].x & 0x3FFFFF, D = rc[u].y & 0x3FFFFF;
+                const uint32_t mlow = rc[u].x >> 22 | ((rc[u].y >> 22) & 0x1FF) << 10;
+                const uint32_t rel = (m - mlow) & 0x7FFFF;             // a match is shorter than 2^19 bytes
+                if (int(rc[u].y) < 0 && rel >= off) sp[u] = (m - rel) + D - off + rel % max(off, 1u);
+            }
+        }
+        const uint32_t bound0 = rdl(dest[0], 0);
+        {
+            uint32_t keep_total = avail; bool cut = false;
+#pragma unroll
+            for (int u = 0; u < K; u++) {
+                const unsigned long long out = __ballot(uint32_t(lane) < nl[u] && dest[u] - bound0 >= uint32_t(kYSpan));
+                if (out && !cut) { cut = true; keep_total = 64u * u + uint32_t(__builtin_ctzll(out)); }
+            }
+            if (cut) {
+                avail = keep_total;
+                const uint32_t lu = (avail - 1) >> 6, ll = (avail - 1) & 63;
+                ck = 0;
+#pragma unroll
+                for (int u = 0; u < K; u++) { nl[u] = avail > 64u * u ? min(avail - 64u * u, 64u) : 0u; if (uint32_t(u) == lu) ck = rdl(km[u], ll); }
+            }
+        }
+        ckraw = ((ck - 1 + base) & 0x7FFF) + 1;
+        // ---- hand the window over: a plan buffer is free once EXEC has read it
+        if (!ywait(S, 2, [&] { xdone = rfl(ldv(&S->exec_done)); }, [&] { return xdone + 2 > wi; }, waited)) return;
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            const bool lv = uint32_t(lane) < nl[u];
+            S->plan[wi & 1][64 * u + lane] = make_uint2(lv ? dest[u] : 0xFFFFFFFFu, sp[u]);
+            if (lv) S->own[(g + 64u * u + uint32_t(lane)) & (kYOwn - 1)] = 0;          // the marks of the window are consumed: cleared
+        }
+        if (lane == 0) S->phdr[wi & 1] = make_uint2(avail, bound0);
+        LDS_ORDER();
+        if (lane == 0) stv(&S->plan_ready, wi + 1);
+        wi++;
+        g += avail;
+    }
+    LDS_ORDER();
+    if (lane == 0) stv(&S->plan_total, wi);
+}
+
+template <int K>
+__device__ void y_exec(YShared* S, gbyte* dst, const int lane, unsigned long long& waited)
+{
+    uint32_t pbound = 0x80000000u, wi = 0, ready = 0, total = 0xFFFFFFFFu;
+    uint32_t pd[K];                                                   // the previous window's bytes, not stored yet: destination | byte << 24
+    bool have_prev = false;
+#pragma unroll
+    for (int u = 0; u < K; u++) pd[u] = 0;
+    for (;;) {
+        pbound = rfl(pbound); wi = rfl(wi); ready = rfl(ready);
+        if (ready <= wi) {
+            auto poll = [&] { total = rfl(ldv(&S->plan_total)); LDS_ORDER(); ready = rfl(ldv(&S->plan_ready)); };
+            if (!ywait(S, 2, poll, [&] { return ready > wi || total == wi; }, waited)) return;
+            if (ready <= wi) break;
+        }
+        const uint2 hd = S->phdr[wi & 1];
+        uint32_t dest[K], sp[K];
+#pragma unroll
+        for (int u = 0; u < K; u++) { const uint2 e = S->plan[wi & 1][64 * u + lane]; dest[u] = e.x; sp[u] = e.y; }
+        const uint32_t bound0 = rfl(hd.y);
+        LDS_ORDER();
+        if (lane == 0) stv(&S->exec_done, wi + 1);                    // (LDS operations execute in order: the reads above are done)
+        // ---- execute.  The window's bytes are stored one window LATE: a load issued behind byte stores cannot return before the
+        // stores are acknowledged (one in-order counter), so this window's loads go out first, then the previous window's stores,
+        // and the wait is for the loads alone.  What this window reads of the previous one it takes from that window's scratch
+        // (the two scratch buffers alternate); anything older was stored at least one iteration ago, in front of these loads.
+        uint16_t* const cur = S->scr[wi & 1];
+        const uint16_t* const prv = S->scr[(wi & 1) ^ 1];
+#pragma unroll
+        for (int i = 0; i < kYSpan * 2 / 1024; i++) reinterpret_cast<uint4*>(cur)[lane + 64 * i] = make_uint4(0, 0, 0, 0);
+        LDS_ORDER();
+        bool lv[K];
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            lv[u] = dest[u] != 0xFFFFFFFFu;
+            if (lv[u]) cur[dest[u] - bound0] = 0x200;
+        }
+        LDS_ORDER();
+        uint32_t t[K], tp[K], val[K];
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            t[u] = cur[(lv[u] && sp[u] >= bound0) ? sp[u] - bound0 : uint32_t(kYSpan)];           // [kYSpan] stays 0
+            tp[u] = prv[(lv[u] && sp[u] - pbound < uint32_t(kYSpan)) ? sp[u] - pbound : uint32_t(kYSpan)];
+        }
+        bool now[K]; unsigned long long pend[K];
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            const bool fwd = t[u] == 0 && (tp[u] & 0x100) != 0;         // produced by the previous window: not in memory yet
+            now[u] = lv[u] && t[u] == 0 && !fwd;
+            pend[u] = __ballot(lv[u] && t[u] != 0);
+            val[u] = tp[u] & 0xff;
+            if (lv[u] && fwd) cur[dest[u] - bound0] = uint16_t(0x100u | val[u]);
+        }
+        uint32_t ldv_[K];
+#pragma unroll
+        for (int u = 0; u < K; u++) ldv_[u] = dst[now[u] ? sp[u] : 0u];
+        if (have_prev) {
+#pragma unroll
+            for (int u = 0; u < K; u++) dst[pd[u] & 0xFFFFFF] = uint8_t(pd[u] >> 24);             // every lane: dead ones repeat the window's first byte
+        }
+#pragma unroll
+        for (int u = 0; u < K; u++) if (now[u]) { val[u] = ldv_[u]; cur[dest[u] - bound0] = uint16_t(0x100u | ldv_[u]); }
+        for (uint32_t rounds = 0;; rounds++) {
+            unsigned long long any = 0;
+#pragma unroll
+            for (int u = 0; u < K; u++) any |= pend[u];
+            if (!any) break;
+            if (rounds > 64u * K) { stv(&S->failed, 1); return; }
+            LDS_ORDER();
+#pragma unroll
+            for (int u = 0; u < K; u++) {
+                if (!pend[u]) continue;
+                const uint32_t tt = cur[((pend[u] >> lane) & 1) ? sp[u] - bound0 : uint32_t(kYSpan)];
+                const bool got = (tt & 0x100) != 0;
+                if (got) { val[u] = tt & 0xff; cur[dest[u] - bound0] = uint16_t(tt); }
+                pend[u] &= ~__ballot(got);
+            }
+        }
+        {
+            const uint32_t first = rdl(dest[0] | val[0] << 24, 0);
+#pragma unroll
+            for (int u = 0; u < K; u++) pd[u] = lv[u] ? (dest[u] | val[u] << 24) : first;
+        }
+        have_prev = true; pbound = bound0; wi++;
+    }
+    if (have_prev) {
+#pragma unroll
+        for (int u = 0; u < K; u++) dst[pd[u] & 0xFFFFFF] = uint8_t(pd[u] >> 24);
+    }
+}
+
+
+__device__ void y_sl(YShared* S, cgbyte* src, gbyte* dst, const int cap, const int lane, unsigned long long& waited)
+{
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    const int oend = cap;
+    uint32_t tail = 0, head_seen = 0, total = kNone;
+    uint32_t q = 0, mb = 0, cq_seen = 0, cg_seen = 0, pend_q = kNone, pend_m = 0;
+    int op = 0;
+    auto fail = [&]() { if (lane == 0) stv(&S->failed, 1); };
+    auto publish = [&] {       // the pending group's stores have completed (the caller waited): show it to PLAN
+        if (pend_q != kNone) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) S->pub[pend_q & (kYQ - 1)] = make_uint2(pend_q + 1, pend_m);
+            pend_q = kNone;
+        }
+    };
+    auto flush_pending = [&] { if (pend_q != kNone) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); publish(); } };
+    auto room = [&] { return cq_seen + kYQ > q && mb <= cg_seen + uint32_t(kYOwn - 512); };
+    auto wait_room = [&]() -> bool {      // a record slot is free and the group's start marks fit the ring
+        if (room()) return true;
+        flush_pending();                   // PLAN may be waiting for what is held back here
+        return ywait(S, K1X_NAP_ROOM, [&] { const uint2 c = ldv2(&S->cc); cq_seen = c.x; cg_seen = c.y; }, room, waited);
+    };
+    auto mark_of = [&](uint32_t l) { return uint16_t(((q & 511) << 6 | l) + 1); };
+    for (;;) {
+        tail = rfl(tail); head_seen = rfl(head_seen); op = int(rfl(uint32_t(op))); q = rfl(q); mb = rfl(mb);
+        cq_seen = rfl(cq_seen); cg_seen = rfl(cg_seen); pend_q = rfl(pend_q); pend_m = rfl(pend_m);
+        if (head_seen == tail) {
+            auto poll = [&] { total = rfl(ldv(&S->total)); LDS_ORDER(); head_seen = rfl(ldv(&S->head)); };
+            poll();
+            if (head_seen == tail && total != tail) {
+                flush_pending();
+                if (!ywait(S, 2, poll, [&] { return head_seen != tail || total == tail; }, waited)) return;
+            }
+            if (head_seen == tail) break;                               // total == tail: every token taken
+        }
+        const uint32_t n = min(head_seen - tail, 64u);
+        const uint32_t e = uint32_t(lane) < n ? S->tq[(tail + uint32_t(lane)) & (kYTQ - 1)] : 0u;
+        const unsigned long long gm = __ballot(uint32_t(lane) < n && (e >> 31));
+        const uint32_t g = gm ? uint32_t(__builtin_ctzll(gm)) : n;
+        if (g == 0) {
+            // ---- a general token: literals by the whole wave, the match as a group of one
+            const int lit_ip = int(rdl(e, 0) & 0x7FFFFFFFu), lit = int(rdl(e, 1)), off = int(rdl(e, 2)), mlen = int(rdl(e, 3));
+            tail += 4;
+            LDS_ORDER();
+            if (lane == 0) stv(&S->tail, tail);
+            if (mlen == 0) {                                            // the block's last sequence: literals only
+                if (op + lit > oend) { fail(); return; }
+                lean_copy(dst + op, src + lit_ip, lit, lane);
+                op += lit;
+                continue;
+            }
+            if (op + lit > oend - 12) { fail(); return; }
+            const int op2 = op + lit;
+            if (off > op2 || op2 + mlen > oend - 5) { fail(); return; }
+            if (!wait_room()) return;
+            flush_pending();                                            // (in front of this group's stores, as below)
+            lean_copy(dst + op, src + lit_ip, lit, lane);
+            if (lane == 0) {
+                S->own[mb & (kYOwn - 1)] = mark_of(0);
+                S->rec[q & (kYQ - 1)][0] = make_uint2(uint32_t(off) | (mb & 0x3FF) << 22, uint32_t(op2 - int(mb)) | ((mb >> 10) & 0x1FF) << 22 | (off < mlen ? 1u : 0u) << 31);
+            }
+            pend_q = q; pend_m = mb + uint32_t(mlen);
+            q++; mb += uint32_t(mlen); op = op2 + mlen;
+            continue;
+        }
+        // ---- up to 64 window tokens, one per lane; the group ends where its literals or the matches in front of a sequence pass the caps
+        const bool in = uint32_t(lane) < g;
+        const uint32_t pos = in ? e : 0u;
+        const uint32_t w = ld4u(src + pos);
+        const uint32_t b = w & 0xff, b1 = (w >> 8) & 0xff, L0 = b >> 4, M0 = b & 15;
+        const uint32_t lextn = L0 == 15 ? 1u : 0u;
+        const uint32_t L_all = in ? L0 + (lextn ? b1 : 0u) : 0u;
+        const uint32_t litpos = pos + 1 + lextn;
+        const uint32_t wo = ld4u(src + litpos + L_all);
+        const uint32_t off = wo & 0xffff;
+        const uint32_t ml_all = in ? M0 + 4 + (M0 == 15 ? (wo >> 16) & 0xff : 0u) : 0u;
+        const uint32_t lli0 = scan_add(L_all), mli0 = scan_add(ml_all);
+        const unsigned long long okm = __ballot(in && lli0 <= kYLitCap && mli0 - ml_all <= kYMatCap);
+        const uint32_t cnt = ~okm ? uint32_t(__builtin_ctzll(~okm)) : 64u;          // >= 1: a window token has at most 62 literals
+        const bool act = uint32_t(lane) < cnt;
+        const uint32_t L = act ? L_all : 0u, ml = act ? ml_all : 0u;
+        tail += cnt;
+        LDS_ORDER();
+        if (lane == 0) stv(&S->tail, tail);
+        const uint32_t Lsum = rdl(lli0, cnt - 1), Msum = rdl(mli0, cnt - 1);
+        const uint32_t lstart = lli0 - L_all, mexcl = mli0 - ml_all;
+        const uint32_t ostart = uint32_t(op) + lstart + mexcl, mdest = ostart + L;
+        if (oend < 12 || __ballot(act && (off == 0 || off > mdest || ostart + L > uint32_t(oend - 12) || mdest + ml > uint32_t(oend - 5)))) { fail(); return; }
+        if (!wait_room()) return;
+        if (act) {
+            const uint32_t mpos = mb + mexcl;
+            S->own[mpos & (kYOwn - 1)] = mark_of(uint32_t(lane));
+            S->rec[q & (kYQ - 1)][lane] = make_uint2(off | (mpos & 0x3FF) << 22, (mdest - mpos) | ((mpos >> 10) & 0x1FF) << 22 | (off < ml ? 1u : 0u) << 31);
+        }
+        // the previous group's literal stores were issued an iteration ago: complete them (normally no wait) and publish it BEFORE
+        // this group's stores go out
+        flush_pending();
+        if (Lsum) {
+            const uint32_t lr = L | lstart << 10 | mexcl << 20;
+            if (act && L) S->lmark[lstart] = uint8_t(lane + 1);
+            LDS_ORDER();
+            uint32_t carry = 0;
+            for (uint32_t j0 = 0; j0 < Lsum; j0 += 64u * kYSteps) {
+                uint32_t m[kYSteps], lw[kYSteps], lp[kYSteps], v[kYSteps];
+#pragma unroll
+                for (int u = 0; u < kYSteps; u++) m[u] = S->lmark[min(j0 + 64u * u + uint32_t(lane), 1024u + 63u)];
+#pragma unroll
+                for (int u = 0; u < kYSteps; u++) { m[u] = max(scan_max(m[u]), carry); carry = rdl(m[u], 63); }
+#pragma unroll
+                for (int u = 0; u < kYSteps; u++) { const uint32_t a4 = ((m[u] - 1) & 63) << 2; lw[u] = bperm(a4, lr); lp[u] = bperm(a4, litpos); }
+#pragma unroll
+                for (int u = 0; u < kYSteps; u++) {
+                    const uint32_t j = j0 + 64u * u + uint32_t(lane);
+                    v[u] = src[j < Lsum ? lp[u] + (j - ((lw[u] >> 10) & 1023)) : 0u];
+                }
+#pragma unroll
+                for (int u = 0; u < kYSteps; u++) { const uint32_t j = j0 + 64u * u + uint32_t(lane); if (j < Lsum) dst[uint32_t(op) + j + (lw[u] >> 20)] = uint8_t(v[u]); }
+            }
+            LDS_ORDER();
+            *reinterpret_cast<uint4*>(S->lmark + 16 * lane) = make_uint4(0, 0, 0, 0);
+            LDS_ORDER();
+        }
+        pend_q = q; pend_m = mb + Msum;
+        q++; op += int(Lsum + Msum); mb += Msum;
+    }
+    flush_pending();
+    if (lane == 0) S->end_value = op;
+    LDS_ORDER();
+    if (lane == 0) stv(&S->total_q, q);
+}
+
+__global__ __launch_bounds__(256, 8)
+void lz4_decode_wx_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
+                          fourmc_block* blocks, uint32_t nblocks, int container_mode, unsigned long long* prof)
+{
+    __shared__ __attribute__((aligned(16))) YShared S;
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    const fourmc_block blk = uniform_block(blocks[b]);
+    if (container_mode && blk.result == FOURMC_BLK_BADSUM) return;
+    const uint8_t* src = src_base + blk.src_off;
+    uint8_t* dst = dst_base + blk.dst_off;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    if (container_mode && blk.src_len == blk.dst_cap) {                 // stored block (native/4mc.c:635-642)
+        if (wave == 0) { wave_copy(dst, src, int(blk.src_len), lane); if (lane == 0) blocks[b].result = int(blk.src_len); }
+        return;
+    }
+    if (blk.src_len < 8 || blk.src_len > lz4par::kSrcMax || blk.dst_cap < 64 || blk.dst_cap > lz4par::kDstMax) {
+        if (threadIdx.x == 0) blocks[b].result = kRetry;
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < uint32_t(kYOwn) / 2; i += 256) reinterpret_cast<uint32_t*>(S.own)[i] = 0;
+    for (uint32_t i = threadIdx.x; i < sizeof(S.lmark) / 4; i += 256) reinterpret_cast<uint32_t*>(S.lmark)[i] = 0;
+    if (threadIdx.x < uint32_t(kYQ)) S.pub[threadIdx.x] = make_uint2(0, 0);
+    if (threadIdx.x == 0) {
+        S.scr[0][kYSpan] = 0; S.scr[1][kYSpan] = 0; S.cc = make_uint2(0, 0); S.head = 0; S.tail = 0; S.total = 0xFFFFFFFFu;
+        S.plan_ready = 0; S.exec_done = 0; S.plan_total = 0xFFFFFFFFu; S.total_q = 0xFFFFFFFFu; S.failed = 0; S.end_value = kRetry;
+    }
+    __syncthreads();
+    Prof pf;
+    unsigned long long waited = 0;
+    const unsigned long long t_role = pf.now();
+    if (wave == 0) lanes_walk<YShared, kYTQ, kYRing, kYAhead>(&S, pf, (cgbyte*)src, int(blk.src_len), lane);
+    else if (wave == 1) y_sl(&S, (cgbyte*)src, (gbyte*)dst, int(blk.dst_cap), lane, waited);
+    else if (wave == 2) y_plan<kYSteps>(&S, lane, waited);
+    else y_exec<kYSteps>(&S, (gbyte*)dst, lane, waited);
+    pf.add(7, t_role); pf.count(6, waited);
 #ifdef K1R_PROF
     if (prof && lane == 0) for (int i = 0; i < 8; i++) prof[(size_t(b) * 4 + wave) * 8 + i] = pf.t[i];
 #endif
@@ -1074,6 +1507,20 @@ extern "C" hipError_t fourmc_launch_lz4_lanes(const void* d_src, void* d_dst, fo
     prof = g_prof;
 #endif
     hipLaunchKernelGGL(lz4_decode_lanes_kernel, dim3(n), dim3(128), 0, stream,
+                       static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n, container_mode, prof);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t fourmc_launch_lz4_wx(const void* d_src, void* d_dst, fourmc_block* d_blocks,
+                                           uint32_t n, int container_mode, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    unsigned long long* prof = nullptr;
+#ifdef K1R_PROF
+    if (n > g_prof_blocks) { if (g_prof) (void)hipFree(g_prof); g_prof = nullptr; if (hipMalloc(&g_prof, size_t(n) * 32 * 8) == hipSuccess) g_prof_blocks = n; }
+    prof = g_prof;
+#endif
+    hipLaunchKernelGGL(lz4_decode_wx_kernel, dim3(n), dim3(256), 0, stream,
                        static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n, container_mode, prof);
     return hipGetLastError();
 }

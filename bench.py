@@ -328,13 +328,13 @@ def main():
 
     def decode_path_comparison():
         """The LZ4 decode fast paths on the same launch (identical results): the wave trio, the row pipeline (lz4_rows.hip) and the
-        block-parallel parse + executor pair; HIP events around the decode_blocks call minus the hash launch.  "auto" (the
-        default) takes the row pipeline up to 1536 blocks per launch and the trio above."""
+        block-parallel parse + executor pair, the walk + window copier (K1x); HIP events around the decode_blocks call minus the hash
+        launch.  "auto" (the default) is the walk + window copier."""
         out = {}
         before = L.fourmc_gpu_get_lz4_decode_path()
         vb = state["dec"].clone()
         x_ver = timed(lambda: p.binding.check(L.fourmc_gpu_xxh32(d_image.data_ptr(), vb.data_ptr(), nb, 0, sp), "xxh32"))
-        for path, name in ((0, "wave_trio"), (4, "row_pipeline"), (1, "block_parallel")):
+        for path, name in ((0, "wave_trio"), (4, "row_pipeline"), (9, "walk_window_copier"), (1, "block_parallel")):
             L.fourmc_gpu_set_lz4_decode_path(path)
             dd = state["dec"].clone(); dd[:, 6] = 0
             t = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_image.data_ptr(), d_out.data_ptr(), dd.data_ptr(), nb, 0, sp), name))
@@ -343,7 +343,7 @@ def main():
         for m in (256, 1024):                          # launches that do not fill the chip: what the file API sends
             if m >= nb: continue
             xv = timed(lambda: p.binding.check(L.fourmc_gpu_xxh32(d_image.data_ptr(), state["dec"][:m].clone().data_ptr(), m, 0, sp), "xxh32"))
-            for path, name in ((0, "wave_trio"), (4, "row_pipeline")):
+            for path, name in ((0, "wave_trio"), (4, "row_pipeline"), (9, "walk_window_copier")):
                 L.fourmc_gpu_set_lz4_decode_path(path)
                 dd = state["dec"][:m].clone(); dd[:, 6] = 0
                 t = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_image.data_ptr(), d_out.data_ptr(), dd.data_ptr(), m, 0, sp), name))

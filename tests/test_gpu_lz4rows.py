@@ -15,12 +15,12 @@ pytestmark = pytest.mark.gpu
 RETRY = -1000000003
 
 
-@pytest.fixture(scope="module", params=[4, 5, 7, 8], ids=["rows", "rows-alone", "lanes", "lanes-alone"])
+@pytest.fixture(scope="module", params=[4, 5, 7, 8, 9, 10], ids=["rows", "rows-alone", "lanes", "lanes-alone", "wx", "wx-alone"])
 def gpu(request):
     p = pkg(); p.gpu_init()
     before = p.lib().fourmc_gpu_get_lz4_decode_path()
     p.lib().fourmc_gpu_set_lz4_decode_path(request.param)
-    p.rows_alone = request.param in (5, 8)
+    p.rows_alone = request.param in (5, 8, 10)
     yield p
     p.lib().fourmc_gpu_set_lz4_decode_path(before)
 

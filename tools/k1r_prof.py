@@ -9,7 +9,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers
 p = importlib.import_module("4mc_amd"); p.gpu_init(0)
 LANES = os.environ.get("LANES") == "1"                                  # the lane-per-sequence path (two roles) instead of the row pipeline
-p.lib().fourmc_gpu_set_lz4_decode_path(8 if LANES else 5)
+WX = os.environ.get("WX") == "1"                                        # walk + window copier (four roles)
+p.lib().fourmc_gpu_set_lz4_decode_path(10 if WX else (8 if LANES else 5))
 L = C.CDLL(os.environ["FOURMC_LIB"])
 L.fourmc_gpu_debug_rows_prof.argtypes = [C.c_void_p, C.c_uint32]; L.fourmc_gpu_debug_rows_prof.restype = C.c_int
 B = p.BLOCKSIZE
@@ -23,6 +24,9 @@ if LANES:
     ROLE = {0: ("walk", ["wait queue room", "#windows", "#window tokens", "#general tokens", "", "", ""]),
             1: ("exec", ["wait tokens", "#batches", "#batch tokens", "#passes", "#overlapping (whole wave)", "#general", "matches"]),
             2: ("-", [""] * 7), 3: ("-", [""] * 7)}
+if WX:
+    ROLE = {0: ("walk", ["wait queue room", "#windows", "#window tokens", "#general tokens", "", "", "#polls"]),
+            1: ("seq+lit", ["", "", "", "", "", "", "#polls"]), 2: ("plan", ["", "", "", "", "", "", "#polls"]), 3: ("exec", ["", "", "", "", "", "", "#polls"])}
 
 def show(t, ms, tag):
     print(f"== {tag}: {ms:.2f} ms; Mclk (counts plain)")

@@ -12,12 +12,13 @@ def rows(f, per=5):
     return d
 fe, wr = rows(o + "summary_fetch.md"), rows(o + "summary_write.md")
 xk = [k for k in fe if k.startswith("xxh32")][0]
+dk = [k for k in ("lz4_decode_wx_kernel", "lz4_decode_rows_kernel", "lz4_decode_fast_kernel") if k in fe][0]     # the default decode path of the bench
 rnd = re.match(r"(r\d+)", name).group(1)
 traffic_json = f"profiles/{rnd}_traffic.json"
 t = json.load(open(traffic_json if os.path.exists(traffic_json) else "profiles/r01_traffic.json"))
 t["lz4_encode"] = {"fetch_KiB": fe["lz4_encode_fast_kernel"]["FETCH_SIZE"], "write_KiB": wr["lz4_encode_fast_kernel"]["WRITE_SIZE"]}
-t["lz4_decode"] = {"fetch_KiB": fe["lz4_decode_fast_kernel"]["FETCH_SIZE"] + fe.get("lz4_decode_retry_kernel", {}).get("FETCH_SIZE", 0),
-                   "write_KiB": wr["lz4_decode_fast_kernel"]["WRITE_SIZE"]}
+t["lz4_decode"] = {"fetch_KiB": fe[dk]["FETCH_SIZE"] + fe.get("lz4_decode_retry_kernel", {}).get("FETCH_SIZE", 0),
+                   "write_KiB": wr[dk]["WRITE_SIZE"], "kernel": dk}
 t["xxh32"] = {"fetch_KiB": fe[xk]["FETCH_SIZE"], "write_KiB": wr[xk]["WRITE_SIZE"]}
 t["pack"] = {"fetch_KiB": fe["pack_image_kernel"]["FETCH_SIZE"], "write_KiB": wr["pack_image_kernel"]["WRITE_SIZE"]}
 json.dump(t, open(traffic_json, "w"), indent=1)
@@ -28,17 +29,17 @@ open(f"profiles/{name}_bench.json", "w").write(open(o + "bench_stats.json").read
 a, b = rows(o + "summary_sq.md"), rows(o + "summary_sq2.md")
 out = "# rocprofv3 --pmc <SQ group> -- python bench.py --no-extras --no-cpu --steps 2 --warmup 1   (2048 blocks; two passes, tools/profile_round.sh)\n# per-dispatch sums over all waves; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs\n\n"
 out += "| kernel | waves' time parked (s_waitcnt) | issuing | issue stalls | VALU busy (of 1024 SIMDs) | SALU : VALU instructions | cycles per issued instruction | LDS instr | VMEM rd / wr instr |\n|---|---|---|---|---|---|---|---|---|\n"
-for k in ("lz4_encode_fast_kernel", "lz4_decode_fast_kernel", [k for k in a if k.startswith("xxh32")][0]):
+for k in ("lz4_encode_fast_kernel", dk, [k for k in a if k.startswith("xxh32")][0]):
     x, y = a[k], b[k]; wc = x["SQ_WAVE_CYCLES"]; cyc = y["GRBM_GUI_ACTIVE"] / 8
     n = x["SQ_INSTS_VALU"] + x["SQ_INSTS_SALU"] + y["SQ_INSTS_LDS"] + y["SQ_INSTS_VMEM_RD"] + y["SQ_INSTS_VMEM_WR"]
     out += "| %s | %.0f %% | %.0f %% | %.0f %% | %.0f %% | %.2f | %.1f | %.2e | %.2e / %.2e |\n" % (k, 100 * x["SQ_WAIT_ANY"] / wc, 100 * x["SQ_ACTIVE_INST_ANY"] / wc, 100 * x["SQ_WAIT_INST_ANY"] / wc, 100 * 4 * x["SQ_ACTIVE_INST_VALU"] / (1024 * cyc), x["SQ_INSTS_SALU"] / x["SQ_INSTS_VALU"], 4 * x["SQ_ACTIVE_INST_ANY"] / n, y["SQ_INSTS_LDS"], y["SQ_INSTS_VMEM_RD"], y["SQ_INSTS_VMEM_WR"])
 out += "\n" + open(o + "summary_sq.md").read() + "\n" + open(o + "summary_sq2.md").read()
 open(f"profiles/{name}_sq_counters.md", "w").write(out)
 # the LZ4 decode paths side by side (tools/k1_timing.py under FOURMC_DECODE=rows / trio)
-if os.path.exists(o + "summary_rows_stats.md"):
-    txt = "# FOURMC_DECODE=rows | trio | lanes  rocprofv3 ... -- python tools/k1_timing.py   (2048 and 256 blocks of S-mix, decode only; per mode: two kernel traces, two SQ groups)\n\n"
+if os.path.exists(o + "summary_rows_stats.md") or os.path.exists(o + "summary_wx_stats.md"):
+    txt = "# FOURMC_DECODE=wx | rows | trio | lanes  rocprofv3 ... -- python tools/k1_timing.py   (2048 and 256 blocks of S-mix, decode only; per mode: two kernel traces, two SQ groups)\n\n"
     txt += "| path | kernel | waves' time parked (s_waitcnt) | issuing | issue stalls | VALU busy (of 1024 SIMDs) | SALU : VALU | instructions per output byte (VALU+SALU+LDS+VMEM) | LDS instr | LDS busy (of 256 CUs) | LDS bank-conflict / LDS active |\n|---|---|---|---|---|---|---|---|---|---|---|\n"
-    for mode, kern in (("rows", "lz4_decode_rows_kernel"), ("trio", "lz4_decode_fast_kernel"), ("lanes", "lz4_decode_lanes_kernel")):
+    for mode, kern in (("wx", "lz4_decode_wx_kernel"), ("rows", "lz4_decode_rows_kernel"), ("trio", "lz4_decode_fast_kernel"), ("lanes", "lz4_decode_lanes_kernel")):
         pa, pb = rows(o + f"summary_{mode}_sq.md"), rows(o + f"summary_{mode}_sq2.md")
         if kern not in pa: continue
         x, y = pa[kern], pb.get(kern, {})
@@ -47,7 +48,7 @@ if os.path.exists(o + "summary_rows_stats.md"):
         txt += "| %s | %s | %.0f %% | %.0f %% | %.0f %% | %.0f %% | %.2f | %.2f | %.2e | %.0f %% | %.2f |\n" % (mode, kern, 100 * x["SQ_WAIT_ANY"] / wc, 100 * x["SQ_ACTIVE_INST_ANY"] / wc, 100 * x["SQ_WAIT_INST_ANY"] / wc,
                 100 * 4 * y.get("SQ_ACTIVE_INST_VALU", 0) / (1024 * cyc), x["SQ_INSTS_SALU"] / x["SQ_INSTS_VALU"], n / (2048 * 4194304.0), x["SQ_INSTS_LDS"],
                 100 * 4 * y.get("SQ_ACTIVE_INST_LDS", 0) / (256 * cyc), y.get("SQ_LDS_BANK_CONFLICT", 0) / max(y.get("SQ_LDS_IDX_ACTIVE", 1), 1))
-    for mode in ("rows", "trio", "lanes"):
+    for mode in ("wx", "rows", "trio", "lanes"):
         for sfx in ("_stats", "256_stats", "_sq", "_sq2"):
             f = o + f"summary_{mode}{sfx}.md"
             if os.path.exists(f): txt += f"\n## {mode}{sfx}\n\n" + open(f).read()

@@ -18,7 +18,7 @@ for p in stats fetch write sq sq2; do
 done
 # the row-parallel LZ4 decode pipeline (lz4_rows.hip; default up to 1536 blocks per launch): kernel stats and SQ counters of the
 # decode-only timing tool at 2048 blocks (a full chip) and 256 blocks (what the file API sends), the wave trio beside it
-for mode in rows trio lanes; do
+for mode in wx rows trio lanes; do
   FOURMC_DECODE=$mode rocprofv3 --kernel-trace --stats -d $raw/${mode}_stats -o ${mode}_stats -- python tools/k1_timing.py > $out/${mode}_stats.log 2>&1
   FOURMC_BENCH_BLOCKS=256 FOURMC_DECODE=$mode rocprofv3 --kernel-trace --stats -d $raw/${mode}256_stats -o ${mode}256_stats -- python tools/k1_timing.py > $out/${mode}256_stats.log 2>&1
   FOURMC_DECODE=$mode rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $raw/${mode}_sq -o ${mode}_sq -- python tools/k1_timing.py > $out/${mode}_sq.log 2>&1
