@@ -591,7 +591,7 @@ extern "C" size_t fourmc_lz4_decode_work_bytes(uint32_t n)
 // Which fast path serves LZ4 decode launches.  Both produce identical results (anything irregular goes to the exact
 // walker either way); they differ in how a block is parallelised:
 //   6  "auto"            9: the default since the end of round 3
-//   9  "wx"              walk wave + sequence / literal wave + window copier (plan and execute waves), lz4_rows.hip (K1x)
+//   9  "wx"              walk wave + sequence / literal wave + window copier (plan and execute waves), lz4_rows.hip (K1wx)
 //   4  "rows"            row-parallel pipeline of four waves per block (lz4_rows.hip)
 //   7  "lanes"           one lane per sequence, wide pieces (lz4_rows.hip, K1w): 84 ms on the S-mix, opt-in
 //   0  "wave trio"       one parser wave walks the token chain, two copier waves execute (lz4_decode_fast_kernel)
@@ -627,7 +627,7 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
     const uint8_t* s8 = static_cast<const uint8_t*>(d_src);
     uint8_t* d8 = static_cast<uint8_t*>(d_dst);
     int path = fourmc_gpu_get_lz4_decode_path();
-    // 6 "auto": the walk + window copier (lz4_rows.hip, K1x) has the shortest chain per block at every launch size (29 ms against
+    // 6 "auto": the walk + window copier (lz4_rows.hip, K1wx) has the shortest chain per block at every launch size (29 ms against
     // 36 / 43 ms for the row pipeline / the wave trio at 64..256 blocks, 38 / 44 / 49 at 1024, 55.5 / 59 / 57 at 2048)
     if (path == 6) path = 9;
     if (path == 2) {

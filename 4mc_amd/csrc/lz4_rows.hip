@@ -711,14 +711,14 @@ void lz4_decode_rows_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_b
 //         everything in front of the first unfinished match of the batch covers its source (one pass for most batches of text).
 //         Output-side rules (room behind a sequence, offsets) are checked here.  General tokens are executed by the whole wave.
 // Irregular input of any kind ends in kRetry: the exact walker of lz4_decode.hip decides.
-#ifndef K1X_NAP_ROOM
-#define K1X_NAP_ROOM 16
+#ifndef K1WX_NAP_ROOM
+#define K1WX_NAP_ROOM 16
 #endif
-#ifndef K1X_NAP_PLAN
-#define K1X_NAP_PLAN 4
+#ifndef K1WX_NAP_PLAN
+#define K1WX_NAP_PLAN 4
 #endif
-#ifndef K1X_NAP_WALK
-#define K1X_NAP_WALK 32
+#ifndef K1WX_NAP_WALK
+#define K1WX_NAP_WALK 32
 #endif
 constexpr int kTQ = 2048;                // token queue (entries)
 constexpr int kLaneMatchMax = 80;        // longer matches / literal runs are general tokens (executed by the whole wave)
@@ -765,7 +765,7 @@ __device__ void lanes_walk(SH* S, Prof& pf, cgbyte* src, const int csize, const 
     u32x4 pend = fetch(0);
     auto fail = [&]() { if (lane == 0) stv(&S->failed, 1); };
     auto room = [&](uint32_t n) -> bool {
-        return lwait(S, pf, K1X_NAP_WALK, [&] { tail_seen = rfl(ldv(&S->tail)); }, [&] { return head + n <= tail_seen + uint32_t(kTQ); });
+        return lwait(S, pf, K1WX_NAP_WALK, [&] { tail_seen = rfl(ldv(&S->tail)); }, [&] { return head + n <= tail_seen + uint32_t(kTQ); });
     };
     for (;;) {
         ip = int(rfl(uint32_t(ip))); head = rfl(head); tail_seen = rfl(tail_seen); fill_hi = int(rfl(uint32_t(fill_hi)));
@@ -1049,7 +1049,7 @@ void lz4_decode_lanes_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
 }
 
 
-// ================================================================================================ K1x: the walk in front of the window copier
+// ================================================================================================ K1wx: the walk in front of the window copier
 // FOURMC_DECODE=wx.  Four waves per block: WALK as in K1w (token positions into a queue; the serial part and nothing else), then the
 // execute pipeline of the 4mz decoder (zstd_exec.inc) fed from that queue:
 //   SL    up to 64 queued tokens, one per lane: token and offset from the stream, prefix sums place every sequence in the output,
@@ -1124,7 +1124,7 @@ __device__ void y_plan(YShared* S, const int lane, unsigned long long& waited)
             // records without match bytes (bulk records) are consumed by the look above; nothing to execute
             if (ended && cqv == qa) break;
             if (rfl(ldv(&S->failed))) return;
-            __builtin_amdgcn_s_sleep(K1X_NAP_PLAN);
+            __builtin_amdgcn_s_sleep(K1WX_NAP_PLAN);
             waited++;
             if (++spins > kSpinLimit) { stv(&S->failed, 1); return; }
             continue;
@@ -1315,7 +1315,7 @@ __device__ void y_sl(YShared* S, cgbyte* src, gbyte* dst, const int cap, const i
     auto wait_room = [&]() -> bool {      // a record slot is free and the group's start marks fit the ring
         if (room()) return true;
         flush_pending();                   // PLAN may be waiting for what is held back here
-        return ywait(S, K1X_NAP_ROOM, [&] { const uint2 c = ldv2(&S->cc); cq_seen = c.x; cg_seen = c.y; }, room, waited);
+        return ywait(S, K1WX_NAP_ROOM, [&] { const uint2 c = ldv2(&S->cc); cq_seen = c.x; cg_seen = c.y; }, room, waited);
     };
     auto mark_of = [&](uint32_t l) { return uint16_t(((q & 511) << 6 | l) + 1); };
     for (;;) {

@@ -328,7 +328,7 @@ def main():
 
     def decode_path_comparison():
         """The LZ4 decode fast paths on the same launch (identical results): the wave trio, the row pipeline (lz4_rows.hip) and the
-        block-parallel parse + executor pair, the walk + window copier (K1x); HIP events around the decode_blocks call minus the hash
+        block-parallel parse + executor pair, the walk + window copier (K1wx); HIP events around the decode_blocks call minus the hash
         launch.  "auto" (the default) is the walk + window copier."""
         out = {}
         before = L.fourmc_gpu_get_lz4_decode_path()
