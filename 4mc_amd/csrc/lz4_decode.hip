@@ -627,8 +627,9 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
     const uint8_t* s8 = static_cast<const uint8_t*>(d_src);
     uint8_t* d8 = static_cast<uint8_t*>(d_dst);
     int path = fourmc_gpu_get_lz4_decode_path();
-    // 6 "auto": the walk + window copier (lz4_rows.hip, K1wx) has the shortest chain per block at every launch size (29 ms against
-    // 36 / 43 ms for the row pipeline / the wave trio at 64..256 blocks, 38 / 44 / 49 at 1024, 55.5 / 59 / 57 at 2048)
+    // 6 "auto": the walk + window copier (lz4_rows.hip, K1wx) has the shortest chain per block at every launch size (28 ms against
+    // 36 / 43 ms for the row pipeline / the wave trio at 64..256 blocks, 37 / 44 / 49 at 1024, 53.5 / 59 / 57 at 2048; LZ4-HC streams
+    // at 2048 blocks are the exception: 52 ms against the trio's 48)
     if (path == 6) path = 9;
     if (path == 2) {
         hipLaunchKernelGGL(lz4_decode_exact_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);

@@ -748,7 +748,7 @@ template <class SH, class P, class F> __device__ __forceinline__ bool lwait(SH* 
     return true;
 }
 
-template <class SH, int TQ, int RING, int AHEAD>
+template <class SH, int TQ, int RING, int AHEAD, int MLMAX>
 __device__ void lanes_walk(SH* S, Prof& pf, cgbyte* src, const int csize, const int lane)
 {
     constexpr int kTQ = TQ, kLRing = RING, kLAhead = AHEAD;
@@ -793,7 +793,7 @@ __device__ void lanes_walk(SH* S, Prof& pf, cgbyte* src, const int csize, const 
             const uint32_t e1 = (wo >> 16) & 0xff;
             const uint32_t ml = M0 + 4 + (mext ? e1 : 0u);
             const uint32_t nxt = offpos + 2 + (mext ? 1u : 0u);
-            const bool ok = !(lext && b1 == 255) && !(mext && e1 == 255) && nxt <= 64 && ml <= uint32_t(kLaneMatchMax);
+            const bool ok = !(lext && b1 == 255) && !(mext && e1 == 255) && nxt <= 64 && ml <= uint32_t(MLMAX);
             const uint32_t jump = ok ? nxt : 128u + uint32_t(lane);     // 64: the window ends behind this token; >= 128: no window token
             const uint32_t hop = lane == 63 ? 63u : min(jump, 63u);
             unsigned long long tokmask = 0;
@@ -1038,7 +1038,7 @@ void lz4_decode_lanes_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
     __syncthreads();
     Prof pf;
     const unsigned long long t_role = pf.now();
-    if (wave == 0) lanes_walk<LShared, kTQ, kLRing, kLAhead>(&S, pf, (cgbyte*)src, int(blk.src_len), lane);
+    if (wave == 0) lanes_walk<LShared, kTQ, kLRing, kLAhead, kLaneMatchMax>(&S, pf, (cgbyte*)src, int(blk.src_len), lane);
     else lanes_exec(&S, pf, (cgbyte*)src, (gbyte*)dst, int(blk.dst_cap), lane);
     pf.add(7, t_role);
 #ifdef K1R_PROF
@@ -1457,7 +1457,7 @@ void lz4_decode_wx_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
     Prof pf;
     unsigned long long waited = 0;
     const unsigned long long t_role = pf.now();
-    if (wave == 0) lanes_walk<YShared, kYTQ, kYRing, kYAhead>(&S, pf, (cgbyte*)src, int(blk.src_len), lane);
+    if (wave == 0) lanes_walk<YShared, kYTQ, kYRing, kYAhead, 1023>(&S, pf, (cgbyte*)src, int(blk.src_len), lane);
     else if (wave == 1) y_sl(&S, (cgbyte*)src, (gbyte*)dst, int(blk.dst_cap), lane, waited);
     else if (wave == 2) y_plan<kYSteps>(&S, lane, waited);
     else y_exec<kYSteps>(&S, (gbyte*)dst, lane, waited);

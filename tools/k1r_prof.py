@@ -47,7 +47,7 @@ want = [int(a) for a in args] or ([] if full else [0, 1, 2, 3, 5, 11])
 data = helpers.corpus(12 * B)
 for b in want:
     src = data[b * B:(b + 1) * B]
-    r, comp = helpers.orc_compress(src)
+    r, comp = helpers.orc_compress_hc(src, 4, len(src)) if os.environ.get("HC") == "1" else helpers.orc_compress(src)
     d_src = torch.from_numpy(comp).cuda(); d_dst = torch.zeros(B + 64, dtype=torch.uint8, device="cuda")
     batch = p.DeviceBatch(p.make_blocks([0], [0], [len(comp)], [B]))
     for _ in range(2):
