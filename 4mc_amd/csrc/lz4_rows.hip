@@ -711,6 +711,10 @@ void lz4_decode_rows_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_b
 //         everything in front of the first unfinished match of the batch covers its source (one pass for most batches of text).
 //         Output-side rules (room behind a sequence, offsets) are checked here.  General tokens are executed by the whole wave.
 // Irregular input of any kind ends in kRetry: the exact walker of lz4_decode.hip decides.
+#ifndef K1WX_HOPS
+#define K1WX_HOPS 4                  // v_readlane hops of the walk between two looks at its end (a window holds 21 tokens at most)
+#define K1WX_ROUNDS 6
+#endif
 #ifndef K1WX_NAP_ROOM
 #define K1WX_NAP_ROOM 16
 #endif
@@ -798,9 +802,9 @@ __device__ void lanes_walk(SH* S, Prof& pf, cgbyte* src, const int csize, const 
             const uint32_t hop = lane == 63 ? 63u : min(jump, 63u);
             unsigned long long tokmask = 0;
             uint32_t pos = 0;
-            for (int round = 0; round < 3 && pos != 63; round++) {
+            for (int round = 0; round < K1WX_ROUNDS && pos != 63; round++) {
 #pragma unroll
-                for (int i = 0; i < 7; i++) {
+                for (int i = 0; i < K1WX_HOPS; i++) {
                     asm volatile("s_bitset1_b64 %0, %1" : "+s"(tokmask) : "s"(pos));
                     pos = rdl(hop, pos);
                 }
