@@ -181,3 +181,44 @@ done:
     free(in_buf); free(out_buf); free(store); free(blk); free(cs_pad); free(cs_all); free(usz); free(xs); free(off_all); free(poff);
     return rc;
 }
+
+/* ---- the other direction: one .4mc / .4mz file decompressed by several ranks ------------------------------------------------
+ * Nothing has to be exchanged: the footer index (native/4mc.c:344-358, FourMcBlockIndex.java:92-173) tells every rank where its
+ * blocks lie, and every block but the last decodes to FOURMC_BLOCKSIZE bytes, so block b goes to offset b * FOURMC_BLOCKSIZE of
+ * the output.  Rank r decodes the block range fourmc_shard_range() gives it, in batches (fourmc_file_decode_blocks: one read of
+ * the byte range, one launch, checksums verified on the device), and pwrite()s them; the rank that owns the last block sets the
+ * file's final size (an older, longer file of that name must not leave bytes behind).
+ * Returns 0; -1 input, -2 output, -3 engine / corrupt block (the code of fourmc_file_decode_blocks is in *detail), -5 memory. */
+int fourmc_file_decompress_sharded(const char* in_name, const char* out_name, int rank, int world, long long* detail)
+{
+    int is_zstd = 0, fd = -1, rc = 0;
+    const int64_t nblocks = fourmc_file_block_count(in_name, &is_zstd);
+    uint64_t first, count, b0, nbatch;
+    uint8_t* buf = NULL;
+    const char* e = getenv("FOURMC_BATCH_BLOCKS");
+    if (detail) *detail = 0;
+    if (nblocks < 0) { if (detail) *detail = nblocks; return -1; }
+    fourmc_shard_range((uint64_t)nblocks, rank, world, &first, &count);
+    nbatch = e ? (uint64_t)atol(e) : 512;
+    if (nbatch < 1) nbatch = 1;
+    if (nbatch > 4096) nbatch = 4096;
+    if (nbatch > count) nbatch = count ? count : 1;
+    fd = open(out_name, O_WRONLY | O_CREAT, 0644);
+    if (fd < 0) return -2;
+    if (nblocks == 0) { if (rank == 0 && ftruncate(fd, 0) != 0) rc = -2; close(fd); return rc; }
+    buf = (uint8_t*)malloc((size_t)(nbatch * FOURMC_BLOCKSIZE));
+    if (!buf) { close(fd); return -5; }
+    for (b0 = 0; b0 < count && rc == 0; b0 += nbatch) {
+        const uint64_t nb = count - b0 < nbatch ? count - b0 : nbatch;
+        const int64_t got = fourmc_file_decode_blocks(in_name, (uint32_t)(first + b0), (uint32_t)nb, buf, (size_t)(nb * FOURMC_BLOCKSIZE));
+        const int last_batch = first + b0 + nb == (uint64_t)nblocks;
+        if (got < 0) { if (detail) *detail = got; rc = -3; break; }
+        /* every block in front of the file's last one is a full one: anything else cannot be placed by its index alone */
+        if (last_batch ? ((uint64_t)got <= (nb - 1) * FOURMC_BLOCKSIZE || (uint64_t)got > nb * FOURMC_BLOCKSIZE) : (uint64_t)got != nb * FOURMC_BLOCKSIZE) { if (detail) *detail = got; rc = -3; break; }
+        if (pwrite_all(fd, buf, (size_t)got, (first + b0) * FOURMC_BLOCKSIZE)) { rc = -2; break; }
+        if (last_batch && ftruncate(fd, (off_t)((first + b0) * FOURMC_BLOCKSIZE + (uint64_t)got)) != 0) rc = -2;
+    }
+    free(buf);
+    if (close(fd) != 0 && rc == 0) rc = -2;
+    return rc;
+}

@@ -82,6 +82,11 @@ int  fourmc_shard_write(int fd, uint32_t magic, int rank, uint64_t first, uint64
 int  fourmc_file_compress_sharded(const char* in_name, const char* out_name, int level, uint32_t magic, int rank, int world,
                                   fourmc_allgather_fn allgather, void* ctx);
 
+/* The other direction, no exchange at all: rank r decodes its block range through the footer index and pwrite()s it at
+ * block index * FOURMC_BLOCKSIZE; the owner of the last block sets the final size.  0 ok; -1 input, -2 output, -3 engine / corrupt
+ * block (*detail = the code of fourmc_file_decode_blocks), -5 memory. */
+int  fourmc_file_decompress_sharded(const char* in_name, const char* out_name, int rank, int world, long long* detail);
+
 #ifdef __cplusplus
 }
 #endif

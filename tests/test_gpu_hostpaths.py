@@ -106,6 +106,40 @@ def test_ranks_write_one_file_through_the_c_host(gpu, golden_corpus, tmp_path, w
         assert _sha(out) == man["levels"][key]["sha256"], (world, key)
 
 
+@pytest.mark.parametrize("world", [1, 3])
+def test_ranks_decompress_one_file_through_the_c_host(gpu, golden_corpus, tmp_path, world):
+    """fourmc_file_decompress_sharded: every rank decodes its block range through the footer index and pwrite()s it at
+    block index * 4 MiB - no exchange at all; the owner of the last block sets the file size (an older, longer output must not
+    survive).  The ranks run one after the other here (one GPU); they touch disjoint byte ranges."""
+    import ctypes as C
+    man, data, src = golden_corpus
+    L = gpu.lib()
+    L.fourmc_file_decompress_sharded.restype = C.c_int
+    L.fourmc_file_decompress_sharded.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_longlong)]
+    for flags, key in (([], "4mc-1"), (["-z"], "4mz-1")):
+        comp = tmp_path / ("d%d_%s" % (world, key))
+        r = subprocess.run([gpu.cli_path(), *flags, "-f", str(src), str(comp)], capture_output=True)
+        assert r.returncode == 0, r.stderr
+        back = tmp_path / ("d%d_%s.back" % (world, key))
+        back.write_bytes(b"\xEE" * (len(data) + 54321))
+        os.environ["FOURMC_BATCH_BLOCKS"] = "5"                       # several batches per rank on the small corpus
+        try:
+            for rank in reversed(range(world)):                       # (any order: the ranges are disjoint)
+                det = C.c_longlong(0)
+                assert L.fourmc_file_decompress_sharded(str(comp).encode(), str(back).encode(), rank, world, C.byref(det)) == 0, (rank, det.value)
+        finally:
+            del os.environ["FOURMC_BATCH_BLOCKS"]
+        assert os.path.getsize(back) == len(data)
+        assert _sha(back) == man["corpus"]["sha256"], (world, key)
+        # a damaged block: the rank that owns it reports it (-3, detail -4), the others finish
+        blob = bytearray(comp.read_bytes()); blob[len(blob) // 2] ^= 0x20; bad = tmp_path / "bad"; bad.write_bytes(bytes(blob))
+        codes = []
+        for rank in range(world):
+            det = C.c_longlong(0)
+            codes.append((L.fourmc_file_decompress_sharded(str(bad).encode(), str(back).encode(), rank, world, C.byref(det)), det.value))
+        assert sorted(c[0] for c in codes)[0] == -3 and sum(1 for c in codes if c[0] != 0) == 1, codes
+
+
 def test_concatenated_streams_decode_as_one(gpu, tmp_path):
     """two .4mc files glued together decode to the concatenation of their contents (native/4mc.c:908-912)"""
     a = helpers.corpus(2 * B + 99, first_block=1); b = helpers.corpus(B // 2 + 5, first_block=9)

@@ -3,6 +3,7 @@
  * of the path - the per-block compressed sizes, 4 bytes per block - done with ncclAllGather (RCCL over xGMI).
  *
  *   RANK=r WORLD_SIZE=n LOCAL_RANK=r FOURMC_RDV=/dev/shm/some.id  tools/shard_rccl [-z] [-1..-4] <in> <out>
+ *   RANK=r WORLD_SIZE=n LOCAL_RANK=r                              tools/shard_rccl -d <in.4mc|.4mz> <out>     (no exchange at all)
  *
  * The reference has no communication layer; this is what a deployment that shards one file over the GPUs of
  * a node links instead of the torch.distributed callback the tests use.  librccl.so is loaded at run time (dlopen), so that
@@ -57,7 +58,7 @@ static int env_int(const char* k, int d) { const char* e = getenv(k); return e ?
 
 int main(int argc, char** argv)
 {
-    int level = 1, zstd = 0, i;
+    int level = 1, zstd = 0, decode = 0, i;
     const char *in = NULL, *out = NULL;
     const int rank = env_int("RANK", 0), world = env_int("WORLD_SIZE", 1), local = env_int("LOCAL_RANK", rank);
     const char* rdv = getenv("FOURMC_RDV");
@@ -66,12 +67,19 @@ int main(int argc, char** argv)
     int rc;
     for (i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "-z")) zstd = 1;
+        else if (!strcmp(argv[i], "-d")) decode = 1;
         else if (argv[i][0] == '-' && argv[i][1] >= '1' && argv[i][1] <= '4' && !argv[i][2]) level = argv[i][1] - '0';
         else if (!in) in = argv[i];
         else if (!out) out = argv[i];
     }
     if (!in || !out) { fprintf(stderr, "usage: RANK= WORLD_SIZE= LOCAL_RANK= [FOURMC_RDV=file] shard_rccl [-z] [-1..-4] <in> <out>\n"); return 2; }
     if (fourmc_gpu_init(local) != FOURMC_OK) { fprintf(stderr, "GPU engine: %s\n", fourmc_gpu_last_error()); return 1; }
+    if (decode) {   /* every rank finds its blocks through the footer index: nothing to gather */
+        long long detail = 0;
+        rc = fourmc_file_decompress_sharded(in, out, rank, world, &detail);
+        if (rc != 0) fprintf(stderr, "rank %d: fourmc_file_decompress_sharded = %d (detail %lld, %s)\n", rank, rc, detail, fourmc_gpu_last_error());
+        return rc ? 1 : 0;
+    }
     if (hipSetDevice(local) != hipSuccess || hipStreamCreate(&G.stream) != hipSuccess) { fprintf(stderr, "HIP stream\n"); return 1; }
     h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
