@@ -232,3 +232,9 @@ def test_c_launcher_gathers_the_index_through_rccl(gpu, golden_corpus, tmp_path)
         r = subprocess.run([exe, *flags, str(src), str(out)], capture_output=True, env=env, timeout=300)
         assert r.returncode == 0, r.stderr
         assert _sha(out) == man["levels"][key]["sha256"], key
+        # and back, two launcher processes on the one GPU (the decompress direction has no collective: ranks need not meet)
+        back = tmp_path / ("rccl_" + key + ".back")
+        back.write_bytes(b"\xEE" * (len(data) + 777))
+        ps = [subprocess.Popen([exe, "-d", str(out), str(back)], env=dict(env, RANK=str(rk), WORLD_SIZE="2", LOCAL_RANK="0"), stderr=subprocess.PIPE) for rk in range(2)]
+        assert [p.wait(timeout=300) for p in ps] == [0, 0], [p.stderr.read() for p in ps]
+        assert _sha(back) == man["corpus"]["sha256"], key
