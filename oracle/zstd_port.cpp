@@ -14,6 +14,8 @@
  * Documented deviations: frames carrying a content checksum or a dictionary id are rejected
  * (4mz never writes them, native/4mc.c:467 uses plain ZSTD_compress).
  */
+#include <cstdio>
+#include <cstdlib>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -251,6 +253,24 @@ static inline void copy_lits(uint8_t* dst, const Lits& l, uint32_t n, int)
 }
 
 // Decodes `csize` bytes of zstd frames into dst[0..cap).  Returns bytes or < 0.
+
+// Which Huffman decoder the reference takes for a 4-stream compressed literals section (huf_decompress.c:1595-1617, timings :1568-1587):
+// 1 = the double-symbol decoder (X2).  On valid streams both decoders give the same bytes; they differ in what they make of the LAST
+// symbol of a stream (see huf_stream_end_ok).
+static inline bool huf_select_x2(uint32_t dst_size, uint32_t csrc_size)
+{
+    const uint32_t t0[16] = {0, 0, 150, 170, 177, 197, 221, 256, 359, 582, 688, 825, 976, 1180, 1377, 1412};
+    const uint32_t d0[16] = {0, 0, 216, 205, 199, 194, 192, 189, 188, 187, 187, 186, 185, 186, 185, 185};
+    const uint32_t t1[16] = {1, 1, 381, 514, 539, 644, 735, 881, 1167, 1570, 1712, 1965, 2131, 2070, 1731, 1695};
+    const uint32_t d1[16] = {1, 1, 119, 112, 110, 107, 107, 106, 109, 114, 122, 136, 150, 175, 202, 202};
+    const uint32_t Q = csrc_size >= dst_size ? 15u : uint32_t(uint64_t(csrc_size) * 16 / dst_size);
+    const uint32_t D256 = dst_size >> 8;
+    const uint32_t time0 = t0[Q] + d0[Q] * D256;
+    uint32_t time1 = t1[Q] + d1[Q] * D256;
+    time1 += time1 >> 5;
+    return time1 < time0;
+}
+
 static int zstd_decode_frames(const uint8_t* src, int csize, uint8_t* dst, int cap, uint8_t* litbuf,
                                   ZState* z, int lane)
 {
@@ -303,6 +323,7 @@ static int zstd_decode_frames(const uint8_t* src, int csize, uint8_t* dst, int c
         // ---- per-frame entropy state (zstd_decompress.c: ZSTD_decompressBegin)
         uint32_t rep0 = 1, rep1 = 4, rep2 = 8;                        // zstd_internal.h:70
         bool have_huf = false, have_fse = false;
+        bool huf_x2 = false;                                           // the current Huffman table is the reference's double-symbol kind
         int huf_log = 0, ll_log = 0, of_log = 0, ml_log = 0;
 
         for (;;) {
@@ -351,6 +372,7 @@ static int zstd_decode_frames(const uint8_t* src, int csize, uint8_t* dst, int c
                             if (used < 0) return kErr;
                             hp8 += used; hlen -= used;
                             have_huf = true;
+                            huf_x2 = !one_stream && huf_select_x2(lsize, lcsize);     // zstd_decompress_block.c:183-205: one stream -> X1, four -> by size
                         }
                         // stream layout: one stream, or 6-byte jump table + four streams (huf_decompress.c:561-590)
                         bool ok = true;
@@ -372,14 +394,44 @@ static int zstd_decode_frames(const uint8_t* src, int csize, uint8_t* dst, int c
                             BitsBack bs;
                             if (!bs.init(hp8 + s_off, s_len)) ok = false;
                             else {
+                                // The double-symbol decoder (huf_decompress.c:1141-1221) takes one or two symbols per look-up: two when both
+                                // codes fit its table log T.  `open` follows that pairing (length of a look-up's first symbol while its
+                                // second is undecided), because its end rule depends on it: a stream whose last byte is the FIRST symbol of a
+                                // look-up ends in HUF_decodeLastSymbolX2, which forgives a two-symbol entry that runs past the stream's
+                                // start (:1150-1163).  Every other case needs the stream consumed exactly, as the single-symbol decoder does.
+                                const int T = huf_log <= 11 ? 11 : 12;                    // :1083
+                                int open = -1, last_r = 0, last_len = 0; bool last_alone = false;
                                 for (int i = 0; i < o_len; i++) {
+                                    const int before = bs.pos;
                                     const uint32_t idx = (bs.pos >= huf_log) ? bs.peek_at(bs.pos - huf_log, huf_log)
                                                                              : (bs.peek_at(0, bs.pos > 0 ? bs.pos : 0) << (huf_log - (bs.pos > 0 ? bs.pos : 0)));
                                     const uint32_t e = z->huf[idx];
-                                    bs.pos -= int(e >> 8);
+                                    const int len = int(e >> 8);
+                                    bs.pos -= len;
                                     litbuf[o_off + i] = uint8_t(e);
+                                    if (open >= 0 && open + len <= T) { open = -1; continue; }     // second symbol of a look-up
+                                    open = len;                                                     // first symbol of a look-up
+                                    if (i == o_len - 1) { last_alone = true; last_r = before; last_len = len; }
                                 }
-                                if (bs.pos != 0) ok = false;              // every stream must end exactly at its start
+                                if (huf_x2 && last_alone && o_len > 0) {
+                                    const uint32_t idx2 = (bs.pos >= huf_log) ? bs.peek_at(bs.pos - huf_log, huf_log)
+                                                                              : (bs.peek_at(0, bs.pos > 0 ? bs.pos : 0) << (huf_log - (bs.pos > 0 ? bs.pos : 0)));
+                                    const int len2 = int(z->huf[idx2] >> 8);
+                                    const bool pair = last_len + len2 <= T;
+                                    if (last_r < 0) ok = false;                                     // over-consumed before the last symbol
+                                    else if (last_r == 0) {
+                                        // nothing left: BIT_lookBitsFast shifts by (bitsConsumed & 63) = 0 and looks at the TOP of its
+                                        // container - the stream's first eight bytes - again (bitstream.h:332-337); a two-symbol entry
+                                        // there is accepted without consuming anything, and its first symbol is the stream's last byte
+                                        const uint32_t v = bs.peek_at(64 - T, T);
+                                        const uint32_t ea = z->huf[v >> (T - huf_log)];
+                                        const int la = int(ea >> 8);
+                                        const int lb = int(z->huf[((v << la) & ((1u << T) - 1)) >> (T - huf_log)] >> 8);
+                                        if (la + lb <= T) litbuf[o_off + o_len - 1] = uint8_t(ea); else ok = false;
+                                    }
+                                    else if (pair) { if (last_len + len2 < last_r) ok = false; }
+                                    else if (last_len != last_r) ok = false;
+                                } else if (bs.pos != 0) ok = false;       // every stream must end exactly at its start
                             }
                         }
                         }
@@ -412,7 +464,7 @@ static int zstd_decode_frames(const uint8_t* src, int csize, uint8_t* dst, int c
                     }
                     if (bpos + 1 > bend) return kErr;
                     const uint32_t modes = bp[bpos++];
-                    if (modes & 3) return kErr;                        // reserved bits (the reference ignores them; valid encoders write 0)
+                    // (the two reserved bits of the modes byte are not looked at: zstd_decompress_block.c:689-692)
                     for (int t = 0; t < 3; t++) {                      // LL, OF, ML in this order
                         const int mode_t = int((modes >> (6 - 2 * t)) & 3);
                         uint32_t* tab = t == 0 ? z->ll : (t == 1 ? z->of : z->ml);
