@@ -103,13 +103,18 @@ struct BitsBack {
     }
     // bits [start, start+n), n <= 31.  Reads walk downwards, so one 8-byte load placed just above the
     // request serves the next ~57 bits; the common case is two compares, a shift and a mask.
-    __device__ __forceinline__ uint32_t peek_at(int start, int n) {
+    __device__ __forceinline__ uint32_t peek_at(int start, int n, const bool fast = false) {
         const uint32_t mask = (1u << n) - 1;
         if (start < wlo || start + n > wlo + 64) {
             if (start < 0) {
-                if (start + n <= 0) return 0;
+                // reading past the stream's start: the reference's reader computes its shift as (64 - bitsConsumed - n) & 63
+                // (bitstream.h: BIT_lookBits -> BIT_getMiddleBits) on a container that holds the stream's first eight bytes by
+                // then - it returns wrapped container bits, not zeros, and a frame that still adds up is accepted with them
+                // (BIT_readBitsFast - the extra bits of offsets and lengths - shifts the other way round, bitstream.h:344-349: what is
+                // left of the stream followed by zeros, or, with nothing left, bits from the container's top)
                 if (wlo != 0) { wlo = 0; w = load64_safe(p, len); }
-                return uint32_t(w << (-start)) & mask;
+                if (fast) return n ? uint32_t((w << ((64 - (start + n)) & 63)) >> ((64 - n) & 63)) : 0u;
+                return uint32_t(w >> (start & 63)) & mask;
             }
             const int byte = max(0, ((start + n + 7) >> 3) - 8);
             wlo = 8 * byte; w = load64_safe(p + byte, len - byte);
@@ -117,6 +122,7 @@ struct BitsBack {
         return uint32_t(w >> (start - wlo)) & mask;
     }
     __device__ __forceinline__ uint32_t read(int n) { pos -= n; return peek_at(pos, n); }
+    __device__ __forceinline__ uint32_t read_fast(int n) { pos -= n; return peek_at(pos, n, true); }   // BIT_readBitsFast: extra bits of a sequence
 };
 
 // The sequence bitstream is read by the whole wave (uniform position), so it is staged 1 KiB at a time in an
@@ -154,10 +160,11 @@ struct SeqBits {
     // after refill() the next 57 bits below pos are in the window (fewer only at the very start of the stream)
     __device__ __forceinline__ void refill() { if (pos < wlo + 57 || pos > wlo + 64) window(max(0, ((pos + 7) >> 3) - 8)); }
     // n <= 31 bits below pos; needs a refill() at most 57 bits ago.  Below bit 0 the stream reads as zeros.
-    __device__ __forceinline__ uint32_t read(int n) {
+    __device__ __forceinline__ uint32_t read(int n, const bool fast = false) {
         const uint32_t mask = (1u << n) - 1;
         pos -= n;
-        if (pos < wlo) return (pos + n <= 0) ? 0u : uint32_t(w << (wlo - pos)) & mask;      // only when wlo == 0
+        if (pos < wlo) return fast ? (n ? uint32_t((w << ((64 - (pos + n)) & 63)) >> ((64 - n) & 63)) : 0u)
+                                   : uint32_t(w >> (pos & 63)) & mask;      // only when wlo == 0: past the stream's start (see BitsBack)
         return uint32_t(w >> (pos - wlo)) & mask;
     }
 };
@@ -606,7 +613,7 @@ __device__ __forceinline__ int zstd_decode_frames(const uint8_t* src, int csize,
                                 if (ocode > 31) return kErr;
                                 const uint32_t ll_base = lv & 0xFFFFF;
                                 if (ocode > 1) {
-                                    offset = (1u << ocode) - 3 + bs.read(int(ocode));        // OF_base[code] = 2^code - 3
+                                    offset = (1u << ocode) - 3 + bs.read(int(ocode), true);  // OF_base[code] = 2^code - 3
                                     rep2 = rep1; rep1 = rep0; rep0 = offset;
                                 } else {
                                     const uint32_t ll0 = (ll_base == 0);
@@ -614,16 +621,16 @@ __device__ __forceinline__ int zstd_decode_frames(const uint8_t* src, int csize,
                                         offset = ll0 ? rep1 : rep0;
                                         rep1 = ll0 ? rep0 : rep1; rep0 = offset;
                                     } else {
-                                        const uint32_t v = 1 + ll0 + bs.read(1);          // OF_base[1] = 1
+                                        const uint32_t v = 1 + ll0 + bs.read(1, true);    // OF_base[1] = 1
                                         uint32_t t = (v == 3) ? rep0 - 1 : (v == 1 ? rep1 : rep2);
                                         t += !t;
                                         if (v != 1) rep2 = rep1;
                                         rep1 = rep0; rep0 = offset = t;
                                     }
                                 }
-                                mlen = (mv & 0xFFFFF) + bs.read(int(mv >> 20));
+                                mlen = (mv & 0xFFFFF) + bs.read(int(mv >> 20), true);
                                 bs.refill();
-                                llen = ll_base + bs.read(int(lv >> 20));
+                                llen = ll_base + bs.read(int(lv >> 20), true);
                                 sl = (el >> 16) + bs.read(int((el >> 8) & 0xff));
                                 sm = (em >> 16) + bs.read(int((em >> 8) & 0xff));
                                 so = (eo >> 16) + bs.read(int((eo >> 8) & 0xff));
@@ -893,9 +900,9 @@ __device__ __forceinline__ bool v2_sequences_lane(ZState* zl, const ZState* z, c
                     const uint32_t lv = cle.y, mv = cme.y;
                     const uint32_t ocode = eo & 0xff;
                     if (ocode > 31) { bad = true; break; }
-                    const uint32_t ov = (1u << ocode) + bs.read(int(ocode));                 // Offset_Value: 1..3 repeat codes, else offset + 3
-                    const uint32_t mlen = (mv & 0xFFFFF) + bs.read(int(mv >> 20));
-                    const uint32_t llen = (lv & 0xFFFFF) + bs.read(int(lv >> 20));
+                    const uint32_t ov = (1u << ocode) + bs.read_fast(int(ocode));            // Offset_Value: 1..3 repeat codes, else offset + 3
+                    const uint32_t mlen = (mv & 0xFFFFF) + bs.read_fast(int(mv >> 20));
+                    const uint32_t llen = (lv & 0xFFFFF) + bs.read_fast(int(lv >> 20));
                     sl = (el >> 16) + bs.read(int((el >> 8) & 0xff));
                     sm = (em >> 16) + bs.read(int((em >> 8) & 0xff));
                     so = (eo >> 16) + bs.read(int((eo >> 8) & 0xff));

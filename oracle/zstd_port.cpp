@@ -74,17 +74,23 @@ struct BitsBack {
         pos = 8 * (n - 1) + hibit(last);
         return true;
     }
-    inline uint32_t peek_at(int start, int n) const {       // bits [start, start+n), n <= 32
+    inline uint32_t peek_at(int start, int n, const bool fast = false) const {       // bits [start, start+n), n <= 32
         if (n == 0) return 0;
         const uint64_t mask = (1ull << n) - 1;
         if (start >= 0) {
             const int byte = start >> 3;
             return uint32_t((load64_safe(p + byte, len - byte) >> (start & 7)) & mask);
         }
-        if (start + n <= 0) return 0;
-        return uint32_t((load64_safe(p, len) << (-start)) & mask);
+        // reading past the stream's start: the reference's reader computes its shift as (64 - bitsConsumed - n) & 63 (bitstream.h:
+        // BIT_lookBits -> BIT_getMiddleBits) on a container that holds the stream's first eight bytes by then - it returns wrapped
+        // container bits, not zeros, and a frame that still adds up is accepted with them
+        // (BIT_readBitsFast - the extra bits of offsets and lengths - shifts the other way round, bitstream.h:344-349: what is left of
+        // the stream followed by zeros, or, with nothing left, bits from the container's top)
+        if (fast) return uint32_t((load64_safe(p, len) << ((64 - (start + n)) & 63)) >> ((64 - n) & 63));
+        return uint32_t((load64_safe(p, len) >> (start & 63)) & mask);
     }
     inline uint32_t read(int n) { pos -= n; return peek_at(pos, n); }
+    inline uint32_t read(int n, bool fast) { pos -= n; return peek_at(pos, n, fast); }
 };
 
 // forward bit reader for FSE table descriptions
@@ -510,7 +516,7 @@ static int zstd_decode_frames(const uint8_t* src, int csize, uint8_t* dst, int c
                         uint32_t offset;
                         const uint32_t ll_base = kLLBase[lcode];
                         if (ocode > 1) {
-                            offset = (1u << ocode) - 3 + bs.read(int(ocode));        // OF_base[code] = 2^code - 3
+                            offset = (1u << ocode) - 3 + bs.read(int(ocode), true);  // OF_base[code] = 2^code - 3
                             rep2 = rep1; rep1 = rep0; rep0 = offset;
                         } else {
                             const uint32_t ll0 = (ll_base == 0);
@@ -519,15 +525,15 @@ static int zstd_decode_frames(const uint8_t* src, int csize, uint8_t* dst, int c
                                 rep1 = ll0 ? rep0 : rep1; rep0 = offset;
                                 if (ll0) { /* swapped */ }
                             } else {
-                                const uint32_t v = 1 + ll0 + bs.read(1);          // OF_base[1] = 1
+                                const uint32_t v = 1 + ll0 + bs.read(1, true);    // OF_base[1] = 1
                                 uint32_t t = (v == 3) ? rep0 - 1 : (v == 1 ? rep1 : rep2);
                                 t += !t;
                                 if (v != 1) rep2 = rep1;
                                 rep1 = rep0; rep0 = offset = t;
                             }
                         }
-                        const uint32_t mlen = kMLBase[mcode] + bs.read(int(kMLBits[mcode]));
-                        const uint32_t llen = ll_base + bs.read(int(kLLBits[lcode]));
+                        const uint32_t mlen = kMLBase[mcode] + bs.read(int(kMLBits[mcode]), true);
+                        const uint32_t llen = ll_base + bs.read(int(kLLBits[lcode]), true);
                         sl = (el >> 16) + bs.read(int((el >> 8) & 0xff));
                         sm = (em >> 16) + bs.read(int((em >> 8) & 0xff));
                         so = (eo >> 16) + bs.read(int((eo >> 8) & 0xff));

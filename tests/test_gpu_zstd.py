@@ -117,7 +117,7 @@ def test_zstd_corrupt_frames_rejected_like_reference(gpu):
             assert r == rr and np.array_equal(o, dst[:rr])
         else:
             lenient += 1            # see tests/test_oracle_golden.py: X2-decoder leniency of the reference
-    assert lenient <= 0.01 * len(frames)
+    assert lenient == 0
 
 
 def test_cli_decodes_4mz_files(gpu, tmp_path):
