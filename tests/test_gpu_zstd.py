@@ -116,7 +116,7 @@ def test_zstd_corrupt_frames_rejected_like_reference(gpu):
         elif r >= 0:
             assert r == rr and np.array_equal(o, dst[:rr])
         else:
-            lenient += 1            # see tests/test_oracle_golden.py: X2-decoder leniency of the reference
+            lenient += 1            # see tests/test_oracle_golden.py: none may be left since round 3
     assert lenient == 0
 
 

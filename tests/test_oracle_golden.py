@@ -166,8 +166,8 @@ def test_zstd_port_equals_reference_sources():
                 elif r >= 0:
                     assert r == rr and np.array_equal(out, dst[:rr]), (name, lvl, t, r, rr)   # same bytes when both accept
                 else:
-                    lenient += 1    # corrupt Huffman stream the reference's double-symbol (X2) decoder lets
-                                    # through with unspecified literals (huf_decompress.c:1199-1216); X1 rules reject
+                    lenient += 1    # (until round 3: damaged streams the reference's double-symbol Huffman decoder let through;
+                                    #  its end rules are restated now and none may be left)
                 n += 1
     assert n > 1500 and lenient == 0, (n, lenient)             # (round 3: both Huffman decoders' end rules and the bit reader's reads past a stream's start are restated)
 
