@@ -1061,7 +1061,7 @@ void lz4_decode_lanes_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
 //         per lane, owner by max-scan over a byte map of literal starts, read from where the token's literals lie in the stream.
 //         A group reaches PLAN only after its literal stores have completed.  General tokens: literals by the whole wave, the match
 //         as a group of one.
-//   PLAN / EXEC   the window copier (256 match-space positions per window, stores one window late), as in zstd_exec.inc.
+//   PLAN / EXEC   the window copier (window_copier.inc: 256 match-space positions per window, stores one window late).
 constexpr int kYQ = 4, kYOwn = 1024, kYSpan = 512, kYSteps = 4, kYTQ = 512, kYRing = 2048, kYAhead = 1024;
 constexpr uint32_t kYLitCap = 1023, kYMatCap = 511;
 struct YShared {
@@ -1099,205 +1099,7 @@ template <class P, class F> __device__ __forceinline__ bool ywait(YShared* S, in
     return true;
 }
 
-template <int K>
-__device__ void y_plan(YShared* S, const int lane, unsigned long long& waited)
-{
-    uint32_t g = 0, qa = 0, cqv = 0, ext = 0, ckraw = 0, wi = 0, xdone = 0;
-    for (uint32_t spins = 0;;) {
-        g = rfl(g); qa = rfl(qa); cqv = rfl(cqv); ext = rfl(ext); ckraw = rfl(ckraw); wi = rfl(wi); xdone = rfl(xdone);
-        const bool look = ext - g < 64u * K;
-        uint2 pb = make_uint2(0, 0);
-        if (look) pb = S->pub[lane & (kYQ - 1)];
-        LDS_ORDER();
-        uint32_t mark[K];
-#pragma unroll
-        for (int u = 0; u < K; u++) mark[u] = S->own[(g + 64u * u + uint32_t(lane)) & (kYOwn - 1)];
-        if (look) {
-            const uint32_t ql = cqv + ((uint32_t(lane) - cqv) & (kYQ - 1));
-            cqv += uint32_t(__builtin_popcountll(__ballot(lane < kYQ && ql < qa && pb.y <= g)));
-            const uint32_t qn = qa + ((uint32_t(lane) - qa) & (kYQ - 1));
-            const uint32_t ok = uint32_t(__ballot(lane < kYQ && pb.x == qn + 1)) & ((1u << kYQ) - 1);
-            const uint32_t rot = uint32_t(((unsigned long long)ok | (unsigned long long)ok << kYQ) >> (qa & (kYQ - 1))) & ((1u << kYQ) - 1);
-            const uint32_t n = uint32_t(__builtin_ctz(~rot));
-            if (n) { ext = rdl(pb.y, (qa + n - 1) & (kYQ - 1)); qa += n; }
-        }
-        LDS_ORDER();
-        if (lane == 0) *reinterpret_cast<volatile unsigned long long*>(&S->cc) = (unsigned long long)cqv | (unsigned long long)g << 32;
-        const bool ended = rfl(ldv(&S->total_q)) == qa;
-        if (ext == g) {
-            // records without match bytes (bulk records) are consumed by the look above; nothing to execute
-            if (ended && cqv == qa) break;
-            if (rfl(ldv(&S->failed))) return;
-            __builtin_amdgcn_s_sleep(K1WX_NAP_PLAN);
-            waited++;
-            if (++spins > kSpinLimit) { stv(&S->failed, 1); return; }
-            continue;
-        }
-        spins = 0;
-        uint32_t avail = min(ext - g, 64u * K);
-        const uint32_t base = ((cqv - 1) & 511) << 6;
-        uint32_t dest[K], sp[K], km[K], nl[K];
-#pragma unroll
-        for (int u = 0; u < K; u++) {
-            nl[u] = avail > 64u * u ? min(avail - 64u * u, 64u) : 0u;
-            km[u] = scan_max(mark[u] ? ((mark[u] - 1 - base) & 0x7FFF) + 1 : 0u);
-        }
-        // (the carried owner may belong to a record consumed long ago when records without match bytes lie in between: it is
-        // not needed then - the window starts with a mark of its own - and must not win the comparison)
-        uint32_t ck = ckraw ? ((ckraw - 1 - base) & 0x7FFF) + 1 : 0u;
-        if (ck > uint32_t(kYQ + 2) * 64u) ck = 0;
-#pragma unroll
-        for (int u = 0; u < K; u++) { km[u] = max(km[u], ck); const uint32_t last = rdl(km[u], nl[u] ? nl[u] - 1 : 0u); ck = nl[u] ? last : ck; }
-        uint2 rc[K];
-#pragma unroll
-        for (int u = 0; u < K; u++) {
-            const uint32_t x = km[u] - 1 + base;                        // (q & 511) << 6 | lane of the sequence
-            rc[u] = S->rec[(x >> 6) & (kYQ - 1)][x & 63];
-        }
-        unsigned long long anyovl = 0;
-#pragma unroll
-        for (int u = 0; u < K; u++) {
-            const uint32_t m = g + 64u * u + uint32_t(lane);
-            dest[u] = m + (rc[u].y & 0x3FFFFF);
-            sp[u] = dest[u] - (rc[u].x & 0x3FFFFF);
-            anyovl |= __ballot(int(rc[u].y) < 0 && uint32_t(lane) < nl[u]);
-        }
-        if (anyovl) {                                                   // overlapping matches: read the period, not the match itself
-#pragma unroll
-            for (int u = 0; u < K; u++) {
-                const uint32_t m = g + 64u * u + uint32_t(lane);
-                const uint32_t off = rc[u].x & 0x3FFFFF, D = rc[u].y & 0x3FFFFF;
-                const uint32_t mlow = rc[u].x >> 22 | ((rc[u].y >> 22) & 0x1FF) << 10;
-                const uint32_t rel = (m - mlow) & 0x7FFFF;             // a match is shorter than 2^19 bytes
-                if (int(rc[u].y) < 0 && rel >= off) sp[u] = (m - rel) + D - off + rel % max(off, 1u);
-            }
-        }
-        const uint32_t bound0 = rdl(dest[0], 0);
-        {
-            uint32_t keep_total = avail; bool cut = false;
-#pragma unroll
-            for (int u = 0; u < K; u++) {
-                const unsigned long long out = __ballot(uint32_t(lane) < nl[u] && dest[u] - bound0 >= uint32_t(kYSpan));
-                if (out && !cut) { cut = true; keep_total = 64u * u + uint32_t(__builtin_ctzll(out)); }
-            }
-            if (cut) {
-                avail = keep_total;
-                const uint32_t lu = (avail - 1) >> 6, ll = (avail - 1) & 63;
-                ck = 0;
-#pragma unroll
-                for (int u = 0; u < K; u++) { nl[u] = avail > 64u * u ? min(avail - 64u * u, 64u) : 0u; if (uint32_t(u) == lu) ck = rdl(km[u], ll); }
-            }
-        }
-        ckraw = ((ck - 1 + base) & 0x7FFF) + 1;
-        // ---- hand the window over: a plan buffer is free once EXEC has read it
-        if (!ywait(S, 2, [&] { xdone = rfl(ldv(&S->exec_done)); }, [&] { return xdone + 2 > wi; }, waited)) return;
-#pragma unroll
-        for (int u = 0; u < K; u++) {
-            const bool lv = uint32_t(lane) < nl[u];
-            S->plan[wi & 1][64 * u + lane] = make_uint2(lv ? dest[u] : 0xFFFFFFFFu, sp[u]);
-            if (lv) S->own[(g + 64u * u + uint32_t(lane)) & (kYOwn - 1)] = 0;          // the marks of the window are consumed: cleared
-        }
-        if (lane == 0) S->phdr[wi & 1] = make_uint2(avail, bound0);
-        LDS_ORDER();
-        if (lane == 0) stv(&S->plan_ready, wi + 1);
-        wi++;
-        g += avail;
-    }
-    LDS_ORDER();
-    if (lane == 0) stv(&S->plan_total, wi);
-}
-
-template <int K>
-__device__ void y_exec(YShared* S, gbyte* dst, const int lane, unsigned long long& waited)
-{
-    uint32_t pbound = 0x80000000u, wi = 0, ready = 0, total = 0xFFFFFFFFu;
-    uint32_t pd[K];                                                   // the previous window's bytes, not stored yet: destination | byte << 24
-    bool have_prev = false;
-#pragma unroll
-    for (int u = 0; u < K; u++) pd[u] = 0;
-    for (;;) {
-        pbound = rfl(pbound); wi = rfl(wi); ready = rfl(ready);
-        if (ready <= wi) {
-            auto poll = [&] { total = rfl(ldv(&S->plan_total)); LDS_ORDER(); ready = rfl(ldv(&S->plan_ready)); };
-            if (!ywait(S, 2, poll, [&] { return ready > wi || total == wi; }, waited)) return;
-            if (ready <= wi) break;
-        }
-        const uint2 hd = S->phdr[wi & 1];
-        uint32_t dest[K], sp[K];
-#pragma unroll
-        for (int u = 0; u < K; u++) { const uint2 e = S->plan[wi & 1][64 * u + lane]; dest[u] = e.x; sp[u] = e.y; }
-        const uint32_t bound0 = rfl(hd.y);
-        LDS_ORDER();
-        if (lane == 0) stv(&S->exec_done, wi + 1);                    // (LDS operations execute in order: the reads above are done)
-        // ---- execute.  The window's bytes are stored one window LATE: a load issued behind byte stores cannot return before the
-        // stores are acknowledged (one in-order counter), so this window's loads go out first, then the previous window's stores,
-        // and the wait is for the loads alone.  What this window reads of the previous one it takes from that window's scratch
-        // (the two scratch buffers alternate); anything older was stored at least one iteration ago, in front of these loads.
-        uint16_t* const cur = S->scr[wi & 1];
-        const uint16_t* const prv = S->scr[(wi & 1) ^ 1];
-#pragma unroll
-        for (int i = 0; i < kYSpan * 2 / 1024; i++) reinterpret_cast<uint4*>(cur)[lane + 64 * i] = make_uint4(0, 0, 0, 0);
-        LDS_ORDER();
-        bool lv[K];
-#pragma unroll
-        for (int u = 0; u < K; u++) {
-            lv[u] = dest[u] != 0xFFFFFFFFu;
-            if (lv[u]) cur[dest[u] - bound0] = 0x200;
-        }
-        LDS_ORDER();
-        uint32_t t[K], tp[K], val[K];
-#pragma unroll
-        for (int u = 0; u < K; u++) {
-            t[u] = cur[(lv[u] && sp[u] >= bound0) ? sp[u] - bound0 : uint32_t(kYSpan)];           // [kYSpan] stays 0
-            tp[u] = prv[(lv[u] && sp[u] - pbound < uint32_t(kYSpan)) ? sp[u] - pbound : uint32_t(kYSpan)];
-        }
-        bool now[K]; unsigned long long pend[K];
-#pragma unroll
-        for (int u = 0; u < K; u++) {
-            const bool fwd = t[u] == 0 && (tp[u] & 0x100) != 0;         // produced by the previous window: not in memory yet
-            now[u] = lv[u] && t[u] == 0 && !fwd;
-            pend[u] = __ballot(lv[u] && t[u] != 0);
-            val[u] = tp[u] & 0xff;
-            if (lv[u] && fwd) cur[dest[u] - bound0] = uint16_t(0x100u | val[u]);
-        }
-        uint32_t ldv_[K];
-#pragma unroll
-        for (int u = 0; u < K; u++) ldv_[u] = dst[now[u] ? sp[u] : 0u];
-        if (have_prev) {
-#pragma unroll
-            for (int u = 0; u < K; u++) dst[pd[u] & 0xFFFFFF] = uint8_t(pd[u] >> 24);             // every lane: dead ones repeat the window's first byte
-        }
-#pragma unroll
-        for (int u = 0; u < K; u++) if (now[u]) { val[u] = ldv_[u]; cur[dest[u] - bound0] = uint16_t(0x100u | ldv_[u]); }
-        for (uint32_t rounds = 0;; rounds++) {
-            unsigned long long any = 0;
-#pragma unroll
-            for (int u = 0; u < K; u++) any |= pend[u];
-            if (!any) break;
-            if (rounds > 64u * K) { stv(&S->failed, 1); return; }
-            LDS_ORDER();
-#pragma unroll
-            for (int u = 0; u < K; u++) {
-                if (!pend[u]) continue;
-                const uint32_t tt = cur[((pend[u] >> lane) & 1) ? sp[u] - bound0 : uint32_t(kYSpan)];
-                const bool got = (tt & 0x100) != 0;
-                if (got) { val[u] = tt & 0xff; cur[dest[u] - bound0] = uint16_t(tt); }
-                pend[u] &= ~__ballot(got);
-            }
-        }
-        {
-            const uint32_t first = rdl(dest[0] | val[0] << 24, 0);
-#pragma unroll
-            for (int u = 0; u < K; u++) pd[u] = lv[u] ? (dest[u] | val[u] << 24) : first;
-        }
-        have_prev = true; pbound = bound0; wi++;
-    }
-    if (have_prev) {
-#pragma unroll
-        for (int u = 0; u < K; u++) dst[pd[u] & 0xFFFFFF] = uint8_t(pd[u] >> 24);
-    }
-}
-
+#include "window_copier.inc"
 
 __device__ void y_sl(YShared* S, cgbyte* src, gbyte* dst, const int cap, const int lane, unsigned long long& waited)
 {
@@ -1463,8 +1265,8 @@ void lz4_decode_wx_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
     const unsigned long long t_role = pf.now();
     if (wave == 0) lanes_walk<YShared, kYTQ, kYRing, kYAhead, 1023>(&S, pf, (cgbyte*)src, int(blk.src_len), lane);
     else if (wave == 1) y_sl(&S, (cgbyte*)src, (gbyte*)dst, int(blk.dst_cap), lane, waited);
-    else if (wave == 2) y_plan<kYSteps>(&S, lane, waited);
-    else y_exec<kYSteps>(&S, (gbyte*)dst, lane, waited);
+    else if (wave == 2) wc_plan<YShared, kYSteps, kYQ, kYOwn, kYSpan, K1WX_NAP_PLAN>(&S, lane, waited);
+    else wc_exec<YShared, kYSteps, kYSpan, false>(&S, (wc_g8*)dst, lane, waited);
     pf.add(7, t_role); pf.count(6, waited);
 #ifdef K1R_PROF
     if (prof && lane == 0) for (int i = 0; i < 8; i++) prof[(size_t(b) * 4 + wave) * 8 + i] = pf.t[i];

@@ -31,10 +31,6 @@ for b in range(min(nb, 12)):
     buf = (C.c_uint64 * 8)()
     assert lib.fourmc_gpu_debug_read_workspace(buf, b * slot + slot - 192, 64) == 0
     v = [int(x) for x in buf]
-    cb = (C.c_uint64 * 6)()
-    assert lib.fourmc_gpu_debug_read_workspace(cb, b * slot + slot - 256, 48) == 0
-    w = [int(x) for x in cb]
     eb = (C.c_uint64 * 4)()
     assert lib.fourmc_gpu_debug_read_workspace(eb, b * slot + slot - 64, 32) == 0
-    print(f"{names[b % 12]:7s} entropy kernel: literals {eb[0]/1e6:6.2f} headers {eb[1]/1e6:5.2f} sequences {eb[2]/1e6:6.2f} Mclk (cycle counter) || " + "  ".join(f"{r} {v[2*i]/1e6:7.2f} Mclk (waiting {100*v[2*i+1]/max(v[2*i],1):4.1f}%)" for i, r in enumerate(("SEQ", "LIT", "PLAN", "EXEC")))
-          + f" | windows {w[0]} full {w[1]} one-sequence {w[2]} (offset >= 256: {w[3]}, 16..255: {w[4]}) extra rounds {w[5]}")
+    print(f"{names[b % 12]:7s} entropy kernel: literals {eb[0]/1e6:6.2f} headers {eb[1]/1e6:5.2f} sequences {eb[2]/1e6:6.2f} Mclk (cycle counter) || " + "  ".join(f"{r} {v[2*i]/1e6:7.2f} Mclk (waiting {100*v[2*i+1]/max(v[2*i],1):4.1f}%)" for i, r in enumerate(("SEQ", "LIT", "PLAN", "EXEC"))))
