@@ -27,7 +27,7 @@ hipError_t fourmc_launch_lz4_rows(const void* d_src, void* d_dst, fourmc_block* 
 hipError_t fourmc_launch_lz4_lanes(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                                   uint32_t n, int container_mode, hipStream_t stream);
 hipError_t fourmc_launch_lz4_wx(const void* d_src, void* d_dst, fourmc_block* d_blocks,
-                                  uint32_t n, int container_mode, hipStream_t stream);
+                                  uint32_t n, int container_mode, hipStream_t stream, const uint32_t* pick, uint32_t want);
 hipError_t fourmc_launch_lz4_parse(const void* d_src, const void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                    int container_mode, void* d_work, hipStream_t stream);
 hipError_t fourmc_launch_lz4_exec(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,

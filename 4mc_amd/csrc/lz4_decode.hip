@@ -24,6 +24,7 @@
 #include "devcopy.h"
 #include "lz4par.h"
 #include <string.h>
+#include <atomic>
 
 namespace {
 
@@ -524,8 +525,9 @@ __device__ void lz4_fast_copy(const uint8_t* src, uint8_t* dst, Rec* recs, DSync
 // retry_only = 0: fast path for every block (container rules as in the exact kernel);
 __global__ __launch_bounds__(64 * (kCopiers + 1))
 void lz4_decode_fast_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
-                            fourmc_block* blocks, uint32_t nblocks, int container_mode)
+                            fourmc_block* blocks, uint32_t nblocks, int container_mode, const uint32_t* pick, uint32_t want)
 {
+    if (pick && *pick != want) return;                                  // (see lz4_pick_kernel)
     __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
     __shared__ __attribute__((aligned(16))) uint8_t own[kCopiers][kOwnBytes];
     __shared__ Rec recs[kRec];
@@ -567,6 +569,19 @@ void lz4_decode_retry_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
                              ring, threadIdx.x);
     if (container_mode && r < 0) r = FOURMC_BLK_CORRUPT;
     if (threadIdx.x == 0) blocks[b].result = r;
+}
+
+// 1 in *slot: the launch decodes more than 2.2 bytes per stream byte (the wave trio's case when the chip is full), else 0
+__device__ uint32_t g_pick_ring[256];
+__global__ __launch_bounds__(256) void lz4_pick_kernel(const fourmc_block* blocks, uint32_t n, uint32_t* slot)
+{
+    __shared__ unsigned long long su[256], sc[256];
+    unsigned long long u = 0, c = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) { u += blocks[i].dst_cap; c += blocks[i].src_len; }
+    su[threadIdx.x] = u; sc[threadIdx.x] = c;
+    __syncthreads();
+    for (int k = 128; k; k >>= 1) { if (int(threadIdx.x) < k) { su[threadIdx.x] += su[threadIdx.x + k]; sc[threadIdx.x] += sc[threadIdx.x + k]; } __syncthreads(); }
+    if (threadIdx.x == 0) *slot = su[0] * 10 >= sc[0] * 22 ? 1u : 0u;
 }
 
 } // namespace
@@ -630,6 +645,22 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
     // 6 "auto": the walk + window copier (lz4_rows.hip, K1wx) has the shortest chain per block at every launch size (28 ms against
     // 36 / 43 ms for the row pipeline / the wave trio at 64..256 blocks, 37 / 44 / 49 at 1024, 53.5 / 59 / 57 at 2048; LZ4-HC streams
     // at 2048 blocks are the exception: 52 ms against the trio's 48)
+    if (path == 6 && n >= 1792) {
+        // ... except for a launch that fills the chip with SHORT streams (LZ4-HC output: 2.5 bytes out per byte in): the trio's parser
+        // is bound by stream bytes and then ahead (48 ms against 53).  The sizes are in device memory: a one-block kernel adds them up
+        // and leaves the choice in a slot both decode kernels look at (a ring of slots: launches on other streams take other slots).
+        static uint32_t* ring = nullptr; static std::atomic<uint32_t> next{0};
+        if (!ring && hipGetSymbolAddress(reinterpret_cast<void**>(&ring), HIP_SYMBOL(g_pick_ring)) != hipSuccess) ring = nullptr;
+        if (ring) {
+            uint32_t* const slot = ring + (next.fetch_add(1) & 255u);
+            hipLaunchKernelGGL(lz4_pick_kernel, dim3(1), dim3(256), 0, stream, d_blocks, n, slot);
+            hipError_t e = fourmc_launch_lz4_wx(d_src, d_dst, d_blocks, n, container_mode, stream, slot, 0);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(lz4_decode_fast_kernel, dim3(n), dim3(64 * (kCopiers + 1)), 0, stream, s8, d8, d_blocks, n, container_mode, (const uint32_t*)slot, 1u);
+            hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
+            return hipGetLastError();
+        }
+    }
     if (path == 6) path = 9;
     if (path == 2) {
         hipLaunchKernelGGL(lz4_decode_exact_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
@@ -642,7 +673,7 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
         return hipGetLastError();
     }
     if (path == 9 || path == 10) {
-        hipError_t e = fourmc_launch_lz4_wx(d_src, d_dst, d_blocks, n, container_mode, stream);
+        hipError_t e = fourmc_launch_lz4_wx(d_src, d_dst, d_blocks, n, container_mode, stream, nullptr, 0);
         if (e != hipSuccess || path == 10) return e;      // 10: test aid, shows what the path alone did
         hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
         return hipGetLastError();
@@ -654,7 +685,7 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
         return hipGetLastError();
     }
     if (path == 0) {
-        hipLaunchKernelGGL(lz4_decode_fast_kernel, dim3(n), dim3(64 * (kCopiers + 1)), 0, stream, s8, d8, d_blocks, n, container_mode);
+        hipLaunchKernelGGL(lz4_decode_fast_kernel, dim3(n), dim3(64 * (kCopiers + 1)), 0, stream, s8, d8, d_blocks, n, container_mode, (const uint32_t*)nullptr, 0u);
         hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
         return hipGetLastError();
     }

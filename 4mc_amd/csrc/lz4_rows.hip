@@ -1234,11 +1234,13 @@ __device__ void y_sl(YShared* S, cgbyte* src, gbyte* dst, const int cap, const i
 
 __global__ __launch_bounds__(256, 8)
 void lz4_decode_wx_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
-                          fourmc_block* blocks, uint32_t nblocks, int container_mode, unsigned long long* prof)
+                          fourmc_block* blocks, uint32_t nblocks, int container_mode, unsigned long long* prof,
+                          const uint32_t* pick, uint32_t want)
 {
     __shared__ __attribute__((aligned(16))) YShared S;
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
+    if (pick && *pick != want) return;                                  // a full launch of short streams is the wave trio's (lz4_decode.hip: lz4_pick_kernel)
     const fourmc_block blk = uniform_block(blocks[b]);
     if (container_mode && blk.result == FOURMC_BLK_BADSUM) return;
     const uint8_t* src = src_base + blk.src_off;
@@ -1318,7 +1320,7 @@ extern "C" hipError_t fourmc_launch_lz4_lanes(const void* d_src, void* d_dst, fo
 }
 
 extern "C" hipError_t fourmc_launch_lz4_wx(const void* d_src, void* d_dst, fourmc_block* d_blocks,
-                                           uint32_t n, int container_mode, hipStream_t stream)
+                                           uint32_t n, int container_mode, hipStream_t stream, const uint32_t* pick, uint32_t want)
 {
     if (n == 0) return hipSuccess;
     unsigned long long* prof = nullptr;
@@ -1327,6 +1329,6 @@ extern "C" hipError_t fourmc_launch_lz4_wx(const void* d_src, void* d_dst, fourm
     prof = g_prof;
 #endif
     hipLaunchKernelGGL(lz4_decode_wx_kernel, dim3(n), dim3(256), 0, stream,
-                       static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n, container_mode, prof);
+                       static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n, container_mode, prof, pick, want);
     return hipGetLastError();
 }
