@@ -649,8 +649,13 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
         // ... except for a launch that fills the chip with SHORT streams (LZ4-HC output: 2.5 bytes out per byte in): the trio's parser
         // is bound by stream bytes and then ahead (48 ms against 53).  The sizes are in device memory: a one-block kernel adds them up
         // and leaves the choice in a slot both decode kernels look at (a ring of slots: launches on other streams take other slots).
-        static uint32_t* ring = nullptr; static std::atomic<uint32_t> next{0};
-        if (!ring && hipGetSymbolAddress(reinterpret_cast<void**>(&ring), HIP_SYMBOL(g_pick_ring)) != hipSuccess) ring = nullptr;
+        static std::atomic<uint32_t*> rings[64]; static std::atomic<uint32_t> next{0};       // (a device symbol has one address per device)
+        int dev = 0;
+        uint32_t* ring = nullptr;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            ring = rings[dev].load();
+            if (!ring && hipGetSymbolAddress(reinterpret_cast<void**>(&ring), HIP_SYMBOL(g_pick_ring)) == hipSuccess) rings[dev].store(ring);
+        }
         if (ring) {
             uint32_t* const slot = ring + (next.fetch_add(1) & 255u);
             hipLaunchKernelGGL(lz4_pick_kernel, dim3(1), dim3(256), 0, stream, d_blocks, n, slot);

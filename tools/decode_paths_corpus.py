@@ -23,5 +23,5 @@ for path, name in ((6, "auto"), (9, "wx"), (0, "trio"), (4, "rows")):
     for it in range(3):
         dec = p.DeviceBatch(p.make_blocks(offs, offs, e["result"].astype(np.uint32), lens, e["xxh32"]))
         s = torch.cuda.Event(enable_timing=True); t = torch.cuda.Event(enable_timing=True)
-        s.record(); p.decode_blocks(st, out, dec); t.record(); torch.cuda.synchronize(); ts.append(s.elapsed_time(t))
+        s.record(); p.decode_blocks(st, out, dec, codec=(p.CODEC_LZ4_HC if encoder == "hc4" and os.environ.get("DEC_HC") else p.CODEC_LZ4_FAST)); t.record(); torch.cuda.synchronize(); ts.append(s.elapsed_time(t))
     print(f"{corpus} {encoder} ratio {ratio:.2f} blocks {nb}: {name} {min(ts):.2f} ms", torch.equal(out[: nb * B], d_src))
