@@ -23,6 +23,7 @@
 #include "kernels.h"
 #include "devcopy.h"
 #include "lz4par.h"
+#include "lz4seg.h"
 #include <string.h>
 #include <atomic>
 
@@ -124,8 +125,10 @@ __device__ __forceinline__ void copy_literals(Stream& s, const uint8_t* src, uin
 }
 
 // One wave decodes one block.  Mirrors the control flow restated in oracle/lz4_port.c.
+// (ip0, op0) != (0, 0): resume behind sequences another kernel has executed (lz4_seg.hip) - only ever at a token the reference's
+// fast loop would still be in (at least kMargin stream bytes and kOMargin output bytes from the ends, lz4seg.h)
 __device__ __forceinline__ int lz4_decode_block(const uint8_t* src, int csize, uint8_t* dst, int cap,
-                                uint8_t* lds, int lane)
+                                uint8_t* lds, int lane, int ip0 = 0, int op0 = 0)
 {
     if (cap < 0) return -1;
     if (cap == 0) return (csize == 1 && src[0] == 0) ? 0 : -1;          // lz4.c:1977-1981
@@ -133,7 +136,7 @@ __device__ __forceinline__ int lz4_decode_block(const uint8_t* src, int csize, u
 
     Stream s; s.init(src, csize, lds, lane);
     const int iend = csize, oend = cap;
-    int ip = 0, op = 0;
+    int ip = ip0, op = op0;
     bool fast = (oend - op) >= 64;                                      // lz4.c:1990
 
     for (;;) {
@@ -571,6 +574,28 @@ void lz4_decode_retry_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
     if (threadIdx.x == 0) blocks[b].result = r;
 }
 
+// the same for the segment-parallel path (lz4_seg.hip): blocks it handed back entirely (kRetry), and blocks it executed up to the
+// token where the reference's end-of-block rules begin (kResume: token and output position in the block's workspace slot)
+__global__ __launch_bounds__(64)
+void lz4_decode_resume_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
+                              fourmc_block* blocks, uint32_t nblocks, int container_mode, const uint32_t* ws, int redo)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    const fourmc_block blk = uniform_block(blocks[b]);
+    int ip0 = 0, op0 = 0;
+    if (blk.result == lz4seg::kResumeCode) {
+        const uint32_t* meta = ws + size_t(b) * lz4seg::kWsWords;
+        ip0 = __builtin_amdgcn_readfirstlane(int(meta[lz4seg::kMetaResIp]));
+        op0 = __builtin_amdgcn_readfirstlane(int(meta[lz4seg::kMetaResOp]));
+    } else if (blk.result != kRetry || !redo) return;
+    int r = lz4_decode_block(src_base + blk.src_off, int(blk.src_len), dst_base + blk.dst_off, int(blk.dst_cap),
+                             ring, threadIdx.x, ip0, op0);
+    if (container_mode && r < 0) r = FOURMC_BLK_CORRUPT;
+    if (threadIdx.x == 0) blocks[b].result = r;
+}
+
 // 1 in *slot: the launch decodes more than 2.2 bytes per stream byte (the wave trio's case when the chip is full), else 0
 __device__ uint32_t g_pick_ring[256];
 __global__ __launch_bounds__(256) void lz4_pick_kernel(const fourmc_block* blocks, uint32_t n, uint32_t* slot)
@@ -600,6 +625,7 @@ extern "C" int fourmc_gpu_get_lz4_decode_path(void);
 extern "C" size_t fourmc_lz4_decode_work_bytes(uint32_t n)
 {
     const int path = fourmc_gpu_get_lz4_decode_path();
+    if (path == 11 || path == 12 || (path == 6 && n >= 1792)) return fourmc_lz4_seg_work_bytes(n < fourmc_lz4_seg_batch() ? n : fourmc_lz4_seg_batch());
     return (path == 1 || path == 3) ? fourmc_lz4_parse_work_bytes(n) : 0;
 }
 
@@ -629,6 +655,8 @@ extern "C" int fourmc_gpu_get_lz4_decode_path(void)
         if (mode && !strcmp(mode, "wx")) g_decode_path = 9;
         if (mode && !strcmp(mode, "wxonly")) g_decode_path = 10;
         if (mode && !strcmp(mode, "exact")) g_decode_path = 2;
+        if (mode && !strcmp(mode, "seg")) g_decode_path = 11;
+        if (mode && !strcmp(mode, "segonly")) g_decode_path = 12;
         if (mode && !strcmp(mode, "par")) g_decode_path = 1;
         if (mode && !strcmp(mode, "paronly")) g_decode_path = 3;
     }
@@ -645,28 +673,24 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
     // 6 "auto": the walk + window copier (lz4_rows.hip, K1wx) has the shortest chain per block at every launch size (28 ms against
     // 36 / 43 ms for the row pipeline / the wave trio at 64..256 blocks, 37 / 44 / 49 at 1024, 53.5 / 59 / 57 at 2048; LZ4-HC streams
     // at 2048 blocks are the exception: 52 ms against the trio's 48)
-    if (path == 6 && n >= 1792) {
-        // ... except for a launch that fills the chip with SHORT streams (LZ4-HC output: 2.5 bytes out per byte in): the trio's parser
-        // is bound by stream bytes and then ahead (48 ms against 53).  The sizes are in device memory: a one-block kernel adds them up
-        // and leaves the choice in a slot both decode kernels look at (a ring of slots: launches on other streams take other slots).
-        static std::atomic<uint32_t*> rings[64]; static std::atomic<uint32_t> next{0};       // (a device symbol has one address per device)
-        int dev = 0;
-        uint32_t* ring = nullptr;
-        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-            ring = rings[dev].load();
-            if (!ring && hipGetSymbolAddress(reinterpret_cast<void**>(&ring), HIP_SYMBOL(g_pick_ring)) == hipSuccess) rings[dev].store(ring);
-        }
-        if (ring) {
-            uint32_t* const slot = ring + (next.fetch_add(1) & 255u);
-            hipLaunchKernelGGL(lz4_pick_kernel, dim3(1), dim3(256), 0, stream, d_blocks, n, slot);
-            hipError_t e = fourmc_launch_lz4_wx(d_src, d_dst, d_blocks, n, container_mode, stream, slot, 0);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(lz4_decode_fast_kernel, dim3(n), dim3(64 * (kCopiers + 1)), 0, stream, s8, d8, d_blocks, n, container_mode, (const uint32_t*)slot, 1u);
-            hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
-            return hipGetLastError();
-        }
-    }
+    // 6 "auto": a launch that fills the chip goes to the segment-parallel path (lz4_seg.hip: one wave per block, a fifth of the
+    // instructions per byte of the wave pipelines - 8192 blocks in 116 ms against 184); smaller launches to the walk + window copier
+    // (K1wx: four waves per block, the shortest chain per block)
+    if (path == 6 && n >= 1792) path = 11;
     if (path == 6) path = 9;
+    if (path == 11 || path == 12) {
+        // segment-parallel walk + batch executor (lz4_seg.hip), then the exact walker for the last bytes of every block and for
+        // whatever was handed back; 12: test aid, blocks handed back stay kRetry
+        const uint32_t step = fourmc_lz4_seg_batch();
+        for (uint32_t b0 = 0; b0 < n; b0 += step) {
+            const uint32_t m = n - b0 < step ? n - b0 : step;
+            hipError_t e = fourmc_launch_lz4_seg(d_src, d_dst, d_blocks + b0, m, container_mode, d_work, stream);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(lz4_decode_resume_kernel, dim3(m), dim3(64), 0, stream, s8, d8, d_blocks + b0, m, container_mode,
+                               static_cast<const uint32_t*>(d_work), path == 11 ? 1 : 0);
+        }
+        return hipGetLastError();
+    }
     if (path == 2) {
         hipLaunchKernelGGL(lz4_decode_exact_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
         return hipGetLastError();

@@ -15,12 +15,16 @@ pytestmark = pytest.mark.gpu
 RETRY = -1000000003
 
 
-@pytest.fixture(scope="module", params=[4, 5, 7, 8, 9, 10], ids=["rows", "rows-alone", "lanes", "lanes-alone", "wx", "wx-alone"])
+@pytest.fixture(scope="module", params=[4, 5, 7, 8, 9, 10, 11, 12],
+                ids=["rows", "rows-alone", "lanes", "lanes-alone", "wx", "wx-alone", "seg", "seg-alone"])
 def gpu(request):
     p = pkg(); p.gpu_init()
     before = p.lib().fourmc_gpu_get_lz4_decode_path()
     p.lib().fourmc_gpu_set_lz4_decode_path(request.param)
-    p.rows_alone = request.param in (5, 8, 10)
+    p.rows_alone = request.param in (5, 8, 10, 12)
+    # below these sizes a path leaves the block to the exact walker (seg: lz4seg.h kMinSrc / kMinCap; "alone" = blocks handed
+    # back entirely stay RETRY - the exact walker still finishes the last bytes of the blocks the segment path executed)
+    p.min_cap, p.min_src = (256, 256) if request.param == 12 else (64, 8)
     yield p
     p.lib().fourmc_gpu_set_lz4_decode_path(before)
 
@@ -34,7 +38,7 @@ def test_decode_shapes(gpu):
         comps.append(comp); caps.append(len(ins[k])); shifts.append((i * 29) % 128)
     res, out, doffs = par._decode(gpu, comps, caps, shifts)
     for i, k in enumerate(names):
-        if gpu.rows_alone and (caps[i] < 64 or len(comps[i]) < 8):
+        if gpu.rows_alone and (caps[i] < gpu.min_cap or len(comps[i]) < gpu.min_src):
             assert res[i] == RETRY, (k, int(res[i]))                 # below the pipeline's sizes: the exact walker's
             continue
         assert res[i] == caps[i], (k, int(res[i]))

@@ -73,17 +73,23 @@ def main():
             if k.startswith(kern) and c in v: return v[c][0] * KiB          # one dispatch per kernel in the child
         return None
     cs, us, nb = meta["csize_sum"], meta["usize_sum"], meta["blocks"]
-    dec_kernel = "lz4_decode_fast_kernel" if get("lz4_decode_fast_kernel", "FETCH_SIZE") is not None else "lz4_decode_rows_kernel"
+    # every kernel of the decode path that ran (a path is several launches: the segment-parallel one is walk + executor + the exact
+    # walker's tail; kernels of a path that was launched but left at once move nothing and add nothing): their counters are summed
+    dec_kernels = sorted(k for k in res if (k.startswith("lz4_seg_") or k.startswith("lz4_decode_")) and (res[k].get("WRITE_SIZE", (0, 0))[0] + res[k].get("FETCH_SIZE", (0, 0))[0]) > 0)
+    dec_kernel = "+".join(dec_kernels)
+    def get_dec(c):
+        return sum(res[k][c][0] for k in dec_kernels if c in res[k]) * KiB
     # the hash kernel runs twice (over the staging slots after the encode, over the image before the decode): per dispatch
     xx = [k for k in res if k.startswith("xxh32")]
     xf = sum(res[k]["FETCH_SIZE"][0] for k in xx) * KiB / max(sum(res[k]["FETCH_SIZE"][1] for k in xx), 1)
     out = {"blocks": nb, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) around one encode / hash / pack / verify / decode of the launch size, inside this bench run",
            "lz4_encode": {"fetch": get("lz4_encode_fast_kernel", "FETCH_SIZE"), "write": get("lz4_encode_fast_kernel", "WRITE_SIZE"), "algorithmic": us + cs},
-           "lz4_decode": {"kernel": dec_kernel, "fetch": get(dec_kernel, "FETCH_SIZE"), "write": get(dec_kernel, "WRITE_SIZE"), "algorithmic": us + cs},
+           "lz4_decode": {"kernel": dec_kernel, "fetch": get_dec("FETCH_SIZE"), "write": get_dec("WRITE_SIZE"), "algorithmic": us + cs,
+                          "per_kernel": {k: {c: res[k][c][0] * KiB for c in ("FETCH_SIZE", "WRITE_SIZE") if c in res[k]} for k in dec_kernels}},
            "calibration": {"xxh32_fetch_reported_over_known": round(xf / cs, 4), "pack_fetch_reported_over_known": round(get("pack_image_kernel", "FETCH_SIZE") / cs, 4),
                            "pack_write_reported_over_known": round(get("pack_image_kernel", "WRITE_SIZE") / (cs + 12 * nb), 4),
-                           "decode_write_reported_over_known": round(get(dec_kernel, "WRITE_SIZE") / us, 4),
-                           "note": "known = the bytes the kernel has to move exactly once (xxh32: every payload byte read; pack: payloads read, payloads + 12 B headers written; decode: 4 MiB written per block)"}}
+                           "decode_write_reported_over_known": round(get_dec("WRITE_SIZE") / us, 4),
+                           "note": "known = the bytes the kernel has to move exactly once (xxh32: every payload byte read; pack: payloads read, payloads + 12 B headers written; decode: 4 MiB written per block - the segment-parallel path also writes and reads back 4 bytes per sequence of token records, which this ratio then includes)"}}
     for k in ("lz4_encode", "lz4_decode"):
         out[k]["traffic"] = int(out[k]["fetch"] + out[k]["write"])
         out[k]["traffic_over_algorithmic"] = round(out[k]["traffic"] / out[k]["algorithmic"], 4)
