@@ -36,8 +36,9 @@ int ensure_device()
 {
     int d = g_device.load(std::memory_order_acquire);
     if (d < 0) { if (int r = fourmc_gpu_init(-1)) return r; d = g_device.load(std::memory_order_acquire); }
-    thread_local int t_device = -1;
-    if (t_device != d) { HIP_TRY(hipSetDevice(d)); t_device = d; }
+    // (the embedding application may have changed this thread's current device between two calls: ask, do not remember)
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != d) HIP_TRY(hipSetDevice(d));
     return FOURMC_OK;
 }
 
@@ -563,29 +564,44 @@ int fourmc_host_4mc_encode_image(const void* src, size_t src_bytes, fourmc_block
     if (int r = ensure_device()) return r;
     if (n == 0) { *image_bytes = 0; return FOURMC_OK; }
     std::lock_guard<std::mutex> lk(g_mu);
-    static void* d_img = nullptr; static size_t img_cap = 0;          // guarded by g_mu, like the arena
-    static uint64_t* d_ioff = nullptr; static size_t ioff_cap = 0;
+    static void* d_img = nullptr; static size_t img_cap = 0; static int img_dev = -1;          // guarded by g_mu, like the arena; keyed by the device
+    static uint64_t* d_ioff = nullptr; static size_t ioff_cap = 0; static int ioff_dev = -1;
     size_t dst_bytes = 0;
     for (uint32_t b = 0; b < n; b++) dst_bytes = std::max<size_t>(dst_bytes, blocks[b].dst_off + blocks[b].dst_cap);
     if (int r = arena_reserve(g_arena, src_bytes, dst_bytes, n)) return r;
     hipStream_t s = g_arena.stream;
-    HIP_TRY(hipMemcpyAsync(g_arena.d_src, src, src_bytes, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(g_arena.d_blk, blocks, n * sizeof(fourmc_block), hipMemcpyHostToDevice, s));
-    if (int r = launch_host_op(0, codec, level, g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s)) return r;
-    HIP_TRY(hipMemcpyAsync(blocks, g_arena.d_blk, n * sizeof(fourmc_block), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    uint64_t pos = 0;
-    for (uint32_t b = 0; b < n; b++) {
-        if (blocks[b].result <= 0 || uint32_t(blocks[b].result) > blocks[b].src_len) { snprintf(g_err, sizeof g_err, "block %u: encoder returned %d", b, blocks[b].result); return FOURMC_EINVAL; }
-        image_off[b] = pos; pos += 12ull + uint32_t(blocks[b].result);
-    }
-    if (pos > image_cap) { snprintf(g_err, sizeof g_err, "image capacity %zu below %llu", image_cap, (unsigned long long)pos); return FOURMC_EINVAL; }
-    if (pos > img_cap) { if (d_img) HIP_TRY(hipFree(d_img)); d_img = nullptr; img_cap = 0; HIP_TRY(hipMalloc(&d_img, pos + pos / 8 + 4096)); img_cap = pos + pos / 8 + 4096; }
-    if (n > ioff_cap) { if (d_ioff) HIP_TRY(hipFree(d_ioff)); d_ioff = nullptr; ioff_cap = 0; HIP_TRY(hipMalloc(&d_ioff, (size_t(n) + 64) * 8)); ioff_cap = size_t(n) + 64; }
-    HIP_TRY(hipMemcpyAsync(d_ioff, image_off, size_t(n) * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(fourmc_launch_pack_image(g_arena.d_dst, d_img, g_arena.d_blk, d_ioff, n, s));
-    HIP_TRY(hipMemcpyAsync(image, d_img, pos, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    // every exit behind the first asynchronous copy waits for the stream: the copies read and write the CALLER's memory (the
+    // descriptor array, the mapped files), and the next user of the arena must not meet them still in flight
+    int rc = FOURMC_OK; uint64_t pos = 0;
+    auto step = [&](hipError_t e, const char* what) { if (rc == FOURMC_OK && e != hipSuccess) rc = fail_hip(e, what); return rc == FOURMC_OK; };
+    do {
+        if (!step(hipMemcpyAsync(g_arena.d_src, src, src_bytes, hipMemcpyHostToDevice, s), "H2D source")) break;
+        if (!step(hipMemcpyAsync(g_arena.d_blk, blocks, n * sizeof(fourmc_block), hipMemcpyHostToDevice, s), "H2D descriptors")) break;
+        if (int r = launch_host_op(0, codec, level, g_arena.d_src, g_arena.d_dst, g_arena.d_blk, n, s)) { rc = r; break; }
+        if (!step(hipMemcpyAsync(blocks, g_arena.d_blk, n * sizeof(fourmc_block), hipMemcpyDeviceToHost, s), "D2H descriptors")) break;
+        if (!step(hipStreamSynchronize(s), "hipStreamSynchronize")) break;
+        for (uint32_t b = 0; b < n && rc == FOURMC_OK; b++) {
+            if (blocks[b].result <= 0 || uint32_t(blocks[b].result) > blocks[b].src_len) { snprintf(g_err, sizeof g_err, "block %u: encoder returned %d", b, blocks[b].result); rc = FOURMC_EINVAL; break; }
+            image_off[b] = pos; pos += 12ull + uint32_t(blocks[b].result);
+        }
+        if (rc != FOURMC_OK) break;
+        if (pos > image_cap) { snprintf(g_err, sizeof g_err, "image capacity %zu below %llu", image_cap, (unsigned long long)pos); rc = FOURMC_EINVAL; break; }
+        if (pos > img_cap || img_dev != g_device.load()) {
+            if (d_img) step(hipFree(d_img), "hipFree"); d_img = nullptr; img_cap = 0;
+            if (!step(hipMalloc(&d_img, pos + pos / 8 + 4096), "hipMalloc image")) break;
+            img_cap = pos + pos / 8 + 4096; img_dev = g_device.load();
+        }
+        if (n > ioff_cap || ioff_dev != g_device.load()) {
+            if (d_ioff) step(hipFree(d_ioff), "hipFree"); d_ioff = nullptr; ioff_cap = 0;
+            if (!step(hipMalloc(&d_ioff, (size_t(n) + 64) * 8), "hipMalloc offsets")) break;
+            ioff_cap = size_t(n) + 64; ioff_dev = g_device.load();
+        }
+        if (!step(hipMemcpyAsync(d_ioff, image_off, size_t(n) * 8, hipMemcpyHostToDevice, s), "H2D offsets")) break;
+        if (!step(fourmc_launch_pack_image(g_arena.d_dst, d_img, g_arena.d_blk, d_ioff, n, s), "pack")) break;
+        if (!step(hipMemcpyAsync(image, d_img, pos, hipMemcpyDeviceToHost, s), "D2H image")) break;
+    } while (0);
+    { const hipError_t e = hipStreamSynchronize(s); if (rc == FOURMC_OK && e != hipSuccess) rc = fail_hip(e, "hipStreamSynchronize"); }
+    if (rc != FOURMC_OK) return rc;
     *image_bytes = pos;
     return FOURMC_OK;
 }

@@ -17,6 +17,7 @@
  */
 #define _FILE_OFFSET_BITS 64
 #define _POSIX_C_SOURCE 200809L
+#include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -226,6 +227,20 @@ static int compress_file_mapped(int displayLevel, FILE* fin, const char* out_nam
             blk[b].src_off = (uint64_t)b * BLOCKSIZE; blk[b].dst_off = (uint64_t)b * BLOCKSIZE;
             blk[b].src_len = (uint32_t)((bytes - (uint64_t)b * BLOCKSIZE < BLOCKSIZE) ? bytes - (uint64_t)b * BLOCKSIZE : BLOCKSIZE);
             blk[b].dst_cap = blk[b].src_len; blk[b].result = 0; blk[b].xxh32 = 0;
+        }
+        /* the blocks this launch may write are RESERVED before it: a store into a hole of a sparse mapping on a full disk (or over
+         * quota) is a SIGBUS in the middle of a device copy, where the reference - and the streaming path - report "Write error" and
+         * exit 3.  Nothing has been written by then at the first launch: the streaming path takes over; later: the reference's exit. */
+        {
+            const uint64_t want = (uint64_t)nb * 12 + bytes;
+            const int fe = posix_fallocate(fdo, (off_t)pos, (off_t)(want < bound - pos ? want : bound - pos));
+            if (fe != 0 && fe != EOPNOTSUPP && fe != EINVAL) {
+                if (b0 != 0) DIE(3, "Write error : cannot write compressed block");
+                munmap(out, (size_t)bound); munmap(in, (size_t)N); free(offsets); free(ioff); free(blk);
+                if (ftruncate(fdo, 0) != 0) {}
+                close(fdo);
+                return -1;
+            }
         }
         rc = fourmc_host_4mc_encode_image(in + base, (size_t)bytes, blk, nb, codec, codec_level, out + pos, (size_t)(bound - pos), ioff, &ib);
         if (rc != FOURMC_OK) DIE(1, "GPU engine error %d : %s", rc, fourmc_gpu_last_error());

@@ -283,33 +283,52 @@ void lz4_seg_walk_kernel(const uint8_t* __restrict__ src_base, const fourmc_bloc
 // destination: string byte b sits at byte (da + b) of R, da = pd & 3; bytes of R outside the string are arbitrary.
 __device__ __forceinline__ void or_store(uint8_t* st, uint32_t pd, const uint32_t (&R)[9], uint32_t len, bool on)
 {
+    // A lane is switched off for the dwords it does not reach (measured: letting it OR a zero instead - no exec-mask round trip -
+    // made the kernel 1.5 x SLOWER: an LDS atomic costs per lane and per lane that meets another on the same dword); the dwords
+    // beyond the fifth are skipped as a whole when no lane reaches them (strings of up to 17 bytes: most batches)
     const uint32_t da = pd & 3u, end = da + len, last = (end + 3u) / 4u - 1u, tb = end & 3u;
     const uint32_t hmask = 0xFFFFFFFFu << (8u * da), tmask = tb ? ((1u << (8u * tb)) - 1u) : 0xFFFFFFFFu;
     uint32_t* w = reinterpret_cast<uint32_t*>(st + (pd & ~3u));
 #pragma unroll
-    for (uint32_t j = 0; j < 9; j++) {
+    for (uint32_t j = 0; j < 5; j++) {
         uint32_t v = R[j];
         if (j == 0) v &= hmask;
         v = j == last ? (v & tmask) : v;
         if (on && j <= last) __hip_atomic_fetch_or(w + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
+    if (__ballot(on && last >= 5u)) {
+#pragma unroll
+        for (uint32_t j = 5; j < 9; j++) {
+            uint32_t v = R[j];
+            v = j == last ? (v & tmask) : v;
+            if (on && j <= last) __hip_atomic_fetch_or(w + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    }
 }
 // nine dwords from memory so that the byte at `base + a` lands on byte `da` of R[0]
-__device__ __forceinline__ void load_phase(cgbyte* base, uint32_t a, uint32_t da, uint32_t (&R)[9], bool on)
+__device__ __forceinline__ void load_phase(cgbyte* base, uint32_t a, uint32_t da, uint32_t (&R)[9], bool on, uint32_t len)
 {
+    // (the second 16 bytes and the last dword are loaded only when some lane's string reaches them: a load of 64 lanes at 64
+    // places costs the L1 64 look-ups whatever it returns)
+    const bool far1 = __ballot(on && da + len > 16u) != 0, far2 = __ballot(on && da + len > 32u) != 0;
+#pragma unroll
+    for (int j = 4; j < 9; j++) R[j] = 0;
     if (on) {
         if (a >= da) {
             cgbyte* p = base + (a - da);
-            const u32x4 v0 = ld16u_g(p), v1 = ld16u_g(p + 16); const uint32_t v2 = ld4u(p + 32);
-            R[0] = v0.x; R[1] = v0.y; R[2] = v0.z; R[3] = v0.w; R[4] = v1.x; R[5] = v1.y; R[6] = v1.z; R[7] = v1.w; R[8] = v2;
+            const u32x4 v0 = ld16u_g(p);
+            R[0] = v0.x; R[1] = v0.y; R[2] = v0.z; R[3] = v0.w;
+            if (far1) { const u32x4 v1 = ld16u_g(p + 16); R[4] = v1.x; R[5] = v1.y; R[6] = v1.z; R[7] = v1.w; }
+            if (far2) R[8] = ld4u(p + 32);
         } else {
-            // the first bytes of the buffer with a destination phase that would read in front of it: byte by byte
+            // the first bytes of the buffer with a destination phase that would read in front of it (a < da <= 3): the same
+            // loads from the buffer's first byte, shifted up by da - a bytes in registers
+            uint32_t L[9];
+            const u32x4 v0 = ld16u_g(base), v1 = ld16u_g(base + 16); const uint32_t v2 = ld4u(base + 32);
+            L[0] = v0.x; L[1] = v0.y; L[2] = v0.z; L[3] = v0.w; L[4] = v1.x; L[5] = v1.y; L[6] = v1.z; L[7] = v1.w; L[8] = v2;
+            const uint32_t k = 4u - (da - a);
 #pragma unroll
-            for (int j = 0; j < 9; j++) {
-                uint32_t v = 0;
-                for (int i = 0; i < 4; i++) { const int o = 4 * j + i - int(da); if (o >= -int(a)) v |= uint32_t(base[int(a) + o]) << (8 * i); }
-                R[j] = v;
-            }
+            for (int j = 0; j < 9; j++) R[j] = __builtin_amdgcn_alignbyte(L[j], j ? L[j - 1] : 0u, k);
         }
     }
 }
@@ -415,7 +434,7 @@ void lz4_seg_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base
                     const bool on = rem > 0u;
                     const uint32_t len = rem < 32u ? rem : 32u, pd = P0 + dp;
                     uint32_t R[9];
-                    load_phase(s, sp, pd & 3u, R, on);
+                    load_phase(s, sp, pd & 3u, R, on, len);
                     or_store(st, pd, R, len, on);
                     sp += len; dp += len; rem -= len;
                 }
@@ -431,7 +450,7 @@ void lz4_seg_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base
                     const bool on = rem > 0u;
                     const uint32_t len = rem < 32u ? rem : 32u, pd = P0 + dp;
                     uint32_t R[9];
-                    load_phase((cgbyte*)dst, sa, pd & 3u, R, on);
+                    load_phase((cgbyte*)dst, sa, pd & 3u, R, on, len);
                     or_store(st, pd, R, len, on);
                     sa += len; dp += len; rem -= len;
                 }

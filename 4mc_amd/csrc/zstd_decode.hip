@@ -1320,6 +1320,14 @@ void zstd_decode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
     else {
         r = zstd_decode_frame_v2(src, int(blk.src_len), dst, int(blk.dst_cap), work, &zs, lane, split, fl);
         release_helper();
+        // A helper wave that was given its go reads the block table and the tables of the shared state until it reports: the serial
+        // path below rebuilds those tables, so it must not start (after a decline on damaged input, say) before the helper is done
+        if (two_wave && r == kDecline && __hip_atomic_load(&flags[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 1u) {
+            for (uint32_t spins = 0; spins < (1u << 24); spins++) {
+                if (__hip_atomic_load(&flags[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                __builtin_amdgcn_s_sleep(16);
+            }
+        }
         if (r == kDecline) r = zstd_decode_frames(src, int(blk.src_len), dst, int(blk.dst_cap), litbuf, &zs, lane);
         if (container_mode && r < 0 && r != kPendingExec) r = FOURMC_BLK_CORRUPT;
     }
