@@ -14,7 +14,7 @@ The directory name starts with a digit (the reference is called 4mc), so import 
 """
 from .binding import (  # noqa: F401
     BLOCK_DTYPE, BLOCKSIZE, MAGIC_4MC, MAGIC_4MZ, CODEC_LZ4_FAST, CODEC_LZ4_MC, CODEC_LZ4_HC,
-    CODEC_ZSTD, BLK_BADSUM, BLK_CORRUPT, EngineError, lib, lib_path, cli_path, exported_symbols,
+    CODEC_ZSTD, BLK_BADSUM, BLK_CORRUPT, EngineError, lib, lib_path, research_lib_path, use_research, cli_path, exported_symbols,
     make_blocks, gpu_init,
 )
 from .engine import (  # noqa: F401

@@ -23,8 +23,13 @@ class EngineError(RuntimeError):
 
 
 def lib_path():
-    # FOURMC_LIB: load an alternative build (profiling variants, tools/k2_phases.py); default = the in-tree library
+    # FOURMC_LIB: load an alternative build (research / profiling variants); default = the in-tree product library
     return os.environ.get("FOURMC_LIB") or os.path.join(_HERE, "lib", "libhadoop-4mc.so")
+
+
+def research_lib_path():
+    # the product plus the alternative LZ4 decode designs and the debug exports (make -C 4mc_amd/csrc research)
+    return os.path.join(_HERE, "lib", "libhadoop-4mc-research.so")
 
 
 def cli_path():
@@ -32,6 +37,9 @@ def cli_path():
 
 
 _lib = None
+_product_lib = None
+# declared by include/fourmc_gpu.h under FOURMC_RESEARCH only: the product library does not export them
+_RESEARCH_ONLY = ("fourmc_gpu_debug_read_workspace", "fourmc_gpu_debug_zstd_exec_counts", "fourmc_gpu_debug_lz4_parse", "fourmc_debug_one_block_counters")
 
 # every symbol include/fourmc_gpu.h and include/fourmc.h declare
 _GPU_API = {
@@ -97,8 +105,8 @@ _FILE_API = {
 
 
 def exported_symbols():
-    """Names the headers declare (C-ABI + file API); the JNI names are listed in tests."""
-    return list(_GPU_API) + list(_FILE_API)
+    """Names the headers declare for the PRODUCT (C-ABI + file API); the JNI names are listed in tests."""
+    return [n for n in list(_GPU_API) + list(_FILE_API) if n not in _RESEARCH_ONLY]
 
 
 def lib():
@@ -109,11 +117,37 @@ def lib():
         if not os.path.exists(path):
             raise EngineError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(the HIP extension is mandatory; there is no fallback path)")
-        L = C.CDLL(path)
-        for name, (res, args) in {**_GPU_API, **_FILE_API}.items():
+        _lib = _load(path)
+    return _lib
+
+
+def _load(path):
+    L = C.CDLL(path)
+    for name, (res, args) in {**_GPU_API, **_FILE_API}.items():
+        try:
             fn = getattr(L, name)
-            fn.restype, fn.argtypes = res, args
-        _lib = L
+        except AttributeError:
+            if name in _RESEARCH_ONLY:
+                continue
+            raise
+        fn.restype, fn.argtypes = res, args
+    return L
+
+
+def use_research(on=True):
+    """Point lib() at the research side build (a superset of the product: every call keeps working) or back at the product.
+    Tests of the alternative decode designs and of the debug counters switch for the duration of a module."""
+    global _lib, _product_lib
+    if on:
+        path = research_lib_path()
+        if not os.path.exists(path):
+            raise EngineError(f"{path} is missing: make -C 4mc_amd/csrc research")
+        if _product_lib is None:
+            _product_lib = _lib
+        _lib = _load(path)
+    else:
+        _lib = _product_lib
+        _product_lib = None
     return _lib
 
 

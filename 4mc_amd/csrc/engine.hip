@@ -200,6 +200,7 @@ int fourmc_gpu_lz4_compress_mc(const void* d_src, void* d_dst, fourmc_block* d_b
     return FOURMC_OK;
 }
 
+#ifdef FOURMC_RESEARCH      /* debug / profiling exports: the research side build only (make research), never the product's ABI */
 /* profiling aid: copies `bytes` of the shared per-block workspace at `offset` to the host (phase cycle counters
  * the zstd kernels leave behind their literal buffers) */
 int fourmc_gpu_debug_read_workspace(void* host, size_t offset, size_t bytes)
@@ -228,6 +229,8 @@ int fourmc_gpu_debug_lz4_parse(const void* d_src, const void* d_dst, fourmc_bloc
     if (host && bytes) HIP_TRY(hipMemcpy(host, work, bytes < have ? bytes : have, hipMemcpyDeviceToHost));
     return FOURMC_OK;
 }
+
+#endif
 
 int fourmc_gpu_zstd_decompress(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, void* stream)
 {
@@ -528,12 +531,15 @@ static int host_roundtrip(const void* src, size_t src_bytes, void* dst, size_t d
     return host_roundtrip_many(src, src_bytes, dst, dst_bytes, blocks, n, op, codec, level);
 }
 
+#ifdef FOURMC_RESEARCH
 void fourmc_debug_one_block_counters(unsigned long long* calls, unsigned long long* launches)
 {
     std::lock_guard<std::mutex> lk(g_qmu);
     if (calls) *calls = g_one_calls;
     if (launches) *launches = g_one_launches;
 }
+
+#endif
 
 /* page-locked host buffers for the file API's staging (H2D / D2H at PCIe rate instead of the pageable path's bounce copies);
  * NULL when no device is usable or the allocation fails - the caller then falls back to malloc() */

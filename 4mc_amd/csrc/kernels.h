@@ -8,6 +8,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+// The launchers are the engine's own: C linkage for the objects of this library, but not part of its dynamic symbol table
+// (the boundary is include/fourmc_gpu.h, include/fourmc.h and the JNI names).
+#pragma GCC visibility push(hidden)
 
 // what a hash launch covers for each block descriptor
 enum {
@@ -55,6 +58,7 @@ hipError_t fourmc_launch_zstd_encode(const void* d_src, void* d_dst, fourmc_bloc
 hipError_t fourmc_launch_xxh32(const void* d_base, fourmc_block* d_blocks, uint32_t n,
                                uint32_t seed, int mode, hipStream_t stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

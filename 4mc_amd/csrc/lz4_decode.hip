@@ -596,19 +596,6 @@ void lz4_decode_resume_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst
     if (threadIdx.x == 0) blocks[b].result = r;
 }
 
-// 1 in *slot: the launch decodes more than 2.2 bytes per stream byte (the wave trio's case when the chip is full), else 0
-__device__ uint32_t g_pick_ring[256];
-__global__ __launch_bounds__(256) void lz4_pick_kernel(const fourmc_block* blocks, uint32_t n, uint32_t* slot)
-{
-    __shared__ unsigned long long su[256], sc[256];
-    unsigned long long u = 0, c = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) { u += blocks[i].dst_cap; c += blocks[i].src_len; }
-    su[threadIdx.x] = u; sc[threadIdx.x] = c;
-    __syncthreads();
-    for (int k = 128; k; k >>= 1) { if (int(threadIdx.x) < k) { su[threadIdx.x] += su[threadIdx.x + k]; sc[threadIdx.x] += sc[threadIdx.x + k]; } __syncthreads(); }
-    if (threadIdx.x == 0) *slot = su[0] * 10 >= sc[0] * 22 ? 1u : 0u;
-}
-
 } // namespace
 
 // Block-parallel path (lz4_parse.hip + lz4_exec.hip) for every block, then the exact walker for whatever they handed back
@@ -626,7 +613,11 @@ extern "C" size_t fourmc_lz4_decode_work_bytes(uint32_t n)
 {
     const int path = fourmc_gpu_get_lz4_decode_path();
     if (path == 11 || path == 12 || (path == 6 && n >= 1792)) return fourmc_lz4_seg_work_bytes(n < fourmc_lz4_seg_batch() ? n : fourmc_lz4_seg_batch());
+#ifdef FOURMC_RESEARCH
     return (path == 1 || path == 3) ? fourmc_lz4_parse_work_bytes(n) : 0;
+#else
+    return 0;
+#endif
 }
 
 // Which fast path serves LZ4 decode launches.  Both produce identical results (anything irregular goes to the exact
@@ -641,24 +632,36 @@ extern "C" size_t fourmc_lz4_decode_work_bytes(uint32_t n)
 // Measured on 2048 x 4 MiB of S-mix (profiles/r02_*): 0 = 57 ms, 1 = 38 + 52 ms, so 0 stays the default; the
 // environment variable FOURMC_DECODE (auto | wx | rows | lanes | exact | trio | par | paronly | rowsonly | lanesonly | wxonly) or fourmc_gpu_set_lz4_decode_path() select.
 static int g_decode_path = -1;
-extern "C" void fourmc_gpu_set_lz4_decode_path(int path) { g_decode_path = path; }
+// The product library carries three decoders: the exact walker (2), the walk + window copier (9, 10) and the segment-parallel path
+// (11, 12); 6 = auto.  The wave trio, the row pipeline, the lane-per-sequence path and the block-parallel pair are measured
+// alternatives kept in the research side build (make research: libhadoop-4mc-research.so, -DFOURMC_RESEARCH).
+static bool path_known(int path)
+{
+#ifdef FOURMC_RESEARCH
+    return path >= 0 && path <= 12;
+#else
+    return path == 2 || path == 6 || path == 9 || path == 10 || path == 11 || path == 12;
+#endif
+}
+extern "C" void fourmc_gpu_set_lz4_decode_path(int path) { g_decode_path = path_known(path) ? path : 6; }
 extern "C" int fourmc_gpu_get_lz4_decode_path(void)
 {
     if (g_decode_path < 0) {
         const char* mode = getenv("FOURMC_DECODE");
-        g_decode_path = 6;
-        if (mode && !strcmp(mode, "rows")) g_decode_path = 4;
-        if (mode && !strcmp(mode, "trio")) g_decode_path = 0;
-        if (mode && !strcmp(mode, "rowsonly")) g_decode_path = 5;
-        if (mode && !strcmp(mode, "lanes")) g_decode_path = 7;
-        if (mode && !strcmp(mode, "lanesonly")) g_decode_path = 8;
-        if (mode && !strcmp(mode, "wx")) g_decode_path = 9;
-        if (mode && !strcmp(mode, "wxonly")) g_decode_path = 10;
-        if (mode && !strcmp(mode, "exact")) g_decode_path = 2;
-        if (mode && !strcmp(mode, "seg")) g_decode_path = 11;
-        if (mode && !strcmp(mode, "segonly")) g_decode_path = 12;
-        if (mode && !strcmp(mode, "par")) g_decode_path = 1;
-        if (mode && !strcmp(mode, "paronly")) g_decode_path = 3;
+        int p = 6;
+        if (mode && !strcmp(mode, "rows")) p = 4;
+        if (mode && !strcmp(mode, "trio")) p = 0;
+        if (mode && !strcmp(mode, "rowsonly")) p = 5;
+        if (mode && !strcmp(mode, "lanes")) p = 7;
+        if (mode && !strcmp(mode, "lanesonly")) p = 8;
+        if (mode && !strcmp(mode, "wx")) p = 9;
+        if (mode && !strcmp(mode, "wxonly")) p = 10;
+        if (mode && !strcmp(mode, "exact")) p = 2;
+        if (mode && !strcmp(mode, "seg")) p = 11;
+        if (mode && !strcmp(mode, "segonly")) p = 12;
+        if (mode && !strcmp(mode, "par")) p = 1;
+        if (mode && !strcmp(mode, "paronly")) p = 3;
+        g_decode_path = path_known(p) ? p : 6;
     }
     return g_decode_path;
 }
@@ -670,9 +673,6 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
     const uint8_t* s8 = static_cast<const uint8_t*>(d_src);
     uint8_t* d8 = static_cast<uint8_t*>(d_dst);
     int path = fourmc_gpu_get_lz4_decode_path();
-    // 6 "auto": the walk + window copier (lz4_rows.hip, K1wx) has the shortest chain per block at every launch size (28 ms against
-    // 36 / 43 ms for the row pipeline / the wave trio at 64..256 blocks, 37 / 44 / 49 at 1024, 53.5 / 59 / 57 at 2048; LZ4-HC streams
-    // at 2048 blocks are the exception: 52 ms against the trio's 48)
     // 6 "auto": a launch that fills the chip goes to the segment-parallel path (lz4_seg.hip: one wave per block, a fifth of the
     // instructions per byte of the wave pipelines - 8192 blocks in 116 ms against 184); smaller launches to the walk + window copier
     // (K1wx: four waves per block, the shortest chain per block)
@@ -695,15 +695,16 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
         hipLaunchKernelGGL(lz4_decode_exact_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
         return hipGetLastError();
     }
-    if (path == 4 || path == 5) {
-        hipError_t e = fourmc_launch_lz4_rows(d_src, d_dst, d_blocks, n, container_mode, stream);
-        if (e != hipSuccess || path == 5) return e;       // 5: test aid, shows what the row pipeline alone did
-        hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
-        return hipGetLastError();
-    }
     if (path == 9 || path == 10) {
         hipError_t e = fourmc_launch_lz4_wx(d_src, d_dst, d_blocks, n, container_mode, stream, nullptr, 0);
         if (e != hipSuccess || path == 10) return e;      // 10: test aid, shows what the path alone did
+        hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
+        return hipGetLastError();
+    }
+#ifdef FOURMC_RESEARCH
+    if (path == 4 || path == 5) {
+        hipError_t e = fourmc_launch_lz4_rows(d_src, d_dst, d_blocks, n, container_mode, stream);
+        if (e != hipSuccess || path == 5) return e;       // 5: test aid, shows what the row pipeline alone did
         hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
         return hipGetLastError();
     }
@@ -728,4 +729,7 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
     if (path == 3) return hipGetLastError();              // test aid: show what the parallel path alone did
     hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
     return hipGetLastError();
+#else
+    return hipErrorInvalidValue;                          // (path_known() keeps every other value out)
+#endif
 }

@@ -1282,6 +1282,7 @@ void lz4_decode_wx_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
 #ifdef K1R_PROF
 static unsigned long long* g_prof = nullptr; static uint32_t g_prof_blocks = 0;
 #endif
+#ifdef FOURMC_RESEARCH      // the row pipeline and the lane-per-sequence path: measured alternatives, side build only
 extern "C" hipError_t fourmc_launch_lz4_rows(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                                              uint32_t n, int container_mode, hipStream_t stream)
 {
@@ -1318,6 +1319,8 @@ extern "C" hipError_t fourmc_launch_lz4_lanes(const void* d_src, void* d_dst, fo
                        static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n, container_mode, prof);
     return hipGetLastError();
 }
+
+#endif
 
 extern "C" hipError_t fourmc_launch_lz4_wx(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                                            uint32_t n, int container_mode, hipStream_t stream, const uint32_t* pick, uint32_t want)

@@ -1342,6 +1342,7 @@ extern "C" size_t fourmc_zstd_scratch_bytes(uint32_t n) { return size_t(n) * kV2
 extern "C" size_t fourmc_zstd_dec_counter_offset(void) { return kV2Bytes - 64; }   // phase counters of block 0 (profiling aid)
 
 // test aid: blocks the execute kernel completed / handed back to the one-wave kernel since the last call (this device)
+#ifdef FOURMC_RESEARCH
 extern "C" int fourmc_gpu_debug_zstd_exec_counts(unsigned long long* executed, unsigned long long* handed_back)
 {
     unsigned long long c[2] = {0, 0}, z[2] = {0, 0};
@@ -1351,6 +1352,7 @@ extern "C" int fourmc_gpu_debug_zstd_exec_counts(unsigned long long* executed, u
     if (handed_back) *handed_back = c[1];
     return 0;
 }
+#endif
 
 // FOURMC_ZDECODE = split (default: entropy kernel + execute kernel + hand-backs) | single (everything in the one-wave kernel)
 static int g_zdecode_split = -1;

@@ -339,14 +339,14 @@ def main():
         return names.get(path, "path %d" % path)
 
     def decode_path_comparison():
-        """The LZ4 decode fast paths on the same launch (identical results): the wave trio, the row pipeline (lz4_rows.hip) and the
-        block-parallel parse + executor pair, the walk + window copier (K1wx); HIP events around the decode_blocks call minus the hash
-        launch.  "auto" (the default) is the walk + window copier."""
+        """The two LZ4 decode fast paths of the product on the same launch (identical results): the walk + window copier (K1wx) and
+        the segment-parallel path; HIP events around the decode_blocks call minus the hash launch.  "auto" (the default) takes the
+        segment-parallel path from 1792 blocks per launch.  (The older designs live in the research side build: tools/k1_timing.py.)"""
         out = {}
         before = L.fourmc_gpu_get_lz4_decode_path()
         vb = state["dec"].clone()
         x_ver = timed(lambda: p.binding.check(L.fourmc_gpu_xxh32(d_image.data_ptr(), vb.data_ptr(), nb, 0, sp), "xxh32"))
-        for path, name in ((0, "wave_trio"), (4, "row_pipeline"), (9, "walk_window_copier"), (11, "segment_parallel")):
+        for path, name in ((9, "walk_window_copier"), (11, "segment_parallel")):
             L.fourmc_gpu_set_lz4_decode_path(path)
             dd = state["dec"].clone(); dd[:, 6] = 0
             t = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_image.data_ptr(), d_out.data_ptr(), dd.data_ptr(), nb, 0, sp), name))
@@ -355,7 +355,7 @@ def main():
         for m in (256, 1024):                          # launches that do not fill the chip: what the file API sends
             if m >= nb: continue
             xv = timed(lambda: p.binding.check(L.fourmc_gpu_xxh32(d_image.data_ptr(), state["dec"][:m].clone().data_ptr(), m, 0, sp), "xxh32"))
-            for path, name in ((0, "wave_trio"), (4, "row_pipeline"), (9, "walk_window_copier"), (11, "segment_parallel")):
+            for path, name in ((9, "walk_window_copier"), (11, "segment_parallel")):
                 L.fourmc_gpu_set_lz4_decode_path(path)
                 dd = state["dec"][:m].clone(); dd[:, 6] = 0
                 t = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_image.data_ptr(), d_out.data_ptr(), dd.data_ptr(), m, 0, sp), name))

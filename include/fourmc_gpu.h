@@ -76,27 +76,15 @@ int fourmc_gpu_lz4_compress_hc(const void* d_src, void* d_dst, fourmc_block* d_b
  * when dst_cap == 0xFFFFFFFF; byte-identical payloads           native/lz4/lz4mc.c:582-606         */
 int fourmc_gpu_lz4_compress_mc(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                                uint32_t n, void* stream);
-/* Profiling aid (not part of the reference boundary): copy a range of the engine's per-block device
- * workspace to the host; the zstd kernels leave per-phase cycle counters there (tools/zstd_timing.py). */
-int fourmc_gpu_debug_read_workspace(void* host, size_t offset, size_t bytes);
-/* Tuning knob (not part of the reference boundary): which LZ4 decode fast path serves the launches, 0 = parser wave + two
- * copier waves per block (default), 1 = block-parallel parse kernel + executor kernel; results are identical. */
+/* Tuning knob (not part of the reference boundary): which LZ4 decode path serves the launches - 6 auto (default: the
+ * segment-parallel path for launches that fill the chip, the walk + window copier below), 2 the exact walker alone, 9 the walk +
+ * window copier, 11 the segment-parallel path; results are identical (env FOURMC_DECODE = auto | exact | wx | seg). */
 void fourmc_gpu_set_lz4_decode_path(int path);
 int  fourmc_gpu_get_lz4_decode_path(void);
 /* Tuning knob: 4mz decode as entropy kernel + execute kernel (1, default; FOURMC_ZDECODE=split) or all in the one-wave kernel
  * (0; FOURMC_ZDECODE=single); results are identical. */
 void fourmc_gpu_set_zstd_decode_split(int on);
 int  fourmc_gpu_get_zstd_decode_split(void);
-/* Test aid: blocks the 4mz execute kernel completed / handed back to the one-wave kernel since the last call. */
-int  fourmc_gpu_debug_zstd_exec_counts(unsigned long long* executed, unsigned long long* handed_back);
-/* Test aid: runs only the parser kernel of the block-parallel LZ4 decoder on `n` blocks and copies the first `bytes` of
- * the workspace (block 0's slot first: header, window descriptors, token positions) to `host`; layout[0..2] = slot bytes,
- * descriptor offset, token offset. */
-int fourmc_gpu_debug_lz4_parse(const void* d_src, const void* d_dst, fourmc_block* d_blocks, uint32_t n, int container_mode,
-                               void* host, size_t bytes, size_t* layout);
-/* one-block host calls (LZ4_* / ZSTD_* twins, JNI) made so far, and the launches that served them (concurrent calls share one) */
-void fourmc_debug_one_block_counters(unsigned long long* calls, unsigned long long* launches);
-
 /* result = ZSTD_compress(dst + dst_off, dst_cap, src + src_off, src_len, level) as int: frame bytes, or
  * -(ZSTD error number), e.g. -70 = dstSize_tooSmall        native/zstd/compress/zstd_compress.c:4806
  * Level 1 (strategy "fast", 4mz -1) is on the device; other levels return FOURMC_EUNSUP. */
@@ -161,6 +149,24 @@ int fourmc_host_4mc_decode(const void* src, size_t src_bytes, void* dst, size_t 
  * (a shared mapping).  image_off[b]: where block b's header sits in the piece; *image_bytes: the piece's length. */
 int fourmc_host_4mc_encode_image(const void* src, size_t src_bytes, fourmc_block* blocks, uint32_t n, int codec, int level,
                                  void* image, size_t image_cap, uint64_t* image_off, size_t* image_bytes);
+
+/* ---- debug / profiling exports: the research side build only (make -C 4mc_amd/csrc research -> libhadoop-4mc-research.so,
+ * -DFOURMC_RESEARCH); the drop-in library does not export them ------------------------------------------------------------ */
+#ifdef FOURMC_RESEARCH
+/* Profiling aid (not part of the reference boundary): copy a range of the engine's per-block device
+ * workspace to the host; the zstd kernels leave per-phase cycle counters there (tools/zstd_timing.py). */
+int fourmc_gpu_debug_read_workspace(void* host, size_t offset, size_t bytes);
+/* Test aid: blocks the 4mz execute kernel completed / handed back to the one-wave kernel since the last call. */
+int  fourmc_gpu_debug_zstd_exec_counts(unsigned long long* executed, unsigned long long* handed_back);
+/* Test aid: runs only the parser kernel of the block-parallel LZ4 decoder on `n` blocks and copies the first `bytes` of
+ * the workspace (block 0's slot first: header, window descriptors, token positions) to `host`; layout[0..2] = slot bytes,
+ * descriptor offset, token offset. */
+int fourmc_gpu_debug_lz4_parse(const void* d_src, const void* d_dst, fourmc_block* d_blocks, uint32_t n, int container_mode,
+                               void* host, size_t bytes, size_t* layout);
+/* one-block host calls (LZ4_* / ZSTD_* twins, JNI) made so far, and the launches that served them (concurrent calls share one) */
+void fourmc_debug_one_block_counters(unsigned long long* calls, unsigned long long* launches);
+
+#endif
 
 #ifdef __cplusplus
 }

@@ -101,6 +101,7 @@ def test_concurrent_one_block_calls_share_launches(gpu):
     import ctypes as C, threading
     import numpy as np
     import helpers
+    gpu.use_research(True); gpu.gpu_init()             # the call / launch counters are a debug export: research side build (same queue code)
     L = gpu.binding.lib()
     data = helpers.corpus(helpers.B)
     rng = np.random.default_rng(5)
@@ -145,4 +146,5 @@ def test_concurrent_one_block_calls_share_launches(gpu):
     c1, l1 = C.c_ulonglong(), C.c_ulonglong()
     L.fourmc_debug_one_block_counters(C.byref(c1), C.byref(l1))
     assert c1.value - c0.value == len(jobs)
+    gpu.use_research(False)
     assert l1.value - l0.value < len(jobs), "no two concurrent calls ever shared a launch"

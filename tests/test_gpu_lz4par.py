@@ -59,10 +59,12 @@ def _inputs():
 def gpu():
     """the block-parallel path is opt-in (the wave-trio path is faster today): select it for this module"""
     p = pkg(); p.gpu_init()
+    p.use_research(True); p.gpu_init()                 # the pair and its debug export are in the research side build only
     before = p.lib().fourmc_gpu_get_lz4_decode_path()
     p.lib().fourmc_gpu_set_lz4_decode_path(1)
     yield p
     p.lib().fourmc_gpu_set_lz4_decode_path(before)
+    p.use_research(False)
 
 
 def test_parser_records_equal_the_oracle_sequence_list(gpu):

@@ -191,6 +191,7 @@ def test_zstd_execute_kernel_shapes_both_paths(gpu):
     """The two-kernel decode (entropy stage + execute kernel, zstd_exec.inc) and the one-wave kernel give the input back, on frames
     of every shape the execute kernel treats specially, at levels 1 and 3; on damaged frames they give the same verdicts and bytes."""
     srcs = _shaped_blocks()
+    gpu.use_research(True); gpu.gpu_init()             # the counters of the execute kernel are a debug export: research side build
     lib = gpu.lib()
     before = lib.fourmc_gpu_get_zstd_decode_split()
     try:
@@ -233,3 +234,4 @@ def test_zstd_execute_kernel_shapes_both_paths(gpu):
                 if r >= 0: assert np.array_equal(a, b2)
     finally:
         lib.fourmc_gpu_set_zstd_decode_split(before)
+        gpu.use_research(False)

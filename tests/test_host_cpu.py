@@ -32,11 +32,23 @@ def test_library_loads_and_exports_every_declared_symbol():
     raw = C.CDLL(p.lib_path())
     for name in JNI:
         assert getattr(raw, name) is not None, name
-    # every prototype in the public headers is exported
+    # every prototype in the public headers is exported; the block under FOURMC_RESEARCH (debug / profiling exports) by the research
+    # side build ONLY - the drop-in library's dynamic table carries the boundary and nothing else
+    pat = r"\b(four[mM][cC][A-Za-z0-9_]*|fourM[cZ][A-Za-z]+)\s*\("
+    research = C.CDLL(p.research_lib_path())
     for hdr in ("fourmc_gpu.h", "fourmc.h"):
         text = open(os.path.join(ROOT, "include", hdr)).read()
-        for name in set(re.findall(r"\b(four[mM][cC][A-Za-z0-9_]*|fourM[cZ][A-Za-z]+)\s*\(", text)):
-            assert getattr(raw, name) is not None, (hdr, name)
+        rs = re.search(r"#ifdef FOURMC_RESEARCH(.*?)#endif", text, re.S)
+        rnames = set(re.findall(pat, rs.group(1))) if rs else set()
+        for name in set(re.findall(pat, text)):
+            assert getattr(research, name) is not None, (hdr, name)
+            if name in rnames:
+                assert not hasattr(raw, name), (hdr, name, "a debug export in the product library")
+            else:
+                assert getattr(raw, name) is not None, (hdr, name)
+    import subprocess as sp
+    dyn = sp.run(["nm", "-D", "--defined-only", p.lib_path()], capture_output=True, text=True).stdout
+    assert "debug" not in dyn and "fourmc_launch" not in dyn, "the product library exports debug symbols or internal launchers"
 
 
 def test_no_gpu_calls_fail_loudly_not_silently():

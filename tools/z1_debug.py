@@ -8,6 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers
 p = importlib.import_module("4mc_amd"); p.gpu_init(0)
+if not os.environ.get("FOURMC_LIB"): p.use_research(True); p.gpu_init(0)     # debug exports: research side build
 SEQCAP = 32768 + 64
 TABLES = []
 LEVEL = int(os.environ.get("ZL", "1"))          # 1 or 3 (FOURMC_ZSTD_SERIAL=1: the wave-uniform transcription at level 1, the batched search alone at level 3)
