@@ -1,3 +1,4 @@
+#define _POSIX_C_SOURCE 200809L
 /*
  * 4mc_amd/csrc/jni_zstd.c — JNI entry points of ZstdCompressor / ZstdDecompressor (4mz block
  * codec) and of the streaming zstd classes, so that libhadoop-4mc.so keeps the reference's full
@@ -15,6 +16,7 @@
  * engine; their symbols exist and report "unsupported".
  */
 #include <stdio.h>
+#include <stdlib.h>
 #include "jni_min.h"
 #include "fourmc.h"
 #include "fourmc_gpu.h"
@@ -123,44 +125,133 @@ JNIEXPORT jint JNICALL
 Java_com_fing_compression_fourmc_ZstdDecompressor_xxhash32(JNIEnv* env, jclass cls, jbyteArray buf, jint off, jint len, jint seed)
 { (void)cls; return fourmc_jni_xxhash32(env, buf, off, len, seed); }
 
-/* ---------------------------------------------------------------- streaming zstd: unsupported */
-JNIEXPORT jboolean JNICALL Java_com_fing_compression_fourmc_zstd_Zstd_isError(JNIEnv* env, jclass c, jlong code)
-{ (void)env; (void)c; return z_is_error((size_t)code) != 0; }
-JNIEXPORT jstring JNICALL Java_com_fing_compression_fourmc_zstd_Zstd_getErrorName(JNIEnv* env, jclass c, jlong code)
-{ (void)c; return (*env)->NewStringUTF(env, z_is_error((size_t)code) ? "Unsupported in the MI355X block build (streaming zstd)" : "No error detected"); }
-JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_Zstd_cStreamInSize(JNIEnv* env, jclass c)  { (void)env; (void)c; return 1 << 17; }
-JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_Zstd_cStreamOutSize(JNIEnv* env, jclass c) { (void)env; (void)c; return (1 << 17) + ((1 << 17) >> 8) + 3 + 4; }
-JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_Zstd_dStreamInSize(JNIEnv* env, jclass c)  { (void)env; (void)c; return (1 << 17) + 3; }
-JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_Zstd_dStreamOutSize(JNIEnv* env, jclass c) { (void)env; (void)c; return 1 << 17; }
+/* ---------------------------------------------------------------- streaming zstd (ZstCodec): a host pass-through
+ * the streaming codec is not part of the block path; the reference serves it with its vendored zstd's
+ * ZSTD_compressStream / ZSTD_decompressStream on the host (native/jniZStreamCompressor.c:65-134, jniZStreamDecompressor.c:66-112,
+ * jniZstd.c:49-104).  Here the same eleven entry points call the SYSTEM's libzstd, loaded on first use (dlopen "libzstd.so.1";
+ * FOURMC_LIBZSTD names another file): the frames are standard zstd frames, readable by the reference and vice versa; their bytes are
+ * that library version's, not the vendored 1.5.3's (the block codecs above - the Lz4 and Zstd compressor / decompressor classes - stay on the device and byte-identical).
+ * Without a usable libzstd the stream constructors throw UnsupportedOperationException and every other call returns an error code:
+ * loud, never a null handle. */
+#include <dlfcn.h>
+typedef struct { void* dst; size_t size; size_t pos; } zs_out_t;            /* ZSTD_outBuffer (zstd.h) */
+typedef struct { const void* src; size_t size; size_t pos; } zs_in_t;       /* ZSTD_inBuffer  (zstd.h) */
+static struct {
+    int tried, ok;
+    void* (*createCStream)(void); size_t (*freeCStream)(void*); size_t (*initCStream)(void*, int);
+    size_t (*compressStream)(void*, zs_out_t*, zs_in_t*); size_t (*endStream)(void*, zs_out_t*);
+    void* (*createDStream)(void); size_t (*freeDStream)(void*); size_t (*initDStream)(void*);
+    size_t (*decompressStream)(void*, zs_out_t*, zs_in_t*);
+    unsigned (*isError)(size_t); const char* (*getErrorName)(size_t);
+    size_t (*CStreamInSize)(void); size_t (*CStreamOutSize)(void); size_t (*DStreamInSize)(void); size_t (*DStreamOutSize)(void);
+    const char* (*versionString)(void);
+} zs;
+static int zs_load(void)
+{
+    /* (two threads racing here load the same library twice at worst: dlopen counts references, the pointers are the same) */
+    if (!zs.tried) {
+        const char* name = getenv("FOURMC_LIBZSTD");
+        void* h = dlopen(name && *name ? name : "libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+        int ok = h != NULL;
+#define ZS_SYM(field, sym) do { if (ok) { *(void**)(&zs.field) = dlsym(h, sym); if (!zs.field) ok = 0; } } while (0)
+        ZS_SYM(createCStream, "ZSTD_createCStream"); ZS_SYM(freeCStream, "ZSTD_freeCStream"); ZS_SYM(initCStream, "ZSTD_initCStream");
+        ZS_SYM(compressStream, "ZSTD_compressStream"); ZS_SYM(endStream, "ZSTD_endStream");
+        ZS_SYM(createDStream, "ZSTD_createDStream"); ZS_SYM(freeDStream, "ZSTD_freeDStream"); ZS_SYM(initDStream, "ZSTD_initDStream");
+        ZS_SYM(decompressStream, "ZSTD_decompressStream"); ZS_SYM(isError, "ZSTD_isError"); ZS_SYM(getErrorName, "ZSTD_getErrorName");
+        ZS_SYM(CStreamInSize, "ZSTD_CStreamInSize"); ZS_SYM(CStreamOutSize, "ZSTD_CStreamOutSize");
+        ZS_SYM(DStreamInSize, "ZSTD_DStreamInSize"); ZS_SYM(DStreamOutSize, "ZSTD_DStreamOutSize"); ZS_SYM(versionString, "ZSTD_versionString");
+#undef ZS_SYM
+        zs.ok = ok; zs.tried = 1;
+    }
+    return zs.ok;
+}
+/* for INTEGRATION.md / logs: which library serves the streaming codec ("" when none) */
+const char* fourmc_zstd_stream_backend(void) { return zs_load() ? zs.versionString() : ""; }
 
-static jfieldID zs_src_pos, zs_dst_pos, zds_src_pos, zds_dst_pos;
+JNIEXPORT jboolean JNICALL Java_com_fing_compression_fourmc_zstd_Zstd_isError(JNIEnv* env, jclass c, jlong code)
+{ (void)env; (void)c; return (zs_load() ? zs.isError((size_t)code) != 0 : z_is_error((size_t)code) != 0); }
+JNIEXPORT jstring JNICALL Java_com_fing_compression_fourmc_zstd_Zstd_getErrorName(JNIEnv* env, jclass c, jlong code)
+{
+    (void)c;
+    if (zs_load()) return (*env)->NewStringUTF(env, zs.getErrorName((size_t)code));
+    return (*env)->NewStringUTF(env, z_is_error((size_t)code) ? "streaming zstd needs libzstd.so.1 on this host (not found)" : "No error detected");
+}
+JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_Zstd_cStreamInSize(JNIEnv* env, jclass c)  { (void)env; (void)c; return zs_load() ? (jint)zs.CStreamInSize() : 1 << 17; }
+JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_Zstd_cStreamOutSize(JNIEnv* env, jclass c) { (void)env; (void)c; return zs_load() ? (jint)zs.CStreamOutSize() : (1 << 17) + ((1 << 17) >> 8) + 3 + 4; }
+JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_Zstd_dStreamInSize(JNIEnv* env, jclass c)  { (void)env; (void)c; return zs_load() ? (jint)zs.DStreamInSize() : (1 << 17) + 3; }
+JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_Zstd_dStreamOutSize(JNIEnv* env, jclass c) { (void)env; (void)c; return zs_load() ? (jint)zs.DStreamOutSize() : 1 << 17; }
+
+static jfieldID zs_src_pos, zs_dst_pos, zs_olen, zds_src_pos, zds_dst_pos, zds_olen;
+#define ZS_EMEM ((size_t)0 - 64)                         /* (size_t)(0 - ZSTD_error_memory_allocation): what the reference returns without a buffer */
 JNIEXPORT void JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamCompressor_initIDs(JNIEnv* env, jclass cls)
-{ zs_src_pos = (*env)->GetFieldID(env, cls, "srcPos", "J"); zs_dst_pos = (*env)->GetFieldID(env, cls, "dstPos", "J"); }
-/* the streaming ZstCodec (native/jniZStreamCompressor.c:96-134, jniZStreamDecompressor.c:112) is not part of the block path:
- * fail at creation, loudly, instead of handing Java a null stream handle */
+{
+    zs_src_pos = (*env)->GetFieldID(env, cls, "srcPos", "J"); zs_dst_pos = (*env)->GetFieldID(env, cls, "dstPos", "J");
+    zs_olen = (*env)->GetFieldID(env, cls, "oBuffLen", "I");
+}
 static void throw_unsupported(JNIEnv* env)
 {
     jclass cls = (*env)->FindClass(env, "java/lang/UnsupportedOperationException");
-    if (cls) { (*env)->ThrowNew(env, cls, "streaming zstd (ZstCodec) is not served by the MI355X block build; use the 4mz block codecs"); (*env)->DeleteLocalRef(env, cls); }
+    if (cls) { (*env)->ThrowNew(env, cls, "streaming zstd (ZstCodec) is a host pass-through to libzstd.so.1, which this host does not have; use the 4mz block codecs"); (*env)->DeleteLocalRef(env, cls); }
 }
 JNIEXPORT jlong JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamCompressor_createCStream(JNIEnv* env, jclass c)
-{ (void)c; throw_unsupported(env); return 0; }
+{ (void)c; if (!zs_load()) { throw_unsupported(env); return 0; } return (jlong)(size_t)zs.createCStream(); }
 JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamCompressor_freeCStream(JNIEnv* env, jclass c, jlong s)
-{ (void)env; (void)c; (void)s; return 0; }
+{ (void)env; (void)c; return zs_load() && s ? (jint)zs.freeCStream((void*)(size_t)s) : 0; }
 JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamCompressor_initCStream(JNIEnv* env, jclass c, jlong s, jint level)
-{ (void)env; (void)c; (void)s; (void)level; return (jint)ZERR_GENERIC; }
+{ (void)env; (void)c; return zs_load() && s ? (jint)zs.initCStream((void*)(size_t)s, level) : (jint)ZERR_GENERIC; }
 JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamCompressor_compressStream(JNIEnv* env, jobject self, jlong s, jobject dst, jint dst_size, jobject src, jint src_size)
-{ (void)env; (void)self; (void)s; (void)dst; (void)dst_size; (void)src; (void)src_size; return (jint)ZERR_GENERIC; }
+{
+    size_t r; size_t src_pos; void *db, *sb; zs_out_t out; zs_in_t in;
+    if (!zs_load() || !s) return (jint)ZERR_GENERIC;
+    src_pos = (size_t)(*env)->GetLongField(env, self, zs_src_pos);
+    db = (*env)->GetDirectBufferAddress(env, dst); if (!db) return (jint)ZS_EMEM;
+    sb = (*env)->GetDirectBufferAddress(env, src); if (!sb) return (jint)ZS_EMEM;
+    out.dst = db; out.size = (size_t)dst_size; out.pos = 0;
+    in.src = sb; in.size = (size_t)src_size; in.pos = src_pos;
+    r = zs.compressStream((void*)(size_t)s, &out, &in);                       /* jniZStreamCompressor.c:107-113 */
+    (*env)->SetLongField(env, self, zs_src_pos, (jlong)in.pos);
+    (*env)->SetLongField(env, self, zs_dst_pos, (jlong)out.pos);
+    (*env)->SetIntField(env, self, zs_olen, (jint)out.pos);
+    return (jint)r;
+}
 JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamCompressor_endStream(JNIEnv* env, jobject self, jlong s, jobject dst, jint dst_off, jint dst_size)
-{ (void)env; (void)self; (void)s; (void)dst; (void)dst_off; (void)dst_size; return (jint)ZERR_GENERIC; }
+{
+    size_t r = ZS_EMEM; void* db; zs_out_t out;
+    if (!zs_load() || !s) return (jint)ZERR_GENERIC;
+    db = (*env)->GetDirectBufferAddress(env, dst);
+    if (db) {
+        out.dst = (char*)db + dst_off; out.size = (size_t)dst_size; out.pos = 0;
+        r = zs.endStream((void*)(size_t)s, &out);                             /* jniZStreamCompressor.c:126-131 */
+        (*env)->SetLongField(env, self, zs_dst_pos, (jlong)out.pos);
+        (*env)->SetIntField(env, self, zs_olen, (jint)((size_t)dst_off + out.pos));
+    }
+    return (jint)r;
+}
 
 JNIEXPORT void JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamDecompressor_initIDs(JNIEnv* env, jclass cls)
-{ zds_src_pos = (*env)->GetFieldID(env, cls, "srcPos", "J"); zds_dst_pos = (*env)->GetFieldID(env, cls, "dstPos", "J"); }
+{
+    zds_src_pos = (*env)->GetFieldID(env, cls, "srcPos", "J"); zds_dst_pos = (*env)->GetFieldID(env, cls, "dstPos", "J");
+    zds_olen = (*env)->GetFieldID(env, cls, "oBuffLen", "I");
+}
 JNIEXPORT jlong JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamDecompressor_createDStream(JNIEnv* env, jclass c)
-{ (void)c; throw_unsupported(env); return 0; }
+{ (void)c; if (!zs_load()) { throw_unsupported(env); return 0; } return (jlong)(size_t)zs.createDStream(); }
 JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamDecompressor_freeDStream(JNIEnv* env, jclass c, jlong s)
-{ (void)env; (void)c; (void)s; return 0; }
+{ (void)env; (void)c; return zs_load() && s ? (jint)zs.freeDStream((void*)(size_t)s) : 0; }
 JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamDecompressor_initDStream(JNIEnv* env, jclass c, jlong s)
-{ (void)env; (void)c; (void)s; return (jint)ZERR_GENERIC; }
+{ (void)env; (void)c; return zs_load() && s ? (jint)zs.initDStream((void*)(size_t)s) : (jint)ZERR_GENERIC; }
 JNIEXPORT jint JNICALL Java_com_fing_compression_fourmc_zstd_ZstdStreamDecompressor_decompressStream(JNIEnv* env, jobject self, jlong s, jobject dst, jint dst_size, jobject src, jint src_size)
-{ (void)env; (void)self; (void)s; (void)dst; (void)dst_size; (void)src; (void)src_size; return (jint)ZERR_GENERIC; }
+{
+    size_t r, src_pos, dst_pos; void *db, *sb; zs_out_t out; zs_in_t in;
+    if (!zs_load() || !s) return (jint)ZERR_GENERIC;
+    src_pos = (size_t)(*env)->GetLongField(env, self, zds_src_pos);
+    dst_pos = (size_t)(*env)->GetLongField(env, self, zds_dst_pos);
+    db = (*env)->GetDirectBufferAddress(env, dst); if (!db) return (jint)ZS_EMEM;
+    sb = (*env)->GetDirectBufferAddress(env, src); if (!sb) return (jint)ZS_EMEM;
+    out.dst = db; out.size = (size_t)dst_size; out.pos = dst_pos;
+    in.src = sb; in.size = (size_t)src_size; in.pos = src_pos;
+    r = zs.decompressStream((void*)(size_t)s, &out, &in);                     /* jniZStreamDecompressor.c:104-109 */
+    (*env)->SetIntField(env, self, zds_olen, (jint)out.pos);
+    (*env)->SetLongField(env, self, zds_src_pos, (jlong)in.pos);
+    (*env)->SetLongField(env, self, zds_dst_pos, (jlong)out.pos);
+    return (jint)r;
+}

@@ -33,6 +33,9 @@
 #include "devcopy.h"
 #include "lz4par.h"
 #include "lz4seg.h"
+#ifndef FOURMC_SEG_RING
+#define FOURMC_SEG_RING 64
+#endif
 
 namespace {
 
@@ -132,15 +135,17 @@ struct LaneSeg {            // one lane's segment
 // topped up together whenever one of them has less than 64 bytes ahead (up to 15 loads of 16 bytes per lane, issued back to back: one
 // trip to memory per ~25 hops instead of two per hop; 64 lanes x 8 waves per CU walking lines of their own overflow the L1: 2.1 us per
 // hop without the window), and four records leave in one 16-byte store.
+constexpr uint32_t kRingDw = FOURMC_SEG_RING;   // dwords of stream window per lane (LDS: 256 bytes x kRingDw per wave)
 __device__ __forceinline__ void walk_from(LaneSeg& g, cgbyte* s, uint32_t csize, uint32_t limit, uint32_t start, uint32_t* ring)
 {
+    constexpr uint32_t M = kRingDw - 1u, W = 4u * kRingDw, LOW = W / 4u;       // refill when less than a quarter of the window is ahead
     uint32_t p = start, n = 0; bool tail;
     uint32_t wlo = start & ~15u, whi = wlo;                            // the ring holds stream bytes [wlo, whi), both multiples of 16
     const uint32_t fill_end = csize & ~15u;                            // whole 16-byte pieces only
     uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
     auto get4 = [&](uint32_t a) -> uint32_t {
         if (a >= wlo && a + 4u <= whi) {
-            const uint32_t d = a >> 2, lo = ring[(d & 63u) * 64u], hi = ring[((d + 1u) & 63u) * 64u];
+            const uint32_t d = a >> 2, lo = ring[(d & M) * 64u], hi = ring[((d + 1u) & M) * 64u];
             return __builtin_amdgcn_alignbyte(hi, lo, a & 3u);
         }
         return ld4u(s + a);
@@ -148,10 +153,10 @@ __device__ __forceinline__ void walk_from(LaneSeg& g, cgbyte* s, uint32_t csize,
     for (;;) {
         if (p >= g.seg_end) { tail = false; break; }
         if (p >= limit) { tail = true; break; }
-        if (__ballot(p + 64u > whi && whi < fill_end)) {
+        if (__ballot(p + LOW > whi && whi < fill_end)) {
             if (p >= whi || p < wlo) { wlo = p & ~15u; whi = wlo; }
-            uint32_t target = (p & ~15u) + 240u; target = target < fill_end ? target : fill_end;
-            for (int round = 0; round < 2; round++) {
+            uint32_t target = (p & ~15u) + (W - 16u); target = target < fill_end ? target : fill_end;
+            for (int round = 0; round < (W > 128u ? 2 : 1); round++) {
                 if (!__ballot(whi < target)) break;
                 u32x4 v[8];
 #pragma unroll
@@ -159,11 +164,11 @@ __device__ __forceinline__ void walk_from(LaneSeg& g, cgbyte* s, uint32_t csize,
 #pragma unroll
                 for (int j = 0; j < 8; j++) if (whi + 16u * j < target) {
                     const uint32_t d = (whi >> 2) + 4u * j;
-                    ring[(d & 63u) * 64u] = v[j].x; ring[((d + 1u) & 63u) * 64u] = v[j].y; ring[((d + 2u) & 63u) * 64u] = v[j].z; ring[((d + 3u) & 63u) * 64u] = v[j].w;
+                    ring[(d & M) * 64u] = v[j].x; ring[((d + 1u) & M) * 64u] = v[j].y; ring[((d + 2u) & M) * 64u] = v[j].z; ring[((d + 3u) & M) * 64u] = v[j].w;
                 }
                 const uint32_t got = target - whi; whi += got < 128u ? got : 128u;
             }
-            if (whi - wlo > 256u) wlo = whi - 256u;
+            if (whi - wlo > W) wlo = whi - W;
         }
         // the token (as decode_tok)
         const uint32_t L0 = get4(p);
@@ -236,7 +241,7 @@ void lz4_seg_walk_kernel(const uint8_t* __restrict__ src_base, const fourmc_bloc
     const uint32_t seglen = ((limit + nseg - 1) / nseg + 3) & ~3u;
     const uint32_t stride = (kFixCap + seglen / 3 + 7) & ~3u;          // lists start on 16-byte boundaries
     const uint32_t area = kMetaWords + lane * stride;
-    __shared__ uint32_t win[64 * 64];
+    __shared__ uint32_t win[kRingDw * 64];
     uint32_t* ring = win + lane;
 
     LaneSeg g;

@@ -13,7 +13,7 @@
 #include "jni_min.h"
 
 /* a mock object = named int fields + two direct buffers */
-typedef struct { const char* name; int is_buf; jint ival; void* buf; } field_t;
+typedef struct { const char* name; int is_buf; jint ival; void* buf; jlong lval; } field_t;
 typedef struct { field_t f[8]; int nf; } obj_t;
 static char g_thrown[512];
 
@@ -30,6 +30,9 @@ static field_t* find(jobject o, jfieldID id)
 static jobject  m_GetObjectField(JNIEnv* e, jobject o, jfieldID id) { (void)e; return (jobject)find(o, id); }
 static jint     m_GetIntField(JNIEnv* e, jobject o, jfieldID id) { (void)e; return find(o, id)->ival; }
 static void     m_SetIntField(JNIEnv* e, jobject o, jfieldID id, jint v) { (void)e; find(o, id)->ival = v; }
+static jlong    m_GetLongField(JNIEnv* e, jobject o, jfieldID id) { (void)e; return find(o, id)->lval; }
+static void     m_SetLongField(JNIEnv* e, jobject o, jfieldID id, jlong v) { (void)e; find(o, id)->lval = v; }
+static jstring  m_NewStringUTF(JNIEnv* e, const char* t) { (void)e; return (jstring)strdup(t); }
 static void*    m_GetDirectBufferAddress(JNIEnv* e, jobject b) { (void)e; return ((field_t*)b)->buf; }
 static void*    m_GetCritical(JNIEnv* e, jarray a, jboolean* c) { (void)e; if (c) *c = 0; return a; }
 static void     m_ReleaseCritical(JNIEnv* e, jarray a, void* p, jint m) { (void)e; (void)a; (void)p; (void)m; }
@@ -79,7 +82,94 @@ int main(int argc, char** argv)
     tab.GetFieldID = m_GetFieldID; tab.GetObjectField = m_GetObjectField; tab.GetIntField = m_GetIntField;
     tab.SetIntField = m_SetIntField; tab.GetDirectBufferAddress = m_GetDirectBufferAddress;
     tab.GetPrimitiveArrayCritical = m_GetCritical; tab.ReleasePrimitiveArrayCritical = m_ReleaseCritical;
+    tab.GetLongField = m_GetLongField; tab.SetLongField = m_SetLongField; tab.NewStringUTF = m_NewStringUTF;
     JNIEnv env = &tab;
+
+    if (argc > 6 && !strcmp(argv[5], "zstream")) {
+        /* the streaming ZstCodec (ZstdStreamCompressor / ZstdStreamDecompressor, native/jniZStreamCompressor.c, jniZStreamDecompressor.c):
+         * the call pattern of ZstdStreamOutputStream / InputStream - input fed `chunk` bytes at a time through a direct buffer, output
+         * drained whenever the compressor filled it, endStream until it returns 0; then the stream is read back the same way.
+         * argv[6] = chunk; argv[7] (optional) = a .zst file to DECODE instead of compressing (cross-library check). */
+        typedef jlong (*create_fn)(JNIEnv*, jclass);
+        typedef jint (*free_fn)(JNIEnv*, jclass, jlong);
+        typedef jint (*initc_fn)(JNIEnv*, jclass, jlong, jint);
+        typedef jint (*initd_fn)(JNIEnv*, jclass, jlong);
+        typedef jint (*cs_fn)(JNIEnv*, jobject, jlong, jobject, jint, jobject, jint);
+        typedef jint (*end_fn)(JNIEnv*, jobject, jlong, jobject, jint, jint);
+        typedef jint (*size_fn)(JNIEnv*, jclass);
+        typedef jboolean (*iserr_fn)(JNIEnv*, jclass, jlong);
+        typedef jstring (*name_fn)(JNIEnv*, jclass, jlong);
+        const int chunk = atoi(argv[6]);
+        const char* C = "zstd_ZstdStreamCompressor"; const char* D = "zstd_ZstdStreamDecompressor"; const char* Z = "zstd_Zstd";
+        ((init_fn)sym(lib, C, "initIDs"))(&env, (jclass)C);
+        ((init_fn)sym(lib, D, "initIDs"))(&env, (jclass)D);
+        const int cin = ((size_fn)sym(lib, Z, "cStreamInSize"))(&env, (jclass)Z), cout = ((size_fn)sym(lib, Z, "cStreamOutSize"))(&env, (jclass)Z);
+        const int din = ((size_fn)sym(lib, Z, "dStreamInSize"))(&env, (jclass)Z), dout = ((size_fn)sym(lib, Z, "dStreamOutSize"))(&env, (jclass)Z);
+        iserr_fn is_err = (iserr_fn)sym(lib, Z, "isError");
+        printf("zstream_sizes %d %d %d %d | err(-1)=%d name=%s\n", cin, cout, din, dout, (int)is_err(&env, (jclass)Z, -1),
+               (const char*)((name_fn)sym(lib, Z, "getErrorName"))(&env, (jclass)Z, -1));
+        char* obuf = (char*)malloc((size_t)cout + (size_t)dout + 64);
+        long clen = 0;
+        if (argc > 7) {                                     /* a stream written by somebody else */
+            FILE* fz = fopen(argv[7], "rb");
+            clen = fz ? (long)fread(comp, 1, (size_t)ccap, fz) : -1;
+            if (fz) fclose(fz);
+            if (clen <= 0) { fprintf(stderr, "mock: cannot read %s\n", argv[7]); return 2; }
+        } else {
+            g_thrown[0] = 0;
+            jlong cs = ((create_fn)sym(lib, C, "createCStream"))(&env, (jclass)C);
+            if (!cs || g_thrown[0]) { printf("zstream_create 0 %s\n", g_thrown[0] ? g_thrown : "-"); return 0; }
+            jint r = ((initc_fn)sym(lib, C, "initCStream"))(&env, (jclass)C, cs, 3);
+            if (is_err(&env, (jclass)Z, r)) { printf("zstream_init %d\n", r); return 0; }
+            int bad = 0;
+            for (int at = 0; at < n && !bad; at += chunk) {
+                const int len = n - at < chunk ? n - at : chunk;
+                field_t sb = {"src", 1, 0, raw + at, 0}, db = {"dst", 1, 0, obuf, 0};
+                obj_t o = {{{"srcPos", 0, 0, 0, 0}, {"dstPos", 0, 0, 0, 0}, {"oBuffLen", 0, 0, 0, 0}}, 3};
+                while (o.f[0].lval < len) {                 /* until the compressor has taken the whole chunk */
+                    r = ((cs_fn)sym(lib, C, "compressStream"))(&env, &o, cs, &db, cout, &sb, len);
+                    if (is_err(&env, (jclass)Z, r)) { bad = 1; break; }
+                    if (clen + o.f[2].ival > ccap) { bad = 1; break; }
+                    memcpy(comp + clen, obuf, (size_t)o.f[2].ival); clen += o.f[2].ival;
+                }
+            }
+            for (int guard = 0; !bad && guard < 1000; guard++) {
+                field_t db = {"dst", 1, 0, obuf, 0};
+                obj_t o = {{{"srcPos", 0, 0, 0, 0}, {"dstPos", 0, 0, 0, 0}, {"oBuffLen", 0, 0, 0, 0}}, 3};
+                r = ((end_fn)sym(lib, C, "endStream"))(&env, &o, cs, &db, 0, cout);
+                if (is_err(&env, (jclass)Z, r)) { bad = 1; break; }
+                memcpy(comp + clen, obuf, (size_t)o.f[2].ival); clen += o.f[2].ival;
+                if (r == 0) break;
+            }
+            ((free_fn)sym(lib, C, "freeCStream"))(&env, (jclass)C, cs);
+            printf("zstream_compress %ld - | bad=%d\n", clen, bad);
+            dump(dir, "zstream", comp, clen);
+            if (bad) return 0;
+        }
+        {
+            g_thrown[0] = 0;
+            jlong ds = ((create_fn)sym(lib, D, "createDStream"))(&env, (jclass)D);
+            if (!ds || g_thrown[0]) { printf("zstream_createD 0 %s\n", g_thrown[0] ? g_thrown : "-"); return 0; }
+            jint r = ((initd_fn)sym(lib, D, "initDStream"))(&env, (jclass)D, ds);
+            long total = 0; int bad = is_err(&env, (jclass)Z, r) ? 1 : 0;
+            for (long at = 0; at < clen && !bad; at += din) {
+                const int len = (int)(clen - at < din ? clen - at : din);
+                field_t sb = {"src", 1, 0, comp + at, 0}, db = {"dst", 1, 0, obuf, 0};
+                obj_t o = {{{"srcPos", 0, 0, 0, 0}, {"dstPos", 0, 0, 0, 0}, {"oBuffLen", 0, 0, 0, 0}}, 3};
+                for (int guard = 0; guard < 100000; guard++) {
+                    o.f[1].lval = 0;                        /* the Java side hands over an empty output buffer every call */
+                    r = ((cs_fn)sym(lib, D, "decompressStream"))(&env, &o, ds, &db, dout, &sb, len);
+                    if (is_err(&env, (jclass)Z, r)) { bad = 1; break; }
+                    if (total + o.f[2].ival > cap) { bad = 1; break; }
+                    memcpy(back + total, obuf, (size_t)o.f[2].ival); total += o.f[2].ival;
+                    if (o.f[0].lval >= len && o.f[2].ival < dout) break;      /* input taken, output not full: nothing more for now */
+                }
+            }
+            ((free_fn)sym(lib, D, "freeDStream"))(&env, (jclass)D, ds);
+            printf("zstream_roundtrip %ld - | bad=%d same=%d\n", total, bad, total == n && !memcmp(back, raw, (size_t)n));
+        }
+        return 0;
+    }
 
     const char* codecs[2] = {"Lz4", "Zstd"};
     if (argc > 5) {
