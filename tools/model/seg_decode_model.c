@@ -21,7 +21,9 @@ void corpus_fill_logs(uint8_t* dst, size_t len, uint64_t seed, uint64_t first_bl
 #define MARGIN    64            /* tokens whose bytes end beyond csize - MARGIN belong to the tail (exact walker) */
 #define OMARGIN   128           /* sequences whose output ends beyond cap - OMARGIN belong to the tail */
 #define MINSEG    1024
-#define ESC_LL    1023u
+#define ESC_LL    511u
+#define POS_BITS  23
+#define POS_MASK  ((1u << POS_BITS) - 1u)
 #define CAPB      4032          /* staging bytes a batch may produce */
 #define PRO       32            /* prologue: the 32 output bytes in front of the batch */
 #define SBYTES    (64 + 16 + CAPB + 64)
@@ -47,7 +49,7 @@ static Tok decode_tok(const uint8_t* s, int csize, uint32_t p)
     t.ll = ll; t.ml = ml; t.next = q2; t.esc = (ll >= ESC_LL) || (mlx > 2);
     return t;
 }
-static uint32_t pack_rec(const Tok* t) { return t->pos | ((t->esc ? ESC_LL : t->ll) << 22); }
+static uint32_t pack_rec(const Tok* t) { return t->pos | ((t->esc ? ESC_LL : t->ll) << POS_BITS); }
 
 /* ------------------------------------------------------------------------------------------------ step 1 + 2: walk and resolve */
 typedef struct {
@@ -76,8 +78,8 @@ static void fix_from(Walk* W, const uint8_t* s, int csize, int j, uint32_t e)
     uint32_t q = e, idx = 0, f = 0; const uint32_t n = W->n[j];
     /* NB the recorded list may itself be the product of an earlier fix: only valid when f == 0 && k == 0 (pure list) */
     for (;;) {
-        while (idx < n && (W->L[j][idx] & 0x3FFFFFu) < q) idx++;
-        if (idx < n && (W->L[j][idx] & 0x3FFFFFu) == q) { W->k[j] = idx; break; }                 /* merged */
+        while (idx < n && (W->L[j][idx] & POS_MASK) < q) idx++;
+        if (idx < n && (W->L[j][idx] & POS_MASK) == q) { W->k[j] = idx; break; }                 /* merged */
         if (idx == n && q == W->exitp[j]) { W->k[j] = n; break; }                                    /* merged at the chain's end */
         if (q >= seg_end) { W->k[j] = n; W->exitp[j] = q; W->tail[j] = 0; break; }
         Tok t = decode_tok(s, csize, q);
@@ -172,9 +174,9 @@ static int exec_block(Exec* X, const Walk* W, const uint8_t* s, int csize, uint8
                 const uint32_t t = t0 + l; valid[l] = t < c; esc[l] = 0; sz[l] = 0; ll[l] = ml[l] = off[l] = lsrc[l] = pos[l] = 0;
                 if (!valid[l]) continue;
                 const uint32_t rec = t < f ? W->F[j][t] : W->L[j][k + t - f];
-                pos[l] = rec & 0x3FFFFFu; ll[l] = rec >> 22; esc[l] = ll[l] == ESC_LL;
+                pos[l] = rec & POS_MASK; ll[l] = rec >> POS_BITS; esc[l] = ll[l] == ESC_LL;
                 if (esc[l]) continue;
-                const uint32_t llx = ll[l] < 15 ? 0 : 1 + (ll[l] >= 270) + (ll[l] >= 525) + (ll[l] >= 780);
+                const uint32_t llx = ll[l] < 15 ? 0 : 1 + (ll[l] >= 270);
                 lsrc[l] = pos[l] + 1 + llx;
                 const uint32_t tok = s[pos[l]], mo = lsrc[l] + ll[l];
                 const uint32_t w1 = s[mo] | (s[mo + 1] << 8) | (s[mo + 2] << 16) | ((uint32_t)s[mo + 3] << 24);
@@ -231,17 +233,21 @@ static int exec_block(Exec* X, const Walk* W, const uint8_t* s, int csize, uint8
                     }
                 }
             }
-            /* ---- matches.  M1: sources that lie more than a prologue in front of the batch and fit one chunk - all lanes at once,
-               from memory.  M2: everything else (sources in the batch or its prologue, overlapping matches, long matches), one
-               sequence at a time in lane order, a byte per lane, inside the staging buffer (bytes from before the prologue: memory). */
+            /* ---- matches.  M1: sources that END in front of the batch - 32 bytes per lane and step, from memory (everything below
+               opos has been flushed).  M2: everything else (sources in the batch or its prologue, overlapping matches), one sequence at
+               a time in lane order, a byte per lane, inside the staging buffer (bytes from before the prologue: memory). */
             {
                 uint64_t m2 = 0;
                 for (int l = 0; l < cnt; l++) {
                     const long x = (long)mrel[l] - (long)off[l];
-                    if (x < -(long)PRO && ml[l] <= 32) {
-                        const uint32_t pd = P0 + mrel[l]; uint32_t R[9];
-                        load_phase_global(dst, (long)opos + x, pd & 3, R, 0);
-                        or_store(X->st, pd, R, ml[l]); X->sets++;
+                    if (x + (long)ml[l] <= 0) {
+                        uint32_t rem = ml[l], dp = mrel[l]; long sa = (long)opos + x;
+                        while (rem) {
+                            const uint32_t len = rem < 32 ? rem : 32, pd = P0 + dp; uint32_t R[9];
+                            load_phase_global(dst, sa, pd & 3, R, 0);
+                            or_store(X->st, pd, R, len); X->sets++;
+                            sa += len; dp += len; rem -= len;
+                        }
                     } else m2 |= 1ull << l;
                 }
                 while (m2) {
