@@ -432,33 +432,44 @@ void lz4_seg_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base
             const uint32_t P0 = 64u + uint32_t(uintptr_t(dst + opos) & 15u);
             const uint32_t outl = incl - sz, mrel = outl + ll;
             if (__ballot(act && (off == 0u || off > opos + mrel))) { failed = true; break; }
-            // ---- literals: 32 bytes per lane and step from the stream
-            {
-                uint32_t rem = act ? ll : 0u, sp = lsrc, dp = outl;
-                while (__ballot(rem > 0u)) {
-                    const bool on = rem > 0u;
-                    const uint32_t len = rem < 32u ? rem : 32u, pd = P0 + dp;
+            // ---- strings into the staging buffer: the first 32 bytes of every string by its own lane, then the rest of the long ones
+            // four at a time, sixteen lanes and 32 bytes per lane each (a string a lane can hold is at most 528 bytes long: one step
+            // per string, and four strings' loads in flight together - a lane looping over its own string makes a trip to memory per
+            // 32 bytes: 14 K clk per step on audio-like data)
+            auto copy_strings = [&](cgbyte* base, uint32_t srcpos, uint32_t dstrel, uint32_t len, bool on) {
+                {
+                    const uint32_t l1 = len < 32u ? len : 32u, pd = P0 + dstrel;
                     uint32_t R[9];
-                    load_phase(s, sp, pd & 3u, R, on, len);
-                    or_store(st, pd, R, len, on);
-                    sp += len; dp += len; rem -= len;
+                    load_phase(base, srcpos, pd & 3u, R, on, l1);
+                    or_store(st, pd, R, l1, on);
                 }
-            }
+                unsigned long long lm = __ballot(on && len > 32u);
+                while (lm) {
+                    uint32_t q[4];
+#pragma unroll
+                    for (int g = 0; g < 4; g++) { q[g] = lm ? uint32_t(__builtin_ctzll(lm)) : 64u; lm &= lm - 1; }
+                    const uint32_t g = uint32_t(lane) >> 4, i = uint32_t(lane) & 15u;
+                    const uint32_t lq = g == 0 ? q[0] : g == 1 ? q[1] : g == 2 ? q[2] : q[3];
+                    const uint32_t sp_ = uint32_t(__builtin_amdgcn_ds_bpermute(int(lq << 2), int(srcpos)));
+                    const uint32_t dr_ = uint32_t(__builtin_amdgcn_ds_bpermute(int(lq << 2), int(dstrel)));
+                    const uint32_t ln_ = uint32_t(__builtin_amdgcn_ds_bpermute(int(lq << 2), int(len)));
+                    const uint32_t o = 32u + 32u * i;
+                    const bool on2 = lq < 64u && o < ln_;
+                    const uint32_t l2 = on2 ? (ln_ - o < 32u ? ln_ - o : 32u) : 0u, pd = P0 + dr_ + o;
+                    uint32_t R[9];
+                    load_phase(base, sp_ + o, pd & 3u, R, on2, l2);
+                    or_store(st, pd, R, l2, on2);
+                }
+            };
+            // ---- literals, from the stream
+            copy_strings(s, lsrc, outl, ll, act && ll > 0u);
             pf.add(1, tp);
-            // ---- matches.  M1: sources that end in front of the batch - 32 bytes per lane and step, from memory
+            // ---- matches.  M1: sources that end in front of the batch, from memory
             const int x = int(mrel) - int(off);                         // source, relative to the batch's first byte
             const bool m1 = act && x + int(ml) <= 0;
             if (__ballot(m1)) {
                 VM_DRAIN();                                              // the flush of the batch before has to have arrived
-                uint32_t rem = m1 ? ml : 0u, sa = opos + uint32_t(x), dp = mrel;
-                while (__ballot(rem > 0u)) {
-                    const bool on = rem > 0u;
-                    const uint32_t len = rem < 32u ? rem : 32u, pd = P0 + dp;
-                    uint32_t R[9];
-                    load_phase((cgbyte*)dst, sa, pd & 3u, R, on, len);
-                    or_store(st, pd, R, len, on);
-                    sa += len; dp += len; rem -= len;
-                }
+                copy_strings((cgbyte*)dst, opos + uint32_t(x), mrel, ml, m1);
             }
             LDS_FENCE();
             pf.add(2, tp);
