@@ -104,6 +104,19 @@ public:
     }
 };
 
+// The LZ4 decode workspace: the segment-parallel path sizes it for the worst stream (11 MB per block) times the blocks of a piece
+// of the launch; when the device cannot give that much, the pieces get smaller (the launch is then cut into more of them) instead of
+// the call failing (nothing retried with a smaller batch)
+int lease_lz4_decode(WsLease& ws, hipStream_t s, uint32_t n, void** work)
+{
+    for (;;) {
+        const int r = ws.get(s, fourmc_lz4_decode_work_bytes(n), work);
+        if (r == FOURMC_OK) return r;
+        (void)hipGetLastError();
+        if (!fourmc_lz4_seg_shrink_batch()) return r;
+    }
+}
+
 int arena_reserve(Arena& g_arena, size_t src_bytes, size_t dst_bytes, size_t nblk)
 {
     if (!g_arena.stream) HIP_TRY(hipStreamCreateWithFlags(&g_arena.stream, hipStreamNonBlocking));
@@ -169,7 +182,7 @@ int fourmc_gpu_lz4_decompress(const void* d_src, void* d_dst, fourmc_block* d_bl
     if (int r = ensure_device()) return r;
     hipStream_t s = static_cast<hipStream_t>(stream);
     WsLease ws; void* work = nullptr;
-    if (int r = ws.get(s, fourmc_lz4_decode_work_bytes(n), &work)) return r;
+    if (int r = lease_lz4_decode(ws, s, n, &work)) return r;
     HIP_TRY(fourmc_launch_lz4_decode(d_src, d_dst, d_blocks, n, 0, work, s));
     return FOURMC_OK;
 }
@@ -323,7 +336,7 @@ int fourmc_gpu_4mc_decode_blocks(const void* d_src, void* d_dst, fourmc_block* d
         return FOURMC_EUNSUP;
     }
     WsLease ws; void* work = nullptr;
-    if (int r = ws.get(s, fourmc_lz4_decode_work_bytes(n), &work)) return r;
+    if (int r = lease_lz4_decode(ws, s, n, &work)) return r;
     HIP_TRY(fourmc_launch_xxh32(d_src, d_blocks, n, 0, FOURMC_VERIFY_SRC, s));
     HIP_TRY(fourmc_launch_lz4_decode(d_src, d_dst, d_blocks, n, 1, work, s));
     return FOURMC_OK;

@@ -33,6 +33,7 @@ hipError_t fourmc_launch_lz4_wx(const void* d_src, void* d_dst, fourmc_block* d_
                                   uint32_t n, int container_mode, hipStream_t stream, const uint32_t* pick, uint32_t want);
 size_t     fourmc_lz4_seg_work_bytes(uint32_t n);
 uint32_t   fourmc_lz4_seg_batch(void);              /* blocks per launch of the segment-parallel path (bounds its workspace) */
+int        fourmc_lz4_seg_shrink_batch(void);       /* the workspace could not be allocated: halve the pieces (0: cannot) */
 hipError_t fourmc_launch_lz4_seg(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                  int container_mode, void* d_work, hipStream_t stream);
 hipError_t fourmc_launch_lz4_parse(const void* d_src, const void* d_dst, fourmc_block* d_blocks, uint32_t n,

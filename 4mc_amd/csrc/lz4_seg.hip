@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
 #include "fourmc_gpu.h"
 #include "kernels.h"
 #include "devcopy.h"
@@ -90,12 +91,12 @@ struct Prof {
 #endif
 
 // ================================================================================================ token at a position
-struct Hop { uint32_t ll, next; bool stop, esc; };
+struct Hop { uint32_t ll, next, offml; bool stop, esc; };      // offml: match offset | match length << 16 (exact unless esc)
 // One token at p (per lane).  stop: the token or its bytes reach beyond limit = csize - kMargin; the chain halts AT p and the exact
 // walker takes over there.  Every byte read lies below csize.
 __device__ __forceinline__ Hop decode_tok(cgbyte* s, uint32_t limit, uint32_t p)
 {
-    Hop h; h.ll = 0; h.next = p; h.stop = true; h.esc = false;
+    Hop h; h.ll = 0; h.next = p; h.offml = 0; h.stop = true; h.esc = false;
     if (p >= limit) return h;
     const u32x2 L0 = ld8u(s + p);                               // p + 8 <= csize - 56
     const uint32_t tok = L0.x & 255u, mn = tok & 15u;
@@ -109,19 +110,19 @@ __device__ __forceinline__ Hop decode_tok(cgbyte* s, uint32_t limit, uint32_t p)
     const uint32_t mo = q + ll;
     if (mo + 2 > limit) return h;
     const uint32_t L1 = ld4u(s + mo);                           // mo + 4 <= limit + 2
-    uint32_t q2 = mo + 2; bool esc = ll >= kEscLL;
+    uint32_t q2 = mo + 2, ml = mn + 4u; bool esc = ll >= kEscLL;
     if (mn == 15) {
-        const uint32_t e0 = (L1 >> 16) & 255u; q2++;
+        const uint32_t e0 = (L1 >> 16) & 255u; q2++; ml += e0;
         if (e0 == 255u) {
-            const uint32_t e1 = L1 >> 24; q2++;
+            const uint32_t e1 = L1 >> 24; q2++; ml += e1;
             if (e1 == 255u) { esc = true; for (;;) { if (q2 >= limit) return h; const uint32_t b = s[q2++]; if (b != 255u) break; } }
         }
     }
     if (q2 > limit) return h;
-    h.ll = ll; h.next = q2; h.stop = false; h.esc = esc;
+    h.ll = ll; h.next = q2; h.offml = (L1 & 0xFFFFu) | (ml << 16); h.stop = false; h.esc = esc;
     return h;
 }
-__device__ __forceinline__ uint32_t pack_rec(uint32_t p, const Hop& h) { return p | ((h.esc ? kEscLL : h.ll) << kPosBits); }
+__device__ __forceinline__ uint32_t pack_rec(uint32_t p, const Hop& h) { return p | ((h.esc ? kEscLL : h.ll) << kPosBits); }     // a record's first word; the second is h.offml
 
 // ================================================================================================ WALK kernel
 struct LaneSeg {            // one lane's segment
@@ -181,42 +182,37 @@ __device__ __forceinline__ void walk_from(LaneSeg& g, cgbyte* s, uint32_t csize,
         const uint32_t mo = q + ll;
         if (stop || mo + 2 > limit) { tail = true; break; }
         const uint32_t L1 = get4(mo);
-        uint32_t q2 = mo + 2; bool esc = ll >= kEscLL;
+        uint32_t q2 = mo + 2, ml = mn + 4u; bool esc = ll >= kEscLL;
         if (mn == 15) {
-            const uint32_t e0 = (L1 >> 16) & 255u; q2++;
+            const uint32_t e0 = (L1 >> 16) & 255u; q2++; ml += e0;
             if (e0 == 255u) {
-                const uint32_t e1 = L1 >> 24; q2++;
+                const uint32_t e1 = L1 >> 24; q2++; ml += e1;
                 if (e1 == 255u) { esc = true; for (;;) { if (q2 >= limit) { stop = true; break; } const uint32_t bq = s[q2++]; if (bq != 255u) break; } }
             }
         }
         if (stop || q2 > limit) { tail = true; break; }
-        r0 = r1; r1 = r2; r2 = r3; r3 = p | ((esc ? kEscLL : ll) << kPosBits);
+        r0 = r2; r1 = r3; r2 = p | ((esc ? kEscLL : ll) << kPosBits); r3 = (L1 & 0xFFFFu) | (ml << 16);      // two records (of two words) per 16-byte store
         n++;
-        if ((n & 3u) == 0) *reinterpret_cast<__attribute__((address_space(1))) u32x4*>(g.L + (n - 4)) = u32x4{r0, r1, r2, r3};
+        if ((n & 1u) == 0) *reinterpret_cast<__attribute__((address_space(1))) u32x4*>(g.L + 2 * (n - 2)) = u32x4{r0, r1, r2, r3};
         p = q2;
     }
-    {   // the records still in the registers
-        const uint32_t c = n & 3u, base = n - c;
-        if (c == 1) g.L[base] = r3;
-        if (c == 2) { g.L[base] = r2; g.L[base + 1] = r3; }
-        if (c == 3) { g.L[base] = r1; g.L[base + 1] = r2; g.L[base + 2] = r3; }
-    }
+    if (n & 1u) { g.L[2 * (n - 1)] = r2; g.L[2 * (n - 1) + 1] = r3; }       // the record still in the registers
     g.exitp = p; g.n = n; g.f = 0; g.k = 0; g.entry = start; g.tail = tail; g.pure = true;
 }
 // the true chain enters the segment at e: walk it until it falls onto the recorded chain (which must be a pure one)
 __device__ __forceinline__ void fix_from(LaneSeg& g, cgbyte* s, uint32_t csize, uint32_t limit, uint32_t e, uint32_t* ring)
 {
     uint32_t q = e, idx = 0, f = 0; const uint32_t n = g.n;
-    uint32_t cur = n ? (g.L[0] & kPosMask) : 0xFFFFFFFFu;        // position of L[idx]
+    uint32_t cur = n ? (g.L[0] & kPosMask) : 0xFFFFFFFFu;        // position of record idx
     for (;;) {
-        while (idx < n && cur < q) { idx++; cur = idx < n ? (g.L[idx] & kPosMask) : 0xFFFFFFFFu; }
+        while (idx < n && cur < q) { idx++; cur = idx < n ? (g.L[2 * idx] & kPosMask) : 0xFFFFFFFFu; }
         if (idx < n && cur == q) { g.k = idx; break; }
         if (idx == n && q == g.exitp) { g.k = n; break; }
         if (q >= g.seg_end) { g.k = n; g.exitp = q; g.tail = false; break; }
         const Hop h = decode_tok(s, limit, q);
         if (h.stop) { g.k = n; g.exitp = q; g.tail = true; break; }
         if (f == kFixCap) { walk_from(g, s, csize, limit, e, ring); return; }
-        g.F[f++] = pack_rec(q, h); q = h.next;
+        g.F[2 * f] = pack_rec(q, h); g.F[2 * f + 1] = h.offml; f++; q = h.next;
     }
     g.f = f; g.entry = e; g.pure = (f == 0 && g.k == 0);
 }
@@ -239,13 +235,13 @@ void lz4_seg_walk_kernel(const uint8_t* __restrict__ src_base, const fourmc_bloc
     const uint32_t csize = blk.src_len, limit = csize - kMargin;
     uint32_t nseg = limit / kMinSeg; nseg = nseg < 1 ? 1 : (nseg > uint32_t(kSegs) ? uint32_t(kSegs) : nseg);
     const uint32_t seglen = ((limit + nseg - 1) / nseg + 3) & ~3u;
-    const uint32_t stride = (kFixCap + seglen / 3 + 7) & ~3u;          // lists start on 16-byte boundaries
+    const uint32_t stride = kRecWords * ((kFixCap + seglen / 3 + 7) & ~3u);          // lists start on 16-byte boundaries
     const uint32_t area = kMetaWords + lane * stride;
     __shared__ uint32_t win[kRingDw * 64];
     uint32_t* ring = win + lane;
 
     LaneSeg g;
-    g.F = meta + area; g.L = g.F + kFixCap;
+    g.F = meta + area; g.L = g.F + kRecWords * kFixCap;
     g.seg_end = (lane + 1 == nseg) ? 0xFFFFFFFFu : (lane + 1) * seglen;
     g.f = g.k = g.n = 0; g.exitp = 0; g.entry = 0xFFFFFFFFu; g.tail = true; g.pure = true;
     const bool mine = lane < nseg;
@@ -376,17 +372,15 @@ void lz4_seg_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base
             // ---- records and fields, one sequence per lane
             const uint32_t t = t0 + lane;
             const bool valid = t < c;
-            uint32_t rec = 0;
-            if (valid) rec = FL[t < f ? t : kFixCap + k + (t - f)];
-            const uint32_t pos = rec & kPosMask, ll = rec >> kPosBits;
+            u32x2 rec2 = u32x2{0, 0};
+            if (valid) rec2 = *reinterpret_cast<__attribute__((address_space(1))) const u32x2*>(FL + 2 * (t < f ? t : kFixCap + k + (t - f)));
+            const uint32_t rec = rec2.x, pos = rec & kPosMask, ll = rec >> kPosBits;
             const bool esc = valid && ll == kEscLL;
             uint32_t off = 0, ml = 0, lsrc = 0;
             if (valid && !esc) {
                 const uint32_t llx = ll < 15u ? 0u : 1u + (ll >= 270u);
                 lsrc = pos + 1u + llx;
-                const uint32_t tok = s[pos], w1 = ld4u(s + lsrc + ll);
-                off = w1 & 0xFFFFu; ml = (tok & 15u) + 4u;
-                if ((tok & 15u) == 15u) { const uint32_t e0 = (w1 >> 16) & 255u; ml += e0; if (e0 == 255u) ml += w1 >> 24; }
+                off = rec2.y & 0xFFFFu; ml = rec2.y >> 16;               // (the walk read them: no trip to the stream for the token and the offset)
             }
             const uint32_t sz = ll + ml;                               // 0 for lanes without a sequence (ll = ml = 0) - escapes are cut off below
             const uint32_t incl = scan_add(valid && !esc ? sz : 0u);
@@ -566,9 +560,11 @@ extern "C" size_t fourmc_lz4_seg_work_bytes(uint32_t n) { return size_t(n) * lz4
 // Blocks per launch pair: the workspace is sized for the largest stream a block can hold (5.7 MB of records per block), so a
 // launch is cut into pieces whose workspace stays below 40 % of the device's memory (8192 blocks = 46 GB on a 288 GB MI355X:
 // one wave per block then fills the chip's 32 waves per CU).  FOURMC_SEG_BATCH overrides.
+static std::atomic<uint32_t> g_seg_batch{0};
 extern "C" uint32_t fourmc_lz4_seg_batch(void)
 {
-    static const uint32_t v = [] {
+    uint32_t v = g_seg_batch.load(std::memory_order_relaxed);
+    if (v == 0) {
         uint32_t b = 8192;
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) {
@@ -576,9 +572,18 @@ extern "C" uint32_t fourmc_lz4_seg_batch(void)
             if (fit < b) b = fit < 1 ? 1u : uint32_t(fit);
         }
         if (const char* e = getenv("FOURMC_SEG_BATCH")) { const long x = atol(e); if (x > 0) b = uint32_t(x); }
-        return b;
-    }();
+        g_seg_batch.store(b, std::memory_order_relaxed);
+        v = b;
+    }
     return v;
+}
+// the workspace of a piece could not be had: halve the pieces (false: they cannot get smaller)
+extern "C" int fourmc_lz4_seg_shrink_batch(void)
+{
+    const uint32_t b = fourmc_lz4_seg_batch();
+    if (b <= 64) return 0;
+    g_seg_batch.store(b / 2, std::memory_order_relaxed);
+    return 1;
 }
 
 extern "C" hipError_t fourmc_launch_lz4_seg(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,

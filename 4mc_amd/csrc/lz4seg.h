@@ -7,8 +7,9 @@
 //   [kMetaTailIp]  stream position of the first token the fast path does not take (its bytes end inside the last kMargin bytes)
 //   [kMetaResIp], [kMetaResOp]   written by the executor: where the exact walker resumes (token position, output position)
 //   [kMetaLive + 4 i ..]  live segment i: {word offset of its lists, fix records f, first true recorded record k, records c = f + n - k}
-//   lists of segment j at kMetaWords + j * stride, stride = (kFixCap + seglen / 3 + 7) & ~3:  kFixCap fix records, then the recorded chain.
-//   A record is  token position | min(literal length, kEscLL) << 23;  kEscLL marks a sequence the executor decodes on its own
+//   lists of segment j at kMetaWords + j * stride, stride = 2 * ((kFixCap + seglen / 3 + 7) & ~3) words:  kFixCap fix records, then the recorded chain.
+//   A record is two words:  token position | min(literal length, kEscLL) << 23,  match offset | match length << 16  (what the executor
+//   would otherwise fetch from the stream with two more loads per sequence);  kEscLL marks a sequence the executor decodes on its own
 //   (literal run of 511 bytes and more, or a match length with more than two extension bytes).
 #ifndef FOURMC_LZ4SEG_H
 #define FOURMC_LZ4SEG_H
@@ -34,7 +35,8 @@ constexpr int      kStage   = 4224;          // 64 + 16 + kCapB + slack, a multi
 constexpr uint32_t kMetaStatus = 0, kMetaNLive = 1, kMetaTailIp = 2, kMetaResIp = 3, kMetaResOp = 4, kMetaLive = 16;
 constexpr uint32_t kMetaProf   = kMetaLive + 4 * kSegs;      // 48 words: cycle counters of profiling builds (walk: 24, executor: 24)
 constexpr uint32_t kMetaWords  = kMetaProf + 48;                                              // 320
-constexpr uint32_t kWsWords    = (kMetaWords + kSegs * (kFixCap + 8) + kMaxSrc / 3 + 512 + 3) & ~3u;
+constexpr uint32_t kRecWords   = 2;                                                            // words per record
+constexpr uint32_t kWsWords    = (kMetaWords + kRecWords * (kSegs * (kFixCap + 8) + kMaxSrc / 3 + 512) + 3) & ~3u;
 constexpr int kResumeCode = -1000000004;     // blocks[b].result while a block waits for the exact walker to finish it
 
 } // namespace lz4seg

@@ -4,6 +4,9 @@
  * Written BEFORE the kernels: it fixes the arithmetic of the three steps (speculative segment walk, resolution of the true token
  * chain, batch execution through a zeroed staging buffer with OR stores) and checks them against the oracle on the corpus, on edge
  * inputs and on damaged streams.  A "wave" is a loop over 64 lanes; every per-lane expression is the one the kernel evaluates.
+ * (The kernels' records carry two words since the end of round 4 - position | literal length, offset | match length - so that the
+ * executor need not fetch token and offset from the stream; the model keeps the first word and reads the second's contents from the
+ * stream: the same values.)
  * Design aid / test infrastructure only (links the oracle); not product.
  *
  *   gcc -O2 -o /tmp/seg_decode_model tools/model/seg_decode_model.c tools/corpus.c -Ioracle oracle/liboracle.so -Wl,-rpath,$PWD/oracle

@@ -19,8 +19,8 @@ def ws_words():
     h = open(os.path.join(ROOT, "4mc_amd", "csrc", "lz4seg.h")).read()
     return 5 * 1024 * 1024   # read generously; slot size comes from the header below
 def slot_bytes():
-    # (kMetaWords + kSegs * (kFixCap + 8) + kMaxSrc / 3 + 512 + 3) & ~3, kMaxSrc = 4210768 + 32
-    return ((320 + 64 * 136 + (4210768 + 32) // 3 + 512 + 3) & ~3) * 4
+    # lz4seg.h: (kMetaWords + kRecWords * (kSegs * (kFixCap + 8) + kMaxSrc / 3 + 512) + 3) & ~3, kMaxSrc = 4210768 + 32
+    return ((320 + 2 * (64 * 136 + (4210768 + 32) // 3 + 512) + 3) & ~3) * 4
 def run(comps, caps, which, tag):
     nb = len(comps)
     offs, pos = [], 0
