@@ -612,7 +612,7 @@ extern "C" int fourmc_gpu_get_lz4_decode_path(void);
 extern "C" size_t fourmc_lz4_decode_work_bytes(uint32_t n)
 {
     const int path = fourmc_gpu_get_lz4_decode_path();
-    if (path == 11 || path == 12 || (path == 6 && n >= 1792)) return fourmc_lz4_seg_work_bytes(n < fourmc_lz4_seg_batch() ? n : fourmc_lz4_seg_batch());
+    if (path == 11 || path == 12 || (path == 6 && n >= 768)) return fourmc_lz4_seg_work_bytes(n < fourmc_lz4_seg_batch() ? n : fourmc_lz4_seg_batch());
 #ifdef FOURMC_RESEARCH
     return (path == 1 || path == 3) ? fourmc_lz4_parse_work_bytes(n) : 0;
 #else
@@ -676,7 +676,7 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
     // 6 "auto": a launch that fills the chip goes to the segment-parallel path (lz4_seg.hip: one wave per block, a fifth of the
     // instructions per byte of the wave pipelines - 8192 blocks in 116 ms against 184); smaller launches to the walk + window copier
     // (K1wx: four waves per block, the shortest chain per block)
-    if (path == 6 && n >= 1792) path = 11;
+    if (path == 6 && n >= 768) path = 11;
     if (path == 6) path = 9;
     if (path == 11 || path == 12) {
         // segment-parallel walk + batch executor (lz4_seg.hip), then the exact walker for the last bytes of every block and for

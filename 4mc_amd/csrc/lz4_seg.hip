@@ -480,11 +480,38 @@ void lz4_seg_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base
             uint32_t recip = 0;
             if (omask) recip = uint32_t(65536.0f * __builtin_amdgcn_rcpf(float(off))) + 2u;   // floor(i * recip / 65536) = i / off for i < 64
             if (m2 & ~tmask) VM_DRAIN();
+            // which sequences may share an LDS round trip with the pending one in front of them: both short-loop, not overlapping, and
+            // this one's source clear of that one's destination (chains of near matches are a few sequences apart: database-like
+            // records copy the record before them field by field, so neighbours are independent) - decided for all lanes at once
+            unsigned long long pairm = 0;
+            if (__builtin_popcountll(m2) >= 4) {
+                const uint32_t lo = uint32_t(m2) & ((1u << (lane & 31)) - 1u) & (lane < 32 ? 0xFFFFFFFFu : 0xFFFFFFFFu);
+                const uint32_t below_lo = lane < 32 ? lo : uint32_t(m2), below_hi = lane < 32 ? 0u : (uint32_t(m2 >> 32) & ((1u << (lane & 31)) - 1u));
+                const uint32_t p = below_hi ? 63u - uint32_t(__builtin_clz(below_hi)) : (below_lo ? 31u - uint32_t(__builtin_clz(below_lo)) : 64u);
+                const uint32_t pdst = uint32_t(__builtin_amdgcn_ds_bpermute(int(p << 2), int(dstA)));
+                const uint32_t plen = uint32_t(__builtin_amdgcn_ds_bpermute(int(p << 2), int(ml)));
+                const bool simple = tight && off >= ml;
+                const unsigned long long simm = __ballot(simple);
+                const bool psimple = p < 64u && ((simm >> p) & 1ull);
+                pairm = __ballot(simple && psimple && (srcA + ml <= pdst || srcA >= pdst + plen));
+            }
+            uint8_t* const dummy = st + kStage - 8;                       // where lanes beyond a sequence's length read and write
             while (m2) {
                 const uint32_t l = uint32_t(__builtin_ctzll(m2));
                 m2 &= m2 - 1;
                 if ((tmask >> l) & 1) {
                     const uint32_t sA = rdl(srcA, l), dA = rdl(dstA, l), n = rdl(ml, l);
+                    const uint32_t l2 = m2 ? uint32_t(__builtin_ctzll(m2)) : 0u;
+                    if (m2 && ((pairm >> l2) & 1)) {                       // l2's pending predecessor is l
+                        m2 &= m2 - 1;
+                        const uint32_t sB = rdl(srcA, l2), dB = rdl(dstA, l2), nB = rdl(ml, l2);
+                        const bool oa = uint32_t(lane) < n, ob = uint32_t(lane) < nB;
+                        const uint8_t va = *(oa ? st + sA + lane : dummy), vb = *(ob ? st + sB + lane : dummy);
+                        *(oa ? st + dA + lane : dummy) = va;
+                        *(ob ? st + dB + lane : dummy + 1) = vb;
+                        pf.count(10);
+                        continue;
+                    }
                     uint32_t idx = uint32_t(lane);
                     if ((omask >> l) & 1) { const uint32_t o = rdl(off, l), M = rdl(recip, l); idx = uint32_t(lane) - ((uint32_t(lane) * M) >> 16) * o; }
                     if (uint32_t(lane) < n) { const uint8_t v = st[sA + idx]; st[dA + lane] = v; }

@@ -335,13 +335,13 @@ def main():
                  7: "one lane per sequence (lz4_rows.hip)", 9: "walk + window copier (K1wx: four waves per block; lz4_rows.hip)",
                  11: "segment-parallel (lz4_seg.hip: walk kernel, one lane per stream segment + batch executor, one wave per block + exact walker for the last bytes of each block)"}
         if path == 6:
-            return "auto: segment-parallel from 1792 blocks per launch, walk + window copier below (this launch of %d blocks: %s)" % (n, names[11 if n >= 1792 else 9])
+            return "auto: segment-parallel from 768 blocks per launch, walk + window copier below (this launch of %d blocks: %s)" % (n, names[11 if n >= 768 else 9])
         return names.get(path, "path %d" % path)
 
     def decode_path_comparison():
         """The two LZ4 decode fast paths of the product on the same launch (identical results): the walk + window copier (K1wx) and
         the segment-parallel path; HIP events around the decode_blocks call minus the hash launch.  "auto" (the default) takes the
-        segment-parallel path from 1792 blocks per launch.  (The older designs live in the research side build: tools/k1_timing.py.)"""
+        segment-parallel path from 768 blocks per launch.  (The older designs live in the research side build: tools/k1_timing.py.)"""
         out = {}
         before = L.fourmc_gpu_get_lz4_decode_path()
         vb = state["dec"].clone()
