@@ -54,6 +54,8 @@ _GPU_API = {
     "fourmc_gpu_zstd_decompress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "fourmc_gpu_zstd_compress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
     "fourmc_gpu_debug_read_workspace": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t]),
+    "fourmc_gpu_set_lz4_encode_mode": (None, [C.c_int]),
+    "fourmc_gpu_get_lz4_encode_mode": (C.c_int, []),
     "fourmc_gpu_set_lz4_decode_path": (None, [C.c_int]),
     "fourmc_gpu_get_lz4_decode_path": (C.c_int, []),
     "fourmc_gpu_set_zstd_decode_split": (None, [C.c_int]),

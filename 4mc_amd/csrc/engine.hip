@@ -187,11 +187,42 @@ int fourmc_gpu_lz4_decompress(const void* d_src, void* d_dst, fourmc_block* d_bl
     return FOURMC_OK;
 }
 
+// LZ4 fast encoder of the launches: 0 the reference parse, byte for byte (default); 1 the ratio-tolerance encoder
+// (lz4_par_encode.hip: valid LZ4 blocks, not the reference's bytes).  FOURMC_LZ4_ENCODE = exact | parallel.
+static std::atomic<int> g_lz4_encode_mode{-1};
+void fourmc_gpu_set_lz4_encode_mode(int mode) { g_lz4_encode_mode.store(mode == 1 ? 1 : 0, std::memory_order_release); }
+int fourmc_gpu_get_lz4_encode_mode(void)
+{
+    int m = g_lz4_encode_mode.load(std::memory_order_acquire);
+    if (m < 0) {
+        const char* e = getenv("FOURMC_LZ4_ENCODE");
+        m = (e && (!strcmp(e, "parallel") || !strcmp(e, "par") || !strcmp(e, "1"))) ? 1 : 0;
+        g_lz4_encode_mode.store(m, std::memory_order_release);
+    }
+    return m;
+}
+
+static int lz4_fast_encode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, int container_mode, hipStream_t s)
+{
+    if (fourmc_gpu_get_lz4_encode_mode() == 1) {
+        // pieces bound the workspace (4 MiB per block)
+        const uint32_t piece = 4096;
+        for (uint32_t b0 = 0; b0 < n; b0 += piece) {
+            const uint32_t m = n - b0 < piece ? n - b0 : piece;
+            WsLease ws; void* work = nullptr;
+            if (int r = ws.get(s, fourmc_lz4_par_work_bytes(m), &work)) return r;
+            HIP_TRY(fourmc_launch_lz4_encode_par(d_src, d_dst, d_blocks + b0, m, container_mode, work, s));
+        }
+        return FOURMC_OK;
+    }
+    HIP_TRY(fourmc_launch_lz4_encode_fast(d_src, d_dst, d_blocks, n, container_mode, s));
+    return FOURMC_OK;
+}
+
 int fourmc_gpu_lz4_compress_fast(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, void* stream)
 {
     if (int r = ensure_device()) return r;
-    HIP_TRY(fourmc_launch_lz4_encode_fast(d_src, d_dst, d_blocks, n, 0, static_cast<hipStream_t>(stream)));
-    return FOURMC_OK;
+    return lz4_fast_encode(d_src, d_dst, d_blocks, n, 0, static_cast<hipStream_t>(stream));
 }
 
 int fourmc_gpu_lz4_compress_hc(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, int level, void* stream)
@@ -314,7 +345,7 @@ int fourmc_gpu_4mc_encode_blocks(const void* d_src, void* d_dst, fourmc_block* d
         snprintf(g_err, sizeof g_err, "codec %d not implemented on the device yet", codec);
         return FOURMC_EUNSUP;
     }
-    HIP_TRY(fourmc_launch_lz4_encode_fast(d_src, d_dst, d_blocks, n, 1, s));
+    if (int r = lz4_fast_encode(d_src, d_dst, d_blocks, n, 1, s)) return r;
     HIP_TRY(fourmc_launch_xxh32(d_dst, d_blocks, n, 0, FOURMC_HASH_DST_RESULT, s));
     return FOURMC_OK;
 }

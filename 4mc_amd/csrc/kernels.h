@@ -42,6 +42,9 @@ hipError_t fourmc_launch_lz4_exec(const void* d_src, void* d_dst, fourmc_block* 
                                   const void* d_work, hipStream_t stream);
 hipError_t fourmc_launch_lz4_encode_fast(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                                          uint32_t n, int container_mode, hipStream_t stream);
+size_t     fourmc_lz4_par_work_bytes(uint32_t n);
+hipError_t fourmc_launch_lz4_encode_par(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
+                                        int container_mode, void* d_work, hipStream_t stream);
 hipError_t fourmc_launch_pack_image(const void* d_staging, void* d_image, const fourmc_block* d_blocks,
                                     const uint64_t* d_image_off, uint32_t n, hipStream_t stream);
 size_t     fourmc_lz4hc_work_bytes(uint32_t n);

@@ -76,6 +76,13 @@ int fourmc_gpu_lz4_compress_hc(const void* d_src, void* d_dst, fourmc_block* d_b
  * when dst_cap == 0xFFFFFFFF; byte-identical payloads           native/lz4/lz4mc.c:582-606         */
 int fourmc_gpu_lz4_compress_mc(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                                uint32_t n, void* stream);
+/* LZ4 fast encoder of fourmc_gpu_lz4_compress_fast and of the LZ4-fast container encode: 0 (default) the reference parse, payload
+ * bytes identical to the reference build; 1 the ratio-tolerance encoder (lz4_par_encode.hip): every payload is one valid LZ4 block
+ * that LZ4_decompress_safe decodes to the input, but NOT the reference's bytes - sizes within 3 % of the reference parse on the
+ * S-mix (north_star: "otherwise compression ratio is reported within a stated tolerance").  Blocks up to 4 MiB are compressed as
+ * 64 KiB segments in parallel; what lies beyond 4 MiB of a block goes out as literals.  env FOURMC_LZ4_ENCODE = exact | parallel. */
+void fourmc_gpu_set_lz4_encode_mode(int mode);
+int  fourmc_gpu_get_lz4_encode_mode(void);
 /* Tuning knob (not part of the reference boundary): which LZ4 decode path serves the launches - 6 auto (default: the
  * segment-parallel path for launches that fill the chip, the walk + window copier below), 2 the exact walker alone, 9 the walk +
  * window copier, 11 the segment-parallel path; results are identical (env FOURMC_DECODE = auto | exact | wx | seg). */
