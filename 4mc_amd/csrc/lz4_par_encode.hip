@@ -33,16 +33,17 @@
 #include "devenc.h"
 
 #ifndef FOURMC_PAR_NENT
-#define FOURMC_PAR_NENT 5056
+#define FOURMC_PAR_NENT 4864
 #endif
 
 namespace {
 
 constexpr int      kSeg       = 65536;                 // bytes of a segment
 constexpr int      kSegs      = 64;                    // segments of a block (what lies beyond goes out as literals)
-constexpr int      kNent      = FOURMC_PAR_NENT;       // table entries per wave (u16); 4 waves: 40 448 B of LDS, 4 groups per CU
+constexpr int      kNent      = FOURMC_PAR_NENT;       // table entries per wave (u16): 9728 B + 512 B of staging = 10 KiB, 16 waves per CU
 constexpr int      kFwd       = 12;                    // bytes compared forwards in the lanes (4 backwards)
 constexpr uint32_t kSegStride = 66048;                 // workspace bytes of a segment: 65536 + 65536/255 + 16, rounded up to 256
+constexpr int      kStage     = 512;                   // staging area of a wave: 256 bytes leave at a time, a sequence adds < 200
 constexpr uint32_t kMetaBytes = kSegs * 8;             // {bytes written, literals left} per segment
 static_assert((kNent * 2) % 16 == 0, "table is zeroed 16 bytes at a time");
 
@@ -51,7 +52,8 @@ __device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l) { return uint32_
 __device__ __forceinline__ uint32_t bperm(uint32_t v, uint32_t srclane) { return uint32_t(__builtin_amdgcn_ds_bpermute(int(srclane << 2), int(v))); }
 // lane l <- lane l + 1 (lane 63 <- 0)
 __device__ __forceinline__ int next_lane(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
-__device__ __forceinline__ uint32_t ffbl(uint32_t x) { return x ? uint32_t(__builtin_ctz(x)) : 0xFFFFFFFFu; }   // v_ffbl_b32
+// index of the lowest set bit, 0xFFFFFFFF for 0 (what the instruction returns; `x ? ctz(x) : -1` costs a compare and a select more)
+__device__ __forceinline__ uint32_t ffbl(uint32_t x) { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
 
 __device__ __forceinline__ uint4 ld16(const uint8_t* p)
 {
@@ -66,14 +68,42 @@ __device__ __forceinline__ uint8_t* seg_area(uint8_t* work, uint32_t nblocks, ui
 __device__ __forceinline__ SegMeta* seg_meta(uint8_t* work, uint32_t b) { return reinterpret_cast<SegMeta*>(work + size_t(b) * kMetaBytes); }
 
 // --------------------------------------------------------------------------------------------------------------- segments
-__global__ __launch_bounds__(256)
+// Sequence bytes collect in an LDS staging area and leave 256 bytes at a time (16 lanes x 16 bytes, aligned): a wave's loads and
+// stores share one in-order counter, and a store per sequence in front of every candidate gather made each window wait for its
+// stores to be acknowledged.
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return uint32_t(uintptr_t((const __attribute__((address_space(3))) void*)p)); }
+// lanes of `mask` store the low byte of val at LDS address vaddr (the mask comes from scalars: no vector compare)
+template <int OFF>
+__device__ __forceinline__ void put_lanes(uint32_t vaddr, uint32_t val, unsigned long long mask)
+{ asm volatile("s_mov_b64 exec, %0\n\tds_write_b8 %1, %2 offset:%3\n\ts_mov_b64 exec, -1" :: "s"(mask), "v"(vaddr), "v"(val), "i"(OFF) : "memory"); }
+__device__ __forceinline__ uint32_t prev_lane(uint32_t v) { return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x138, 0xf, 0xf, false)); }   // lane l <- lane l - 1 (lane 0 <- 0)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dppz(uint32_t v) { return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, ROWMASK, 0xf, false)); }
+__device__ __forceinline__ uint32_t scan_max(uint32_t v)       // inclusive prefix maximum over the wave
+{
+    v = max(v, dppz<0x111, 0xf>(v)); v = max(v, dppz<0x112, 0xf>(v)); v = max(v, dppz<0x114, 0xf>(v)); v = max(v, dppz<0x118, 0xf>(v));
+    v = max(v, dppz<0x142, 0xa>(v)); v = max(v, dppz<0x143, 0xc>(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t scan_add_incl(uint32_t v)
+{
+    v += dppz<0x111, 0xf>(v); v += dppz<0x112, 0xf>(v); v += dppz<0x114, 0xf>(v); v += dppz<0x118, 0xf>(v);
+    v += dppz<0x142, 0xa>(v); v += dppz<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ unsigned long long lane_range(int lo, int cnt)      // lanes [lo, lo + cnt), cnt 0..64
+{ return (cnt >= 64 ? ~0ull : ((1ull << cnt) - 1)) << lo; }
+
+struct Win { uint32_t prev4, cur0, cur1, cur2; int c; bool valid; uint4 gv; };
+
+__global__ __launch_bounds__(64)
 void lz4_par_segment_kernel(const uint8_t* __restrict__ src_base, const fourmc_block* __restrict__ blocks, uint32_t nblocks,
                             uint8_t* __restrict__ work)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t tabs[4][kNent];
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = U(threadIdx.x >> 6);
-    const uint32_t gseg = blockIdx.x * 4 + wave, b = gseg / kSegs, k = gseg % kSegs;
+    __shared__ __attribute__((aligned(16))) uint16_t tab[kNent];
+    __shared__ __attribute__((aligned(16))) uint8_t stg[kStage];
+    const int lane = threadIdx.x;
+    const uint32_t gseg = blockIdx.x, b = gseg / kSegs, k = gseg % kSegs;
     if (b >= nblocks) return;
     const fourmc_block blk = uniform_block(blocks[b]);
     const uint8_t* in = src_base + blk.src_off;
@@ -83,51 +113,102 @@ void lz4_par_segment_kernel(const uint8_t* __restrict__ src_base, const fourmc_b
     if (s0 >= n) { if (lane == 0) { meta->len = 0; meta->tail = 0; } return; }
     const int s1 = min(s0 + kSeg, n);
     uint8_t* out = seg_area(work, nblocks, b, k);
-    uint16_t* tab = tabs[wave];
     for (int i = lane; i < kNent * 2 / 16; i += 64) reinterpret_cast<uint4*>(tab)[i] = make_uint4(0, 0, 0, 0);
 
     const int pmax = min(s1 - 4, n - 32);             // the last position that may start a match (reads stay inside the block)
     const int mend = min(s1, n - 5);                  // matches end at or before (lz4.c:1265: the last 5 bytes are literals)
-    const uint32_t sh8 = uint32_t(lane & 3) * 8, j0 = uint32_t(lane) >> 2;
-    uint32_t op = 0;                                  // bytes of sequences written
+    const uint32_t sh8 = uint32_t(lane & 3) * 8, j0 = uint32_t(lane) >> 2, lane8 = uint32_t(lane) * 8;
+    const uint32_t sbase = lds_addr(stg), vstg = sbase + uint32_t(lane);
+    uint32_t flushed = 0, pend = 0;                   // sequence bytes in the workspace / in the staging area
     int sp = s0;                                      // cursor: end of the last match = start of the pending literals
     uint32_t prevbyte = 0;                            // the previous window's byte of this lane
 
     // dword `lane` of [wb - 4, wb + 84)
+    // (every lane loads, from a clamped address: a load the wave might skip would make the number of loads in flight unknown to
+    // the compiler, and every wait a wait for all of them)
     auto load_win = [&](int wb) -> uint32_t {
-        const int a = wb - 4 + 4 * lane;
-        return (lane < 22 && a >= 0 && a + 4 <= n) ? ld4(in + a) : 0u;
+        const int a = wb - 4 + 4 * min(lane, 21);
+        const uint32_t v = ld4(in + min(max(a, 0), n - 4));
+        return (a >= 0 && a + 4 <= n) ? v : 0u;
     };
-    uint32_t wd = load_win(s0);
-    for (int wb = s0; wb < s1 && wb <= pmax; wb += 64) {
-        const uint32_t wdn = load_win(wb + 64);
+    // first half of a window: the lanes' bytes, the table, the candidate gather (nothing here depends on the parse)
+    auto stage_a = [&](int wb, uint32_t wd) -> Win {
+        Win w;
         const int p = wb + lane;
-        // the lane's 4 bytes before p and 12 from p
         const uint32_t d0 = bperm(wd, j0), d1 = bperm(wd, j0 + 1), d2 = bperm(wd, j0 + 2), d3 = bperm(wd, j0 + 3), d4 = bperm(wd, j0 + 4);
-        const uint32_t prev4 = __builtin_amdgcn_alignbit(d1, d0, sh8), cur0 = __builtin_amdgcn_alignbit(d2, d1, sh8);
-        const uint32_t cur1 = __builtin_amdgcn_alignbit(d3, d2, sh8), cur2 = __builtin_amdgcn_alignbit(d4, d3, sh8);
+        w.prev4 = __builtin_amdgcn_alignbit(d1, d0, sh8); w.cur0 = __builtin_amdgcn_alignbit(d2, d1, sh8);
+        w.cur1 = __builtin_amdgcn_alignbit(d3, d2, sh8); w.cur2 = __builtin_amdgcn_alignbit(d4, d3, sh8);
         const bool act = p <= pmax;
-        const uint32_t ia = (((cur0 * 2654435761u) >> 16) * uint32_t(kNent)) >> 16;
-        uint32_t c16 = 0;
+        const uint32_t ia = (((w.cur0 * 2654435761u) >> 16) * uint32_t(kNent)) >> 16;
+        uint32_t cg[4] = {0, 0, 0, 0};                // (one register per group: the reads do not wait for each other)
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            if ((lane >> 4) == g && act) { c16 = tab[ia]; tab[ia] = uint16_t(p - s0); }
+            if ((lane >> 4) == g && act) { cg[g] = tab[ia]; tab[ia] = uint16_t(p - s0); }
             asm volatile("" ::: "memory");            // the four groups stay four read-then-write pairs, in this order
         }
-        const int c = s0 + int(c16);
-        const bool valid = act && c < p && c >= 4;
-        uint4 gv = make_uint4(0, 0, 0, 0);
-        if (valid) gv = ld16(in + c - 4);
-        const uint32_t xb = prev4 ^ gv.x;
+        w.c = s0 + int(cg[0] | cg[1] | cg[2] | cg[3]);
+        w.valid = act && w.c < p && w.c >= 4;
+        w.gv = ld16(in + (w.valid ? w.c - 4 : 0));
+        return w;
+    };
+    auto flush256 = [&]() {
+        if (lane < 16) *reinterpret_cast<uint4*>(out + flushed + 16 * lane) = *reinterpret_cast<const uint4*>(stg + 16 * lane);
+        const uint32_t rem = pend - 256;
+        if (uint32_t(4 * lane) < rem) { const uint32_t t = *reinterpret_cast<const uint32_t*>(stg + 256 + 4 * lane); *reinterpret_cast<uint32_t*>(stg + 4 * lane) = t; }
+        flushed += 256; pend = rem;
+    };
+    // the general routes (long literal runs, long lengths): through the staging area too, a piece at a time
+    auto stage_len = [&](uint32_t r) {
+        uint32_t n255 = r / 255; const uint32_t last = r - n255 * 255;
+        while (n255) {
+            const uint32_t c = min(n255, 64u);
+            if (uint32_t(lane) < c) stg[pend + lane] = 255;
+            pend += c; n255 -= c;
+            if (pend >= 256) flush256();
+        }
+        if (lane == 0) stg[pend] = uint8_t(last);
+        pend += 1;
+        if (pend >= 256) flush256();
+    };
+    auto stage_copy = [&](const uint8_t* from, uint32_t cnt) {
+        while (cnt) {
+            const uint32_t c = min(cnt, 128u);
+            if (uint32_t(lane) < c) stg[pend + lane] = from[lane];
+            if (uint32_t(lane) + 64 < c) stg[pend + 64 + lane] = from[64 + lane];
+            pend += c; cnt -= c; from += c;
+            if (pend >= 256) flush256();
+        }
+    };
+
+    if (pmax < s0) { if (lane == 0) { meta->len = 0; meta->tail = uint32_t(s1 - s0); } return; }      // (n >= 36 from here on)
+    int wb = s0;
+    uint32_t wdn = load_win(s0 + 64);
+    Win cur = stage_a(s0, load_win(s0));
+    for (bool more = true; more; ) {
+        // the next window's first half runs ahead of this window's walk (past the last window: a window without positions)
+        const int wbn = wb + 64;
+        const bool more_n = wbn < s1 && wbn <= pmax;
+        const uint32_t wdnn = load_win(wbn + 64);
+        const Win nxt = stage_a(wbn, wdn);
+
+        // second half: match lengths, who is eligible
+        const int p = wb + lane;
+        const uint32_t xb = cur.prev4 ^ cur.gv.x;
         int bk = int(min(uint32_t(__clz(int(xb))), 32u) >> 3);                     // equal bytes before p, 0..4
-        const uint32_t bits = min(min(ffbl(cur0 ^ gv.y), ffbl(cur1 ^ gv.z) | 32u), min(ffbl(cur2 ^ gv.w) | 64u, 96u));
-        int mlen = valid ? max(min(int(bits >> 3), mend - p), 0) : 0;              // equal bytes from p, 0..12
-        if (!valid) bk = 0;
+        const uint32_t bits = min(min(ffbl(cur.cur0 ^ cur.gv.y), ffbl(cur.cur1 ^ cur.gv.z) | 32u), min(ffbl(cur.cur2 ^ cur.gv.w) | 64u, 96u));
+        const int mlen = cur.valid ? max(min(int(bits >> 3), mend - p), 0) : 0;    // equal bytes from p, 0..12
+        if (!cur.valid) bk = 0;
         // a position waits when one of the next three has a longer match
         const int m1 = next_lane(mlen), m2 = next_lane(m1), m3 = next_lane(m2);
         const bool elig = mlen >= 4 && max(m1, max(m2 - 1, m3 - 2)) <= mlen;
         const unsigned long long E = __ballot(elig);
 
+        // the walk: which eligible lanes become sequences.  Scalar, and nothing but the cursor: a wave's scalar instructions are
+        // what its SIMD runs out of first (four waves share one scalar issue slot every fourth clock), so everything that can
+        // be said for all the window's sequences at once is said by the lanes afterwards.
+        const int sp_in = sp;
+        unsigned long long C = 0;
+        int mlx = mlen;                               // the chosen lanes' lengths, extended
         for (;;) {
             const int rel = max(sp - wb, 0);
             if (rel >= 64) break;
@@ -136,9 +217,9 @@ void lz4_par_segment_kernel(const uint8_t* __restrict__ src_base, const fourmc_b
             const int l = __builtin_ctzll(em);
             const int pp = wb + l;
             int ml = int(rdl(uint32_t(mlen), l));
-            const int cc = int(rdl(uint32_t(c), l));
             if (ml == kFwd) {
                 // the whole wave compares on: 4 bytes per lane, 256 per step
+                const int cc = int(rdl(uint32_t(cur.c), l));
                 int e = kFwd;
                 for (;;) {
                     const int q = pp + e + 4 * lane;
@@ -150,60 +231,76 @@ void lz4_par_segment_kernel(const uint8_t* __restrict__ src_base, const fourmc_b
                     if (pp + e >= mend) break;
                 }
                 ml = min(e, mend - pp);
+                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(mlx) : "s"(ml), "s"(l) : "m0");
             }
-            const int back = min(int(rdl(uint32_t(bk), l)), pp - sp);
-            const int start = pp - back, ll = start - sp, mt = ml + back - 4;
-            const uint32_t off = uint32_t(pp - cc);
-            uint8_t* o = out + op;
-            // token and literal length
-            uint32_t hdr = 1, hlanes = 1;
-            uint32_t head = uint32_t(min(ll, 15)) << 4 | uint32_t(min(mt, 15));
-            if (ll >= 15) {
-                const uint32_t r = uint32_t(ll - 15);
-                if (r < 255) { head |= r << 8; hdr = hlanes = 2; }
-                else hdr = 1 + emit_len(o + 1, r, lane);
-            }
-            if (uint32_t(lane) < hlanes) o[lane] = uint8_t(head >> (8 * lane));
-            // literals [sp, start): older windows from memory, the previous and this window from the lanes
-            uint8_t* lit = o + hdr;
-            if (sp < wb) {
-                if (sp < wb - 64) copy_bytes(lit, in + sp, uint32_t(wb - 64 - sp), lane);
-                const int lo = max(sp, wb - 64) - (wb - 64), hi = min(start, wb) - (wb - 64);
-                if (lane >= lo && lane < hi) (lit + (wb - 64 - sp))[lane] = uint8_t(prevbyte);
-            }
-            {
-                const int lo = max(sp, wb) - wb, hi = start - wb;
-                if (lane >= lo && lane < hi) (lit + (wb - sp))[lane] = uint8_t(cur0);
-            }
-            // offset and match length
-            uint8_t* tr = lit + ll;
-            uint32_t tbytes = 2, tlanes = 2, trail = off;
-            if (mt >= 15) {
-                const uint32_t r = uint32_t(mt - 15);
-                if (r < 255) { trail |= r << 16; tbytes = tlanes = 3; }
-                else tbytes = 2 + emit_len(tr + 2, r, lane);
-            }
-            if (uint32_t(lane) < tlanes) tr[lane] = uint8_t(trail >> (8 * lane));
-            op += hdr + uint32_t(ll) + tbytes;
+            C |= 1ull << l;
             sp = pp + ml;
         }
-        prevbyte = cur0;
-        wd = wdn;
+        if (C) {
+            // the sequences of the window, all at once: lane i of C is a sequence
+            uint32_t cm; asm("v_cndmask_b32 %0, 0, -1, %1" : "=v"(cm) : "s"(C));
+            const uint32_t endv = uint32_t(p + mlx) & cm;
+            const uint32_t einc = scan_max(endv);                                       // end of the last match at or before the lane
+            const int prevend = max(int(prev_lane(einc)), sp_in);                       // ... before the lane
+            const int back = min(bk, p - prevend);
+            const int start = p - back, ll = start - prevend, mt = mlx + back - 4;
+            const unsigned long long slow = __ballot((uint32_t(max(ll, mt)) & cm) >= 15u + 255u);
+            if (slow == 0 && sp_in >= wb - 64) {
+                const uint32_t hdr = ll >= 15 ? 2u : 1u, tb = mt >= 15 ? 3u : 2u;
+                const uint32_t size = (hdr + uint32_t(ll) + tb) & cm;
+                const uint32_t sinc = scan_add_incl(size);
+                const uint32_t o = pend + sinc - size;                                  // where the sequence starts in the staging area
+                const uint32_t a1 = sbase + o, a2 = a1 + hdr + uint32_t(ll);
+                const uint32_t off = uint32_t(p - cur.c);
+                put_lanes<0>(a1, uint32_t(min(ll, 15)) << 4 | uint32_t(min(mt, 15)), C);
+                put_lanes<1>(a1, uint32_t(ll - 15), __ballot(ll >= 15) & C);
+                put_lanes<0>(a2, off, C);
+                put_lanes<1>(a2, off >> 8, C);
+                put_lanes<2>(a2, uint32_t(mt - 15), __ballot(mt >= 15) & C);
+                // literals: a lane no match covers belongs to the next sequence of the window, if there is one
+                const uint32_t pack = ((o + hdr - uint32_t(prevend - wb)) & 0xFFFFu) | uint32_t(start - wb + 4) << 16;
+                const unsigned long long up = C >> lane;
+                const uint32_t nextidx = uint32_t(lane) + min(ffbl(uint32_t(up)), ffbl(uint32_t(up >> 32)) | 32u);
+                const uint32_t pk = bperm(pack, nextidx & 63u);
+                const bool lit = p >= max(int(einc), sp_in) && up != 0 && lane + 4 < int(pk >> 16);
+                put_lanes<0>(vstg + uint32_t(int(int16_t(pk))), cur.cur0, __ballot(lit));
+                if (sp_in < wb) {
+                    // what the previous window left belongs to the first sequence
+                    const uint32_t pk0 = rdl(pack, uint32_t(__builtin_ctzll(C)));
+                    const int lo = sp_in - (wb - 64), hi = min(int(pk0 >> 16) - 4, 0) + 64;
+                    put_lanes<0>(vstg + uint32_t(int(int16_t(pk0)) - 64), prevbyte, lane_range(lo, hi - lo));
+                }
+                pend += rdl(sinc, 63);
+                if (pend >= 256) flush256();
+            } else {
+                // the general route (long literal runs, long lengths), a sequence at a time from memory
+                int spx = sp_in;
+                for (unsigned long long m = C; m; m &= m - 1) {
+                    const int l = __builtin_ctzll(m);
+                    const int pp = wb + l, ml = int(rdl(uint32_t(mlx), l)), cc = int(rdl(uint32_t(cur.c), l));
+                    const int bb = min(int(rdl(uint32_t(bk), l)), pp - spx);
+                    const int st = pp - bb, sll = st - spx, smt = ml + bb - 4;
+                    const uint32_t soff = uint32_t(pp - cc);
+                    if (lane == 0) stg[pend] = uint8_t(uint32_t(min(sll, 15)) << 4 | uint32_t(min(smt, 15)));
+                    pend += 1;
+                    if (sll >= 15) stage_len(uint32_t(sll - 15));
+                    stage_copy(in + spx, uint32_t(sll));
+                    if (lane < 2) stg[pend + lane] = uint8_t(soff >> lane8);
+                    pend += 2;
+                    if (smt >= 15) stage_len(uint32_t(smt - 15));
+                    if (pend >= 256) flush256();
+                    spx = pp + ml;
+                }
+            }
+        }
+        prevbyte = cur.cur0;
+        cur = nxt; wdn = wdnn; wb = wbn; more = more_n;
     }
-    if (lane == 0) { meta->len = op; meta->tail = uint32_t(s1 - sp); }
+    for (uint32_t i = lane; i < pend; i += 64) out[flushed + i] = stg[i];
+    if (lane == 0) { meta->len = flushed + pend; meta->tail = uint32_t(s1 - sp); }
 }
 
 // ----------------------------------------------------------------------------------------------------------------- stitch
-__device__ __forceinline__ uint32_t scan_add_incl(uint32_t v)
-{
-    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xf, 0xf, false));
-    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xf, 0xf, false));
-    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xf, 0xf, false));
-    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xf, 0xf, false));
-    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xa, 0xf, false));
-    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xc, 0xf, false));
-    return v;
-}
 __device__ __forceinline__ uint32_t len_bytes(uint32_t ll) { return ll >= 15 ? (ll - 15) / 255 + 1 : 0; }
 
 // container_mode = 0: result = bytes of the LZ4 block, 0 when it does not fit dst_cap (the convention of LZ4_compress_default).
@@ -292,7 +389,7 @@ extern "C" hipError_t fourmc_launch_lz4_encode_par(const void* d_src, void* d_ds
 {
     if (n == 0) return hipSuccess;
     const dim3 grid(n * (kSegs / 4)), wg(256);
-    hipLaunchKernelGGL(lz4_par_segment_kernel, grid, wg, 0, stream, static_cast<const uint8_t*>(d_src), d_blocks, n,
+    hipLaunchKernelGGL(lz4_par_segment_kernel, dim3(n * kSegs), dim3(64), 0, stream, static_cast<const uint8_t*>(d_src), d_blocks, n,
                        static_cast<uint8_t*>(d_work));
     hipLaunchKernelGGL(lz4_par_stitch_kernel, grid, wg, 0, stream, static_cast<const uint8_t*>(d_src),
                        static_cast<uint8_t*>(d_dst), d_blocks, n, container_mode, static_cast<uint8_t*>(d_work));
