@@ -5,13 +5,13 @@
 // under north_star's clause "otherwise compression ratio is reported within a stated tolerance": the payload is ONE valid LZ4
 // block that the reference's LZ4_decompress_safe (lz4.c:2345) decodes to the input, but not the reference's parse.  The
 // reference parse is a chain (each table read depends on every earlier decision); this one has no chain longer than a window:
-//   * a 4 MiB block is 64 segments of 64 KiB, one wavefront each, 16 waves per CU (an NENT x u16 table per wave in LDS:
-//     10 KiB).  A segment's matches stay inside the segment (offsets < 64 Ki by construction);
+//   * a 4 MiB block is 64 segments of 64 KiB, one wavefront each, 18 waves per CU (an NENT x u16 table per wave in LDS:
+//     8 KiB, + 512 bytes of staging).  A segment's matches stay inside the segment (offsets < 64 Ki by construction);
 //   * a window is 64 consecutive positions, lane l <-> position wb + l.  EVERY position enters the table (the table does not
 //     depend on the parse), in four groups of 16 lanes, a group reading before it writes, so that a lane sees the positions
 //     of the groups before it - candidates 16 and more bytes back are never missed, nearer ones are picked up by the
 //     lanes behind (the match extends);
-//   * one candidate per position, ONE 16-byte gather per lane (4 bytes before the candidate, 12 from it) against the lane's
+//   * one candidate per position (the table's, or the position 1, 2 or 4 back when it holds the same 4 bytes), ONE 16-byte gather per lane (4 bytes before the candidate, 12 from it) against the lane's
 //     own bytes (the window is loaded once as 22 dwords and handed out with ds_bpermute): match length 0..12 forwards and
 //     0..4 backwards;
 //   * a position is skipped when one of the next three positions holds a longer match (by 1, 2, 3 - what a lazy parser finds
@@ -23,7 +23,7 @@
 //     sequence of the next one that has a sequence, and writes the block's last literals (lz4.c:1265-1290 rules: last 5 bytes
 //     literals, no match starting in the last 12) - one LZ4 block, no new format.
 // `tools/model/lz4p_model.c` is the executable statement of the same rules (sizes on the S-mix: 2.2 % above the reference
-// parse at NENT = 5056); `tests/test_gpu_lz4par_encode.py` holds the tolerance and the reference decoder's verdict.
+// parse at NENT = 4096); `tests/test_gpu_lz4par_encode.py` holds the tolerance and the reference decoder's verdict.
 // HBM traffic per block: n read (candidates re-read from L1/L2), csize written to the workspace, read and written once more by
 // the stitch.
 #include <hip/hip_runtime.h>
@@ -33,14 +33,14 @@
 #include "devenc.h"
 
 #ifndef FOURMC_PAR_NENT
-#define FOURMC_PAR_NENT 4864
+#define FOURMC_PAR_NENT 4096
 #endif
 
 namespace {
 
 constexpr int      kSeg       = 65536;                 // bytes of a segment
 constexpr int      kSegs      = 64;                    // segments of a block (what lies beyond goes out as literals)
-constexpr int      kNent      = FOURMC_PAR_NENT;       // table entries per wave (u16): 9728 B + 512 B of staging = 10 KiB, 16 waves per CU
+constexpr int      kNent      = FOURMC_PAR_NENT;       // table entries per wave (u16): 8 KiB + 512 B of staging, 18 waves per CU
 constexpr int      kFwd       = 12;                    // bytes compared forwards in the lanes (4 backwards)
 constexpr uint32_t kSegStride = 66048;                 // workspace bytes of a segment: 65536 + 65536/255 + 16, rounded up to 256
 constexpr int      kStage     = 512;                   // staging area of a wave: 256 bytes leave at a time, a sequence adds < 200
@@ -126,29 +126,48 @@ void lz4_par_segment_kernel(const uint8_t* __restrict__ src_base, const fourmc_b
     // dword `lane` of [wb - 4, wb + 84)
     // (every lane loads, from a clamped address: a load the wave might skip would make the number of loads in flight unknown to
     // the compiler, and every wait a wait for all of them)
-    auto load_win = [&](int wb) -> uint32_t {
-        const int a = wb - 4 + 4 * min(lane, 21);
-        const uint32_t v = ld4(in + min(max(a, 0), n - 4));
-        return (a >= 0 && a + 4 <= n) ? v : 0u;
-    };
+    const uint32_t lane4 = 4u * uint32_t(min(lane, 21));
+    // The address is clamped into the block and nothing else: a lane that gets other bytes than its own that way is either one of
+    // the block's first 4 positions looking back (their candidates are refused: c < 4) or lies behind pmax + 12.
+    auto load_win = [&](int wb) -> uint32_t { return ld4(in + uint32_t(min(max(wb - 4 + int(lane4), 0), n - 4))); };
     // first half of a window: the lanes' bytes, the table, the candidate gather (nothing here depends on the parse)
     auto stage_a = [&](int wb, uint32_t wd) -> Win {
         Win w;
         const int p = wb + lane;
-        const uint32_t d0 = bperm(wd, j0), d1 = bperm(wd, j0 + 1), d2 = bperm(wd, j0 + 2), d3 = bperm(wd, j0 + 3), d4 = bperm(wd, j0 + 4);
-        w.prev4 = __builtin_amdgcn_alignbit(d1, d0, sh8); w.cur0 = __builtin_amdgcn_alignbit(d2, d1, sh8);
-        w.cur1 = __builtin_amdgcn_alignbit(d3, d2, sh8); w.cur2 = __builtin_amdgcn_alignbit(d4, d3, sh8);
+        const uint32_t d1 = bperm(wd, j0 + 1), d2 = bperm(wd, j0 + 2);
+        w.cur0 = __builtin_amdgcn_alignbit(d2, d1, sh8);
         const bool act = p <= pmax;
-        const uint32_t ia = (((w.cur0 * 2654435761u) >> 16) * uint32_t(kNent)) >> 16;
-        uint32_t cg[4] = {0, 0, 0, 0};                // (one register per group: the reads do not wait for each other)
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            if ((lane >> 4) == g && act) { cg[g] = tab[ia]; tab[ia] = uint16_t(p - s0); }
-            asm volatile("" ::: "memory");            // the four groups stay four read-then-write pairs, in this order
-        }
-        w.c = s0 + int(cg[0] | cg[1] | cg[2] | cg[3]);
+        // (two 24-bit multiplies: full rate; a 32-bit multiply issues for four instructions' time and hashes no better here)
+        const uint32_t hh = (uint32_t(__umul24(w.cur0, 0x9E3779u)) + uint32_t(__umul24(w.cur0 >> 8, 0x85EBCAu))) >> 16;   // (__umul24 returns int)
+        const uint32_t ta = lds_addr(tab) + (((hh * uint32_t(kNent)) >> 16) << 1);
+        // the table, four groups of 16 lanes, each group reading before it writes (LDS operations of a wave execute in order),
+        // and the other three dwords the lane needs; one wait for all of it
+        const unsigned long long am = __ballot(act);
+        uint32_t c0, c1, c2, c3, d0, d3, d4;
+        asm volatile(
+            "s_mov_b64 exec, %[m0]\n\tds_read_u16 %[c0], %[a]\n\tds_write_b16 %[a], %[v]\n\t"
+            "s_mov_b64 exec, %[m1]\n\tds_read_u16 %[c1], %[a]\n\tds_write_b16 %[a], %[v]\n\t"
+            "s_mov_b64 exec, %[m2]\n\tds_read_u16 %[c2], %[a]\n\tds_write_b16 %[a], %[v]\n\t"
+            "s_mov_b64 exec, %[m3]\n\tds_read_u16 %[c3], %[a]\n\tds_write_b16 %[a], %[v]\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "ds_bpermute_b32 %[d0], %[j], %[wd]\n\tds_bpermute_b32 %[d3], %[j], %[wd] offset:12\n\tds_bpermute_b32 %[d4], %[j], %[wd] offset:16\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : [c0] "=&v"(c0), [c1] "=&v"(c1), [c2] "=&v"(c2), [c3] "=&v"(c3), [d0] "=&v"(d0), [d3] "=&v"(d3), [d4] "=&v"(d4)
+            : [a] "v"(ta), [v] "v"(uint32_t(p - s0)), [j] "v"(j0 << 2), [wd] "v"(wd),
+              [m0] "s"(am & 0xFFFFull), [m1] "s"(am & 0xFFFF0000ull), [m2] "s"(am & 0xFFFF00000000ull), [m3] "s"(am & 0xFFFF000000000000ull)
+            : "memory");
+        w.prev4 = __builtin_amdgcn_alignbit(d1, d0, sh8);
+        w.cur1 = __builtin_amdgcn_alignbit(d3, d2, sh8); w.cur2 = __builtin_amdgcn_alignbit(d4, d3, sh8);
+        const uint32_t c16 = lane < 32 ? (lane < 16 ? c0 : c1) : (lane < 48 ? c2 : c3);     // (a register is only defined in its group)
+        w.c = s0 + int(c16);
+        // the same 4 bytes 1, 2 or 4 positions back (the lane holds them): the nearest goes before what the table said - a
+        // lane does not see its own group's positions in the table, and runs and 4-byte strides are what that loses most
+        const uint32_t b1 = __builtin_amdgcn_alignbit(w.cur0, w.prev4, 24), b2 = __builtin_amdgcn_alignbit(w.cur0, w.prev4, 16);
+        w.c = w.cur0 == w.prev4 ? p - 4 : w.c;
+        w.c = w.cur0 == b2 ? p - 2 : w.c;
+        w.c = w.cur0 == b1 ? p - 1 : w.c;
         w.valid = act && w.c < p && w.c >= 4;
-        w.gv = ld16(in + (w.valid ? w.c - 4 : 0));
+        w.gv = ld16(in + uint32_t(w.valid ? w.c - 4 : 0));
         return w;
     };
     auto flush256 = [&]() {
@@ -196,7 +215,9 @@ void lz4_par_segment_kernel(const uint8_t* __restrict__ src_base, const fourmc_b
         const uint32_t xb = cur.prev4 ^ cur.gv.x;
         int bk = int(min(uint32_t(__clz(int(xb))), 32u) >> 3);                     // equal bytes before p, 0..4
         const uint32_t bits = min(min(ffbl(cur.cur0 ^ cur.gv.y), ffbl(cur.cur1 ^ cur.gv.z) | 32u), min(ffbl(cur.cur2 ^ cur.gv.w) | 64u, 96u));
-        const int mlen = cur.valid ? max(min(int(bits >> 3), mend - p), 0) : 0;    // equal bytes from p, 0..12
+        int mlen = int(bits >> 3);                                                 // equal bytes from p, 0..12
+        if (wb + 63 + kFwd > mend) mlen = max(min(mlen, mend - p), 0);
+        if (!cur.valid) mlen = 0;
         if (!cur.valid) bk = 0;
         // a position waits when one of the next three has a longer match
         const int m1 = next_lane(mlen), m2 = next_lane(m1), m3 = next_lane(m2);
@@ -221,7 +242,8 @@ void lz4_par_segment_kernel(const uint8_t* __restrict__ src_base, const fourmc_b
                 // the whole wave compares on: 4 bytes per lane, 256 per step
                 const int cc = int(rdl(uint32_t(cur.c), l));
                 int e = kFwd;
-                for (;;) {
+                bool open = true;
+                while (open) {
                     const int q = pp + e + 4 * lane;
                     uint32_t x = 1;
                     if (q + 4 <= n) x = ld4(in + q) ^ ld4(in + cc + e + 4 * lane);

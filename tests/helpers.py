@@ -134,6 +134,29 @@ def orc_container(src, magic=0x344D4300):
     return dst[:n].copy()
 
 
+def lz4p_model():
+    """tools/model/lz4p_model.c: the executable statement of the ratio-tolerance LZ4 encoder's rules (test infrastructure, like
+    oracle/: the product never links it)."""
+    if "lz4p" not in _cache:
+        d = os.path.join(ROOT, "tools", "model")
+        so = os.path.join(d, "liblz4p_model.so")
+        src = os.path.join(d, "lz4p_model.c")
+        if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
+            subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-DLZ4P_NO_MAIN", "-o", so, src], check=True)
+        L = C.CDLL(so)
+        L.lz4p_model_encode.restype = C.c_int
+        L.lz4p_model_encode.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        _cache["lz4p"] = L
+    return _cache["lz4p"]
+
+
+def lz4p_model_encode(src, cap):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    out = np.zeros(cap + 8, dtype=np.uint8)
+    r = lz4p_model().lz4p_model_encode(src.ctypes.data if len(src) else None, len(src), out.ctypes.data, cap)
+    return r, out[:max(r, 0)].copy()
+
+
 def orc_container_decode(img, cap, magic=0x344D4300):
     img = np.ascontiguousarray(img, dtype=np.uint8)
     L = oracle()

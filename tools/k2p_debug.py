@@ -17,7 +17,7 @@ model = C.CDLL(so); model.lz4p_model_encode.restype = C.c_int
 model.lz4p_model_encode.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
 import re
 NENT = int(re.search(r"#define FOURMC_PAR_NENT (\d+)", open(os.path.join(ROOT, "4mc_amd/csrc/lz4_par_encode.hip")).read()).group(1))
-model.lz4p_model_set(NENT, 16, 4, 3, 12)
+model.lz4p_model_set(NENT, 16, 4, 3, 12, 0x16)
 orc = helpers.oracle()
 p.lib().fourmc_gpu_set_lz4_encode_mode(1)
 

@@ -2,7 +2,8 @@
  * tools/model/lz4p_model.c - executable model of the ratio-tolerance LZ4 encoder (4mc_amd/csrc/lz4_par_encode.hip), statement
  * by statement what the kernels do: 64 KiB segments of a block compressed independently by one wave each (window of 64
  * positions, every position inserted into an NENT x u16 table in groups of 16 - a group reads before it writes -, one candidate
- * per position compared 4 bytes backwards and 12 forwards, a position skipped when one of the next three has a longer match,
+ * per position - the table's, or the position 1, 2 or 4 back when it holds the same 4 bytes - compared 4 bytes backwards and 12
+ * forwards, a position skipped when one of the next three has a longer match,
  * first eligible position at or after the cursor taken, matches that reach the 12 bytes extended), then the segments' sequences
  * stitched into ONE LZ4 block (the literals a segment ends with join the first sequence of the next).
  * Prints the size against the reference parse (oracle) per S-mix block and checks every payload with the oracle's
@@ -16,11 +17,21 @@
 #include <stdint.h>
 
 #define SEG 65536
-static int NENT = 5056, GROUP = 16, BACK = 4, LAZY = 3, FWD = 12;
+static int NENT = 4096, GROUP = 16, BACK = 4, LAZY = 3, FWD = 12;
+static unsigned NEAR = 0x16;                        /* bit d: a lane also looks d positions back in its row of 16 lanes */
 static long n_ext, n_seq_tot, n_prevwin, n_older;
 
 static uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
-static uint32_t slot(const uint8_t* p) { return (((rd32(p) * 2654435761u) >> 16) * (uint32_t)NENT) >> 16; }
+static int HASHV = 1;
+static uint32_t slot(const uint8_t* p)
+{
+    uint32_t x = rd32(p), h;
+    if (HASHV == 0) h = (x * 2654435761u) >> 16;
+    else if (HASHV == 1) h = ((x & 0xFFFFFF) * 0x9E3779u + (x >> 8) * 0x85EBCAu) >> 16;         /* two 24-bit multiplies */
+    else if (HASHV == 2) h = (((x & 0xFFFFFF) * 0x9E3779u) ^ ((x >> 8) * 0x85EBCBu)) >> 16;
+    else h = ((x & 0xFFFFFF) * 0x9E3779u + ((x >> 8) & 0xFFFFFF) * 0xC2B2AEu) >> 15;
+    return ((h & 0xFFFF) * (uint32_t)NENT) >> 16;
+}
 
 static uint8_t* put_len(uint8_t* o, uint32_t r) { while (r >= 255) { *o++ = 255; r -= 255; } *o++ = (uint8_t)r; return o; }
 /* one sequence: literals [lit, lit+ll), then a match (ml >= 4) or nothing (ml == 0: the last literals of a block) */
@@ -51,6 +62,12 @@ static uint32_t encode_segment(const uint8_t* in, uint32_t n, uint32_t s0, uint3
         for (int g = 0; g < 64; g += GROUP) {
             for (int l = g; l < g + GROUP; l++) { uint32_t p = wb + l; cand[l] = (int)p <= pmax ? s0 + table[slot(in + p)] : 0xFFFFFFFF; }
             for (int l = g; l < g + GROUP; l++) { uint32_t p = wb + l; if ((int)p <= pmax) table[slot(in + p)] = (uint16_t)(p - s0); }
+        }
+        for (int l = 0; l < 64 && NEAR; l++) {
+            uint32_t p = wb + l;
+            if ((int)p > pmax) continue;
+            for (int d = 1; d < 16; d++)
+                if (((NEAR >> d) & 1) && ((l & 15) >= d || d <= 4) && p >= (uint32_t)d && rd32(in + p) == rd32(in + p - d)) { cand[l] = p - d; break; }
         }
         for (int l = 0; l < 64; l++) {
             uint32_t p = wb + l, c = cand[l]; mlen[l] = 0; bk[l] = 0;
@@ -114,7 +131,7 @@ int lz4p_model_encode(const uint8_t* in, uint32_t n, uint8_t* out, uint32_t cap)
     free(scratch); free(tmp);
     return r;
 }
-void lz4p_model_set(int nent, int group, int back, int lazy, int fwd) { NENT = nent; GROUP = group; BACK = back; LAZY = lazy; FWD = fwd; }
+void lz4p_model_set(int nent, int group, int back, int lazy, int fwd, unsigned near) { NENT = nent; GROUP = group; BACK = back; LAZY = lazy; FWD = fwd; NEAR = near; }
 
 #ifndef LZ4P_NO_MAIN
 #include "oracle.h"
@@ -132,6 +149,8 @@ int main(int argc, char** argv)
         else if (!strncmp(argv[i], "back=", 5)) BACK = atoi(argv[i] + 5);
         else if (!strncmp(argv[i], "lazy=", 5)) LAZY = atoi(argv[i] + 5);
         else if (!strncmp(argv[i], "fwd=", 4)) FWD = atoi(argv[i] + 4);
+        else if (!strncmp(argv[i], "hash=", 5)) HASHV = atoi(argv[i] + 5);
+        else if (!strncmp(argv[i], "near=", 5)) NEAR = strtoul(argv[i] + 5, 0, 0);
         else if (!strncmp(argv[i], "bsize=", 6)) bsize = atoi(argv[i] + 6);
     }
     uint8_t* in = malloc(B + 64); uint8_t* c = malloc(B + B / 255 + 64); uint8_t* c2 = malloc(B + B / 255 + 4096); uint8_t* back = malloc(B);
