@@ -167,6 +167,9 @@ void lz4_par_segment_kernel(const uint8_t* __restrict__ src_base, const fourmc_b
         w.c = w.cur0 == b2 ? p - 2 : w.c;
         w.c = w.cur0 == b1 ? p - 1 : w.c;
         w.valid = act && w.c < p && w.c >= 4;
+#ifdef K2P_MAXDIST
+        w.valid = w.valid && p - w.c < K2P_MAXDIST;       // (timing experiment: what the far candidates' reads cost)
+#endif
         w.gv = ld16(in + uint32_t(w.valid ? w.c - 4 : 0));
         return w;
     };
@@ -317,6 +320,7 @@ void lz4_par_segment_kernel(const uint8_t* __restrict__ src_base, const fourmc_b
         }
         prevbyte = cur.cur0;
         cur = nxt; wdn = wdnn; wb = wbn; more = more_n;
+
     }
     for (uint32_t i = lane; i < pend; i += 64) out[flushed + i] = stg[i];
     if (lane == 0) { meta->len = flushed + pend; meta->tail = uint32_t(s1 - sp); }
