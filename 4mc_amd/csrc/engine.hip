@@ -117,6 +117,31 @@ int lease_lz4_decode(WsLease& ws, hipStream_t s, uint32_t n, void** work)
     }
 }
 
+// A launch whose workspace grows with its blocks.  When the device cannot give the memory for all of them at once the launch is cut
+// into pieces, halved until the allocation succeeds: the blocks are independent, so the results are the same and only the chip is
+// filled less well (a 512-block batch of level-12 tables is 25 GiB; nothing retried with a smaller batch).
+// `cap`: the most blocks a piece may have (0: no limit).  FOURMC_WS_FAIL_ABOVE=N makes leases of more than N bytes fail (test aid).
+template <class Bytes, class Launch>
+int in_pieces(hipStream_t s, uint32_t n, uint32_t cap, Bytes bytes, Launch launch)
+{
+    static const size_t fail_above = [] { const char* e = getenv("FOURMC_WS_FAIL_ABOVE"); return e ? size_t(strtoull(e, nullptr, 10)) : size_t(0); }();
+    uint32_t piece = cap && cap < n ? cap : n;
+    WsLease ws; void* work = nullptr;
+    for (;;) {
+        const size_t need = bytes(piece);
+        int r = FOURMC_OK;
+        if (fail_above && need > fail_above) { snprintf(g_err, sizeof g_err, "workspace of %zu bytes refused (FOURMC_WS_FAIL_ABOVE)", need); r = FOURMC_ENOMEM; }
+        else r = ws.get(s, need, &work);
+        if (r == FOURMC_OK) break;
+        (void)hipGetLastError();
+        if (piece <= 1) return r;
+        piece = (piece + 1) / 2;
+    }
+    for (uint32_t b0 = 0; b0 < n; b0 += piece)
+        if (int r = launch(b0, n - b0 < piece ? n - b0 : piece, work)) return r;
+    return FOURMC_OK;
+}
+
 int arena_reserve(Arena& g_arena, size_t src_bytes, size_t dst_bytes, size_t nblk)
 {
     if (!g_arena.stream) HIP_TRY(hipStreamCreateWithFlags(&g_arena.stream, hipStreamNonBlocking));
@@ -206,14 +231,8 @@ static int lz4_fast_encode(const void* d_src, void* d_dst, fourmc_block* d_block
 {
     if (fourmc_gpu_get_lz4_encode_mode() == 1) {
         // pieces bound the workspace (4 MiB per block)
-        const uint32_t piece = 4096;
-        for (uint32_t b0 = 0; b0 < n; b0 += piece) {
-            const uint32_t m = n - b0 < piece ? n - b0 : piece;
-            WsLease ws; void* work = nullptr;
-            if (int r = ws.get(s, fourmc_lz4_par_work_bytes(m), &work)) return r;
-            HIP_TRY(fourmc_launch_lz4_encode_par(d_src, d_dst, d_blocks + b0, m, container_mode, work, s));
-        }
-        return FOURMC_OK;
+        return in_pieces(s, n, 4096, fourmc_lz4_par_work_bytes, [&](uint32_t b0, uint32_t m, void* work) -> int {
+            HIP_TRY(fourmc_launch_lz4_encode_par(d_src, d_dst, d_blocks + b0, m, container_mode, work, s)); return FOURMC_OK; });
     }
     HIP_TRY(fourmc_launch_lz4_encode_fast(d_src, d_dst, d_blocks, n, container_mode, s));
     return FOURMC_OK;
@@ -229,19 +248,17 @@ int fourmc_gpu_lz4_compress_hc(const void* d_src, void* d_dst, fourmc_block* d_b
 {
     if (int r = ensure_device()) return r;
     if (level < 1 || level > 8) { snprintf(g_err, sizeof g_err, "LZ4 HC level %d not on the device (hash-chain levels 1..8 are)", level); return FOURMC_EUNSUP; }
-    WsLease ws; void* work = nullptr;
-    if (int r = ws.get(static_cast<hipStream_t>(stream), fourmc_lz4hc_work_bytes(n), &work)) return r;
-    HIP_TRY(fourmc_launch_lz4hc_encode(d_src, d_dst, d_blocks, n, work, level, 0, static_cast<hipStream_t>(stream)));
-    return FOURMC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return in_pieces(s, n, 0, fourmc_lz4hc_work_bytes, [&](uint32_t b0, uint32_t m, void* work) -> int {
+        HIP_TRY(fourmc_launch_lz4hc_encode(d_src, d_dst, d_blocks + b0, m, work, level, 0, s)); return FOURMC_OK; });
 }
 
 int fourmc_gpu_lz4_compress_mc(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, void* stream)
 {
     if (int r = ensure_device()) return r;
-    WsLease ws; void* work = nullptr;
-    if (int r = ws.get(static_cast<hipStream_t>(stream), fourmc_lz4hc_work_bytes(n), &work)) return r;     // same layout as HC
-    HIP_TRY(fourmc_launch_lz4mc_encode(d_src, d_dst, d_blocks, n, work, 0, static_cast<hipStream_t>(stream)));
-    return FOURMC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return in_pieces(s, n, 0, fourmc_lz4hc_work_bytes, [&](uint32_t b0, uint32_t m, void* work) -> int {      // same layout as HC
+        HIP_TRY(fourmc_launch_lz4mc_encode(d_src, d_dst, d_blocks + b0, m, work, 0, s)); return FOURMC_OK; });
 }
 
 #ifdef FOURMC_RESEARCH      /* debug / profiling exports: the research side build only (make research), never the product's ABI */
@@ -279,10 +296,9 @@ int fourmc_gpu_debug_lz4_parse(const void* d_src, const void* d_dst, fourmc_bloc
 int fourmc_gpu_zstd_decompress(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n, void* stream)
 {
     if (int r = ensure_device()) return r;
-    WsLease ws; void* scratch = nullptr;
-    if (int r = ws.get(static_cast<hipStream_t>(stream), fourmc_zstd_scratch_bytes(n), &scratch)) return r;
-    HIP_TRY(fourmc_launch_zstd_decode(d_src, d_dst, d_blocks, n, scratch, 0, static_cast<hipStream_t>(stream)));
-    return FOURMC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return in_pieces(s, n, 0, fourmc_zstd_scratch_bytes, [&](uint32_t b0, uint32_t m, void* scratch) -> int {
+        HIP_TRY(fourmc_launch_zstd_decode(d_src, d_dst, d_blocks + b0, m, scratch, 0, s)); return FOURMC_OK; });
 }
 
 // zstd levels on the device: 1 (fast), 3 (dfast), 6 (lazy / lazy2), 12 (lazy2, btlazy2, btopt by input size) - the levels 4mz uses;
@@ -300,10 +316,9 @@ int fourmc_gpu_zstd_compress(const void* d_src, void* d_dst, fourmc_block* d_blo
 {
     if (int r = ensure_device()) return r;
     if (int r = zstd_level_ok(d_blocks, n, level, static_cast<hipStream_t>(stream))) return r;
-    WsLease ws; void* work = nullptr;
-    if (int r = ws.get(static_cast<hipStream_t>(stream), fourmc_zstd_enc_work_bytes(n, level), &work)) return r;
-    HIP_TRY(fourmc_launch_zstd_encode(d_src, d_dst, d_blocks, n, work, 0, level, zstd_enc_serial(), static_cast<hipStream_t>(stream)));
-    return FOURMC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return in_pieces(s, n, 0, [&](uint32_t m) { return fourmc_zstd_enc_work_bytes(m, level); }, [&](uint32_t b0, uint32_t m, void* work) -> int {
+        HIP_TRY(fourmc_launch_zstd_encode(d_src, d_dst, d_blocks + b0, m, work, 0, level, zstd_enc_serial(), s)); return FOURMC_OK; });
 }
 
 int fourmc_gpu_xxh32(const void* d_src, fourmc_block* d_blocks, uint32_t n, uint32_t seed, void* stream)
@@ -320,24 +335,21 @@ int fourmc_gpu_4mc_encode_blocks(const void* d_src, void* d_dst, fourmc_block* d
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (codec == FOURMC_CODEC_LZ4_HC) {
         if (level < 1 || level > 8) { snprintf(g_err, sizeof g_err, "LZ4 HC level %d not on the device", level); return FOURMC_EUNSUP; }
-        WsLease ws; void* work = nullptr;
-        if (int r = ws.get(s, fourmc_lz4hc_work_bytes(n), &work)) return r;
-        HIP_TRY(fourmc_launch_lz4hc_encode(d_src, d_dst, d_blocks, n, work, level, 1, s));
+        if (int r = in_pieces(s, n, 0, fourmc_lz4hc_work_bytes, [&](uint32_t b0, uint32_t m, void* work) -> int {
+                HIP_TRY(fourmc_launch_lz4hc_encode(d_src, d_dst, d_blocks + b0, m, work, level, 1, s)); return FOURMC_OK; })) return r;
         HIP_TRY(fourmc_launch_xxh32(d_dst, d_blocks, n, 0, FOURMC_HASH_DST_RESULT, s));
         return FOURMC_OK;
     }
     if (codec == FOURMC_CODEC_LZ4_MC) {
-        WsLease ws; void* work = nullptr;
-        if (int r = ws.get(s, fourmc_lz4hc_work_bytes(n), &work)) return r;
-        HIP_TRY(fourmc_launch_lz4mc_encode(d_src, d_dst, d_blocks, n, work, 1, s));
+        if (int r = in_pieces(s, n, 0, fourmc_lz4hc_work_bytes, [&](uint32_t b0, uint32_t m, void* work) -> int {
+                HIP_TRY(fourmc_launch_lz4mc_encode(d_src, d_dst, d_blocks + b0, m, work, 1, s)); return FOURMC_OK; })) return r;
         HIP_TRY(fourmc_launch_xxh32(d_dst, d_blocks, n, 0, FOURMC_HASH_DST_RESULT, s));
         return FOURMC_OK;
     }
     if (codec == FOURMC_CODEC_ZSTD) {
         if (int r = zstd_level_ok(d_blocks, n, level, s)) return r;
-        WsLease ws; void* work = nullptr;
-        if (int r = ws.get(s, fourmc_zstd_enc_work_bytes(n, level), &work)) return r;
-        HIP_TRY(fourmc_launch_zstd_encode(d_src, d_dst, d_blocks, n, work, 1, level, zstd_enc_serial(), s));
+        if (int r = in_pieces(s, n, 0, [&](uint32_t m) { return fourmc_zstd_enc_work_bytes(m, level); }, [&](uint32_t b0, uint32_t m, void* work) -> int {
+                HIP_TRY(fourmc_launch_zstd_encode(d_src, d_dst, d_blocks + b0, m, work, 1, level, zstd_enc_serial(), s)); return FOURMC_OK; })) return r;
         HIP_TRY(fourmc_launch_xxh32(d_dst, d_blocks, n, 0, FOURMC_HASH_DST_RESULT, s));
         return FOURMC_OK;
     }
@@ -356,11 +368,9 @@ int fourmc_gpu_4mc_decode_blocks(const void* d_src, void* d_dst, fourmc_block* d
     if (int r = ensure_device()) return r;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (codec == FOURMC_CODEC_ZSTD) {              // .4mz: every level decodes with the same kernel
-        WsLease ws; void* scratch = nullptr;
-        if (int r = ws.get(s, fourmc_zstd_scratch_bytes(n), &scratch)) return r;
         HIP_TRY(fourmc_launch_xxh32(d_src, d_blocks, n, 0, FOURMC_VERIFY_SRC, s));
-        HIP_TRY(fourmc_launch_zstd_decode(d_src, d_dst, d_blocks, n, scratch, 1, s));
-        return FOURMC_OK;
+        return in_pieces(s, n, 0, fourmc_zstd_scratch_bytes, [&](uint32_t b0, uint32_t m, void* scratch) -> int {
+            HIP_TRY(fourmc_launch_zstd_decode(d_src, d_dst, d_blocks + b0, m, scratch, 1, s)); return FOURMC_OK; });
     }
     if (codec != FOURMC_CODEC_LZ4_FAST && codec != FOURMC_CODEC_LZ4_MC && codec != FOURMC_CODEC_LZ4_HC) {
         snprintf(g_err, sizeof g_err, "codec %d not implemented on the device yet", codec);

@@ -319,7 +319,7 @@ def main():
                 "encode_kernels_note": "fourmc_gpu_lz4_compress_fast alone (segment kernel + stitch kernel; no checksum launch); algorithmic bytes usize + csize: %.3f of 8 TB/s" % ((nb * B + float(cs.sum())) / (t_k * 1e-3) / 1e9 / HBM_PEAK_GBS),
                 "ratio": round(nb * B / float((cs + 12).sum()), 4),
                 "ratio_vs_reference": round(float((exact + 12).sum()) / float((cs + 12).sum()), 6),
-                "tolerance": "sizes within 3 % of the reference parse over the S-mix (tests/test_gpu_lz4par_encode.py); this run: %+.2f %%" % (100.0 * (float((cs + 12).sum()) / float((exact + 12).sum()) - 1)),
+                "tolerance": "sizes within 3 %% of the reference parse over the S-mix (tests/test_gpu_lz4par_encode.py); this run: %+.2f %%" % (100.0 * (float((cs + 12).sum()) / float((exact + 12).sum()) - 1)),
                 "round_trip": "decoded by the device decoder and compared with the input in this run"}
 
     def decode_64gib():

@@ -238,3 +238,23 @@ def test_c_launcher_gathers_the_index_through_rccl(gpu, golden_corpus, tmp_path)
         ps = [subprocess.Popen([exe, "-d", str(out), str(back)], env=dict(env, RANK=str(rk), WORLD_SIZE="2", LOCAL_RANK="0"), stderr=subprocess.PIPE) for rk in range(2)]
         assert [p.wait(timeout=300) for p in ps] == [0, 0], [p.stderr.read() for p in ps]
         assert _sha(back) == man["corpus"]["sha256"], key
+
+
+@pytest.mark.parametrize("flags,limit", [(["-z", "-1"], 6 << 20), (["-z", "-4"], 120 << 20), (["-3"], 1 << 20)])
+def test_workspace_that_does_not_fit_is_taken_in_pieces(gpu, tmp_path, flags, limit):
+    """A launch whose workspace the device cannot give is cut into pieces instead of failing (engine.hip: in_pieces).
+    FOURMC_WS_FAIL_ABOVE makes every lease above `limit` bytes fail the way hipMalloc would: the files stay the reference's."""
+    data = helpers.corpus(9 * B + 999, first_block=2)
+    src = tmp_path / "in.bin"; src.write_bytes(data.tobytes())
+    outs = []
+    for env in (os.environ, dict(os.environ, FOURMC_WS_FAIL_ABOVE=str(limit))):
+        out = tmp_path / f"o{len(outs)}"
+        r = subprocess.run([gpu.cli_path()] + flags + ["-f", str(src), str(out)], capture_output=True, env=env)
+        assert r.returncode == 0, r.stderr
+        outs.append(out.read_bytes())
+    assert outs[0] == outs[1]
+    back = tmp_path / "back"
+    env = dict(os.environ, FOURMC_WS_FAIL_ABOVE=str(20 << 20))          # the decoders' leases: 14 MiB (4mz) / 11 MiB (4mc) per block
+    r = subprocess.run([gpu.cli_path(), "-d"] + (["-z"] if "-z" in flags else []) + ["-f", str(tmp_path / "o1"), str(back)], capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert back.read_bytes() == data.tobytes()
