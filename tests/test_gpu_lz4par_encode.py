@@ -201,3 +201,11 @@ def test_full_launch_round_trip(par):
     par.lz4_decompress(dst, back, dbatch)
     assert all(r == B for r in dbatch.download()["result"])
     assert torch.equal(back, src)
+
+
+def test_fuzz_slice(gpu):
+    """tools/fuzz_k2p.py (built inputs around the window / segment / end-of-block limits, misaligned, capacities at and below the
+    size): 20 seeds here, thousands by hand (DESIGN.md has the totals)."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "tools", "fuzz_k2p.py"), "5000", "20"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
