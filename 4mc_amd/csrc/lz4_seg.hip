@@ -144,12 +144,22 @@ __device__ __forceinline__ void walk_from(LaneSeg& g, cgbyte* s, uint32_t csize,
     uint32_t wlo = start & ~15u, whi = wlo;                            // the ring holds stream bytes [wlo, whi), both multiples of 16
     const uint32_t fill_end = csize & ~15u;                            // whole 16-byte pieces only
     uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    // 4 stream bytes at a: from the lane's window; from memory for the lanes whose window does not hold them (a literal run longer than
+    // the window, the last bytes of the stream) - on a path of its own, taken when ANY lane needs it: a load under a per-lane condition
+    // would put a wait for all memory operations, the record stores' acknowledgements included, behind every token of every lane
+    auto in_win = [&](uint32_t a) -> bool { return a >= wlo && a + 4u <= whi; };
+    auto win4 = [&](uint32_t a) -> uint32_t {
+        const uint32_t d = a >> 2, lo = ring[(d & M) * 64u], hi = ring[((d + 1u) & M) * 64u];
+        return __builtin_amdgcn_alignbyte(hi, lo, a & 3u);
+    };
     auto get4 = [&](uint32_t a) -> uint32_t {
-        if (a >= wlo && a + 4u <= whi) {
-            const uint32_t d = a >> 2, lo = ring[(d & M) * 64u], hi = ring[((d + 1u) & M) * 64u];
-            return __builtin_amdgcn_alignbyte(hi, lo, a & 3u);
+        if (__builtin_expect(__ballot(!in_win(a)) != 0, 0)) {
+            uint32_t v = 0;
+            if (!in_win(a)) v = ld4u(s + a);
+            asm volatile("" : "+v"(v));                    // the load is waited for HERE, on this path (the compiler's own wait)
+            return in_win(a) ? win4(a) : v;
         }
-        return ld4u(s + a);
+        return win4(a);
     };
     for (;;) {
         if (p >= g.seg_end) { tail = false; break; }
