@@ -51,10 +51,10 @@ def test_xxh32_lengths_and_alignments(gpu):
             assert list(got) == want, (align, seed)
 
 
-@pytest.mark.parametrize("count", [3, 1500, 3000, 6000])
+@pytest.mark.parametrize("count", [3, 1500, 3000, 6000, 17000])
 def test_xxh32_many_blocks_per_wavefront(gpu, count):
     """Batches above 1024 blocks put 2, 4, 8 blocks on one wavefront (staged kernel up to 4): ragged lengths around the
-    64-stripe bank size, blocks that end while their neighbours go on, a last wavefront that is not full."""
+    64-stripe bank size, blocks that end while their neighbours go on, a last wavefront that is not full (17000: 16 per wavefront)."""
     rng = np.random.default_rng(count)
     lens = [int(rng.choice([0, 5, 16, 1023, 1024, 1025, 2047, 2048, 2049, int(rng.integers(0, 9000))])) for _ in range(count)]
     lens[-1] = 40000; lens[0] = 70001
