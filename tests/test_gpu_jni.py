@@ -25,6 +25,38 @@ def test_jni_entry_points_through_mock_env(gpu, tmp_path):
     check_jni_protocol(r.stdout, data, tmp_path, level9_on_device=False)
 
 
+def test_jni_lz4_compressor_under_the_tolerance_switch(gpu, tmp_path):
+    """FOURMC_LZ4_ENCODE=parallel in the JVM's environment: Lz4Compressor.compressBytesDirect hands out the ratio-tolerance encoder's
+    payload (a valid LZ4 block - the model's bytes - that Lz4Decompressor and the oracle decode); HC / MC / zstd entry points are
+    untouched, the protocol (length fields reset, no exception) is the same."""
+    exe = tmp_path / "mock_jni"
+    subprocess.run(["gcc", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "jni_mock", "mock_jni.c"),
+                    "-ldl", "-o", str(exe)], check=True)
+    n = 1_500_000
+    data = helpers.corpus(n, first_block=6)
+    src = tmp_path / "in.bin"; src.write_bytes(data.tobytes())
+    r = subprocess.run([str(exe), gpu.lib_path(), str(src), str(n), str(tmp_path)], capture_output=True, text=True,
+                       env=dict(os.environ, FOURMC_LZ4_ENCODE="parallel"))
+    assert r.returncode == 0, r.stderr
+    out = {}
+    for line in r.stdout.splitlines():
+        name, val, rest = line.split(" ", 2)
+        out[name] = (int(val), rest)
+    bound = helpers.oracle().orc_lz4_compress_bound(n)
+    got_r, rest = out["Lz4_compressBytesDirect"]
+    mr, mb = helpers.lz4p_model_encode(data, bound)
+    assert got_r == mr and "ulen_after=0" in rest
+    payload = np.fromfile(os.path.join(str(tmp_path), "Lz4_compressBytesDirect.bin"), dtype=np.uint8)
+    assert np.array_equal(payload, mb)
+    dr, back = helpers.orc_decompress(payload, n)
+    assert dr == n and np.array_equal(back[:n], data)
+    d, rest = out["Lz4_compressBytesDirect_roundtrip"]
+    assert d == n and "same=1" in rest
+    wr, wbytes = helpers.orc_compress_hc(data, 4, bound)                              # the other encoders: the reference's bytes, as ever
+    assert out["Lz4_compressBytesDirectHC"][0] == wr
+    assert np.array_equal(np.fromfile(os.path.join(str(tmp_path), "Lz4_compressBytesDirectHC.bin"), dtype=np.uint8), wbytes)
+
+
 def check_jni_protocol(stdout, data, out_dir, level9_on_device):
     """What the mock driver's output has to show, whichever library it drove: this repository's (on the GPU) or the reference's
     shipped artefact (tests/test_jni_reference_artifact.py, on the CPU) - the same expectations for both."""
