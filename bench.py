@@ -289,6 +289,21 @@ def main():
         out["4mz_ultra_zstd12_logs"]["corpus"] = "tools/corpus.c corpus_fill_logs, 24 distinct blocks replicated to %d" % nlog
         return out
 
+    def tolerant_roofline(algb, ms):
+        """roofline object of the tolerant encoder's two kernels together; traffic: the PMC passes kept under profiles/ (same launch size)"""
+        traffic = None
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", "r04_k2p_traffic.json")))
+            if t.get("blocks") == nb:
+                traffic = int(sum(1024 * (v.get("fetch_KiB") or 0) + 1024 * (v.get("write_KiB") or 0) for k, v in t.items() if isinstance(v, dict)))
+        except Exception:
+            pass
+        a = algb / (ms * 1e-3) / 1e9
+        return {"kernel": "lz4_par_segment_kernel + lz4_par_stitch_kernel", "bound": "hbm", "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(a / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_source": "profiles/r04_k2p_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 2048 blocks): the candidates' lines miss the L2" if traffic else None,
+                "algorithmic_bytes_per_launch": int(algb), "avg_launch_ms": round(ms, 3)}
+
     def tolerant_leg():
         """The same 2048 blocks through the RATIO-TOLERANCE LZ4 encoder (4mc_amd/csrc/lz4_par_encode.hip; not the default, not in
         `value`): north_star's clause for a parse that is not reproduced.  Payloads are valid LZ4 blocks but not the reference's
@@ -317,6 +332,7 @@ def main():
                 "encode_blocks_ms": round(t_enc, 2), "decode_blocks_ms": round(t_dec, 2),
                 "encode_kernels_ms": round(t_k, 2), "encode_kernels_GBps": round(nb * B / t_k / 1e6, 3),
                 "encode_kernels_note": "fourmc_gpu_lz4_compress_fast alone (segment kernel + stitch kernel; no checksum launch); algorithmic bytes usize + csize: %.3f of 8 TB/s" % ((nb * B + float(cs.sum())) / (t_k * 1e-3) / 1e9 / HBM_PEAK_GBS),
+                "roofline": tolerant_roofline(float(nb) * B + float(cs.sum()), t_k),
                 "ratio": round(nb * B / float((cs + 12).sum()), 4),
                 "ratio_vs_reference": round(float((exact + 12).sum()) / float((cs + 12).sum()), 6),
                 "tolerance": "sizes within 3 %% of the reference parse over the S-mix (tests/test_gpu_lz4par_encode.py); this run: %+.2f %%" % (100.0 * (float((cs + 12).sum()) / float((exact + 12).sum()) - 1)),

@@ -34,4 +34,9 @@ for f in ("st", "sq", "sq2", "fetch", "write", "tcp"):
         keep = [l for l in open(p) if not l.startswith("| void at::") and "elementwise" not in l and "at::native" not in l]
         txt += f"## {f}\n\n" + "".join(keep) + "\n"
 open(f"profiles/{name}.md", "w").write(txt)
+import json
+json.dump({"_source": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes, tools/k2p_sq.sh) at 2048 blocks; KiB per dispatch, calibration in profiles/r04_traffic.json",
+           "blocks": 2048,
+           K: {"fetch_KiB": c[K].get("FETCH_SIZE"), "write_KiB": c[K].get("WRITE_SIZE")},
+           S: {"fetch_KiB": c.get(S, {}).get("FETCH_SIZE"), "write_KiB": c.get(S, {}).get("WRITE_SIZE")}}, open(f"profiles/{name}_traffic.json", "w"), indent=1)
 print(txt[:1800])
