@@ -89,7 +89,7 @@ def main():
            "calibration": {"xxh32_fetch_reported_over_known": round(xf / cs, 4), "pack_fetch_reported_over_known": round(get("pack_image_kernel", "FETCH_SIZE") / cs, 4),
                            "pack_write_reported_over_known": round(get("pack_image_kernel", "WRITE_SIZE") / (cs + 12 * nb), 4),
                            "decode_write_reported_over_known": round(get_dec("WRITE_SIZE") / us, 4),
-                           "note": "known = the bytes the kernel has to move exactly once (xxh32: every payload byte read; pack: payloads read, payloads + 12 B headers written; decode: 4 MiB written per block - the segment-parallel path also writes and reads back 4 bytes per sequence of token records, which this ratio then includes)"}}
+                           "note": "known = the bytes the kernel has to move exactly once (xxh32: every payload byte read; pack: payloads read, payloads + 12 B headers written; decode: 4 MiB written per block - the segment-parallel path also writes and reads back 8 bytes per sequence of records (2.4 MB per block on the S-mix), which this ratio then includes)"}}
     for k in ("lz4_encode", "lz4_decode"):
         out[k]["traffic"] = int(out[k]["fetch"] + out[k]["write"])
         out[k]["traffic_over_algorithmic"] = round(out[k]["traffic"] / out[k]["algorithmic"], 4)
