@@ -104,16 +104,18 @@ public:
     }
 };
 
-// The LZ4 decode workspace: the segment-parallel path sizes it for the worst stream (11 MB per block) times the blocks of a piece
-// of the launch; when the device cannot give that much, the pieces get smaller (the launch is then cut into more of them) instead of
-// the call failing (nothing retried with a smaller batch)
-int lease_lz4_decode(WsLease& ws, hipStream_t s, uint32_t n, void** work)
+// The LZ4 decode workspace.  Path, piece size and bytes are resolved once (fourmc_lz4_decode_plan) and handed to the launcher; when
+// the device cannot give the workspace the pieces halve FOR THIS CALL (the launch is then cut into more of them), and an automatic
+// choice ends at the walk + window copier, which needs none.
+int lease_lz4_decode(WsLease& ws, hipStream_t s, uint32_t n, void** work, fourmc_lz4_plan* plan)
 {
-    for (;;) {
-        const int r = ws.get(s, fourmc_lz4_decode_work_bytes(n), work);
+    for (uint32_t shrink = 0;; shrink++) {
+        *plan = fourmc_lz4_decode_plan(n, shrink);
+        if (!plan->ok) { snprintf(g_err, sizeof g_err, "LZ4 decode workspace cannot be allocated"); return FOURMC_ENOMEM; }
+        if (plan->work_bytes == 0) { *work = nullptr; return FOURMC_OK; }
+        const int r = ws.get(s, plan->work_bytes, work);
         if (r == FOURMC_OK) return r;
         (void)hipGetLastError();
-        if (!fourmc_lz4_seg_shrink_batch()) return r;
     }
 }
 
@@ -207,8 +209,9 @@ int fourmc_gpu_lz4_decompress(const void* d_src, void* d_dst, fourmc_block* d_bl
     if (int r = ensure_device()) return r;
     hipStream_t s = static_cast<hipStream_t>(stream);
     WsLease ws; void* work = nullptr;
-    if (int r = lease_lz4_decode(ws, s, n, &work)) return r;
-    HIP_TRY(fourmc_launch_lz4_decode(d_src, d_dst, d_blocks, n, 0, work, s));
+    fourmc_lz4_plan plan;
+    if (int r = lease_lz4_decode(ws, s, n, &work, &plan)) return r;
+    HIP_TRY(fourmc_launch_lz4_decode(d_src, d_dst, d_blocks, n, 0, &plan, work, s));
     return FOURMC_OK;
 }
 
@@ -377,9 +380,10 @@ int fourmc_gpu_4mc_decode_blocks(const void* d_src, void* d_dst, fourmc_block* d
         return FOURMC_EUNSUP;
     }
     WsLease ws; void* work = nullptr;
-    if (int r = lease_lz4_decode(ws, s, n, &work)) return r;
+    fourmc_lz4_plan plan;
+    if (int r = lease_lz4_decode(ws, s, n, &work, &plan)) return r;
     HIP_TRY(fourmc_launch_xxh32(d_src, d_blocks, n, 0, FOURMC_VERIFY_SRC, s));
-    HIP_TRY(fourmc_launch_lz4_decode(d_src, d_dst, d_blocks, n, 1, work, s));
+    HIP_TRY(fourmc_launch_lz4_decode(d_src, d_dst, d_blocks, n, 1, &plan, work, s));
     return FOURMC_OK;
 }
 

@@ -218,6 +218,17 @@ static int compress_file_mapped(int displayLevel, FILE* fin, const char* out_nam
     offsets = (uint64_t*)malloc((size_t)(nblocks + 1) * 8); ioff = (uint64_t*)malloc((size_t)nbatch * 8);
     blk = (fourmc_block*)calloc(nbatch, sizeof *blk);
     if (!offsets || !ioff || !blk) DIE(1, "Allocation error : not enough memory");
+    /* the frame header's 12 bytes are reserved like every launch's blocks below (a store into a hole of a sparse mapping on a full
+     * disk is a SIGBUS, not a "Write error"): nothing has been written if this fails, the streaming path takes over */
+    {
+        const int fe = posix_fallocate(fdo, 0, 12);
+        if (fe != 0 && fe != EOPNOTSUPP && fe != EINVAL) {
+            munmap(out, (size_t)bound); munmap(in, (size_t)N); free(offsets); free(ioff); free(blk);
+            if (ftruncate(fdo, 0) != 0) {}
+            close(fdo);
+            return -1;
+        }
+    }
     fourmc_frame_header(out, magic);
     for (b0 = 0; b0 < nblocks; b0 += nbatch) {
         const unsigned nb = (unsigned)(nblocks - b0 < nbatch ? nblocks - b0 : nbatch);
@@ -230,9 +241,10 @@ static int compress_file_mapped(int displayLevel, FILE* fin, const char* out_nam
         }
         /* the blocks this launch may write are RESERVED before it: a store into a hole of a sparse mapping on a full disk (or over
          * quota) is a SIGBUS in the middle of a device copy, where the reference - and the streaming path - report "Write error" and
-         * exit 3.  Nothing has been written by then at the first launch: the streaming path takes over; later: the reference's exit. */
+         * exit 3.  Only the frame header has been written by then at the first launch (the file is truncated and the streaming path
+         * takes over); later: the reference's exit.  The last launch also reserves the end mark and the footer behind its blocks. */
         {
-            const uint64_t want = (uint64_t)nb * 12 + bytes;
+            const uint64_t want = (uint64_t)nb * 12 + bytes + (b0 + nb >= nblocks ? 12 + FOURMC_FOOTERSIZE(nblocks) : 0);
             const int fe = posix_fallocate(fdo, (off_t)pos, (off_t)(want < bound - pos ? want : bound - pos));
             if (fe != 0 && fe != EOPNOTSUPP && fe != EINVAL) {
                 if (b0 != 0) DIE(3, "Write error : cannot write compressed block");

@@ -20,11 +20,18 @@ enum {
                                   // match -> result = 0
 };
 
-size_t     fourmc_lz4_decode_work_bytes(uint32_t n);     /* what the selected decode path leases: 0 unless it is the block-parallel pair */
+/* what an LZ4 decode launch of n blocks runs: resolved once per call by fourmc_lz4_decode_plan, handed to the launcher */
+typedef struct fourmc_lz4_plan {
+    int      path;          /* decode path after "auto" has been resolved (lz4_decode.hip) */
+    uint32_t batch;         /* blocks per piece of the launch (paths with a workspace) */
+    size_t   work_bytes;    /* device workspace to lease: 0 for the paths that need none */
+    int      ok;            /* 0: the pieces cannot get smaller (the workspace cannot be had) */
+} fourmc_lz4_plan;
+fourmc_lz4_plan fourmc_lz4_decode_plan(uint32_t n, uint32_t shrink);
 size_t     fourmc_lz4_parse_work_bytes(uint32_t n);
 size_t     fourmc_lz4_decode_tok_offset(void);
 hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, fourmc_block* d_blocks,
-                                    uint32_t n, int container_mode, void* d_work, hipStream_t stream);
+                                    uint32_t n, int container_mode, const fourmc_lz4_plan* plan, void* d_work, hipStream_t stream);
 hipError_t fourmc_launch_lz4_rows(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                                   uint32_t n, int container_mode, hipStream_t stream);
 hipError_t fourmc_launch_lz4_lanes(const void* d_src, void* d_dst, fourmc_block* d_blocks,
@@ -33,7 +40,10 @@ hipError_t fourmc_launch_lz4_wx(const void* d_src, void* d_dst, fourmc_block* d_
                                   uint32_t n, int container_mode, hipStream_t stream, const uint32_t* pick, uint32_t want);
 size_t     fourmc_lz4_seg_work_bytes(uint32_t n);
 uint32_t   fourmc_lz4_seg_batch(void);              /* blocks per launch of the segment-parallel path (bounds its workspace) */
-int        fourmc_lz4_seg_shrink_batch(void);       /* the workspace could not be allocated: halve the pieces (0: cannot) */
+size_t     fourmc_lz4_tile_work_bytes(uint32_t n);
+uint32_t   fourmc_lz4_tile_batch(void);             /* blocks per launch of the tile path */
+hipError_t fourmc_launch_lz4_tile(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
+                                  int container_mode, void* d_work, hipStream_t stream);
 hipError_t fourmc_launch_lz4_seg(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                  int container_mode, void* d_work, hipStream_t stream);
 hipError_t fourmc_launch_lz4_parse(const void* d_src, const void* d_dst, fourmc_block* d_blocks, uint32_t n,
@@ -52,8 +62,14 @@ hipError_t fourmc_launch_lz4hc_encode(const void* d_src, void* d_dst, fourmc_blo
                                       void* d_work, int level, int container_mode, hipStream_t stream);
 hipError_t fourmc_launch_lz4mc_encode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                       void* d_work, int container_mode, hipStream_t stream);
+#ifdef FOURMC_RESEARCH      /* the research side build exports these two: tools/zstd_timing.py and tools/k7x_prof.py size their read-backs with them */
+#pragma GCC visibility push(default)
+#endif
 size_t     fourmc_zstd_scratch_bytes(uint32_t n);
 size_t     fourmc_zstd_dec_counter_offset(void);
+#ifdef FOURMC_RESEARCH
+#pragma GCC visibility pop
+#endif
 hipError_t fourmc_launch_zstd_decode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                      void* d_scratch, int container_mode, hipStream_t stream);
 size_t     fourmc_zstd_enc_work_bytes(uint32_t n, int level);

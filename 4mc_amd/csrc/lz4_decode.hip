@@ -24,6 +24,7 @@
 #include "devcopy.h"
 #include "lz4par.h"
 #include "lz4seg.h"
+#include "lz4tile.h"
 #include <string.h>
 #include <atomic>
 
@@ -578,7 +579,8 @@ void lz4_decode_retry_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
 // token where the reference's end-of-block rules begin (kResume: token and output position in the block's workspace slot)
 __global__ __launch_bounds__(64)
 void lz4_decode_resume_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
-                              fourmc_block* blocks, uint32_t nblocks, int container_mode, const uint32_t* ws, int redo)
+                              fourmc_block* blocks, uint32_t nblocks, int container_mode, const uint32_t* ws, int redo,
+                              uint32_t ws_stride, uint32_t res_at)
 {
     __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
     const uint32_t b = blockIdx.x;
@@ -586,9 +588,9 @@ void lz4_decode_resume_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst
     const fourmc_block blk = uniform_block(blocks[b]);
     int ip0 = 0, op0 = 0;
     if (blk.result == lz4seg::kResumeCode) {
-        const uint32_t* meta = ws + size_t(b) * lz4seg::kWsWords;
-        ip0 = __builtin_amdgcn_readfirstlane(int(meta[lz4seg::kMetaResIp]));
-        op0 = __builtin_amdgcn_readfirstlane(int(meta[lz4seg::kMetaResOp]));
+        const uint32_t* meta = ws + size_t(b) * ws_stride;            // the block's slot: {token position, output position} at res_at
+        ip0 = __builtin_amdgcn_readfirstlane(int(meta[res_at]));
+        op0 = __builtin_amdgcn_readfirstlane(int(meta[res_at + 1]));
     } else if (blk.result != kRetry || !redo) return;
     int r = lz4_decode_block(src_base + blk.src_off, int(blk.src_len), dst_base + blk.dst_off, int(blk.dst_cap),
                              ring, threadIdx.x, ip0, op0);
@@ -609,15 +611,32 @@ extern "C" size_t fourmc_lz4_parse_work_bytes(uint32_t n)
     return size_t(m ? m : 1) * lz4par::kSlotBytes;
 }
 extern "C" int fourmc_gpu_get_lz4_decode_path(void);
-extern "C" size_t fourmc_lz4_decode_work_bytes(uint32_t n)
+// Which kernels a launch of n blocks runs, in pieces of how many blocks, with how much workspace: resolved ONCE per call (the
+// lease and the launch see the same answer even if another thread changes the selection in between).  shrink: how often the
+// workspace could not be had - the pieces halve; below 64 blocks an automatic choice falls back to the walk + window copier,
+// which needs no workspace.
+static const uint32_t kAutoTileMin = 512;          // launches from here on go to the tile path (two workgroups per CU: 512 fill the chip once)
+extern "C" fourmc_lz4_plan fourmc_lz4_decode_plan(uint32_t n, uint32_t shrink)
 {
-    const int path = fourmc_gpu_get_lz4_decode_path();
-    if (path == 11 || path == 12 || (path == 6 && n >= 768)) return fourmc_lz4_seg_work_bytes(n < fourmc_lz4_seg_batch() ? n : fourmc_lz4_seg_batch());
+    fourmc_lz4_plan pl; pl.path = fourmc_gpu_get_lz4_decode_path(); pl.batch = n ? n : 1; pl.work_bytes = 0; pl.ok = 1;
+    const bool automatic = pl.path == 6;
+    if (pl.path == 6) pl.path = n >= kAutoTileMin ? 13 : 9;
+    if (pl.path == 11 || pl.path == 12 || pl.path == 13 || pl.path == 14) {
+        const bool tile = pl.path >= 13;
+        uint32_t b = tile ? fourmc_lz4_tile_batch() : fourmc_lz4_seg_batch();
+        for (uint32_t k = 0; k < shrink && b >= 64; k++) b /= 2;
+        if (b < 64) {
+            if (automatic) { pl.path = 9; return pl; }
+            pl.ok = 0; return pl;
+        }
+        pl.batch = n < b ? (n ? n : 1) : b;
+        pl.work_bytes = tile ? fourmc_lz4_tile_work_bytes(pl.batch) : fourmc_lz4_seg_work_bytes(pl.batch);
+        return pl;
+    }
 #ifdef FOURMC_RESEARCH
-    return (path == 1 || path == 3) ? fourmc_lz4_parse_work_bytes(n) : 0;
-#else
-    return 0;
+    if (pl.path == 1 || pl.path == 3) pl.work_bytes = fourmc_lz4_parse_work_bytes(n);
 #endif
+    return pl;
 }
 
 // Which fast path serves LZ4 decode launches.  Both produce identical results (anything irregular goes to the exact
@@ -638,9 +657,9 @@ static int g_decode_path = -1;
 static bool path_known(int path)
 {
 #ifdef FOURMC_RESEARCH
-    return path >= 0 && path <= 12;
+    return path >= 0 && path <= 14;
 #else
-    return path == 2 || path == 6 || path == 9 || path == 10 || path == 11 || path == 12;
+    return path == 2 || path == 6 || path == 9 || path == 10 || path == 11 || path == 12 || path == 13 || path == 14;
 #endif
 }
 extern "C" void fourmc_gpu_set_lz4_decode_path(int path) { g_decode_path = path_known(path) ? path : 6; }
@@ -659,6 +678,8 @@ extern "C" int fourmc_gpu_get_lz4_decode_path(void)
         if (mode && !strcmp(mode, "exact")) p = 2;
         if (mode && !strcmp(mode, "seg")) p = 11;
         if (mode && !strcmp(mode, "segonly")) p = 12;
+        if (mode && !strcmp(mode, "tile")) p = 13;
+        if (mode && !strcmp(mode, "tileonly")) p = 14;
         if (mode && !strcmp(mode, "par")) p = 1;
         if (mode && !strcmp(mode, "paronly")) p = 3;
         g_decode_path = path_known(p) ? p : 6;
@@ -667,27 +688,28 @@ extern "C" int fourmc_gpu_get_lz4_decode_path(void)
 }
 
 extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, fourmc_block* d_blocks,
-                                               uint32_t n, int container_mode, void* d_work, hipStream_t stream)
+                                               uint32_t n, int container_mode, const fourmc_lz4_plan* plan, void* d_work, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
     const uint8_t* s8 = static_cast<const uint8_t*>(d_src);
     uint8_t* d8 = static_cast<uint8_t*>(d_dst);
-    int path = fourmc_gpu_get_lz4_decode_path();
-    // 6 "auto": a launch that fills the chip goes to the segment-parallel path (lz4_seg.hip: one wave per block, a fifth of the
-    // instructions per byte of the wave pipelines - 8192 blocks in 116 ms against 184); smaller launches to the walk + window copier
-    // (K1wx: four waves per block, the shortest chain per block)
-    if (path == 6 && n >= 768) path = 11;
-    if (path == 6) path = 9;
-    if (path == 11 || path == 12) {
-        // segment-parallel walk + batch executor (lz4_seg.hip), then the exact walker for the last bytes of every block and for
-        // whatever was handed back; 12: test aid, blocks handed back stay kRetry
-        const uint32_t step = fourmc_lz4_seg_batch();
+    const int path = plan->path;
+    // (6 "auto" was resolved by fourmc_lz4_decode_plan: a launch that fills the chip goes to the tile path - lz4_tile.hip, one
+    // workgroup per block with the LZ4 window in LDS; smaller launches to the walk + window copier, K1wx: four waves per block)
+    if (path == 13 || path == 14 || path == 11 || path == 12) {
+        // walk + executor (tile: lz4_tile.hip, segment-parallel: lz4_seg.hip), then the exact walker for the last bytes of every
+        // block and for whatever was handed back; 12 / 14: test aid, blocks handed back stay kRetry
+        const bool tile = path >= 13;
+        const uint32_t step = plan->batch ? plan->batch : n;
+        if (plan->work_bytes == 0 || d_work == nullptr) return hipErrorInvalidValue;
         for (uint32_t b0 = 0; b0 < n; b0 += step) {
             const uint32_t m = n - b0 < step ? n - b0 : step;
-            hipError_t e = fourmc_launch_lz4_seg(d_src, d_dst, d_blocks + b0, m, container_mode, d_work, stream);
+            hipError_t e = tile ? fourmc_launch_lz4_tile(d_src, d_dst, d_blocks + b0, m, container_mode, d_work, stream)
+                                : fourmc_launch_lz4_seg(d_src, d_dst, d_blocks + b0, m, container_mode, d_work, stream);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(lz4_decode_resume_kernel, dim3(m), dim3(64), 0, stream, s8, d8, d_blocks + b0, m, container_mode,
-                               static_cast<const uint32_t*>(d_work), path == 11 ? 1 : 0);
+                               static_cast<const uint32_t*>(d_work), (path == 11 || path == 13) ? 1 : 0,
+                               tile ? uint32_t(lz4tile::kWsWords) : uint32_t(lz4seg::kWsWords), tile ? lz4tile::kMetaResIp : lz4seg::kMetaResIp);
         }
         return hipGetLastError();
     }

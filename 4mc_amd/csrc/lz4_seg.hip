@@ -594,9 +594,9 @@ void lz4_seg_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base
 
 extern "C" size_t fourmc_lz4_seg_work_bytes(uint32_t n) { return size_t(n) * lz4seg::kWsWords * 4u; }
 
-// Blocks per launch pair: the workspace is sized for the largest stream a block can hold (5.7 MB of records per block), so a
-// launch is cut into pieces whose workspace stays below 40 % of the device's memory (8192 blocks = 46 GB on a 288 GB MI355X:
-// one wave per block then fills the chip's 32 waves per CU).  FOURMC_SEG_BATCH overrides.
+// Blocks per launch pair: the workspace is sized for the largest stream a block can hold (11.3 MB of records per block), so a
+// launch is cut into pieces whose workspace stays below 40 % of the device's memory (8192 blocks = 92 GB on a 288 GB MI355X).
+// FOURMC_SEG_BATCH overrides.  (A caller whose lease fails halves the pieces for its own call: fourmc_lz4_decode_plan.)
 static std::atomic<uint32_t> g_seg_batch{0};
 extern "C" uint32_t fourmc_lz4_seg_batch(void)
 {
@@ -613,14 +613,6 @@ extern "C" uint32_t fourmc_lz4_seg_batch(void)
         v = b;
     }
     return v;
-}
-// the workspace of a piece could not be had: halve the pieces (false: they cannot get smaller)
-extern "C" int fourmc_lz4_seg_shrink_batch(void)
-{
-    const uint32_t b = fourmc_lz4_seg_batch();
-    if (b <= 64) return 0;
-    g_seg_batch.store(b / 2, std::memory_order_relaxed);
-    return 1;
 }
 
 extern "C" hipError_t fourmc_launch_lz4_seg(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,

@@ -1,0 +1,576 @@
+// 4mc_amd/csrc/lz4_tile.hip - K1t: tile LZ4 block decode on gfx950 (wave64), the 64 KiB LZ4 window resident in LDS.
+//
+// Replaces LZ4_decompress_safe(in, out, csize, usize) per block (native/4mc.c:661, native/jniDecompressor.c:88 ->
+// native/lz4/lz4.c:2345-2350 -> :1936-2339) for every block the exact walker (lz4_decode.hip) does not have to see.
+//
+//   WALK kernel, one wave per block, one LANE per stream segment (as lz4_seg.hip: a chain started at an arbitrary byte falls onto
+//     the true token chain after a few hops), but what it leaves is ONE BIT PER STREAM BYTE - "a token starts here" - in words the
+//     lane owns (segment lengths are multiples of 32).  A chain that enters a segment somewhere else than assumed rewrites the
+//     segment's words from its start until it falls onto a bit of the chain that is already there.  No record lists: 1/8 byte of
+//     workspace per stream byte instead of 8 bytes per sequence written and read back.
+//   EXEC kernel, one workgroup of 512 threads per block, two per CU.  The last 64 KiB of output - everything an LZ4 offset can
+//     reach - live in an LDS ring, so a match never goes to memory: HBM sees the stream once (coalesced 16-byte loads), the bitmap
+//     once, and the output once (aligned 16-byte stores).  Per CHUNK of 2 KiB of stream: the tokens are compacted out of the
+//     bitmap, decoded one per thread from the staged stream and placed by a prefix sum.  The chunk's output is produced in TILES of
+//     <= 4096 bytes, ONE THREAD PER OUTPUT BYTE: every sequence marks where its literal part and its match part begin, a max-scan
+//     gives every byte its (sequence, part); literal bytes come from the staged stream, match bytes whose source lies in front of
+//     the tile from the ring (every read of old ring contents happens before the tile's first write: the ring is exactly 64 KiB),
+//     match bytes whose source lies INSIDE the tile keep a 16-bit pointer to it and are resolved by chasing pointers to a byte that
+//     is final - the threads need no order among themselves for that, and a resolved byte is final for everyone behind it (what a
+//     serial decoder does as a chain of dependent copies is here a few dependent LDS reads per byte, all bytes at once).
+//     A sequence of any length is simply clipped to the tile: no escape paths.
+//   The last 64 stream bytes / 128 output bytes of a block - where the reference's end-of-block rules apply (lz4.c:2120-2330) - and
+//     anything irregular go to the exact walker: it RESUMES at the token the fast path stopped at (kResume) or redoes the block
+//     (kRetry), so accept / reject set and return codes stay the reference's.
+//
+// All byte work; no MFMA.  tools/model/tile_decode_model.c is the executable model these kernels were written from.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "fourmc_gpu.h"
+#include "kernels.h"
+#include "devcopy.h"
+#include "lz4par.h"
+#include "lz4tile.h"
+#ifndef FOURMC_TILE_WIN
+#define FOURMC_TILE_WIN 64
+#endif
+
+namespace {
+
+using namespace lz4tile;
+
+typedef __attribute__((address_space(1))) uint8_t gbyte;
+typedef __attribute__((address_space(1))) const uint8_t cgbyte;
+typedef __attribute__((address_space(1))) uint32_t gword;
+typedef __attribute__((address_space(1))) const uint32_t cgword;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32_u __attribute__((aligned(1)));
+typedef u32x2 u32x2_u __attribute__((aligned(1)));
+typedef u32x4 u32x4_u __attribute__((aligned(1)));
+__device__ __forceinline__ uint32_t ld4u(cgbyte* p) { return *reinterpret_cast<__attribute__((address_space(1))) const u32_u*>(p); }
+__device__ __forceinline__ u32x2 ld8u(cgbyte* p) { return *reinterpret_cast<__attribute__((address_space(1))) const u32x2_u*>(p); }
+__device__ __forceinline__ u32x4 ld16u_g(cgbyte* p) { return *reinterpret_cast<__attribute__((address_space(1))) const u32x4_u*>(p); }
+__device__ __forceinline__ void st16g(gbyte* p, u32x4 v) { *reinterpret_cast<__attribute__((address_space(1))) u32x4*>(p) = v; }
+
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v)
+{ return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, ROWMASK, 0xf, false)); }
+// inclusive scans over the 64 lanes (values that are 0 where a lane has nothing: 0 is the identity of both)
+__device__ __forceinline__ uint32_t scan_add(uint32_t v)
+{
+    v += dpp0<0x111, 0xf>(v); v += dpp0<0x112, 0xf>(v); v += dpp0<0x114, 0xf>(v); v += dpp0<0x118, 0xf>(v);
+    v += dpp0<0x142, 0xa>(v); v += dpp0<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t scan_max(uint32_t v)
+{
+    v = umax(v, dpp0<0x111, 0xf>(v)); v = umax(v, dpp0<0x112, 0xf>(v)); v = umax(v, dpp0<0x114, 0xf>(v)); v = umax(v, dpp0<0x118, 0xf>(v));
+    v = umax(v, dpp0<0x142, 0xa>(v)); v = umax(v, dpp0<0x143, 0xc>(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l) { return uint32_t(__builtin_amdgcn_readlane(int(v), int(l))); }
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
+
+// profiling build (make tprof, -DK1T_PROF): cycle counters per phase, left in the spare words of the block's meta area
+#ifdef K1T_PROF
+struct Prof {
+    unsigned long long t[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    __device__ __forceinline__ unsigned long long now() const { return __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void add(int i, unsigned long long& since) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t[i] += n - since; since = n; }
+    __device__ __forceinline__ void count(int i, unsigned long long n = 1) { t[i] += n; }
+    __device__ __forceinline__ void dump(gword* meta, uint32_t at, int n, bool who) const { if (who) for (int i = 0; i < n; i++) { meta[at + 2 * i] = uint32_t(t[i]); meta[at + 2 * i + 1] = uint32_t(t[i] >> 32); } }
+};
+#else
+struct Prof {
+    __device__ __forceinline__ unsigned long long now() const { return 0; }
+    __device__ __forceinline__ void add(int, unsigned long long&) {}
+    __device__ __forceinline__ void count(int, unsigned long long = 1) {}
+    __device__ __forceinline__ void dump(gword*, uint32_t, int, bool) const {}
+};
+#endif
+
+__device__ __forceinline__ bool eligible(const fourmc_block& blk)
+{ return blk.src_len >= kMinSrc && blk.src_len <= kMaxSrc && blk.dst_cap >= kMinCap && blk.dst_cap <= lz4par::kDstMax; }
+
+// ================================================================================================ WALK kernel
+struct Hop { uint32_t next; bool stop; };
+// One token at p (per lane), bytes from memory.  stop: the token or its bytes reach beyond limit = csize - kMargin; the chain halts
+// AT p and the exact walker takes over there.  Every byte read lies below csize.
+__device__ __forceinline__ Hop decode_tok(cgbyte* s, uint32_t limit, uint32_t p)
+{
+    Hop h; h.next = p; h.stop = true;
+    if (p >= limit) return h;
+    const u32x2 L0 = ld8u(s + p);                               // p + 8 <= csize - 56
+    const uint32_t tok = L0.x & 255u, mn = tok & 15u;
+    uint32_t ll = tok >> 4, q = p + 1;
+    if (ll == 15) {
+        uint32_t b = (L0.x >> 8) & 255u; ll += b; q++;
+        if (b == 255u) {
+            for (;;) { if (q >= limit) return h; b = s[q++]; ll += b; if (b != 255u) break; if (ll > (1u << 23)) return h; }
+        }
+    }
+    const uint32_t mo = q + ll;
+    if (mo + 2 > limit) return h;
+    uint32_t q2 = mo + 2;
+    if (mn == 15) { for (;;) { if (q2 >= limit) return h; const uint32_t b = s[q2++]; if (b != 255u) break; } }
+    if (q2 > limit) return h;
+    h.next = q2; h.stop = false;
+    return h;
+}
+
+struct LaneSeg {            // one lane's segment: words [sj >> 5, wend) of the bitmap are the lane's
+    gword* bm;
+    uint32_t sj, seg_end, wend;
+    uint32_t exitp, entry; bool tail;
+};
+// leave word `curw` behind with `acc`, zero the words up to `w`
+__device__ __forceinline__ void bm_advance(gword* bm, uint32_t& curw, uint32_t& acc, uint32_t w)
+{
+    bm[curw] = acc;
+    for (uint32_t x = curw + 1; x < w; x++) bm[x] = 0;
+    curw = w; acc = 0;
+}
+// Phase 1: the chain that starts at the segment's first byte, walked to the segment's end, its tokens' bits into the lane's words.
+// The lane reads its stretch of the stream through a window of its own in LDS - a ring of kWinDw dwords, dword k of lane l at word
+// k * 64 + l, so that 64 lanes reading "their" dword never meet in a bank.  The windows of ALL lanes still walking are topped up
+// together whenever one of them has less than a quarter of the window ahead.
+constexpr uint32_t kWinDw = FOURMC_TILE_WIN;    // dwords of stream window per lane (LDS: 256 bytes x kWinDw per wave)
+__device__ __forceinline__ void walk_first(LaneSeg& g, cgbyte* s, uint32_t csize, uint32_t limit, uint32_t* ring)
+{
+    constexpr uint32_t M = kWinDw - 1u, W = 4u * kWinDw, LOW = W / 4u;
+    uint32_t p = g.sj; bool tail;
+    uint32_t curw = g.sj >> 5, acc = 0;
+    uint32_t wlo = p & ~15u, whi = wlo;                                // the ring holds stream bytes [wlo, whi), both multiples of 16
+    const uint32_t fill_end = csize & ~15u;                            // whole 16-byte pieces only
+    auto in_win = [&](uint32_t a) -> bool { return a >= wlo && a + 4u <= whi; };
+    auto win4 = [&](uint32_t a) -> uint32_t {
+        const uint32_t d = a >> 2, lo = ring[(d & M) * 64u], hi = ring[((d + 1u) & M) * 64u];
+        return __builtin_amdgcn_alignbyte(hi, lo, a & 3u);
+    };
+    // 4 stream bytes at a: from the lane's window; from memory for the lanes whose window does not hold them - on a path of its own,
+    // taken when ANY lane needs it (a load under a per-lane condition would put a wait for all memory operations behind every token)
+    auto get4 = [&](uint32_t a) -> uint32_t {
+        if (__builtin_expect(__ballot(!in_win(a)) != 0, 0)) {
+            uint32_t v = 0;
+            if (!in_win(a)) v = ld4u(s + a);
+            asm volatile("" : "+v"(v));
+            return in_win(a) ? win4(a) : v;
+        }
+        return win4(a);
+    };
+    for (;;) {
+        if (p >= g.seg_end) { tail = false; break; }
+        if (p >= limit) { tail = true; break; }
+        if (__ballot(p + LOW > whi && whi < fill_end)) {
+            if (p >= whi || p < wlo) { wlo = p & ~15u; whi = wlo; }
+            uint32_t target = (p & ~15u) + (W - 16u); target = target < fill_end ? target : fill_end;
+            for (int round = 0; round < (W > 128u ? 2 : 1); round++) {
+                if (!__ballot(whi < target)) break;
+                u32x4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) if (whi + 16u * j < target) v[j] = ld16u_g(s + whi + 16u * j);
+#pragma unroll
+                for (int j = 0; j < 8; j++) if (whi + 16u * j < target) {
+                    const uint32_t d = (whi >> 2) + 4u * j;
+                    ring[(d & M) * 64u] = v[j].x; ring[((d + 1u) & M) * 64u] = v[j].y; ring[((d + 2u) & M) * 64u] = v[j].z; ring[((d + 3u) & M) * 64u] = v[j].w;
+                }
+                const uint32_t got = target - whi; whi += got < 128u ? got : 128u;
+            }
+            if (whi - wlo > W) wlo = whi - W;
+        }
+        const uint32_t L0 = get4(p);
+        const uint32_t tok = L0 & 255u, mn = tok & 15u;
+        uint32_t ll = tok >> 4, q = p + 1; bool stop = false;
+        if (ll == 15) {
+            uint32_t bq = (L0 >> 8) & 255u; ll += bq; q++;
+            if (bq == 255u) for (;;) { if (q >= limit) { stop = true; break; } bq = s[q++]; ll += bq; if (bq != 255u) break; if (ll > (1u << 23)) { stop = true; break; } }
+        }
+        const uint32_t mo = q + ll;
+        if (stop || mo + 2 > limit) { tail = true; break; }
+        uint32_t q2 = mo + 2;
+        if (mn == 15) {
+            const uint32_t L1 = get4(mo);
+            const uint32_t e0 = (L1 >> 16) & 255u; q2++;
+            if (e0 == 255u) {
+                const uint32_t e1 = L1 >> 24; q2++;
+                if (e1 == 255u) for (;;) { if (q2 >= limit) { stop = true; break; } const uint32_t bq = s[q2++]; if (bq != 255u) break; }
+            }
+        }
+        if (stop || q2 > limit) { tail = true; break; }
+        const uint32_t w = p >> 5;
+        if (w != curw) bm_advance(g.bm, curw, acc, w);
+        acc |= 1u << (p & 31u);
+        p = q2;
+    }
+    bm_advance(g.bm, curw, acc, g.wend);
+    g.exitp = p; g.entry = g.sj; g.tail = tail;
+}
+// The true chain enters the segment at e: rewrite the lane's words from the segment's start for it, until it falls onto a bit of
+// the chain that is there already (every bit there is a token of ONE chain: what a walk from the segment's start or an earlier
+// entry left) or leaves the segment.
+__device__ __forceinline__ void walk_from_entry(LaneSeg& g, cgbyte* s, uint32_t limit, uint32_t e)
+{
+    uint32_t q = e, curw = g.sj >> 5, acc = 0, old = g.bm[curw];
+    g.entry = e;
+    for (;;) {
+        if (q >= g.seg_end) { g.exitp = q; g.tail = false; break; }
+        const uint32_t w = q >> 5;
+        if (w != curw) { const uint32_t o2 = g.bm[w]; bm_advance(g.bm, curw, acc, w); old = o2; }
+        if ((old >> (q & 31u)) & 1u) { g.bm[curw] = acc | (old & ~((1u << (q & 31u)) - 1u)); return; }      // merged: the bits from q on stay
+        const Hop h = decode_tok(s, limit, q);
+        if (h.stop) { g.exitp = q; g.tail = true; break; }
+        acc |= 1u << (q & 31u);
+        q = h.next;
+    }
+    bm_advance(g.bm, curw, acc, g.wend);
+}
+
+__global__ __launch_bounds__(64)
+void lz4_tile_walk_kernel(const uint8_t* __restrict__ src_base, const fourmc_block* blocks, uint32_t nblocks,
+                          int container_mode, uint32_t* ws)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    const fourmc_block blk = uniform_block(blocks[b]);
+    gword* meta = (gword*)(ws + size_t(b) * kWsWords);
+    const uint32_t lane = threadIdx.x;
+    const bool skip = (container_mode && (blk.result == FOURMC_BLK_BADSUM || blk.src_len == blk.dst_cap)) || !eligible(blk);
+    if (skip) { if (lane == 0) meta[kMetaStatus] = 0; return; }
+    cgbyte* s = (cgbyte*)(src_base + blk.src_off);
+    const uint32_t csize = blk.src_len, limit = csize - kMargin;
+    uint32_t nseg = limit / kMinSeg; nseg = nseg < 1 ? 1 : (nseg > uint32_t(kSegs) ? uint32_t(kSegs) : nseg);
+    const uint32_t seglen = ((limit + nseg - 1) / nseg + 31u) & ~31u;
+    const uint32_t nwords = (csize + 31u) >> 5;
+    __shared__ uint32_t win[kWinDw * 64];
+    uint32_t* ring = win + lane;
+
+    LaneSeg g;
+    g.bm = meta + kMetaWords;
+    g.sj = lane * seglen;
+    g.seg_end = (lane + 1 == nseg) ? 0xFFFFFFFFu : (lane + 1) * seglen;
+    g.wend = (lane + 1 == nseg) ? nwords : ((lane + 1) * seglen) >> 5;
+    g.exitp = 0; g.entry = 0xFFFFFFFFu; g.tail = true;
+    const bool mine = lane < nseg;
+    Prof pf; unsigned long long tp = pf.now();
+    // phase 1: every lane its own chain
+    if (mine) walk_first(g, s, csize, limit, ring);
+    pf.add(0, tp);
+    // phase 2: the chain of the segment in front left at `pe`: assume it is the true one, thread it into this segment
+    {
+        const int from = int(lane ? lane - 1 : 0) * 4;           // lane j reads lane j-1
+        const uint32_t pe = uint32_t(__builtin_amdgcn_ds_bpermute(from, int(g.exitp)));
+        const uint32_t pt = uint32_t(__builtin_amdgcn_ds_bpermute(from, int(g.tail ? 1u : 0u)));
+        uint32_t sj = pe / seglen; sj = sj > nseg - 1 ? nseg - 1 : sj;
+        if (mine && lane >= 1 && !pt && sj == lane && pe != g.sj) walk_from_entry(g, s, limit, pe);
+    }
+    pf.add(1, tp);
+    // phase 3: follow the true chain through the segments; redo what was assumed wrong (one lane at a time: rare); segments the
+    // chain jumps over have no tokens
+    uint32_t cur = 0, tail_ip = 0;
+    for (;;) {
+        const uint32_t ex = rdl(g.exitp, cur);
+        if (rdl(g.tail ? 1u : 0u, cur)) { tail_ip = ex; break; }
+        uint32_t j = ex / seglen; j = j > nseg - 1 ? nseg - 1 : j;
+        if (lane > cur && lane < j) {
+            for (uint32_t x = g.sj >> 5; x < g.wend; x++) g.bm[x] = 0;
+        }
+        if (rdl(g.entry, j) != ex) {
+            if (lane == j) walk_from_entry(g, s, limit, ex);
+            pf.count(3);
+        }
+        cur = j;
+    }
+    pf.add(2, tp); pf.dump(meta, kMetaProf, 4, lane == 0);
+    if (lane == 0) { meta[kMetaTailIp] = tail_ip; meta[kMetaStatus] = 1; }
+}
+
+// ================================================================================================ EXEC kernel
+__global__ __launch_bounds__(kThreads)
+void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks, uint32_t nblocks,
+                          int container_mode, uint32_t* ws)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t  ring[kRing];
+    __shared__ __attribute__((aligned(16))) uint16_t code[kTile];          // per tile byte: (sequence + 1) << 2 | overlap << 1 | part; then pointer / kFinal
+    __shared__ __attribute__((aligned(16))) uint8_t  stage[kStage];
+    __shared__ uint32_t val[2 * kThreads];                                   // [2 i]: literal start in the stream - output start in the chunk; [2 i + 1]: offset | tile-relative match start << 16
+    __shared__ uint16_t toks[kThreads];                                      // token positions of the chunk, relative to the stage
+    __shared__ uint32_t sc[64];
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    const fourmc_block blk = uniform_block(blocks[b]);
+    if (container_mode && blk.result == FOURMC_BLK_BADSUM) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = rfl(tid >> 6);
+    if (container_mode && blk.src_len == blk.dst_cap) {                 // stored block (native/4mc.c:635-642)
+        const uint8_t* sp = src_base + blk.src_off; uint8_t* dp = dst_base + blk.dst_off;
+        const uint32_t n = blk.src_len;
+        const uint32_t head = min(n, uint32_t((16u - uint32_t(uintptr_t(dp) & 15u)) & 15u));
+        if (tid < head) dp[tid] = sp[tid];
+        uint32_t k = head + 16u * tid;
+        for (; k + 16u <= n; k += 16u * kThreads) *reinterpret_cast<uint4*>(dp + k) = ld16u(sp + k);
+        const uint32_t body = head + ((n - head) & ~15u);
+        if (body + tid < n) dp[body + tid] = sp[body + tid];
+        if (tid == 0) blocks[b].result = int(blk.src_len);
+        return;
+    }
+    gword* meta = (gword*)(ws + size_t(b) * kWsWords);
+    if (!eligible(blk) || rfl(meta[kMetaStatus]) != 1u) { if (tid == 0) blocks[b].result = lz4par::kRetryCode; return; }
+    cgbyte* s = (cgbyte*)(src_base + blk.src_off);
+    gbyte* dst = (gbyte*)(dst_base + blk.dst_off);
+    cgword* bm = (cgword*)(meta + kMetaWords);
+    const uint32_t csize = blk.src_len, cap = blk.dst_cap, olimit = cap - kOMargin;
+    const uint32_t nwords = (csize + 31u) >> 5;
+    const uint32_t tail_ip = rfl(meta[kMetaTailIp]);
+    const uint32_t A = uint32_t(uintptr_t(dst)) & 0xFFFFu;             // ring index of output position P: (A + P) & 0xFFFF - congruent to P's address mod 16
+    uint32_t ip = 0, opos = 0, flushed = 0, res_ip = tail_ip;
+    bool cut = false, failed = false;
+    Prof pf; unsigned long long tp = pf.now();
+
+    while (ip < tail_ip && !cut) {
+        // ---- the chunk's stream bytes into the stage, its bitmap words through wave 0: token positions, compacted
+        const uint32_t sbase = ip & ~15u;
+        if (tid < kStage / 16u) {
+            const uint32_t a = sbase + 16u * tid;
+            u32x4 v = u32x4{0, 0, 0, 0};
+            if (a + 16u <= csize) v = ld16u_g(s + a);
+            *reinterpret_cast<u32x4*>(stage + 16u * tid) = v;
+        }
+        if (wv == 0) {
+            const uint32_t w0 = ip >> 5;
+            uint32_t cend = (w0 << 5) + kChunk; cend = cend < tail_ip ? cend : tail_ip;
+            uint32_t w = (w0 + lane) < nwords ? bm[w0 + lane] : 0u;
+            const uint32_t lo = (w0 + lane) << 5;
+            if (lo < ip) w &= ~((1u << (ip - lo)) - 1u);
+            if (lo >= cend) w = 0; else if (cend - lo < 32u) w &= (1u << (cend - lo)) - 1u;
+            const uint32_t c = uint32_t(__builtin_popcount(w)), inc = scan_add(c);
+            uint32_t idx = inc - c;
+            while (w) {
+                const uint32_t bit = uint32_t(__builtin_ctz(w)); w &= w - 1u;
+                if (idx < uint32_t(kThreads)) toks[idx] = uint16_t(lo + bit - sbase);
+                idx++;
+            }
+            if (lane == 63) sc[0] = inc;
+        }
+        __syncthreads();
+        const uint32_t ntok = rfl(sc[0]);
+        uint32_t n = ntok < uint32_t(kThreads) ? ntok : uint32_t(kThreads);
+        if (n == 0) { failed = true; break; }                           // (the bitmap has a token at ip: cannot happen)
+        pf.add(0, tp);
+        // ---- one sequence per thread, fields from the stage (from memory beyond it)
+        uint32_t ll = 0, ml = 0, off = 0, lsrc = 0, sz = 0, tpos = 0;
+        if (tid < n) {
+            auto rd = [&](uint32_t rel) -> uint32_t { return rel < kStage ? uint32_t(stage[rel]) : uint32_t(s[sbase + rel]); };
+            const uint32_t p = toks[tid];
+            const uint32_t t = rd(p), mn = t & 15u;
+            uint32_t q = p + 1; ll = t >> 4;
+            if (ll == 15u) { uint32_t bq; do { bq = rd(q++); ll += bq; } while (bq == 255u && ll < (1u << 24)); }
+            lsrc = sbase + q;
+            const uint32_t mo = q + ll;
+            off = rd(mo) | (rd(mo + 1) << 8);
+            uint32_t q2 = mo + 2; ml = mn + 4u;
+            if (mn == 15u) { uint32_t bq; do { bq = rd(q2++); ml += bq; } while (bq == 255u && q2 + sbase < csize); }
+            tpos = sbase + p;
+            const uint32_t z = ll + ml;                                  // (both below 2^30)
+            sz = z > kSzClamp ? kSzClamp : z;
+            if (tid == n - 1) sc[1] = sbase + q2;                       // where the next chunk begins: the token behind the chunk's last
+        }
+        // ---- placed by a prefix sum over the workgroup
+        const uint32_t winc = scan_add(sz);
+        if (lane == 63) sc[8 + wv] = winc;
+        __syncthreads();
+        uint32_t wbase = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) { const uint32_t x = sc[8 + k]; wbase += k < wv ? x : 0u; }
+        const uint32_t next_ip = rfl(sc[1]);
+        const uint32_t incl = wbase + winc, outl = incl - sz, mst = outl + ll;          // output start of the literals / of the match, chunk-relative
+        // how many sequences the chunk takes: those whose output ends below the output-side margin; an offset beyond the output
+        // among them hands the block back
+        const bool fits = tid < n && opos + incl <= olimit && sz < kSzClamp;
+        const bool bad = tid < n && (off == 0u || off > opos + mst);
+        {
+            const unsigned long long fm = __ballot(fits), bmk = __ballot(bad);
+            const uint32_t nf = uint32_t(__builtin_popcountll(fm));                      // (fits is monotone: a prefix)
+            const uint32_t fb = bmk ? 64u * wv + uint32_t(__builtin_ctzll(bmk)) : 0xFFFFu;
+            uint32_t tot = fits ? incl : 0u;
+            tot = umax(tot, dpp0<0x111, 0xf>(tot)); tot = umax(tot, dpp0<0x112, 0xf>(tot)); tot = umax(tot, dpp0<0x114, 0xf>(tot)); tot = umax(tot, dpp0<0x118, 0xf>(tot));
+            tot = umax(tot, dpp0<0x142, 0xa>(tot)); tot = umax(tot, dpp0<0x143, 0xc>(tot));
+            if (lane == 63) { sc[16 + wv] = nf; sc[24 + wv] = fb; sc[32 + wv] = tot; }
+            if (tid < n) { val[2 * tid] = lsrc - outl; }
+        }
+        __syncthreads();
+        uint32_t nfit = 0, nbad = 0xFFFFu, total = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) { nfit += sc[16 + k]; nbad = min(nbad, sc[24 + k]); total = umax(total, sc[32 + k]); }
+        nfit = rfl(nfit); nbad = rfl(nbad); total = rfl(total);
+        if (nbad < nfit) { failed = true; break; }
+        if (nfit < n) {
+            cut = true;
+            if (tid == nfit) sc[2] = tpos;
+            n = nfit;
+        }
+        pf.add(1, tp);
+        // ---- the chunk's output, a tile at a time
+        for (uint32_t R0 = 0; R0 < total; R0 += kTile) {
+            const uint32_t T = total - R0 < kTile ? total - R0 : kTile;
+            *reinterpret_cast<u32x4*>(code + 8u * tid) = u32x4{0, 0, 0, 0};
+            __syncthreads();
+            // marks: where the sequence's literal part and its match part begin inside the tile
+            if (tid < n) {
+                const uint32_t me = outl + sz;
+                if (ll != 0u && outl < R0 + T && mst > R0) code[(outl > R0 ? outl : R0) - R0] = uint16_t((tid + 1u) << 2);
+                if (mst < R0 + T && me > R0) {
+                    const uint32_t m = (mst > R0 ? mst : R0) - R0;
+                    code[m] = uint16_t(((tid + 1u) << 2) | 1u | (off < ml ? 2u : 0u));
+                    val[2 * tid + 1] = off | (m << 16);
+                }
+            }
+            __syncthreads();
+            // max-scan: every byte gets the mark in front of it (8 consecutive bytes per thread)
+            {
+                const u32x4 cv = *reinterpret_cast<const u32x4*>(code + 8u * tid);
+                uint32_t c[8] = { cv.x & 0xFFFFu, cv.x >> 16, cv.y & 0xFFFFu, cv.y >> 16, cv.z & 0xFFFFu, cv.z >> 16, cv.w & 0xFFFFu, cv.w >> 16 };
+#pragma unroll
+                for (int k = 1; k < 8; k++) c[k] = umax(c[k], c[k - 1]);
+                const uint32_t wi = scan_max(c[7]);
+                if (lane == 63) sc[40 + wv] = wi;
+                uint32_t ex = dpp0<0x138, 0xf>(wi);                      // wave_shr:1 - the lanes in front (0 for lane 0)
+                __syncthreads();
+                uint32_t pre = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) { const uint32_t x = sc[40 + k]; pre = umax(pre, k < wv ? x : 0u); }
+                ex = umax(ex, pre);
+#pragma unroll
+                for (int k = 0; k < 8; k++) c[k] = umax(c[k], ex);
+                *reinterpret_cast<u32x4*>(code + 8u * tid) = u32x4{c[0] | (c[1] << 16), c[2] | (c[3] << 16), c[4] | (c[5] << 16), c[6] | (c[7] << 16)};
+            }
+            __syncthreads();
+            pf.add(2, tp);
+            // pass 1, reads: every byte's source; the value of everything that is final (literals; matches from in front of the tile)
+            uint32_t bv[kTile / kThreads], ptr[kTile / kThreads];
+            const uint32_t rbase = A + opos;
+#pragma unroll
+            for (uint32_t k = 0; k < kTile / kThreads; k++) {
+                const uint32_t r = tid + k * kThreads;
+                bv[k] = 0; ptr[k] = kFinal;
+                if (r < T) {
+                    const uint32_t c = code[r];
+                    const uint32_t v = val[((c >> 2) - 1u) * 2u + (c & 1u)];
+                    if (!(c & 1u)) {
+                        const uint32_t sp = v + R0 + r, si = sp - sbase;
+                        bv[k] = si < kStage ? uint32_t(stage[si]) : uint32_t(s[sp]);
+                    } else {
+                        const uint32_t o = v & 0xFFFFu, m = v >> 16;
+                        int src = int(r) - int(o);
+                        if (c & 2u) {                                    // overlapping: byte k of the match is byte k mod offset of its period
+                            const uint32_t kk = r - m;
+                            uint32_t qd = uint32_t(float(kk) * __builtin_amdgcn_rcpf(float(o)));
+                            int rem = int(kk) - int(qd * o);
+                            if (rem < 0) rem += int(o); else if (rem >= int(o)) rem -= int(o);
+                            src = int(m) - int(o) + rem;
+                        }
+                        if (src < 0) bv[k] = ring[(rbase + uint32_t(src)) & 0xFFFFu];
+                        else ptr[k] = uint32_t(src);
+                    }
+                }
+            }
+            __syncthreads();
+            // pass 1, writes
+#pragma unroll
+            for (uint32_t k = 0; k < kTile / kThreads; k++) {
+                const uint32_t r = tid + k * kThreads;
+                if (r < T) {
+                    if (ptr[k] == kFinal) ring[(rbase + r) & 0xFFFFu] = uint8_t(bv[k]);
+                    code[r] = uint16_t(ptr[k]);
+                }
+            }
+            __syncthreads();
+            pf.add(3, tp);
+            // pass 2: bytes whose source lies in the tile chase pointers down to a final byte
+#pragma unroll
+            for (uint32_t k = 0; k < kTile / kThreads; k++) {
+                const uint32_t r = tid + k * kThreads;
+                const bool nr = ptr[k] != kFinal;
+                if (__ballot(nr)) {
+                    uint32_t p = nr ? ptr[k] : 0u;
+                    bool going = nr;
+                    while (__ballot(going)) {
+                        if (going) {
+                            const uint32_t q = __hip_atomic_load(&code[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (q == kFinal) going = false; else p = q;
+                        }
+                    }
+                    if (nr) {
+                        const uint8_t v = ring[(rbase + p) & 0xFFFFu];
+                        ring[(rbase + r) & 0xFFFFu] = v;
+                        __hip_atomic_store(&code[r], uint16_t(kFinal), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+            __syncthreads();
+            pf.add(4, tp);
+            // flush: whole 16-byte pieces by ADDRESS; the piece the tile ends in waits for the next tile
+            const uint32_t E = opos + T;
+            {
+                const uint32_t mis = (A + flushed) & 15u;
+                if (mis) {                                               // the block's first bytes up to an aligned address
+                    uint32_t h = flushed + 16u - mis; h = h < E ? h : E;
+                    if (tid < h - flushed) dst[flushed + tid] = ring[(A + flushed + tid) & 0xFFFFu];
+                    flushed = h;
+                }
+                if (((A + flushed) & 15u) == 0u) {
+                    const uint32_t np = (E - flushed) >> 4;
+                    for (uint32_t j = tid; j < np; j += kThreads)
+                        st16g(dst + flushed + 16u * j, *reinterpret_cast<const u32x4*>(ring + ((A + flushed + 16u * j) & 0xFFFFu)));
+                    flushed += 16u * np;
+                }
+            }
+            opos = E;
+            pf.add(5, tp); pf.count(6);
+        }
+        ip = next_ip;
+        __syncthreads();                                                 // (sc, toks, val, stage are rewritten by the next chunk)
+    }
+    if (cut && !failed) res_ip = rfl(sc[2]);
+    if (!failed) {
+        // what the last tile left in the piece it ended in
+        if (tid < opos - flushed) dst[flushed + tid] = ring[(A + flushed + tid) & 0xFFFFu];
+    }
+    pf.dump(meta, kMetaProf + 8, 7, tid == 0);
+    if (tid == 0) {
+        if (failed) blocks[b].result = lz4par::kRetryCode;
+        else { meta[kMetaResIp] = res_ip; meta[kMetaResOp] = opos; blocks[b].result = kResumeCode; }
+    }
+}
+
+} // namespace
+
+extern "C" size_t fourmc_lz4_tile_work_bytes(uint32_t n) { return size_t(n) * lz4tile::kWsWords * 4u; }
+// Blocks per launch pair: 0.53 MB of workspace per block (the token bitmap of the largest stream), so the 16 384 blocks of a
+// 64 GiB launch are ONE piece of 8.6 GB; on a smaller device the pieces stay below 20 % of its memory.  FOURMC_TILE_BATCH overrides.
+extern "C" uint32_t fourmc_lz4_tile_batch(void)
+{
+    static const uint32_t batch = [] {
+        uint32_t b = 16384;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) {
+            const size_t fit = tot / 5 / (size_t(lz4tile::kWsWords) * 4u);
+            if (fit < b) b = fit < 64 ? 64u : uint32_t(fit);
+        }
+        if (const char* e = getenv("FOURMC_TILE_BATCH")) { const long x = atol(e); if (x > 0) b = uint32_t(x); }
+        return b;
+    }();
+    return batch;
+}
+
+extern "C" hipError_t fourmc_launch_lz4_tile(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
+                                             int container_mode, void* d_work, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(lz4_tile_walk_kernel, dim3(n), dim3(64), 0, stream, static_cast<const uint8_t*>(d_src), d_blocks, n,
+                       container_mode, static_cast<uint32_t*>(d_work));
+    hipLaunchKernelGGL(lz4_tile_exec_kernel, dim3(n), dim3(lz4tile::kThreads), 0, stream, static_cast<const uint8_t*>(d_src),
+                       static_cast<uint8_t*>(d_dst), d_blocks, n, container_mode, static_cast<uint32_t*>(d_work));
+    return hipGetLastError();
+}

@@ -15,8 +15,8 @@ pytestmark = pytest.mark.gpu
 RETRY = -1000000003
 
 
-@pytest.fixture(scope="module", params=[4, 5, 7, 8, 9, 10, 11, 12],
-                ids=["rows", "rows-alone", "lanes", "lanes-alone", "wx", "wx-alone", "seg", "seg-alone"])
+@pytest.fixture(scope="module", params=[4, 5, 7, 8, 9, 10, 11, 12, 13, 14],
+                ids=["rows", "rows-alone", "lanes", "lanes-alone", "wx", "wx-alone", "seg", "seg-alone", "tile", "tile-alone"])
 def gpu(request):
     p = pkg(); p.gpu_init()
     research = request.param in (4, 5, 7, 8)          # the row pipeline and the lane-per-sequence path live in the research side build
@@ -24,10 +24,10 @@ def gpu(request):
     before = p.lib().fourmc_gpu_get_lz4_decode_path()
     p.lib().fourmc_gpu_set_lz4_decode_path(request.param)
     assert p.lib().fourmc_gpu_get_lz4_decode_path() == request.param
-    p.rows_alone = request.param in (5, 8, 10, 12)
+    p.rows_alone = request.param in (5, 8, 10, 12, 14)
     # below these sizes a path leaves the block to the exact walker (seg: lz4seg.h kMinSrc / kMinCap; "alone" = blocks handed
     # back entirely stay RETRY - the exact walker still finishes the last bytes of the blocks the segment path executed)
-    p.min_cap, p.min_src = (256, 256) if request.param == 12 else (64, 8)
+    p.min_cap, p.min_src = (256, 256) if request.param in (12, 14) else (64, 8)
     yield p
     p.lib().fourmc_gpu_set_lz4_decode_path(before)
     if research: p.use_research(False)
