@@ -288,16 +288,31 @@ void lz4_tile_walk_kernel(const uint8_t* __restrict__ src_base, const fourmc_blo
 }
 
 // ================================================================================================ EXEC kernel
+// A thread owns the 8 bytes of one 8-byte-aligned group of the ring per tile (tile coordinate u = 8 t + k; the tile's first byte
+// sits at u = mis = its ring address & 7): its marks are scanned, its sources fetched, its pointers chased and its bytes written by
+// the same thread - the scan's result stays in registers, the group's states travel as one 16-byte LDS access and its bytes as
+// one 8-byte access.
+//   code[u]   first the MARKS (0: none; e: source entry e begins at u), then the STATES of the tile's bytes: kFinal | value, or - for
+//             a byte whose source lies in the tile - twice the tile coordinate of that source (a byte offset into code[])
+//   ent[e]    {w0, w1}: the byte at tile coordinate u comes from LDS address ((u + w0 + gb) & 0xFFFF) | w1 (w1 = 0x10000: the staged
+//             stream behind the ring); it is a byte of the tile itself when ulo <= u + w0 < 4096 (w0 = -offset for matches,
+//             0x20000 | ... for everything else)
+// The instruction stream per byte is what bounds this kernel (wave64 on SIMD16: one vector instruction per 4 clk and SIMD), so
+// the per-byte passes are written for few vector instructions: 8 in the source pass, 1 per byte and round in the chase.
+constexpr uint32_t kGroup = kTile / kThreads;                              // 8
+constexpr uint32_t kLdsStage = kRing;
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | c; }
+
 __global__ __launch_bounds__(kThreads)
 void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks, uint32_t nblocks,
                           int container_mode, uint32_t* ws)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t  ring[kRing];
-    __shared__ __attribute__((aligned(16))) uint16_t code[kTile];          // per tile byte: (sequence + 1) << 2 | overlap << 1 | part; then pointer / kFinal
-    __shared__ __attribute__((aligned(16))) uint8_t  stage[kStage];
-    __shared__ uint32_t val[2 * kThreads];                                   // [2 i]: literal start in the stream - output start in the chunk; [2 i + 1]: offset | tile-relative match start << 16
-    __shared__ uint16_t toks[kThreads];                                      // token positions of the chunk, relative to the stage
-    __shared__ uint32_t sc[64];
+    __shared__ __attribute__((aligned(16))) uint8_t  lds[kRing + kStage];   // [0, kRing): the output ring; behind it: the chunk's stream bytes
+    __shared__ __attribute__((aligned(16))) uint16_t code[kTile];          // marks, then states (while a chunk's tokens are decoded: their positions)
+    __shared__ __attribute__((aligned(8)))  uint32_t ent[2 * kEntries];
+    __shared__ uint32_t sc[36];                                             // [0] tokens [1] next chunk [2] cut position [3] far literals; [4..11], [12..19], [20..27], [28..35]: per wave
+    uint8_t* const ring = lds; uint8_t* const stage = lds + kRing;
+    uint16_t* const toks = code;
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
     const fourmc_block blk = uniform_block(blocks[b]);
@@ -327,20 +342,31 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
     uint32_t ip = 0, opos = 0, flushed = 0, res_ip = tail_ip;
     bool cut = false, failed = false;
     Prof pf; unsigned long long tp = pf.now();
+    const uint32_t u0 = kGroup * tid;
+    *reinterpret_cast<u32x4*>(code + u0) = u32x4{0, 0, 0, 0};
+    if (tid == 0) { ent[2] = 0x20000u; ent[3] = 0; ent[2 * (kEntries - 1)] = 0x20000u; ent[2 * (kEntries - 1) + 1] = 0; }     // the bytes around a tile keep what the ring holds
+
+    // the next chunk's stream bytes and bitmap word are loaded a chunk ahead, into registers
+    u32x4 nst = u32x4{0, 0, 0, 0}; uint32_t nbw = 0;
+    auto prefetch = [&](uint32_t at) {
+        const uint32_t sb = at & ~15u, a = sb + 16u * tid;
+        nst = u32x4{0, 0, 0, 0}; nbw = 0;
+        if (tid < kStage / 16u && a + 16u <= csize) nst = ld16u_g(s + a);
+        if (tid < kChunk / 32u && (at >> 5) + tid < nwords) nbw = bm[(at >> 5) + tid];
+    };
+    auto arrived = [&]() { asm volatile("" : "+v"(nst.x), "+v"(nst.y), "+v"(nst.z), "+v"(nst.w), "+v"(nbw)); };
+    if (tail_ip > 0) prefetch(0);
+    __syncthreads();
 
     while (ip < tail_ip && !cut) {
         // ---- the chunk's stream bytes into the stage, its bitmap words through wave 0: token positions, compacted
         const uint32_t sbase = ip & ~15u;
-        if (tid < kStage / 16u) {
-            const uint32_t a = sbase + 16u * tid;
-            u32x4 v = u32x4{0, 0, 0, 0};
-            if (a + 16u <= csize) v = ld16u_g(s + a);
-            *reinterpret_cast<u32x4*>(stage + 16u * tid) = v;
-        }
+        arrived();
+        if (tid < kStage / 16u) *reinterpret_cast<u32x4*>(stage + 16u * tid) = nst;
         if (wv == 0) {
             const uint32_t w0 = ip >> 5;
             uint32_t cend = (w0 << 5) + kChunk; cend = cend < tail_ip ? cend : tail_ip;
-            uint32_t w = (w0 + lane) < nwords ? bm[w0 + lane] : 0u;
+            uint32_t w = nbw;
             const uint32_t lo = (w0 + lane) << 5;
             if (lo < ip) w &= ~((1u << (ip - lo)) - 1u);
             if (lo >= cend) w = 0; else if (cend - lo < 32u) w &= (1u << (cend - lo)) - 1u;
@@ -348,29 +374,37 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
             uint32_t idx = inc - c;
             while (w) {
                 const uint32_t bit = uint32_t(__builtin_ctz(w)); w &= w - 1u;
-                if (idx < uint32_t(kThreads)) toks[idx] = uint16_t(lo + bit - sbase);
+                if (idx < kSeqs) toks[idx] = uint16_t(lo + bit - sbase);
                 idx++;
             }
             if (lane == 63) sc[0] = inc;
         }
         __syncthreads();
         const uint32_t ntok = rfl(sc[0]);
-        uint32_t n = ntok < uint32_t(kThreads) ? ntok : uint32_t(kThreads);
+        uint32_t n = ntok < kSeqs ? ntok : kSeqs;
         if (n == 0) { failed = true; break; }                           // (the bitmap has a token at ip: cannot happen)
         pf.add(0, tp);
         // ---- one sequence per thread, fields from the stage (from memory beyond it)
         uint32_t ll = 0, ml = 0, off = 0, lsrc = 0, sz = 0, tpos = 0;
+        bool beyond = false;                                             // literals that reach beyond the stage
         if (tid < n) {
             auto rd = [&](uint32_t rel) -> uint32_t { return rel < kStage ? uint32_t(stage[rel]) : uint32_t(s[sbase + rel]); };
             const uint32_t p = toks[tid];
-            const uint32_t t = rd(p), mn = t & 15u;
+            const uint32_t t = stage[p], t1 = stage[p + 1], mn = t & 15u;
             uint32_t q = p + 1; ll = t >> 4;
-            if (ll == 15u) { uint32_t bq; do { bq = rd(q++); ll += bq; } while (bq == 255u && ll < (1u << 24)); }
-            lsrc = sbase + q;
+            if (ll == 15u) { uint32_t bq = t1; ll += bq; q++; while (bq == 255u && ll < (1u << 24)) { bq = rd(q++); ll += bq; } }
+            lsrc = q;                                                    // (relative to the stage)
             const uint32_t mo = q + ll;
-            off = rd(mo) | (rd(mo + 1) << 8);
+            beyond = ll != 0u && mo > kStage;                            // (only the chunk's last sequence can: no token begins behind its literals)
+            uint32_t o0, o1, e0, e1;
+            if (mo + 3u < kStage) { o0 = stage[mo]; o1 = stage[mo + 1]; e0 = stage[mo + 2]; e1 = stage[mo + 3]; }
+            else { o0 = s[sbase + mo]; o1 = s[sbase + mo + 1]; e0 = s[sbase + mo + 2]; e1 = s[sbase + mo + 3]; }       // (mo + 3 <= limit + 1 < csize)
+            off = o0 | (o1 << 8);
             uint32_t q2 = mo + 2; ml = mn + 4u;
-            if (mn == 15u) { uint32_t bq; do { bq = rd(q2++); ml += bq; } while (bq == 255u && q2 + sbase < csize); }
+            if (mn == 15u) {
+                ml += e0; q2++;
+                if (e0 == 255u) { uint32_t bq = e1; ml += bq; q2++; while (bq == 255u && q2 + sbase < csize) { bq = rd(q2++); ml += bq; } }
+            }
             tpos = sbase + p;
             const uint32_t z = ll + ml;                                  // (both below 2^30)
             sz = z > kSzClamp ? kSzClamp : z;
@@ -378,11 +412,15 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
         }
         // ---- placed by a prefix sum over the workgroup
         const uint32_t winc = scan_add(sz);
-        if (lane == 63) sc[8 + wv] = winc;
+        if (lane == 63) sc[4 + wv] = winc;
+        const bool anybeyond = __ballot(beyond) != 0;
+        if (lane == 0) sc[28 + wv] = anybeyond ? 1u : 0u;
         __syncthreads();
-        uint32_t wbase = 0;
+        if (tid < (kSeqs + kGroup - 1) / kGroup) *reinterpret_cast<u32x4*>(code + u0) = u32x4{0, 0, 0, 0};      // (the token positions were here)
+        uint32_t wbase = 0, glob_any = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) { const uint32_t x = sc[8 + k]; wbase += k < wv ? x : 0u; }
+        for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) { const uint32_t x = sc[4 + k]; wbase += k < wv ? x : 0u; glob_any |= sc[28 + k]; }
+        const bool has_beyond = rfl(glob_any) != 0;
         const uint32_t next_ip = rfl(sc[1]);
         const uint32_t incl = wbase + winc, outl = incl - sz, mst = outl + ll;          // output start of the literals / of the match, chunk-relative
         // how many sequences the chunk takes: those whose output ends below the output-side margin; an offset beyond the output
@@ -393,144 +431,146 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
             const unsigned long long fm = __ballot(fits), bmk = __ballot(bad);
             const uint32_t nf = uint32_t(__builtin_popcountll(fm));                      // (fits is monotone: a prefix)
             const uint32_t fb = bmk ? 64u * wv + uint32_t(__builtin_ctzll(bmk)) : 0xFFFFu;
-            uint32_t tot = fits ? incl : 0u;
-            tot = umax(tot, dpp0<0x111, 0xf>(tot)); tot = umax(tot, dpp0<0x112, 0xf>(tot)); tot = umax(tot, dpp0<0x114, 0xf>(tot)); tot = umax(tot, dpp0<0x118, 0xf>(tot));
-            tot = umax(tot, dpp0<0x142, 0xa>(tot)); tot = umax(tot, dpp0<0x143, 0xc>(tot));
-            if (lane == 63) { sc[16 + wv] = nf; sc[24 + wv] = fb; sc[32 + wv] = tot; }
-            if (tid < n) { val[2 * tid] = lsrc - outl; }
+            const uint32_t tot = scan_max(fits ? incl : 0u);
+            if (lane == 63) { sc[12 + wv] = nf; sc[20 + wv] = fb; }
+            __syncthreads();                                             // (sc[4 ..] and sc[28 ..] have been read)
+            if (lane == 63) sc[4 + wv] = tot;
+            if (tid < n) { ent[2 * (3u + 2u * tid)] = 0u - off; ent[2 * (3u + 2u * tid) + 1] = 0u; }
+            if (beyond) { sc[3] = lsrc - outl; sc[31] = 2u + 2u * tid; }      // its literals' stage index at chunk output 0, its entry
         }
         __syncthreads();
         uint32_t nfit = 0, nbad = 0xFFFFu, total = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) { nfit += sc[16 + k]; nbad = min(nbad, sc[24 + k]); total = umax(total, sc[32 + k]); }
+        for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) { nfit += sc[12 + k]; nbad = min(nbad, sc[20 + k]); total = umax(total, sc[4 + k]); }
         nfit = rfl(nfit); nbad = rfl(nbad); total = rfl(total);
+        const uint32_t by_dl = has_beyond ? rfl(sc[3]) : 0u, by_e = has_beyond ? rfl(sc[31]) : 0u;
         if (nbad < nfit) { failed = true; break; }
         if (nfit < n) {
             cut = true;
             if (tid == nfit) sc[2] = tpos;
             n = nfit;
         }
+        if (!cut && next_ip < tail_ip) prefetch(next_ip);
         pf.add(1, tp);
         // ---- the chunk's output, a tile at a time
-        for (uint32_t R0 = 0; R0 < total; R0 += kTile) {
-            const uint32_t T = total - R0 < kTile ? total - R0 : kTile;
-            *reinterpret_cast<u32x4*>(code + 8u * tid) = u32x4{0, 0, 0, 0};
-            __syncthreads();
+        for (uint32_t R0 = 0; R0 < total;) {
+            const uint32_t gb0 = A + opos, mis = gb0 & 7u, gb = (gb0 - mis) & 0xFFFFu;       // ring address of tile coordinate 0
+            const uint32_t T = total - R0 < kTile - 8u ? total - R0 : kTile - 8u;
+            const uint32_t ulo = mis, uhi = mis + T;                             // the tile's bytes: tile coordinates [ulo, uhi)
+            __syncthreads();                                                     // (code[] is zero, the tile before has left sc[])
             // marks: where the sequence's literal part and its match part begin inside the tile
             if (tid < n) {
                 const uint32_t me = outl + sz;
-                if (ll != 0u && outl < R0 + T && mst > R0) code[(outl > R0 ? outl : R0) - R0] = uint16_t((tid + 1u) << 2);
-                if (mst < R0 + T && me > R0) {
-                    const uint32_t m = (mst > R0 ? mst : R0) - R0;
-                    code[m] = uint16_t(((tid + 1u) << 2) | 1u | (off < ml ? 2u : 0u));
-                    val[2 * tid + 1] = off | (m << 16);
+                if (ll != 0u && outl < R0 + T && mst > R0) {
+                    code[(outl > R0 ? outl : R0) - R0 + mis] = uint16_t(2u + 2u * tid);
+                    // the literal at tile coordinate u is stage byte lsrc + (R0 + u - mis) - outl
+                    ent[2 * (2u + 2u * tid)] = 0x20000u | ((lsrc + R0 - mis - outl - gb) & 0xFFFFu);
+                    ent[2 * (2u + 2u * tid) + 1] = 0x10000u;
                 }
+                if (mst < R0 + T && me > R0) code[(mst > R0 ? mst : R0) - R0 + mis] = uint16_t(3u + 2u * tid);
             }
+            if (tid == kThreads - 1) { if (mis) code[0] = 1; code[uhi] = uint16_t(kEntries - 1u); }
             __syncthreads();
-            // max-scan: every byte gets the mark in front of it (8 consecutive bytes per thread)
+            // max-scan: every byte gets the mark in front of it
+            uint32_t c[kGroup];
             {
-                const u32x4 cv = *reinterpret_cast<const u32x4*>(code + 8u * tid);
-                uint32_t c[8] = { cv.x & 0xFFFFu, cv.x >> 16, cv.y & 0xFFFFu, cv.y >> 16, cv.z & 0xFFFFu, cv.z >> 16, cv.w & 0xFFFFu, cv.w >> 16 };
+                const u32x4 cv = *reinterpret_cast<const u32x4*>(code + u0);
+                c[0] = cv.x & 0xFFFFu; c[1] = cv.x >> 16; c[2] = cv.y & 0xFFFFu; c[3] = cv.y >> 16;
+                c[4] = cv.z & 0xFFFFu; c[5] = cv.z >> 16; c[6] = cv.w & 0xFFFFu; c[7] = cv.w >> 16;
 #pragma unroll
                 for (int k = 1; k < 8; k++) c[k] = umax(c[k], c[k - 1]);
                 const uint32_t wi = scan_max(c[7]);
-                if (lane == 63) sc[40 + wv] = wi;
+                if (lane == 63) sc[4 + wv] = wi;
                 uint32_t ex = dpp0<0x138, 0xf>(wi);                      // wave_shr:1 - the lanes in front (0 for lane 0)
                 __syncthreads();
                 uint32_t pre = 0;
 #pragma unroll
-                for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) { const uint32_t x = sc[40 + k]; pre = umax(pre, k < wv ? x : 0u); }
+                for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) { const uint32_t x = sc[4 + k]; pre = umax(pre, k < wv ? x : 0u); }
                 ex = umax(ex, pre);
 #pragma unroll
                 for (int k = 0; k < 8; k++) c[k] = umax(c[k], ex);
-                *reinterpret_cast<u32x4*>(code + 8u * tid) = u32x4{c[0] | (c[1] << 16), c[2] | (c[3] << 16), c[4] | (c[5] << 16), c[6] | (c[7] << 16)};
             }
-            __syncthreads();
             pf.add(2, tp);
-            // pass 1, reads: every byte's source; the value of everything that is final (literals; matches from in front of the tile)
-            uint32_t bv[kTile / kThreads], ptr[kTile / kThreads];
-            const uint32_t rbase = A + opos;
+            // source pass: every byte's state.  Final: literals, matches from in front of the tile, the bytes around the tile (value
+            // from LDS: stage or ring; every read of what the ring held happens before the tile's first ring write, behind the next
+            // barrier).  Otherwise: a pointer to the byte's source in the tile.
+            const bool active = u0 < uhi;
+            uint32_t st[kGroup];
 #pragma unroll
-            for (uint32_t k = 0; k < kTile / kThreads; k++) {
-                const uint32_t r = tid + k * kThreads;
-                bv[k] = 0; ptr[k] = kFinal;
-                if (r < T) {
-                    const uint32_t c = code[r];
-                    const uint32_t v = val[((c >> 2) - 1u) * 2u + (c & 1u)];
-                    if (!(c & 1u)) {
-                        const uint32_t sp = v + R0 + r, si = sp - sbase;
-                        bv[k] = si < kStage ? uint32_t(stage[si]) : uint32_t(s[sp]);
-                    } else {
-                        const uint32_t o = v & 0xFFFFu, m = v >> 16;
-                        int src = int(r) - int(o);
-                        if (c & 2u) {                                    // overlapping: byte k of the match is byte k mod offset of its period
-                            const uint32_t kk = r - m;
-                            uint32_t qd = uint32_t(float(kk) * __builtin_amdgcn_rcpf(float(o)));
-                            int rem = int(kk) - int(qd * o);
-                            if (rem < 0) rem += int(o); else if (rem >= int(o)) rem -= int(o);
-                            src = int(m) - int(o) + rem;
-                        }
-                        if (src < 0) bv[k] = ring[(rbase + uint32_t(src)) & 0xFFFFu];
-                        else ptr[k] = uint32_t(src);
+            for (uint32_t k = 0; k < kGroup; k++) st[k] = kFinal;
+            if (active) {
+                u32x2 e[kGroup];
+#pragma unroll
+                for (uint32_t k = 0; k < kGroup; k++) e[k] = *reinterpret_cast<const u32x2*>(ent + 2u * c[k]);
+                const uint32_t ub = u0 - ulo, xb = u0 + gb, ulo2 = 2u * ulo;
+                uint32_t tt[kGroup], aa[kGroup], bv[kGroup];
+#pragma unroll
+                for (uint32_t k = 0; k < kGroup; k++) {
+                    tt[k] = ub + k + e[k].x;                             // (source's tile coordinate) - ulo
+                    aa[k] = and_or(xb + k + e[k].x, 0xFFFFu, e[k].y);
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < kGroup; k++) bv[k] = lds[aa[k]];
+                if (has_beyond) {                                        // literals beyond the stage: from memory (rare; long runs: the 16-bit index above is not theirs)
+#pragma unroll
+                    for (uint32_t k = 0; k < kGroup; k++) {
+                        const uint32_t si = by_dl + R0 + (u0 + k) - mis;
+                        if (c[k] == by_e && si >= kStage) bv[k] = s[sbase + si];
                     }
                 }
-            }
-            __syncthreads();
-            // pass 1, writes
 #pragma unroll
-            for (uint32_t k = 0; k < kTile / kThreads; k++) {
-                const uint32_t r = tid + k * kThreads;
-                if (r < T) {
-                    if (ptr[k] == kFinal) ring[(rbase + r) & 0xFFFFu] = uint8_t(bv[k]);
-                    code[r] = uint16_t(ptr[k]);
-                }
+                for (uint32_t k = 0; k < kGroup; k++) st[k] = tt[k] < kTile ? 2u * tt[k] + ulo2 : (bv[k] | kFinal);
+                *reinterpret_cast<u32x4*>(code + u0) = u32x4{st[0] | (st[1] << 16), st[2] | (st[3] << 16), st[4] | (st[5] << 16), st[6] | (st[7] << 16)};
             }
             __syncthreads();
             pf.add(3, tp);
-            // pass 2: bytes whose source lies in the tile chase pointers down to a final byte
+            // chase: a pointer is replaced by the state of the byte it points to until it is a value; what a thread has found so far
+            // goes back into code[] every round, so that everyone who passes through these bytes jumps ahead (pointer jumping)
+            {
+                bool open = active && (((st[0] & st[1] & st[2] & st[3] & st[4] & st[5] & st[6] & st[7]) & kFinal) == 0u);
+                const bool mine = open;
+                while (__ballot(open)) {
+                    uint32_t ad[kGroup];
 #pragma unroll
-            for (uint32_t k = 0; k < kTile / kThreads; k++) {
-                const uint32_t r = tid + k * kThreads;
-                const bool nr = ptr[k] != kFinal;
-                if (__ballot(nr)) {
-                    uint32_t p = nr ? ptr[k] : 0u;
-                    bool going = nr;
-                    while (__ballot(going)) {
-                        if (going) {
-                            const uint32_t q = __hip_atomic_load(&code[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (q == kFinal) going = false; else p = q;
-                        }
-                    }
-                    if (nr) {
-                        const uint8_t v = ring[(rbase + p) & 0xFFFFu];
-                        ring[(rbase + r) & 0xFFFFu] = v;
-                        __hip_atomic_store(&code[r], uint16_t(kFinal), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
+                    for (uint32_t k = 0; k < kGroup; k++) ad[k] = st[k] < kFinal ? st[k] : 2u * (u0 + k);      // (a byte that is final reads its own state)
+#pragma unroll
+                    for (uint32_t k = 0; k < kGroup; k++)
+                        st[k] = __hip_atomic_load(static_cast<uint16_t*>(__builtin_assume_aligned(reinterpret_cast<uint8_t*>(code) + ad[k], 2)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (open) *reinterpret_cast<u32x4*>(code + u0) = u32x4{st[0] | (st[1] << 16), st[2] | (st[3] << 16), st[4] | (st[5] << 16), st[6] | (st[7] << 16)};
+                    open = open && (((st[0] & st[1] & st[2] & st[3] & st[4] & st[5] & st[6] & st[7]) & kFinal) == 0u);
+                }
+                (void)mine;
+                if (active) {
+                    const uint32_t blo = (st[0] & 255u) | ((st[1] & 255u) << 8) | ((st[2] & 255u) << 16) | (st[3] << 24);
+                    const uint32_t bhi = (st[4] & 255u) | ((st[5] & 255u) << 8) | ((st[6] & 255u) << 16) | (st[7] << 24);
+                    *reinterpret_cast<u32x2*>(ring + ((gb + u0) & 0xFFFFu)) = u32x2{blo, bhi};
                 }
             }
             __syncthreads();
             pf.add(4, tp);
-            // flush: whole 16-byte pieces by ADDRESS; the piece the tile ends in waits for the next tile
+            // flush: whole 16-byte pieces by ADDRESS; the piece the tile ends in waits for the next tile.  (The next chunk's bytes
+            // have arrived by now: waited for HERE, in front of this tile's stores, not behind them.)
+            arrived();
             const uint32_t E = opos + T;
             {
-                const uint32_t mis = (A + flushed) & 15u;
-                if (mis) {                                               // the block's first bytes up to an aligned address
-                    uint32_t h = flushed + 16u - mis; h = h < E ? h : E;
+                const uint32_t mis16 = (A + flushed) & 15u;
+                if (mis16) {                                             // the block's first bytes up to an aligned address
+                    uint32_t h = flushed + 16u - mis16; h = h < E ? h : E;
                     if (tid < h - flushed) dst[flushed + tid] = ring[(A + flushed + tid) & 0xFFFFu];
                     flushed = h;
                 }
                 if (((A + flushed) & 15u) == 0u) {
                     const uint32_t np = (E - flushed) >> 4;
-                    for (uint32_t j = tid; j < np; j += kThreads)
-                        st16g(dst + flushed + 16u * j, *reinterpret_cast<const u32x4*>(ring + ((A + flushed + 16u * j) & 0xFFFFu)));
+                    if (tid < np) st16g(dst + flushed + 16u * tid, *reinterpret_cast<const u32x4*>(ring + ((A + flushed + 16u * tid) & 0xFFFFu)));
                     flushed += 16u * np;
                 }
             }
-            opos = E;
+            *reinterpret_cast<u32x4*>(code + u0) = u32x4{0, 0, 0, 0};
+            opos = E; R0 += T;
             pf.add(5, tp); pf.count(6);
         }
         ip = next_ip;
-        __syncthreads();                                                 // (sc, toks, val, stage are rewritten by the next chunk)
+        __syncthreads();                                                 // (sc, code, ent, stage are rewritten by the next chunk)
     }
     if (cut && !failed) res_ip = rfl(sc[2]);
     if (!failed) {

@@ -24,11 +24,13 @@ constexpr uint32_t kMinSrc  = 256, kMinCap = 256;
 constexpr uint32_t kMaxSrc  = lz4par::kSrcMax;
 
 constexpr int      kThreads = 512;           // executor workgroup: one thread per sequence of a chunk, one per output byte of a tile row
-constexpr uint32_t kTile    = 4096;          // output bytes per tile (8 rows of kThreads)
-constexpr uint32_t kChunk   = 2048;          // stream bytes whose tokens one chunk takes: 64 bitmap words, one per lane of a wave
+constexpr uint32_t kTile    = 4096;          // tile coordinates (8 per thread); a tile produces at most kTile - 8 bytes
+constexpr uint32_t kSeqs    = 384;           // sequences per chunk (one per thread of the first six waves)
+constexpr uint32_t kChunk   = 1536;          // stream bytes whose tokens one chunk takes: 48 bitmap words, one per lane of a wave
 constexpr uint32_t kStage   = kChunk + 32 + 272;     // staged stream bytes per chunk (a multiple of 16)
+constexpr uint32_t kEntries = 2 * kSeqs + 3; // source entries of a tile: 1 = bytes in front of the tile, 2 + 2 i / 3 + 2 i = literals / match of sequence i, last = bytes behind it
 constexpr uint32_t kRing    = 65536;         // output window in LDS: everything an LZ4 offset can reach
-constexpr uint32_t kFinal   = 0xFFFFu;       // pointer value of a tile byte whose value is in the ring
+constexpr uint32_t kFinal   = 0x8000u;       // state of a tile byte: kFinal | value, or (below kFinal) twice the tile coordinate of the byte it copies
 constexpr uint32_t kSzClamp = (4u << 20) + 1u;
 
 constexpr uint32_t kMetaStatus = 0, kMetaTailIp = 1, kMetaResIp = 2, kMetaResOp = 3;

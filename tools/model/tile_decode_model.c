@@ -135,6 +135,7 @@ typedef struct {
     uint32_t DL[NT]; uint16_t OFF[NT], MSC[NT];
     uint16_t toks[NT];                  /* (kernel: the same LDS as MSC) */
     long chunks, tiles, near_bytes, hops, maxhops, lit_global;
+    long depth_hist[65], depth_sum, near_seq, seqs;
 } Exec;
 
 static uint32_t perm[NT];
@@ -233,6 +234,11 @@ static int exec_block(Exec* X, const Walk* W, const uint8_t* s, int csize, uint8
             for (uint32_t r = 0; r < T; r++) {
                 if (ptr[r] == FINAL) X->ring[(A + opos + r) & 0xFFFFu] = val[r];
                 X->code[r] = ptr[r];
+            }
+            {   /* statistics: dependency depth of the tile (bytes in ascending order: a source is always below) */
+                static uint16_t dep[TCAP]; uint32_t mx = 0;
+                for (uint32_t r = 0; r < T; r++) { dep[r] = ptr[r] == FINAL ? 0 : (uint16_t)(dep[ptr[r]] + 1); if (dep[r] > mx) mx = dep[r]; }
+                X->depth_hist[mx > 64 ? 64 : mx]++; X->depth_sum += mx;
             }
             /* pass 2: bytes with a source inside the tile, in any order */
             {
@@ -337,6 +343,7 @@ int main(int argc, char** argv)
                pass ? "logs" : "smix", blk, cs, ok ? "OK" : "MISMATCH", W.stat_fix_hops, W.stat_rounds,
                X.chunks, X.tiles, 100.0 * X.near_bytes / B, X.near_bytes ? (double)X.hops / X.near_bytes : 0, X.maxhops, X.lit_global, rip, cs - (int)rip, rop);
         if (!ok) { bad++; for (uint32_t i = 0; i < B; i++) if (out[i] != in[i]) { printf("   first diff at %u (decoded %d)\n", i, fin); break; } }
+        { printf("      tile depth: mean %.1f; tiles with max depth 0..7: ", (double)X.depth_sum / X.tiles); for (int d = 0; d < 8; d++) printf("%ld ", X.depth_hist[d]); long r8 = 0, r16 = 0, r32 = 0; for (int d = 8; d < 65; d++) { if (d < 16) r8 += X.depth_hist[d]; else if (d < 32) r16 += X.depth_hist[d]; else r32 += X.depth_hist[d]; } printf("| 8-15: %ld 16-31: %ld 32+: %ld\n", r8, r16, r32); }
     }
     /* 2. small / odd sizes and damaged streams against the oracle's verdict */
     long accepted = 0, retried = 0, checked = 0;
