@@ -615,12 +615,20 @@ extern "C" int fourmc_gpu_get_lz4_decode_path(void);
 // lease and the launch see the same answer even if another thread changes the selection in between).  shrink: how often the
 // workspace could not be had - the pieces halve; below 64 blocks an automatic choice falls back to the walk + window copier,
 // which needs no workspace.
-static const uint32_t kAutoTileMin = 512;          // launches from here on go to the tile path (two workgroups per CU: 512 fill the chip once)
+// "auto" by launch size (measured on the container corpus, tools/decode_sizes.sh: 128 .. 512 blocks 13.5 - 15 ms through the tile
+// path against 30 ms through either other path, 1024: 24 / 31 ms, 1536: 34 / 34 ms, 2048: 43 / 35 ms, 16 384: 299 / 172 ms): the tile
+// path - one workgroup per block, two per CU, the shortest chain per block - up to kAutoTileMax blocks, the segment-parallel path
+// - one wave per block, 24 per CU - for launches that fill the chip several times over.  FOURMC_TILE_MAX overrides.
+static uint32_t auto_tile_max()
+{
+    static const uint32_t v = [] { const char* e = getenv("FOURMC_TILE_MAX"); const long x = e ? atol(e) : -1; return x >= 0 ? uint32_t(x) : 1536u; }();
+    return v;
+}
 extern "C" fourmc_lz4_plan fourmc_lz4_decode_plan(uint32_t n, uint32_t shrink)
 {
     fourmc_lz4_plan pl; pl.path = fourmc_gpu_get_lz4_decode_path(); pl.batch = n ? n : 1; pl.work_bytes = 0; pl.ok = 1;
     const bool automatic = pl.path == 6;
-    if (pl.path == 6) pl.path = n >= kAutoTileMin ? 13 : 9;
+    if (pl.path == 6) pl.path = n <= auto_tile_max() ? 13 : 11;
     if (pl.path == 11 || pl.path == 12 || pl.path == 13 || pl.path == 14) {
         const bool tile = pl.path >= 13;
         uint32_t b = tile ? fourmc_lz4_tile_batch() : fourmc_lz4_seg_batch();
@@ -694,8 +702,8 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
     const uint8_t* s8 = static_cast<const uint8_t*>(d_src);
     uint8_t* d8 = static_cast<uint8_t*>(d_dst);
     const int path = plan->path;
-    // (6 "auto" was resolved by fourmc_lz4_decode_plan: a launch that fills the chip goes to the tile path - lz4_tile.hip, one
-    // workgroup per block with the LZ4 window in LDS; smaller launches to the walk + window copier, K1wx: four waves per block)
+    // (6 "auto" was resolved by fourmc_lz4_decode_plan: the tile path - lz4_tile.hip, one workgroup per block with the LZ4 window in
+    // LDS - up to 1536 blocks, the segment-parallel path above; the walk + window copier, K1wx, when neither can have its workspace)
     if (path == 13 || path == 14 || path == 11 || path == 12) {
         // walk + executor (tile: lz4_tile.hip, segment-parallel: lz4_seg.hip), then the exact walker for the last bytes of every
         // block and for whatever was handed back; 12 / 14: test aid, blocks handed back stay kRetry

@@ -378,12 +378,24 @@ void lz4_seg_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base
         const uint32_t area = rfl(e[0]), f = rfl(e[1]), k = rfl(e[2]), c = rfl(e[3]);
         cgword* FL = (cgword*)(meta + area);
         uint32_t t0 = 0;
+        // the records of the NEXT step are loaded as soon as this step knows how many sequences it takes; their wait is placed in
+        // front of this step's flush (where nothing else is outstanding), not behind the flush's stores
+        u32x2 nrec = u32x2{0, 0}; bool have = false;
+        auto rec_at = [&](uint32_t t) -> u32x2 { return *reinterpret_cast<__attribute__((address_space(1))) const u32x2*>(FL + 2 * (t < f ? t : kFixCap + k + (t - f))); };
         while (t0 < c) {
             // ---- records and fields, one sequence per lane
             const uint32_t t = t0 + lane;
             const bool valid = t < c;
             u32x2 rec2 = u32x2{0, 0};
-            if (valid) rec2 = *reinterpret_cast<__attribute__((address_space(1))) const u32x2*>(FL + 2 * (t < f ? t : kFixCap + k + (t - f)));
+#ifdef K1S_NOPREFETCH
+            if (valid) rec2 = rec_at(t);
+#else
+            // (a step without prefetched records loads them here and waits INSIDE the branch: a register that is either ready or still
+            // on its way when the paths meet would be waited for on both)
+            if (!have) { nrec = rec_at(t < c ? t : c - 1u); asm volatile("" : "+v"(nrec.x), "+v"(nrec.y)); }
+            if (valid) rec2 = nrec;
+            have = false;
+#endif
             const uint32_t rec = rec2.x, pos = rec & kPosMask, ll = rec >> kPosBits;
             const bool esc = valid && ll == kEscLL;
             uint32_t off = 0, ml = 0, lsrc = 0;
@@ -430,6 +442,9 @@ void lz4_seg_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base
                 pf.add(5, tp);
                 continue;
             }
+#ifndef K1S_NOPREFETCH
+            if (t0 + cnt < c) { const uint32_t tn = t0 + cnt + lane; nrec = rec_at(tn < c ? tn : c - 1u); have = true; }
+#endif
             pf.add(0, tp); pf.count(6);
             const bool act = uint32_t(lane) < cnt;
             const uint32_t T = rdl(incl, cnt - 1);
@@ -558,6 +573,9 @@ void lz4_seg_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base
             LDS_FENCE();
             pf.add(3, tp);
             // ---- flush: aligned 16-byte stores; then the next batch's prologue, and the buffer zeroed again
+#ifndef K1S_NOPREFETCH
+            asm volatile("" : "+v"(nrec.x), "+v"(nrec.y));               // (the next step's records: waited for here)
+#endif
             {
                 gbyte* g = dst + opos;
                 const uint32_t head = min(T, (16u - uint32_t(uintptr_t(g) & 15u)) & 15u);

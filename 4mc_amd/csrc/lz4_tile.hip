@@ -290,28 +290,53 @@ void lz4_tile_walk_kernel(const uint8_t* __restrict__ src_base, const fourmc_blo
 // ================================================================================================ EXEC kernel
 // A thread owns the 8 bytes of one 8-byte-aligned group of the ring per tile (tile coordinate u = 8 t + k; the tile's first byte
 // sits at u = mis = its ring address & 7): its marks are scanned, its sources fetched, its pointers chased and its bytes written by
-// the same thread - the scan's result stays in registers, the group's states travel as one 16-byte LDS access and its bytes as
+// the same thread - the scan's result stays in registers, the group's pointers travel as one 16-byte LDS access and its bytes as
 // one 8-byte access.
-//   code[u]   first the MARKS (0: none; e: source entry e begins at u), then the STATES of the tile's bytes: kFinal | value, or - for
-//             a byte whose source lies in the tile - twice the tile coordinate of that source (a byte offset into code[])
-//   ent[e]    {w0, w1}: the byte at tile coordinate u comes from LDS address ((u + w0 + gb) & 0xFFFF) | w1 (w1 = 0x10000: the staged
-//             stream behind the ring); it is a byte of the tile itself when ulo <= u + w0 < 4096 (w0 = -offset for matches,
-//             0x20000 | ... for everything else)
-// The instruction stream per byte is what bounds this kernel (wave64 on SIMD16: one vector instruction per 4 clk and SIMD), so
-// the per-byte passes are written for few vector instructions: 8 in the source pass, 1 per byte and round in the chase.
-constexpr uint32_t kGroup = kTile / kThreads;                              // 8
-constexpr uint32_t kLdsStage = kRing;
-__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | c; }
+//   code[u]   first the MARKS (0: none; e: source entry e begins at u), then the POINTERS of the tile's bytes: twice the tile
+//             coordinate (= the byte offset in code[]) of the byte it copies - its own for a byte that is final
+//   ent[e]    {w0, w1}: the byte at tile coordinate u comes from ring / stage address ((u + w0 + gb) & 0xFFFF) | w1 (w1 = 0x10000: the
+//             staged stream, which lies 64 KiB behind the ring's first byte); it is a byte of the tile itself when
+//             ulo <= u + w0 < 4096 (w0 = -offset for matches, 0x20000 | ... for everything else)
+// What bounds this kernel is the vector instruction stream (wave64 on a SIMD16: one vector instruction per 4 clk and SIMD; 2.5 G
+// wave-instructions per ms on the chip), so the per-byte passes are written for few of them: ~7 per byte in the source pass, one
+// per byte and round in the chase (the LDS read IS the step: the value read is the next address).
+constexpr uint32_t kGroup    = kTile / kThreads;                           // 8
+constexpr uint32_t kOffCode  = 0;
+constexpr uint32_t kOffEnt   = kOffCode + 2u * kTile;
+constexpr uint32_t kScWords  = 44;
+constexpr uint32_t kOffSc    = kOffEnt + 8u * kEntries;
+constexpr uint32_t kOffRing  = (kOffSc + 4u * kScWords + 15u) & ~15u;
+constexpr uint32_t kOffStage = kOffRing + kRing;
+constexpr uint32_t kLdsBytes = kOffStage + kStage;
+static_assert(kLdsBytes <= 81920, "two workgroups per CU");
+constexpr uint32_t S_NTOK = 0, S_NEXT = 1, S_CUTPOS = 2, S_BYDL = 3, S_SUM = 4, S_NF = 12, S_FB = 20, S_TOT = 28, S_BYE = 36, S_SLOW = 37;
 
+// Workgroup barrier for LDS traffic only: every LDS operation of the wave is done, then the barrier.  (__syncthreads() also waits for
+// the wave's outstanding GLOBAL loads and stores - the next chunk's bytes, loaded a chunk ahead, and the tile's flush would be waited
+// for at the next of the ~8 barriers per tile.)
+#define WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | c; }
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return uint32_t(uintptr_t((const __attribute__((address_space(3))) void*)p)); }
+// p[k] = the 16-bit word at LDS address p[k] (eight independent reads, one wait)
+__device__ __forceinline__ void hop8(uint32_t (&p)[8])
+{
+    uint32_t q0, q1, q2, q3, q4, q5, q6, q7;
+    asm volatile("s_nop 1\n\tds_read_u16 %0, %8\n\tds_read_u16 %1, %9\n\tds_read_u16 %2, %10\n\tds_read_u16 %3, %11\n\t"
+                 "ds_read_u16 %4, %12\n\tds_read_u16 %5, %13\n\tds_read_u16 %6, %14\n\tds_read_u16 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6), "=&v"(q7)
+                 : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]) : "memory");
+    p[0] = q0; p[1] = q1; p[2] = q2; p[3] = q3; p[4] = q4; p[5] = q5; p[6] = q6; p[7] = q7;
+}
 __global__ __launch_bounds__(kThreads)
 void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks, uint32_t nblocks,
                           int container_mode, uint32_t* ws)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t  lds[kRing + kStage];   // [0, kRing): the output ring; behind it: the chunk's stream bytes
-    __shared__ __attribute__((aligned(16))) uint16_t code[kTile];          // marks, then states (while a chunk's tokens are decoded: their positions)
-    __shared__ __attribute__((aligned(8)))  uint32_t ent[2 * kEntries];
-    __shared__ uint32_t sc[36];                                             // [0] tokens [1] next chunk [2] cut position [3] far literals; [4..11], [12..19], [20..27], [28..35]: per wave
-    uint8_t* const ring = lds; uint8_t* const stage = lds + kRing;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[kLdsBytes];
+    uint16_t* const code = reinterpret_cast<uint16_t*>(smem + kOffCode);     // marks, then pointers (while a chunk's tokens are decoded: their positions)
+    uint32_t* const ent  = reinterpret_cast<uint32_t*>(smem + kOffEnt);
+    uint32_t* const sc   = reinterpret_cast<uint32_t*>(smem + kOffSc);
+    uint8_t*  const ring = smem + kOffRing;                                  // [0, 64 KiB): the output window; [64 KiB, + kStage): the chunk's stream bytes
+    uint8_t*  const stage = smem + kOffStage;
     uint16_t* const toks = code;
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
@@ -340,23 +365,29 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
     const uint32_t tail_ip = rfl(meta[kMetaTailIp]);
     const uint32_t A = uint32_t(uintptr_t(dst)) & 0xFFFFu;             // ring index of output position P: (A + P) & 0xFFFF - congruent to P's address mod 16
     uint32_t ip = 0, opos = 0, flushed = 0, res_ip = tail_ip;
+    uint32_t nmax = 256;                                                 // sequences the next chunk decodes: about what fills one tile
     bool cut = false, failed = false;
     Prof pf; unsigned long long tp = pf.now();
     const uint32_t u0 = kGroup * tid;
+    const uint32_t Lcode = lds_addr(code);
+    uint32_t self[kGroup];                                               // LDS addresses of the thread's own pointers
+#pragma unroll
+    for (uint32_t k = 0; k < kGroup; k++) self[k] = Lcode + 2u * (u0 + k);
     *reinterpret_cast<u32x4*>(code + u0) = u32x4{0, 0, 0, 0};
     if (tid == 0) { ent[2] = 0x20000u; ent[3] = 0; ent[2 * (kEntries - 1)] = 0x20000u; ent[2 * (kEntries - 1) + 1] = 0; }     // the bytes around a tile keep what the ring holds
 
     // the next chunk's stream bytes and bitmap word are loaded a chunk ahead, into registers
     u32x4 nst = u32x4{0, 0, 0, 0}; uint32_t nbw = 0;
     auto prefetch = [&](uint32_t at) {
+        // (no "else zero": a value merged with a load's result is waited for where it is merged.  A piece that would reach beyond the
+        // stream is read from its last 16 bytes instead: nothing a token of the bitmap needs lies there.)
         const uint32_t sb = at & ~15u, a = sb + 16u * tid;
-        nst = u32x4{0, 0, 0, 0}; nbw = 0;
-        if (tid < kStage / 16u && a + 16u <= csize) nst = ld16u_g(s + a);
-        if (tid < kChunk / 32u && (at >> 5) + tid < nwords) nbw = bm[(at >> 5) + tid];
+        if (tid < kStage / 16u) nst = ld16u_g(s + (a + 16u <= csize ? a : csize - 16u));
+        if (tid < kChunk / 32u) { const uint32_t wi = (at >> 5) + tid; nbw = bm[wi < nwords ? wi : nwords - 1u]; }      // (words beyond the stream: masked by the chunk's end)
     };
     auto arrived = [&]() { asm volatile("" : "+v"(nst.x), "+v"(nst.y), "+v"(nst.z), "+v"(nst.w), "+v"(nbw)); };
     if (tail_ip > 0) prefetch(0);
-    __syncthreads();
+    WG_BARRIER();
 
     while (ip < tail_ip && !cut) {
         // ---- the chunk's stream bytes into the stage, its bitmap words through wave 0: token positions, compacted
@@ -372,94 +403,121 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
             if (lo >= cend) w = 0; else if (cend - lo < 32u) w &= (1u << (cend - lo)) - 1u;
             const uint32_t c = uint32_t(__builtin_popcount(w)), inc = scan_add(c);
             uint32_t idx = inc - c;
-            while (w) {
+            while (w && idx < nmax) {
                 const uint32_t bit = uint32_t(__builtin_ctz(w)); w &= w - 1u;
-                if (idx < kSeqs) toks[idx] = uint16_t(lo + bit - sbase);
+                toks[idx] = uint16_t(lo + bit - sbase);
                 idx++;
             }
-            if (lane == 63) sc[0] = inc;
+            if (lane == 63) sc[S_NTOK] = inc;
         }
-        __syncthreads();
-        const uint32_t ntok = rfl(sc[0]);
-        uint32_t n = ntok < kSeqs ? ntok : kSeqs;
+        WG_BARRIER();
+        const uint32_t ntok = rfl(sc[S_NTOK]);
+        uint32_t n = ntok < nmax ? ntok : nmax;
         if (n == 0) { failed = true; break; }                           // (the bitmap has a token at ip: cannot happen)
         pf.add(0, tp);
         // ---- one sequence per thread, fields from the stage (from memory beyond it)
         uint32_t ll = 0, ml = 0, off = 0, lsrc = 0, sz = 0, tpos = 0;
         bool beyond = false;                                             // literals that reach beyond the stage
+        const bool seqwave = 64u * wv < n;
         if (tid < n) {
-            auto rd = [&](uint32_t rel) -> uint32_t { return rel < kStage ? uint32_t(stage[rel]) : uint32_t(s[sbase + rel]); };
+            // the common path reads the stage only; a sequence whose fields reach beyond it (the chunk's last one at most: no token of
+            // the chunk begins behind its fields) is decoded from memory and hands its numbers over THROUGH LDS - a register written
+            // by a global load and merged here would put a wait for every outstanding global operation (the flush before) on everyone
             const uint32_t p = toks[tid];
             const uint32_t t = stage[p], t1 = stage[p + 1], mn = t & 15u;
             uint32_t q = p + 1; ll = t >> 4;
-            if (ll == 15u) { uint32_t bq = t1; ll += bq; q++; while (bq == 255u && ll < (1u << 24)) { bq = rd(q++); ll += bq; } }
-            lsrc = q;                                                    // (relative to the stage)
-            const uint32_t mo = q + ll;
-            beyond = ll != 0u && mo > kStage;                            // (only the chunk's last sequence can: no token begins behind its literals)
-            uint32_t o0, o1, e0, e1;
-            if (mo + 3u < kStage) { o0 = stage[mo]; o1 = stage[mo + 1]; e0 = stage[mo + 2]; e1 = stage[mo + 3]; }
-            else { o0 = s[sbase + mo]; o1 = s[sbase + mo + 1]; e0 = s[sbase + mo + 2]; e1 = s[sbase + mo + 3]; }       // (mo + 3 <= limit + 1 < csize)
+            bool slow = false;
+            if (ll == 15u) { uint32_t bq = t1; ll += bq; q++; while (bq == 255u) { if (q >= kStage) { slow = true; break; } bq = stage[q++]; ll += bq; } }
+            uint32_t mo = q + ll;
+            slow = slow || mo + 3u >= kStage;
+            const uint32_t moc = slow ? 0u : mo;
+            const uint32_t o0 = stage[moc], o1 = stage[moc + 1], e0 = stage[moc + 2], e1 = stage[moc + 3];
             off = o0 | (o1 << 8);
             uint32_t q2 = mo + 2; ml = mn + 4u;
             if (mn == 15u) {
                 ml += e0; q2++;
-                if (e0 == 255u) { uint32_t bq = e1; ml += bq; q2++; while (bq == 255u && q2 + sbase < csize) { bq = rd(q2++); ml += bq; } }
+                if (e0 == 255u) { uint32_t bq = e1; ml += bq; q2++; while (bq == 255u) { if (q2 >= kStage) { slow = true; break; } bq = stage[q2++]; ml += bq; } }
             }
+            if (slow) {
+                cgbyte* g = s + sbase;
+                uint32_t L = t >> 4, Q = p + 1;
+                if (L == 15u) { uint32_t bq; do { bq = g[Q++]; L += bq; } while (bq == 255u && L < (1u << 24)); }
+                const uint32_t MO = Q + L;
+                const uint32_t OF = uint32_t(g[MO]) | (uint32_t(g[MO + 1]) << 8);
+                uint32_t Q2 = MO + 2, M = mn + 4u;
+                if (mn == 15u) { uint32_t bq; do { bq = g[Q2++]; M += bq; } while (bq == 255u && Q2 + sbase < csize); }
+                sc[S_SLOW] = L; sc[S_SLOW + 1] = M; sc[S_SLOW + 2] = OF; sc[S_SLOW + 3] = Q; sc[S_SLOW + 4] = Q2;
+            }
+            if (slow) { ll = sc[S_SLOW]; ml = sc[S_SLOW + 1]; off = sc[S_SLOW + 2]; q = sc[S_SLOW + 3]; q2 = sc[S_SLOW + 4]; mo = q + ll; }
+            lsrc = q;                                                    // (relative to the stage)
+            beyond = ll != 0u && mo > kStage;
             tpos = sbase + p;
             const uint32_t z = ll + ml;                                  // (both below 2^30)
             sz = z > kSzClamp ? kSzClamp : z;
-            if (tid == n - 1) sc[1] = sbase + q2;                       // where the next chunk begins: the token behind the chunk's last
+            if (tid == n - 1) sc[S_NEXT] = sbase + q2;                  // where the next chunk begins if it takes all: the token behind the chunk's last
         }
         // ---- placed by a prefix sum over the workgroup
-        const uint32_t winc = scan_add(sz);
-        if (lane == 63) sc[4 + wv] = winc;
-        const bool anybeyond = __ballot(beyond) != 0;
-        if (lane == 0) sc[28 + wv] = anybeyond ? 1u : 0u;
-        __syncthreads();
+        uint32_t winc = 0;
+        if (seqwave) { winc = scan_add(sz); if (lane == 63) sc[S_SUM + wv] = winc; }
+        else if (lane == 63) sc[S_SUM + wv] = 0;
+        WG_BARRIER();
         if (tid < (kSeqs + kGroup - 1) / kGroup) *reinterpret_cast<u32x4*>(code + u0) = u32x4{0, 0, 0, 0};      // (the token positions were here)
-        uint32_t wbase = 0, glob_any = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) { const uint32_t x = sc[4 + k]; wbase += k < wv ? x : 0u; glob_any |= sc[28 + k]; }
-        const bool has_beyond = rfl(glob_any) != 0;
-        const uint32_t next_ip = rfl(sc[1]);
-        const uint32_t incl = wbase + winc, outl = incl - sz, mst = outl + ll;          // output start of the literals / of the match, chunk-relative
-        // how many sequences the chunk takes: those whose output ends below the output-side margin; an offset beyond the output
-        // among them hands the block back
-        const bool fits = tid < n && opos + incl <= olimit && sz < kSzClamp;
-        const bool bad = tid < n && (off == 0u || off > opos + mst);
+        uint32_t incl = 0, outl = 0, mst = 0;
+        if (seqwave) {
+            uint32_t wbase = 0;
+            for (uint32_t k = 0; k < wv; k++) wbase += sc[S_SUM + k];   // (wave-uniform loop: scalar loads would do; the compiler keeps it on the vector side)
+            incl = wbase + winc; outl = incl - sz; mst = outl + ll;      // output start of the literals / of the match, chunk-relative
+        }
+        // how many sequences the chunk takes: those whose output ends below the output-side margin and - but for the first - inside
+        // one tile; an offset beyond the output among them hands the block back
         {
-            const unsigned long long fm = __ballot(fits), bmk = __ballot(bad);
-            const uint32_t nf = uint32_t(__builtin_popcountll(fm));                      // (fits is monotone: a prefix)
+            const bool fits_o = tid < n && opos + incl <= olimit && sz < kSzClamp;
+            const bool fits_t = tid < n && (incl <= kTile - 8u || tid == 0u);
+            const bool bad = tid < n && (off == 0u || off > opos + mst);
+            const unsigned long long fo = __ballot(fits_o), ft = __ballot(fits_t), bmk = __ballot(bad), byb = __ballot(beyond);
             const uint32_t fb = bmk ? 64u * wv + uint32_t(__builtin_ctzll(bmk)) : 0xFFFFu;
-            const uint32_t tot = scan_max(fits ? incl : 0u);
-            if (lane == 63) { sc[12 + wv] = nf; sc[20 + wv] = fb; }
-            __syncthreads();                                             // (sc[4 ..] and sc[28 ..] have been read)
-            if (lane == 63) sc[4 + wv] = tot;
+            uint32_t tot = 0;
+            if (seqwave) tot = scan_max(fits_o && fits_t ? incl : 0u);
+            if (lane == 63) {
+                sc[S_NF + wv] = uint32_t(__builtin_popcountll(fo)) | (uint32_t(__builtin_popcountll(ft)) << 8) | (byb ? 0x10000u : 0u);      // (both are prefixes)
+                sc[S_FB + wv] = fb; sc[S_TOT + wv] = tot;
+            }
             if (tid < n) { ent[2 * (3u + 2u * tid)] = 0u - off; ent[2 * (3u + 2u * tid) + 1] = 0u; }
-            if (beyond) { sc[3] = lsrc - outl; sc[31] = 2u + 2u * tid; }      // its literals' stage index at chunk output 0, its entry
+            if (beyond) { sc[S_BYDL] = lsrc - outl; sc[S_BYE] = 2u + 2u * tid; }      // its literals' stage index at chunk output 0, its entry
         }
-        __syncthreads();
-        uint32_t nfit = 0, nbad = 0xFFFFu, total = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) { nfit += sc[12 + k]; nbad = min(nbad, sc[20 + k]); total = umax(total, sc[4 + k]); }
-        nfit = rfl(nfit); nbad = rfl(nbad); total = rfl(total);
-        const uint32_t by_dl = has_beyond ? rfl(sc[3]) : 0u, by_e = has_beyond ? rfl(sc[31]) : 0u;
+        WG_BARRIER();
+        uint32_t nfo = 0, nft = 0, nbad = 0xFFFFu, total = 0; bool has_beyond = false;
+        for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) {
+            const uint32_t x = rfl(sc[S_NF + k]);
+            nfo += x & 255u; nft += (x >> 8) & 255u; has_beyond |= (x >> 16) != 0u;
+            nbad = min(nbad, rfl(sc[S_FB + k])); total = umax(total, rfl(sc[S_TOT + k]));
+        }
+        const uint32_t nfit = nfo < nft ? nfo : nft;
         if (nbad < nfit) { failed = true; break; }
+        uint32_t next_ip = rfl(sc[S_NEXT]);
         if (nfit < n) {
-            cut = true;
-            if (tid == nfit) sc[2] = tpos;
-            n = nfit;
+            if (nfo <= nft) cut = true;                                  // the output-side tail begins at sequence nfit
+            if (tid == nfit) sc[S_CUTPOS] = tpos;                       // (read behind the barriers of the tile loop)
         }
-        if (!cut && next_ip < tail_ip) prefetch(next_ip);
+        const uint32_t ntaken = nfit;
+        const uint32_t by_dl = has_beyond ? rfl(sc[S_BYDL]) : 0u, by_e = has_beyond ? rfl(sc[S_BYE]) : 0u;
         pf.add(1, tp);
-        // ---- the chunk's output, a tile at a time
+        // ---- the chunk's output, a tile at a time (one tile, unless the first sequence alone is longer)
+        bool first_tile = true;
         for (uint32_t R0 = 0; R0 < total;) {
             const uint32_t gb0 = A + opos, mis = gb0 & 7u, gb = (gb0 - mis) & 0xFFFFu;       // ring address of tile coordinate 0
-            const uint32_t T = total - R0 < kTile - 8u ? total - R0 : kTile - 8u;
+            uint32_t T = total - R0 < kTile - 8u ? total - R0 : kTile - 8u;
+            if (gb + mis + T > kRing) T = kRing - gb - mis;                     // (a tile does not wrap around the ring's end)
             const uint32_t ulo = mis, uhi = mis + T;                             // the tile's bytes: tile coordinates [ulo, uhi)
-            __syncthreads();                                                     // (code[] is zero, the tile before has left sc[])
+            WG_BARRIER();                                                     // (code[] is zero, the tile before has left sc[])
+            if (first_tile) {
+                // which token the next chunk begins with is known now: its bytes are loaded while the tile is produced
+                if (ntaken < n) next_ip = rfl(sc[S_CUTPOS]);
+                if (!cut && next_ip < tail_ip) prefetch(next_ip);
+                first_tile = false;
+            }
             // marks: where the sequence's literal part and its match part begin inside the tile
-            if (tid < n) {
+            if (tid < ntaken) {
                 const uint32_t me = outl + sz;
                 if (ll != 0u && outl < R0 + T && mst > R0) {
                     code[(outl > R0 ? outl : R0) - R0 + mis] = uint16_t(2u + 2u * tid);
@@ -470,7 +528,7 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
                 if (mst < R0 + T && me > R0) code[(mst > R0 ? mst : R0) - R0 + mis] = uint16_t(3u + 2u * tid);
             }
             if (tid == kThreads - 1) { if (mis) code[0] = 1; code[uhi] = uint16_t(kEntries - 1u); }
-            __syncthreads();
+            WG_BARRIER();
             // max-scan: every byte gets the mark in front of it
             uint32_t c[kGroup];
             {
@@ -480,73 +538,80 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
 #pragma unroll
                 for (int k = 1; k < 8; k++) c[k] = umax(c[k], c[k - 1]);
                 const uint32_t wi = scan_max(c[7]);
-                if (lane == 63) sc[4 + wv] = wi;
+                if (lane == 63) sc[S_SUM + wv] = wi;
                 uint32_t ex = dpp0<0x138, 0xf>(wi);                      // wave_shr:1 - the lanes in front (0 for lane 0)
-                __syncthreads();
+                WG_BARRIER();
                 uint32_t pre = 0;
-#pragma unroll
-                for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) { const uint32_t x = sc[4 + k]; pre = umax(pre, k < wv ? x : 0u); }
+                for (uint32_t k = 0; k < wv; k++) pre = umax(pre, rfl(sc[S_SUM + k]));
                 ex = umax(ex, pre);
 #pragma unroll
                 for (int k = 0; k < 8; k++) c[k] = umax(c[k], ex);
             }
             pf.add(2, tp);
-            // source pass: every byte's state.  Final: literals, matches from in front of the tile, the bytes around the tile (value
-            // from LDS: stage or ring; every read of what the ring held happens before the tile's first ring write, behind the next
-            // barrier).  Otherwise: a pointer to the byte's source in the tile.
+            // source pass: where every byte comes from.  Final: literals, matches from in front of the tile, the bytes around the tile
+            // (value from LDS: stage or ring; every read of what the ring held happens before the tile's first ring write, behind the
+            // next barrier).  Otherwise: a pointer to the byte's source in the tile.
             const bool active = u0 < uhi;
-            uint32_t st[kGroup];
+            uint32_t pt[kGroup], bv[kGroup];
 #pragma unroll
-            for (uint32_t k = 0; k < kGroup; k++) st[k] = kFinal;
+            for (uint32_t k = 0; k < kGroup; k++) { pt[k] = self[k]; bv[k] = 0; }
             if (active) {
                 u32x2 e[kGroup];
 #pragma unroll
                 for (uint32_t k = 0; k < kGroup; k++) e[k] = *reinterpret_cast<const u32x2*>(ent + 2u * c[k]);
-                const uint32_t ub = u0 - ulo, xb = u0 + gb, ulo2 = 2u * ulo;
-                uint32_t tt[kGroup], aa[kGroup], bv[kGroup];
+                const uint32_t ub = u0 - ulo, xb = u0 + gb, base2 = Lcode + 2u * ulo;
+                uint32_t aa[kGroup];
 #pragma unroll
                 for (uint32_t k = 0; k < kGroup; k++) {
-                    tt[k] = ub + k + e[k].x;                             // (source's tile coordinate) - ulo
+                    const uint32_t tt = ub + k + e[k].x;                 // (source's tile coordinate) - ulo
                     aa[k] = and_or(xb + k + e[k].x, 0xFFFFu, e[k].y);
+                    pt[k] = tt < kTile ? 2u * tt + base2 : self[k];
                 }
 #pragma unroll
-                for (uint32_t k = 0; k < kGroup; k++) bv[k] = lds[aa[k]];
-                if (has_beyond) {                                        // literals beyond the stage: from memory (rare; long runs: the 16-bit index above is not theirs)
-#pragma unroll
+                for (uint32_t k = 0; k < kGroup; k++) bv[k] = ring[aa[k]];
+            }
+            const uint32_t gaddr = (gb + u0) & 0xFFFFu;
+            WG_BARRIER();
+            if (active) {
+                *reinterpret_cast<u32x2*>(ring + gaddr) = u32x2{bv[0] | (bv[1] << 8) | (bv[2] << 16) | (bv[3] << 24), bv[4] | (bv[5] << 8) | (bv[6] << 16) | (bv[7] << 24)};
+                *reinterpret_cast<u32x4*>(code + u0) = u32x4{(pt[0] - Lcode) | ((pt[1] - Lcode) << 16), (pt[2] - Lcode) | ((pt[3] - Lcode) << 16),
+                                                             (pt[4] - Lcode) | ((pt[5] - Lcode) << 16), (pt[6] - Lcode) | ((pt[7] - Lcode) << 16)};
+                if (has_beyond) {                                        // literals beyond the stage (rare; long runs): from memory into the ring, load and
+#pragma unroll                                                           // store inside the branch - nothing a global load wrote is live behind it
                     for (uint32_t k = 0; k < kGroup; k++) {
                         const uint32_t si = by_dl + R0 + (u0 + k) - mis;
-                        if (c[k] == by_e && si >= kStage) bv[k] = s[sbase + si];
+                        if (c[k] == by_e && si >= kStage) ring[gaddr + k] = s[sbase + si];
                     }
                 }
-#pragma unroll
-                for (uint32_t k = 0; k < kGroup; k++) st[k] = tt[k] < kTile ? 2u * tt[k] + ulo2 : (bv[k] | kFinal);
-                *reinterpret_cast<u32x4*>(code + u0) = u32x4{st[0] | (st[1] << 16), st[2] | (st[3] << 16), st[4] | (st[5] << 16), st[6] | (st[7] << 16)};
             }
-            __syncthreads();
+            WG_BARRIER();
             pf.add(3, tp);
-            // chase: a pointer is replaced by the state of the byte it points to until it is a value; what a thread has found so far
-            // goes back into code[] every round, so that everyone who passes through these bytes jumps ahead (pointer jumping)
+            // chase: a pointer is replaced by the pointer it points to until nothing moves (a final byte points to itself); what a
+            // thread has found so far goes back into code[] every round, so that everyone who passes through these bytes jumps ahead
             {
-                bool open = active && (((st[0] & st[1] & st[2] & st[3] & st[4] & st[5] & st[6] & st[7]) & kFinal) == 0u);
+                bool open = active && ((pt[0] ^ self[0]) | (pt[1] ^ self[1]) | (pt[2] ^ self[2]) | (pt[3] ^ self[3]) |
+                                       (pt[4] ^ self[4]) | (pt[5] ^ self[5]) | (pt[6] ^ self[6]) | (pt[7] ^ self[7])) != 0u;
                 const bool mine = open;
                 while (__ballot(open)) {
-                    uint32_t ad[kGroup];
+                    uint32_t q[kGroup];
 #pragma unroll
-                    for (uint32_t k = 0; k < kGroup; k++) ad[k] = st[k] < kFinal ? st[k] : 2u * (u0 + k);      // (a byte that is final reads its own state)
+                    for (uint32_t k = 0; k < kGroup; k++) q[k] = pt[k];
+                    hop8(q);
+                    uint32_t moved = 0;
 #pragma unroll
-                    for (uint32_t k = 0; k < kGroup; k++)
-                        st[k] = __hip_atomic_load(static_cast<uint16_t*>(__builtin_assume_aligned(reinterpret_cast<uint8_t*>(code) + ad[k], 2)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (open) *reinterpret_cast<u32x4*>(code + u0) = u32x4{st[0] | (st[1] << 16), st[2] | (st[3] << 16), st[4] | (st[5] << 16), st[6] | (st[7] << 16)};
-                    open = open && (((st[0] & st[1] & st[2] & st[3] & st[4] & st[5] & st[6] & st[7]) & kFinal) == 0u);
+                    for (uint32_t k = 0; k < kGroup; k++) { q[k] += Lcode; moved |= q[k] ^ pt[k]; pt[k] = q[k]; }
+                    open = open && moved != 0u;
+                    if (open) *reinterpret_cast<u32x4*>(code + u0) = u32x4{(pt[0] - Lcode) | ((pt[1] - Lcode) << 16), (pt[2] - Lcode) | ((pt[3] - Lcode) << 16),
+                                                                           (pt[4] - Lcode) | ((pt[5] - Lcode) << 16), (pt[6] - Lcode) | ((pt[7] - Lcode) << 16)};
                 }
-                (void)mine;
-                if (active) {
-                    const uint32_t blo = (st[0] & 255u) | ((st[1] & 255u) << 8) | ((st[2] & 255u) << 16) | (st[3] << 24);
-                    const uint32_t bhi = (st[4] & 255u) | ((st[5] & 255u) << 8) | ((st[6] & 255u) << 16) | (st[7] << 24);
-                    *reinterpret_cast<u32x2*>(ring + ((gb + u0) & 0xFFFFu)) = u32x2{blo, bhi};
+                if (mine) {
+                    // the bytes the pointers ended at are final: in the ring since the barrier (tile coordinate = pointer / 2; no wrap inside a tile)
+#pragma unroll
+                    for (uint32_t k = 0; k < kGroup; k++) bv[k] = ring[gb + ((pt[k] - Lcode) >> 1)];
+                    *reinterpret_cast<u32x2*>(ring + gaddr) = u32x2{bv[0] | (bv[1] << 8) | (bv[2] << 16) | (bv[3] << 24), bv[4] | (bv[5] << 8) | (bv[6] << 16) | (bv[7] << 24)};
                 }
             }
-            __syncthreads();
+            WG_BARRIER();
             pf.add(4, tp);
             // flush: whole 16-byte pieces by ADDRESS; the piece the tile ends in waits for the next tile.  (The next chunk's bytes
             // have arrived by now: waited for HERE, in front of this tile's stores, not behind them.)
@@ -569,10 +634,14 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
             opos = E; R0 += T;
             pf.add(5, tp); pf.count(6);
         }
+        if (first_tile && ntaken < n) { WG_BARRIER(); next_ip = rfl(sc[S_CUTPOS]); }      // (no output at all: the cut was at the chunk's first sequence)
+        // the next chunk decodes about as many sequences as fill one tile at this chunk's bytes per sequence
+        if (ntaken) { const uint32_t est = uint32_t(float(ntaken) * float(kTile - 8u) / float(total ? total : 1u)); nmax = est + (est >> 4) + 2u; nmax = nmax < 8u ? 8u : (nmax > kSeqs ? kSeqs : nmax); }
+        nmax = rfl(nmax);
         ip = next_ip;
-        __syncthreads();                                                 // (sc, code, ent, stage are rewritten by the next chunk)
+        WG_BARRIER();                                                 // (sc, code, ent, stage are rewritten by the next chunk)
     }
-    if (cut && !failed) res_ip = rfl(sc[2]);
+    if (cut && !failed) res_ip = ip;
     if (!failed) {
         // what the last tile left in the piece it ended in
         if (tid < opos - flushed) dst[flushed + tid] = ring[(A + flushed + tid) & 0xFFFFu];
