@@ -589,14 +589,14 @@ static int host_roundtrip(const void* src, size_t src_bytes, void* dst, size_t d
     return host_roundtrip_many(src, src_bytes, dst, dst_bytes, blocks, n, op, codec, level);
 }
 
-#ifdef FOURMC_RESEARCH
-void fourmc_debug_one_block_counters(unsigned long long* calls, unsigned long long* launches)
+void fourmc_gpu_one_block_stats(unsigned long long* calls, unsigned long long* launches)
 {
     std::lock_guard<std::mutex> lk(g_qmu);
     if (calls) *calls = g_one_calls;
     if (launches) *launches = g_one_launches;
 }
-
+#ifdef FOURMC_RESEARCH
+void fourmc_debug_one_block_counters(unsigned long long* calls, unsigned long long* launches) { fourmc_gpu_one_block_stats(calls, launches); }
 #endif
 
 /* page-locked host buffers for the file API's staging (H2D / D2H at PCIe rate instead of the pageable path's bounce copies);

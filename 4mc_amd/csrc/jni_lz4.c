@@ -138,6 +138,6 @@ Java_com_fing_compression_fourmc_Lz4Decompressor_xxhash32(JNIEnv* env, jclass cl
 { (void)cls; return xxhash32_common(env, buf, off, len, seed); }
 
 /* shared with jni_zstd.c */
-jint fourmc_jni_xxhash32(JNIEnv* env, jbyteArray buf, jint off, jint len, jint seed)
+__attribute__((visibility("hidden"))) jint fourmc_jni_xxhash32(JNIEnv* env, jbyteArray buf, jint off, jint len, jint seed)
 { return xxhash32_common(env, buf, off, len, seed); }
-void fourmc_jni_throw_internal(JNIEnv* env, const char* msg) { throw_internal(env, msg); }
+__attribute__((visibility("hidden"))) void fourmc_jni_throw_internal(JNIEnv* env, const char* msg) { throw_internal(env, msg); }

@@ -21,8 +21,8 @@
 #include "fourmc.h"
 #include "fourmc_gpu.h"
 
-jint fourmc_jni_xxhash32(JNIEnv* env, jbyteArray buf, jint off, jint len, jint seed);
-void fourmc_jni_throw_internal(JNIEnv* env, const char* msg);
+__attribute__((visibility("hidden"))) jint fourmc_jni_xxhash32(JNIEnv* env, jbyteArray buf, jint off, jint len, jint seed);
+__attribute__((visibility("hidden"))) void fourmc_jni_throw_internal(JNIEnv* env, const char* msg);
 
 #define ZERR_GENERIC        ((size_t)-1)      /* ZSTD_error_GENERIC = 1            */
 #define ZERR_MAXCODE        120               /* ZSTD_error_maxCode                */
@@ -134,6 +134,7 @@ Java_com_fing_compression_fourmc_ZstdDecompressor_xxhash32(JNIEnv* env, jclass c
  * Without a usable libzstd the stream constructors throw UnsupportedOperationException and every other call returns an error code:
  * loud, never a null handle. */
 #include <dlfcn.h>
+#include <pthread.h>
 typedef struct { void* dst; size_t size; size_t pos; } zs_out_t;            /* ZSTD_outBuffer (zstd.h) */
 typedef struct { const void* src; size_t size; size_t pos; } zs_in_t;       /* ZSTD_inBuffer  (zstd.h) */
 static struct {
@@ -146,10 +147,10 @@ static struct {
     size_t (*CStreamInSize)(void); size_t (*CStreamOutSize)(void); size_t (*DStreamInSize)(void); size_t (*DStreamOutSize)(void);
     const char* (*versionString)(void);
 } zs;
-static int zs_load(void)
+static pthread_once_t zs_once = PTHREAD_ONCE_INIT;
+static void zs_load_once(void)
 {
-    /* (two threads racing here load the same library twice at worst: dlopen counts references, the pointers are the same) */
-    if (!zs.tried) {
+    {
         const char* name = getenv("FOURMC_LIBZSTD");
         void* h = dlopen(name && *name ? name : "libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
         int ok = h != NULL;
@@ -163,10 +164,10 @@ static int zs_load(void)
 #undef ZS_SYM
         zs.ok = ok; zs.tried = 1;
     }
-    return zs.ok;
 }
+static int zs_load(void) { pthread_once(&zs_once, zs_load_once); return zs.ok; }      /* (one loader, however many threads create their first stream at once) */
 /* for INTEGRATION.md / logs: which library serves the streaming codec ("" when none) */
-const char* fourmc_zstd_stream_backend(void) { return zs_load() ? zs.versionString() : ""; }
+__attribute__((visibility("hidden"))) const char* fourmc_zstd_stream_backend(void) { return zs_load() ? zs.versionString() : ""; }
 
 JNIEXPORT jboolean JNICALL Java_com_fing_compression_fourmc_zstd_Zstd_isError(JNIEnv* env, jclass c, jlong code)
 { (void)env; (void)c; return (zs_load() ? zs.isError((size_t)code) != 0 : z_is_error((size_t)code) != 0); }

@@ -1323,10 +1323,14 @@ void zstd_decode_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
         // A helper wave that was given its go reads the block table and the tables of the shared state until it reports: the serial
         // path below rebuilds those tables, so it must not start (after a decline on damaged input, say) before the helper is done
         if (two_wave && r == kDecline && __hip_atomic_load(&flags[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 1u) {
+            bool reported = false;
             for (uint32_t spins = 0; spins < (1u << 24); spins++) {
-                if (__hip_atomic_load(&flags[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                if (__hip_atomic_load(&flags[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) { reported = true; break; }
                 __builtin_amdgcn_s_sleep(16);
             }
+            // a helper that never reports is still reading the tables the serial path would rebuild: the block fails (a generic
+            // zstd error; corrupt in a container) rather than being decoded under it
+            if (!reported) r = -1;
         }
         if (r == kDecline) r = zstd_decode_frames(src, int(blk.src_len), dst, int(blk.dst_cap), litbuf, &zs, lane);
         if (container_mode && r < 0 && r != kPendingExec) r = FOURMC_BLK_CORRUPT;

@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_JSON = os.path.join("profiles", "r03_traffic.json")
+TRAFFIC_JSON = os.path.join("profiles", "r05_traffic.json")
 
 
 def cpu_model():
@@ -369,7 +369,10 @@ def main():
         hash_ms = timed(lambda: p.binding.check(L.fourmc_gpu_xxh32(img.data_ptr(), dd.clone().data_ptr(), nd, 0, sp), "xxh32"))
         alg = (cbytes or 0) + nd * B
         del big, img
-        return {"blocks": nd, "uncompressed_GiB": nd * B / 2**30, "decode_blocks_ms": round(t, 2), "of_which_xxh32_verify_ms": round(hash_ms, 2),
+        stored = int((state["csz"] == B).sum().item()) * (nd // nb) if nd % nb == 0 else None
+        return {"blocks": nd, "stored_blocks": stored,
+                "stored_blocks_note": "blocks LZ4 does not shrink are STORED by the container (native/4mc.c:301-329); their decode is a copy.  decode_64GiB_lz4_only has the same corpus with every block an LZ4 stream",
+                "uncompressed_GiB": nd * B / 2**30, "decode_blocks_ms": round(t, 2), "of_which_xxh32_verify_ms": round(hash_ms, 2),
                 "decompress_GBps": round(nd * B / t / 1e6, 2),
                 "lz4_decode_path": decode_path_label(L.fourmc_gpu_get_lz4_decode_path(), nd),
                 "roofline": {"bound": "hbm", "achieved": round(alg / (t * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -378,24 +381,63 @@ def main():
                              "frac_decode_kernels_only": round(alg / ((t - hash_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
                 "note": "%d distinct copies of the 8 GiB image in HBM (%.1f GB of payloads, each read once); 64 GiB of distinct output" % (reps, reps * img_bytes / 1e9)}
 
+    def decode_64gib_lz4_only():
+        """The 64 GiB decode with EVERY block an LZ4 stream: the blocks are compressed with capacity LZ4_compressBound (the raw
+        LZ4 call of jniCompressor.c:91 - no stored fallback), each payload in its own slot, 8 distinct copies of the slots in HBM;
+        decoded by the raw LZ4 decode entry point (no container, no checksum pass).  This is the leg the stored blocks do not flatter."""
+        nd = args.decode_blocks
+        if nd % nb: return {"skipped": "decode blocks not a multiple of the launch"}
+        reps = nd // nb
+        slot = (B + B // 255 + 16 + 4095) & ~4095
+        free, _ = torch.cuda.mem_get_info()
+        if free < nd * B + reps * nb * slot + (12 << 30):
+            return {"skipped": "not enough free HBM"}
+        o = np.arange(nb, dtype=np.uint64); ln = np.full(nb, B, dtype=np.uint32)
+        one = torch.empty(nb * slot + 64, dtype=torch.uint8, device=dev)
+        kb = p.DeviceBatch(p.make_blocks(o * B, o * slot, ln, np.full(nb, slot, dtype=np.uint32)), dev)
+        p.binding.check(L.fourmc_gpu_lz4_compress_fast(d_src.data_ptr(), one.data_ptr(), kb.ptr, nb, sp), "lz4-only encode")
+        cs = kb.download()["result"].astype(np.int64)
+        assert (cs > 0).all()
+        img = torch.empty(reps * nb * slot + 64, dtype=torch.uint8, device=dev)
+        for k in range(reps): img[k * nb * slot: (k + 1) * nb * slot] = one[: nb * slot]
+        del one
+        big = torch.empty(nd * B + 64, dtype=torch.uint8, device=dev)
+        so = (np.arange(nd, dtype=np.uint64) % nb) * slot + (np.arange(nd, dtype=np.uint64) // nb) * (nb * slot)
+        db = p.DeviceBatch(p.make_blocks(so, np.arange(nd, dtype=np.uint64) * B, np.tile(cs.astype(np.uint32), reps), np.full(nd, B, dtype=np.uint32)), dev)
+        t = timed(lambda: p.binding.check(L.fourmc_gpu_lz4_decompress(img.data_ptr(), big.data_ptr(), db.ptr, nd, sp), "lz4-only decode"))
+        ok = bool((torch.from_numpy(db.download()["result"].astype(np.int64)) == B).all())
+        for k in range(0, nd, nb): ok = ok and bool(torch.equal(big[k * B:(k + nb) * B], d_src[: nb * B]))
+        assert ok, "64 GiB LZ4-only decode: round trip failed"
+        alg = int(cs.sum()) * reps + nd * B
+        del big, img
+        return {"blocks": nd, "stored_blocks": 0, "decode_blocks_ms": round(t, 2), "decompress_GBps": round(nd * B / t / 1e6, 2),
+                "compressed_GB": round(int(cs.sum()) * reps / 1e9, 2),
+                "lz4_decode_path": decode_path_label(L.fourmc_gpu_get_lz4_decode_path(), nd),
+                "roofline": {"bound": "hbm", "achieved": round(alg / (t * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "over": "the raw LZ4 decode call (walk + executor + exact walker for the block ends), no checksum pass",
+                             "algorithmic_bytes_per_launch": alg}}
+
     def decode_path_label(path, n):
         names = {0: "wave trio (parser wave + 2 copier waves per block; lz4_decode.hip)", 1: "block parallel (parse + executor kernels)",
                  2: "exact walker only", 4: "row pipeline (pre / walk / post / copy waves per block; lz4_rows.hip)",
                  7: "one lane per sequence (lz4_rows.hip)", 9: "walk + window copier (K1wx: four waves per block; lz4_rows.hip)",
-                 11: "segment-parallel (lz4_seg.hip: walk kernel, one lane per stream segment + batch executor, one wave per block + exact walker for the last bytes of each block)"}
+                 11: "segment-parallel (lz4_seg.hip: walk kernel, one lane per stream segment + batch executor, one wave per block + exact walker for the last bytes of each block)",
+                 13: "tile (lz4_tile.hip: walk kernel leaves a token bitmap; executor: one workgroup per block, the 64 KiB window in LDS, one thread per output byte, pointer chase for sources inside a tile + exact walker for the last bytes of each block)"}
         if path == 6:
-            return "auto: segment-parallel from 768 blocks per launch, walk + window copier below (this launch of %d blocks: %s)" % (n, names[11 if n >= 768 else 9])
+            tmax = int(os.environ.get("FOURMC_TILE_MAX", 1536))
+            return "auto: tile path up to %d blocks per launch, segment-parallel above (this launch of %d blocks: %s)" % (tmax, n, names[13 if n <= tmax else 11])
         return names.get(path, "path %d" % path)
 
     def decode_path_comparison():
-        """The two LZ4 decode fast paths of the product on the same launch (identical results): the walk + window copier (K1wx) and
-        the segment-parallel path; HIP events around the decode_blocks call minus the hash launch.  "auto" (the default) takes the
-        segment-parallel path from 768 blocks per launch.  (The older designs live in the research side build: tools/k1_timing.py.)"""
+        """The three LZ4 decode fast paths of the product on the same launch (identical results): the walk + window copier (K1wx), the
+        segment-parallel path and the tile path; HIP events around the decode_blocks call minus the hash launch.  "auto" (the default)
+        takes the tile path up to 1536 blocks per launch, the segment-parallel path above.  (The older designs live in the research
+        side build: tools/k1_timing.py.)"""
         out = {}
         before = L.fourmc_gpu_get_lz4_decode_path()
         vb = state["dec"].clone()
         x_ver = timed(lambda: p.binding.check(L.fourmc_gpu_xxh32(d_image.data_ptr(), vb.data_ptr(), nb, 0, sp), "xxh32"))
-        for path, name in ((9, "walk_window_copier"), (11, "segment_parallel")):
+        for path, name in ((9, "walk_window_copier"), (11, "segment_parallel"), (13, "tile")):
             L.fourmc_gpu_set_lz4_decode_path(path)
             dd = state["dec"].clone(); dd[:, 6] = 0
             t = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_image.data_ptr(), d_out.data_ptr(), dd.data_ptr(), nb, 0, sp), name))
@@ -404,7 +446,7 @@ def main():
         for m in (256, 1024):                          # launches that do not fill the chip: what the file API sends
             if m >= nb: continue
             xv = timed(lambda: p.binding.check(L.fourmc_gpu_xxh32(d_image.data_ptr(), state["dec"][:m].clone().data_ptr(), m, 0, sp), "xxh32"))
-            for path, name in ((9, "walk_window_copier"), (11, "segment_parallel")):
+            for path, name in ((9, "walk_window_copier"), (11, "segment_parallel"), (13, "tile")):
                 L.fourmc_gpu_set_lz4_decode_path(path)
                 dd = state["dec"][:m].clone(); dd[:, 6] = 0
                 t = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_image.data_ptr(), d_out.data_ptr(), dd.data_ptr(), m, 0, sp), name))
@@ -442,10 +484,30 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    own_wall = wall
+    per_rank = None; rccl_ranks = None
     if world > 1:
         w = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
+        # every rank's own numbers into rank 0's line, and the gathered footer index checked against a prefix sum recomputed locally
+        mine = {"rank": rank, "ms_per_step": round(own_wall / args.steps * 1e3, 3), "blocks": nb,
+                "compress_GBps": round(nb * B / (float(np.mean(phase["compress"])) * 1e-3) / 1e9, 3),
+                "decompress_GBps": round(nb * B / (float(np.mean(phase["decompress"])) * 1e-3) / 1e9, 3),
+                "first_block_offset": int(state["img_off"][0].item()), "shard_bytes": int((state["csz"] + 12).sum().item())}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        run = 12
+        for g in sorted(gathered, key=lambda x: x["rank"]):
+            assert g["first_block_offset"] == run, "footer index: rank %d begins at %d, the prefix sum says %d" % (g["rank"], g["first_block_offset"], run)
+            run += g["shard_bytes"]
+        per_rank = sorted(gathered, key=lambda x: x["rank"])
+        try:
+            v = torch.cuda.nccl.version(); ver = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+        except Exception:
+            ver = "unknown"
+        rccl_ranks = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": ver,
+                      "collective": "all_gather_into_tensor of %d int64 sizes per rank and step (the footer index); no data-path collective" % nb}
 
     # ---- correctness of what was timed (size-independent properties at full size)
     out_ok = bool(torch.equal(d_out[: nb * B], d_src))
@@ -510,11 +572,15 @@ def main():
             "compress_GBps": round(world * U / (comp_ms * 1e-3) / 1e9, 3),
             "decompress_GBps": round(world * U / (dec_ms * 1e-3) / 1e9, 3),
             "ratio": round(U / (12 + Cbytes + 12 + 20 + 4 * nb), 4),
+            "stored_blocks": int((csz == B).sum().item()),
             "kernel_ms": {k: round(v, 3) for k, v in kts.items()},
             "kernel_ms_note": "HIP events on the launch stream in an extra pass after the timed steps; the hash launches are timed alone and subtracted from the fused calls, so the parts need not add up to ms_per_step",
             "roofline": roof(dom, alg),
             "roofline_decode": roof(DEC, alg_dec),
         }
+        if per_rank is not None:
+            line["per_rank"] = per_rank; line["rccl_ranks"] = rccl_ranks
+            line["footer_index_check"] = "every rank's first block offset equals 12 + the bytes of the ranks before it (recomputed from the gathered sizes)"
         if probe is not None:
             line["traffic_probe"] = probe
         if world == 1 and not args.no_cpu:             # the host-core baseline is measured at N = 1 only
@@ -530,8 +596,19 @@ def main():
         if world == 1 and not args.no_extras:
             line["other_configs"] = other_configs()
             line["lz4_fast_tolerant"] = tolerant_leg()
+            tl = line["lz4_fast_tolerant"]
+            # the second headline north_star allows: the same metric with the ratio-tolerance parse.  `value` stays the exact encoder's:
+            # it is what the CLI, the file API and the JNI names run by default, because files then equal the reference's byte for byte
+            line["value_tolerant"] = tl["compress_decompress_GBps"]
+            line["value_tolerant_note"] = {"encoder": "ratio-tolerance LZ4 parse (lz4_par_encode.hip), opt-in: fourmc_gpu_set_lz4_encode_mode(1) / FOURMC_LZ4_ENCODE=parallel",
+                                           "ratio_vs_reference": tl["ratio_vs_reference"], "tolerance": tl["tolerance"],
+                                           "default": "`value` is the byte-identical encoder: what a user gets without asking (4mc files then have the reference's SHA-256); this is what a user gets who asks for throughput and accepts payloads up to 3 % larger (valid LZ4 blocks, read by the reference's decoder)"}
             line["decode_paths"] = decode_path_comparison()
             line["decode_64GiB"] = decode_64gib()
+            try:
+                line["decode_64GiB_lz4_only"] = decode_64gib_lz4_only()
+            except Exception as e:
+                line["decode_64GiB_lz4_only"] = {"error": repr(e)[:300]}
             try:
                 line["cli_wallclock"] = cli_wallclock()
             except Exception as e:                          # never lose the line over a temp-file problem

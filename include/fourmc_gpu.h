@@ -83,18 +83,23 @@ int fourmc_gpu_lz4_compress_mc(const void* d_src, void* d_dst, fourmc_block* d_b
  * 64 KiB segments in parallel; what lies beyond 4 MiB of a block goes out as literals.  env FOURMC_LZ4_ENCODE = exact | parallel. */
 void fourmc_gpu_set_lz4_encode_mode(int mode);
 int  fourmc_gpu_get_lz4_encode_mode(void);
-/* Tuning knob (not part of the reference boundary): which LZ4 decode path serves the launches - 6 auto (default: the
- * segment-parallel path for launches that fill the chip, the walk + window copier below), 2 the exact walker alone, 9 the walk +
- * window copier, 11 the segment-parallel path; results are identical (env FOURMC_DECODE = auto | exact | wx | seg). */
+/* Tuning knob (not part of the reference boundary): which LZ4 decode path serves the launches - 6 auto (default: the tile path
+ * up to 1536 blocks per launch, the segment-parallel path above), 2 the exact walker alone, 9 the walk + window copier, 11 the
+ * segment-parallel path, 13 the tile path; results are identical (env FOURMC_DECODE = auto | exact | wx | seg | tile). */
 void fourmc_gpu_set_lz4_decode_path(int path);
 int  fourmc_gpu_get_lz4_decode_path(void);
 /* Tuning knob: 4mz decode as entropy kernel + execute kernel (1, default; FOURMC_ZDECODE=split) or all in the one-wave kernel
  * (0; FOURMC_ZDECODE=single); results are identical. */
 void fourmc_gpu_set_zstd_decode_split(int on);
 int  fourmc_gpu_get_zstd_decode_split(void);
+/* Statistics (read-only, not part of the reference boundary): one-block host calls made so far (the LZ4_* / ZSTD_* twins and the
+ * JNI entry points: one call = one block) and the launches that served them - calls that arrive while a launch is in flight
+ * share the next one (engine.hip: host_one), so launches < calls under concurrency. */
+void fourmc_gpu_one_block_stats(unsigned long long* calls, unsigned long long* launches);
 /* result = ZSTD_compress(dst + dst_off, dst_cap, src + src_off, src_len, level) as int: frame bytes, or
  * -(ZSTD error number), e.g. -70 = dstSize_tooSmall        native/zstd/compress/zstd_compress.c:4806
- * Level 1 (strategy "fast", 4mz -1) is on the device; other levels return FOURMC_EUNSUP. */
+ * Levels 1, 3, 6 and 12 (what 4mz -1 .. -4 use: strategies fast, dfast, lazy2 + row hash / btlazy2 / btopt) are on the device,
+ * byte-identical for every input size; any other level returns FOURMC_EUNSUP - never different bytes. */
 int fourmc_gpu_zstd_compress(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                              uint32_t n, int level, void* stream);
 

@@ -157,3 +157,39 @@ def test_both_lz4_decode_paths_at_full_size(gpu, path):
         assert torch.equal(d_out[: nb * B], d_src)
     finally:
         gpu.lib().fourmc_gpu_set_lz4_decode_path(before)
+
+
+@pytest.mark.parametrize("path", [6, 13], ids=["auto", "tile"])
+def test_64gib_launch(gpu, path):
+    """16 384 blocks in ONE decode call (the 64 GiB configuration of north_star): through `auto` - the segment-parallel path in
+    pieces of 8192 blocks, the split of the launch loop in lz4_decode.hip - and through the tile path (one piece); every one of
+    the 64 GiB compared with the input.  Needs ~110 GB of HBM (skipped on a smaller device)."""
+    base_n, nb, reps = 48, 2048, 8
+    nd = nb * reps
+    free = torch.cuda.mem_get_info()[0]
+    if free < 230 * (1 << 30):
+        pytest.skip("needs 230 GiB of free HBM (64 GiB out, 8 images, the segment-parallel workspace)")
+    base = helpers.corpus(base_n * B)
+    d_src = torch.from_numpy(base).cuda().repeat(-(-nb // base_n))[: nb * B].contiguous()
+    offs = np.arange(nb, dtype=np.uint64) * B
+    lens = np.full(nb, B, dtype=np.uint32)
+    enc = gpu.DeviceBatch(gpu.make_blocks(offs, offs, lens, lens))
+    d_stage = torch.empty(nb * B, dtype=torch.uint8, device="cuda")
+    gpu.encode_blocks(d_src, d_stage, enc)
+    e = enc.download()
+    img = d_stage.repeat(reps)                                   # 8 physically distinct copies of the payload slots
+    del d_stage
+    so = np.tile(offs, reps) + (np.arange(nd, dtype=np.uint64) // nb) * np.uint64(nb * B)
+    before = gpu.lib().fourmc_gpu_get_lz4_decode_path()
+    gpu.lib().fourmc_gpu_set_lz4_decode_path(path)
+    try:
+        dec = gpu.DeviceBatch(gpu.make_blocks(so, np.arange(nd, dtype=np.uint64) * B, np.tile(e["result"].astype(np.uint32), reps),
+                                              np.full(nd, B, dtype=np.uint32), np.tile(e["xxh32"], reps)))
+        big = torch.zeros(nd * B + 64, dtype=torch.uint8, device="cuda")
+        gpu.decode_blocks(img, big, dec)
+        assert bool((torch.from_numpy(dec.download()["result"].astype(np.int64)) == B).all())
+        for k in range(reps):
+            assert torch.equal(big[k * nb * B:(k + 1) * nb * B], d_src), k
+        assert bool((big[nd * B:] == 0).all())
+    finally:
+        gpu.lib().fourmc_gpu_set_lz4_decode_path(before)

@@ -133,8 +133,7 @@ def test_concurrent_one_block_calls_share_launches(gpu):
     import ctypes as C, threading
     import numpy as np
     import helpers
-    gpu.use_research(True); gpu.gpu_init()             # the call / launch counters are a debug export: research side build (same queue code)
-    L = gpu.binding.lib()
+    L = gpu.binding.lib()                              # the PRODUCT library: its queue statistics are a read-only export (fourmc_gpu_one_block_stats)
     data = helpers.corpus(helpers.B)
     rng = np.random.default_rng(5)
     jobs = []
@@ -142,7 +141,7 @@ def test_concurrent_one_block_calls_share_launches(gpu):
         n = int(rng.integers(1000, 300000)); o = int(rng.integers(0, helpers.B - n))
         jobs.append((i, np.ascontiguousarray(data[o:o + n]), ("fast", "hc", "zstd", "dec")[i % 4]))
     c0, l0 = C.c_ulonglong(), C.c_ulonglong()
-    L.fourmc_debug_one_block_counters(C.byref(c0), C.byref(l0))
+    L.fourmc_gpu_one_block_stats(C.byref(c0), C.byref(l0))
     results = {}
     def work(job):
         i, s, kind = job
@@ -176,7 +175,6 @@ def test_concurrent_one_block_calls_share_launches(gpu):
         assert r == wr, (i, kind, r, wr)
         assert np.array_equal(out, wb), (i, kind)
     c1, l1 = C.c_ulonglong(), C.c_ulonglong()
-    L.fourmc_debug_one_block_counters(C.byref(c1), C.byref(l1))
+    L.fourmc_gpu_one_block_stats(C.byref(c1), C.byref(l1))
     assert c1.value - c0.value == len(jobs)
-    gpu.use_research(False)
     assert l1.value - l0.value < len(jobs), "no two concurrent calls ever shared a launch"

@@ -73,9 +73,9 @@ def main():
             if k.startswith(kern) and c in v: return v[c][0] * KiB          # one dispatch per kernel in the child
         return None
     cs, us, nb = meta["csize_sum"], meta["usize_sum"], meta["blocks"]
-    # every kernel of the decode path that ran (a path is several launches: the segment-parallel one is walk + executor + the exact
+    # every kernel of the decode path that ran (a path is several launches: the tile / segment-parallel ones are walk + executor + the exact
     # walker's tail; kernels of a path that was launched but left at once move nothing and add nothing): their counters are summed
-    dec_kernels = sorted(k for k in res if (k.startswith("lz4_seg_") or k.startswith("lz4_decode_")) and (res[k].get("WRITE_SIZE", (0, 0))[0] + res[k].get("FETCH_SIZE", (0, 0))[0]) > 0)
+    dec_kernels = sorted(k for k in res if (k.startswith("lz4_seg_") or k.startswith("lz4_tile_") or k.startswith("lz4_decode_")) and (res[k].get("WRITE_SIZE", (0, 0))[0] + res[k].get("FETCH_SIZE", (0, 0))[0]) > 0)
     dec_kernel = "+".join(dec_kernels)
     def get_dec(c):
         return sum(res[k][c][0] for k in dec_kernels if c in res[k]) * KiB
@@ -89,7 +89,7 @@ def main():
            "calibration": {"xxh32_fetch_reported_over_known": round(xf / cs, 4), "pack_fetch_reported_over_known": round(get("pack_image_kernel", "FETCH_SIZE") / cs, 4),
                            "pack_write_reported_over_known": round(get("pack_image_kernel", "WRITE_SIZE") / (cs + 12 * nb), 4),
                            "decode_write_reported_over_known": round(get_dec("WRITE_SIZE") / us, 4),
-                           "note": "known = the bytes the kernel has to move exactly once (xxh32: every payload byte read; pack: payloads read, payloads + 12 B headers written; decode: 4 MiB written per block - the segment-parallel path also writes and reads back 8 bytes per sequence of records (2.4 MB per block on the S-mix), which this ratio then includes)"}}
+                           "note": "known = the bytes the kernel has to move exactly once (xxh32: every payload byte read; pack: payloads read, payloads + 12 B headers written; decode: 4 MiB written per block - the segment-parallel path also writes and reads back 8 bytes per sequence of records (2.4 MB per block on the S-mix), the tile path one bit per stream byte, which this ratio then includes)"}}
     for k in ("lz4_encode", "lz4_decode"):
         out[k]["traffic"] = int(out[k]["fetch"] + out[k]["write"])
         out[k]["traffic_over_algorithmic"] = round(out[k]["traffic"] / out[k]["algorithmic"], 4)
