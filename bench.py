@@ -344,6 +344,7 @@ def main():
         its own copy: nothing is read twice).  Runs as 8 launches' worth of blocks in one call (the engine's decode entry point)."""
         nd = args.decode_blocks
         reps = -(-nd // nb)
+        torch.cuda.empty_cache()
         img_bytes = int((state["loc_off"][-1] + 12 + state["csz"][-1]).item())
         img_pad = (img_bytes + 4095) & ~4095
         free, _ = torch.cuda.mem_get_info()
@@ -389,9 +390,10 @@ def main():
         if nd % nb: return {"skipped": "decode blocks not a multiple of the launch"}
         reps = nd // nb
         slot = (B + B // 255 + 16 + 4095) & ~4095
+        torch.cuda.empty_cache()
         free, _ = torch.cuda.mem_get_info()
-        if free < nd * B + reps * nb * slot + (12 << 30):
-            return {"skipped": "not enough free HBM"}
+        if free < nd * B + (reps + 1) * nb * slot + (4 << 30):
+            return {"skipped": "not enough free HBM (%d GiB free)" % (free >> 30)}
         o = np.arange(nb, dtype=np.uint64); ln = np.full(nb, B, dtype=np.uint32)
         one = torch.empty(nb * slot + 64, dtype=torch.uint8, device=dev)
         kb = p.DeviceBatch(p.make_blocks(o * B, o * slot, ln, np.full(nb, slot, dtype=np.uint32)), dev)
