@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include "fourmc_gpu.h"
 #include "kernels.h"
 #include "devcopy.h"
@@ -96,6 +97,29 @@ __device__ __forceinline__ bool eligible(const fourmc_block& blk)
 { return blk.src_len >= kMinSrc && blk.src_len <= kMaxSrc && blk.dst_cap >= kMinCap && blk.dst_cap <= lz4par::kDstMax; }
 
 // ================================================================================================ WALK kernel
+// Length extension bytes from q on - 255, 255, ..., b (b < 255) - eight per load: adds them to `len`, leaves q behind the last.
+// false: they reach `limit`, or (as lz4_seg.hip's walk: lengths beyond `cap` are the exact walker's) len passes cap on a 255.
+__device__ __forceinline__ bool ext_run(cgbyte* s, uint32_t limit, uint32_t& q, uint32_t& len, uint32_t cap)
+{
+    for (;;) {
+        if (q + 8u <= limit) {
+            const u32x2 v = ld8u(s + q);
+            const uint32_t nlo = ~v.x, nhi = ~v.y;
+            if ((nlo | nhi) == 0u) { len += 8u * 255u; q += 8u; if (len > cap) return false; continue; }
+            const uint32_t k = nlo ? uint32_t(__builtin_ctz(nlo)) >> 3 : 4u + (uint32_t(__builtin_ctz(nhi)) >> 3);
+            const uint32_t b = k < 4u ? (v.x >> (8u * k)) & 255u : (v.y >> (8u * (k - 4u))) & 255u;
+            len += 255u * k;
+            if (k && len > cap) return false;
+            len += b; q += k + 1u;
+            return true;
+        }
+        if (q >= limit) return false;
+        const uint32_t b = s[q++]; len += b;
+        if (b != 255u) return true;
+        if (len > cap) return false;
+    }
+}
+
 struct Hop { uint32_t next; bool stop; };
 // One token at p (per lane), bytes from memory.  stop: the token or its bytes reach beyond limit = csize - kMargin; the chain halts
 // AT p and the exact walker takes over there.  Every byte read lies below csize.
@@ -109,13 +133,13 @@ __device__ __forceinline__ Hop decode_tok(cgbyte* s, uint32_t limit, uint32_t p)
     if (ll == 15) {
         uint32_t b = (L0.x >> 8) & 255u; ll += b; q++;
         if (b == 255u) {
-            for (;;) { if (q >= limit) return h; b = s[q++]; ll += b; if (b != 255u) break; if (ll > (1u << 23)) return h; }
+            if (ll > (1u << 23) || !ext_run(s, limit, q, ll, 1u << 23)) return h;
         }
     }
     const uint32_t mo = q + ll;
     if (mo + 2 > limit) return h;
     uint32_t q2 = mo + 2;
-    if (mn == 15) { for (;;) { if (q2 >= limit) return h; const uint32_t b = s[q2++]; if (b != 255u) break; } }
+    if (mn == 15) { uint32_t ml = 0; if (!ext_run(s, limit, q2, ml, 0xFFFFFFFFu)) return h; }
     if (q2 > limit) return h;
     h.next = q2; h.stop = false;
     return h;
@@ -138,6 +162,7 @@ __device__ __forceinline__ void bm_advance(gword* bm, uint32_t& curw, uint32_t& 
 // k * 64 + l, so that 64 lanes reading "their" dword never meet in a bank.  The windows of ALL lanes still walking are topped up
 // together whenever one of them has less than a quarter of the window ahead.
 constexpr uint32_t kWinDw = FOURMC_TILE_WIN;    // dwords of stream window per lane (LDS: 256 bytes x kWinDw per wave)
+template <uint32_t kWinDw>
 __device__ __forceinline__ void walk_first(LaneSeg& g, cgbyte* s, uint32_t csize, uint32_t limit, uint32_t* ring)
 {
     constexpr uint32_t M = kWinDw - 1u, W = 4u * kWinDw, LOW = W / 4u;
@@ -186,7 +211,7 @@ __device__ __forceinline__ void walk_first(LaneSeg& g, cgbyte* s, uint32_t csize
         uint32_t ll = tok >> 4, q = p + 1; bool stop = false;
         if (ll == 15) {
             uint32_t bq = (L0 >> 8) & 255u; ll += bq; q++;
-            if (bq == 255u) for (;;) { if (q >= limit) { stop = true; break; } bq = s[q++]; ll += bq; if (bq != 255u) break; if (ll > (1u << 23)) { stop = true; break; } }
+            if (bq == 255u) stop = ll > (1u << 23) || !ext_run(s, limit, q, ll, 1u << 23);
         }
         const uint32_t mo = q + ll;
         if (stop || mo + 2 > limit) { tail = true; break; }
@@ -196,7 +221,7 @@ __device__ __forceinline__ void walk_first(LaneSeg& g, cgbyte* s, uint32_t csize
             const uint32_t e0 = (L1 >> 16) & 255u; q2++;
             if (e0 == 255u) {
                 const uint32_t e1 = L1 >> 24; q2++;
-                if (e1 == 255u) for (;;) { if (q2 >= limit) { stop = true; break; } const uint32_t bq = s[q2++]; if (bq != 255u) break; }
+                if (e1 == 255u) { uint32_t ml = 0; stop = !ext_run(s, limit, q2, ml, 0xFFFFFFFFu); }
             }
         }
         if (stop || q2 > limit) { tail = true; break; }
@@ -256,7 +281,7 @@ void lz4_tile_walk_kernel(const uint8_t* __restrict__ src_base, const fourmc_blo
     const bool mine = lane < nseg;
     Prof pf; unsigned long long tp = pf.now();
     // phase 1: every lane its own chain
-    if (mine) walk_first(g, s, csize, limit, ring);
+    if (mine) walk_first<kWinDw>(g, s, csize, limit, ring);
     pf.add(0, tp);
     // phase 2: the chain of the segment in front left at `pe`: assume it is the true one, thread it into this segment
     {
@@ -327,6 +352,13 @@ __device__ __forceinline__ void hop8(uint32_t (&p)[8])
                  : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]) : "memory");
     p[0] = q0; p[1] = q1; p[2] = q2; p[3] = q3; p[4] = q4; p[5] = q5; p[6] = q6; p[7] = q7;
 }
+// FUSED: the walk runs in front, by the same workgroup - one stream segment per THREAD (512 chains in lockstep instead of 64: a
+// block's walk takes a tenth of the one-wave kernel's time, which is what a launch of a few hundred blocks waits for), the per-lane
+// stream windows in the LDS that becomes the ring afterwards, the hand-over words in what becomes code[]; the chain through the
+// segments is followed by one thread over those words.
+constexpr uint32_t kFusedWin = 32;               // dwords of stream window per lane: 8 KiB per wave, 64 KiB for the workgroup = the ring's bytes
+constexpr uint32_t S_TAIL = 42, S_ANY = 43;
+template <bool FUSED>
 __global__ __launch_bounds__(kThreads)
 void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks, uint32_t nblocks,
                           int container_mode, uint32_t* ws)
@@ -356,18 +388,89 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
         return;
     }
     gword* meta = (gword*)(ws + size_t(b) * kWsWords);
-    if (!eligible(blk) || rfl(meta[kMetaStatus]) != 1u) { if (tid == 0) blocks[b].result = lz4par::kRetryCode; return; }
+    if (!eligible(blk) || (!FUSED && rfl(meta[kMetaStatus]) != 1u)) { if (tid == 0) blocks[b].result = lz4par::kRetryCode; return; }
     cgbyte* s = (cgbyte*)(src_base + blk.src_off);
     gbyte* dst = (gbyte*)(dst_base + blk.dst_off);
     cgword* bm = (cgword*)(meta + kMetaWords);
     const uint32_t csize = blk.src_len, cap = blk.dst_cap, olimit = cap - kOMargin;
     const uint32_t nwords = (csize + 31u) >> 5;
-    const uint32_t tail_ip = rfl(meta[kMetaTailIp]);
+    Prof pf; unsigned long long tp = pf.now();
+    uint32_t tail_ip;
+    if (FUSED) {
+        const uint32_t limit = csize - kMargin;
+        uint32_t nseg = limit / kMinSeg; nseg = nseg < 1 ? 1 : (nseg > uint32_t(kThreads) ? uint32_t(kThreads) : nseg);
+        const uint32_t seglen = ((limit + nseg - 1) / nseg + 31u) & ~31u;
+        uint32_t* const X = reinterpret_cast<uint32_t*>(code);          // [t] where the chain of segment t left, [512 + t] whether it ended in the tail,
+        constexpr uint32_t XT = kThreads, XE = 2 * kThreads, XD = 3 * kThreads;     // [1024 + t] where it was entered, [1536 + t] no token of the true chain in it
+        auto seg_of = [&](uint32_t j) -> LaneSeg {
+            LaneSeg g; g.bm = meta + kMetaWords; g.sj = j * seglen;
+            g.seg_end = (j + 1 == nseg) ? 0xFFFFFFFFu : (j + 1) * seglen;
+            g.wend = (j + 1 == nseg) ? nwords : ((j + 1) * seglen) >> 5;
+            g.exitp = 0; g.entry = 0xFFFFFFFFu; g.tail = true;
+            return g;
+        };
+        LaneSeg g = seg_of(tid);
+        const bool mine = tid < nseg;
+        // phase 1: every thread its own chain
+        if (mine) walk_first<kFusedWin>(g, s, csize, limit, reinterpret_cast<uint32_t*>(ring) + wv * (kFusedWin * 64u) + lane);
+        pf.add(8, tp);
+        X[tid] = g.exitp; X[XT + tid] = g.tail ? 1u : 0u; X[XD + tid] = 0u;
+        if (tid == 0) sc[S_ANY] = 0u;
+        WG_BARRIER();
+        pf.add(9, tp);
+        // phase 2: the chain of the segment in front left at `pe`: assume it is the true one, thread it into this segment
+        {
+            const uint32_t pj = tid ? tid - 1u : 0u;
+            const uint32_t pe = X[pj], pt = X[XT + pj];
+            WG_BARRIER();                                                // (everyone has read what phase 1 left)
+            uint32_t sj = pe / seglen; sj = sj > nseg - 1 ? nseg - 1 : sj;
+            if (mine && tid >= 1 && !pt && sj == tid && pe != g.sj) walk_from_entry(g, s, limit, pe);
+            X[tid] = g.exitp; X[XT + tid] = g.tail ? 1u : 0u; X[XE + tid] = g.entry;
+        }
+        WG_BARRIER();
+        // ... and again where the chain in front did not fall back onto its own before its segment ended (it then leaves somewhere
+        // else than assumed): all such segments at once, a few rounds; what is still open after them is the one thread's below
+        for (uint32_t round = 1; round <= 6u; round++) {
+            const uint32_t pj = tid ? tid - 1u : 0u;
+            const uint32_t pe = X[pj], pt = X[XT + pj];
+            uint32_t sj = pe / seglen; sj = sj > nseg - 1 ? nseg - 1 : sj;
+            const bool need = mine && tid >= 1 && !pt && sj == tid && pe != g.entry;
+            if (__ballot(need) && lane == 0) sc[S_ANY] = round;
+            WG_BARRIER();                                                // (and everyone has read what the round before left)
+            if (rfl(sc[S_ANY]) != round) break;
+            if (need) { walk_from_entry(g, s, limit, pe); X[tid] = g.exitp; X[XT + tid] = g.tail ? 1u : 0u; X[XE + tid] = g.entry; }
+            WG_BARRIER();
+        }
+        pf.add(10, tp);
+        // phase 3: one thread follows the true chain through the segments and redoes what was assumed wrong (rare)
+        if (tid == 0) {
+            uint32_t cur = 0, tip = 0;
+            for (;;) {
+                const uint32_t ex = X[cur];
+                if (X[XT + cur]) { tip = ex; break; }
+                uint32_t j = ex / seglen; j = j > nseg - 1 ? nseg - 1 : j;
+                for (uint32_t d = cur + 1; d < j; d++) X[XD + d] = 1u;
+                if (X[XE + j] != ex) {
+                    LaneSeg h = seg_of(j); h.exitp = X[j]; h.tail = X[XT + j] != 0u;
+                    walk_from_entry(h, s, limit, ex);
+                    X[j] = h.exitp; X[XT + j] = h.tail ? 1u : 0u;
+                }
+                cur = j;
+            }
+            sc[S_TAIL] = tip;
+        }
+        WG_BARRIER();
+        pf.add(11, tp);
+        if (mine && X[XD + tid]) for (uint32_t x = g.sj >> 5; x < g.wend; x++) g.bm[x] = 0;       // segments the chain jumps over have no tokens
+        tail_ip = rfl(sc[S_TAIL]);
+        __threadfence();                                                 // the bitmap is read back by other threads of the workgroup
+        WG_BARRIER();
+        pf.add(12, tp);
+    } else tail_ip = rfl(meta[kMetaTailIp]);
     const uint32_t A = uint32_t(uintptr_t(dst)) & 0xFFFFu;             // ring index of output position P: (A + P) & 0xFFFF - congruent to P's address mod 16
     uint32_t ip = 0, opos = 0, flushed = 0, res_ip = tail_ip;
     uint32_t nmax = 256;                                                 // sequences the next chunk decodes: about what fills one tile
     bool cut = false, failed = false;
-    Prof pf; unsigned long long tp = pf.now();
     const uint32_t u0 = kGroup * tid;
     const uint32_t Lcode = lds_addr(code);
     uint32_t self[kGroup];                                               // LDS addresses of the thread's own pointers
@@ -441,11 +544,11 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
             if (slow) {
                 cgbyte* g = s + sbase;
                 uint32_t L = t >> 4, Q = p + 1;
-                if (L == 15u) { uint32_t bq; do { bq = g[Q++]; L += bq; } while (bq == 255u && L < (1u << 24)); }
+                if (L == 15u) { uint32_t qa = sbase + Q; (void)ext_run(s, csize - kMargin, qa, L, 0xFFFFFFFFu); Q = qa - sbase; }
                 const uint32_t MO = Q + L;
                 const uint32_t OF = uint32_t(g[MO]) | (uint32_t(g[MO + 1]) << 8);
                 uint32_t Q2 = MO + 2, M = mn + 4u;
-                if (mn == 15u) { uint32_t bq; do { bq = g[Q2++]; M += bq; } while (bq == 255u && Q2 + sbase < csize); }
+                if (mn == 15u) { uint32_t qa = sbase + Q2; (void)ext_run(s, csize - kMargin, qa, M, 0xFFFFFFFFu); Q2 = qa - sbase; }
                 sc[S_SLOW] = L; sc[S_SLOW + 1] = M; sc[S_SLOW + 2] = OF; sc[S_SLOW + 3] = Q; sc[S_SLOW + 4] = Q2;
             }
             if (slow) { ll = sc[S_SLOW]; ml = sc[S_SLOW + 1]; off = sc[S_SLOW + 2]; q = sc[S_SLOW + 3]; q2 = sc[S_SLOW + 4]; mo = q + ll; }
@@ -646,7 +749,7 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
         // what the last tile left in the piece it ended in
         if (tid < opos - flushed) dst[flushed + tid] = ring[(A + flushed + tid) & 0xFFFFu];
     }
-    pf.dump(meta, kMetaProf + 8, 7, tid == 0);
+    pf.dump(meta, kMetaProf + 8, 13, tid == 0);
     if (tid == 0) {
         if (failed) blocks[b].result = lz4par::kRetryCode;
         else { meta[kMetaResIp] = res_ip; meta[kMetaResOp] = opos; blocks[b].result = kResumeCode; }
@@ -673,13 +776,25 @@ extern "C" uint32_t fourmc_lz4_tile_batch(void)
     return batch;
 }
 
+// FOURMC_TILE_WALK=separate: the walk as a kernel of its own, one wave per block (what a launch of many thousand blocks would
+// rather have: 64 chains per block are enough to fill the chip then); default: fused into the executor's workgroup
+static bool tile_walk_fused()
+{
+    static const bool v = [] { const char* e = getenv("FOURMC_TILE_WALK"); return !(e && !strcmp(e, "separate")); }();
+    return v;
+}
 extern "C" hipError_t fourmc_launch_lz4_tile(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                              int container_mode, void* d_work, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
+    if (tile_walk_fused()) {
+        hipLaunchKernelGGL(lz4_tile_exec_kernel<true>, dim3(n), dim3(lz4tile::kThreads), 0, stream, static_cast<const uint8_t*>(d_src),
+                           static_cast<uint8_t*>(d_dst), d_blocks, n, container_mode, static_cast<uint32_t*>(d_work));
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(lz4_tile_walk_kernel, dim3(n), dim3(64), 0, stream, static_cast<const uint8_t*>(d_src), d_blocks, n,
                        container_mode, static_cast<uint32_t*>(d_work));
-    hipLaunchKernelGGL(lz4_tile_exec_kernel, dim3(n), dim3(lz4tile::kThreads), 0, stream, static_cast<const uint8_t*>(d_src),
+    hipLaunchKernelGGL(lz4_tile_exec_kernel<false>, dim3(n), dim3(lz4tile::kThreads), 0, stream, static_cast<const uint8_t*>(d_src),
                        static_cast<uint8_t*>(d_dst), d_blocks, n, container_mode, static_cast<uint32_t*>(d_work));
     return hipGetLastError();
 }

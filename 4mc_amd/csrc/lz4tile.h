@@ -34,8 +34,8 @@ constexpr uint32_t kFinal   = 0x8000u;       // state of a tile byte: kFinal | v
 constexpr uint32_t kSzClamp = (4u << 20) + 1u;
 
 constexpr uint32_t kMetaStatus = 0, kMetaTailIp = 1, kMetaResIp = 2, kMetaResOp = 3;
-constexpr uint32_t kMetaProf   = 4;                                      // 28 words: cycle counters of profiling builds
-constexpr uint32_t kMetaWords  = 32;
+constexpr uint32_t kMetaProf   = 4;                                      // 44 words: cycle counters of profiling builds
+constexpr uint32_t kMetaWords  = 48;
 constexpr uint32_t kBmWords    = (kMaxSrc + 31) / 32 + 96;      // (+ the words segment ends rounded up to 32 bytes may reach beyond the stream)
 constexpr uint32_t kWsWords    = (kMetaWords + kBmWords + 3) & ~3u;      // 131.6 K words = 526 KB per block
 constexpr int kResumeCode = -1000000004;     // blocks[b].result while a block waits for the exact walker to finish it (= lz4seg's)

@@ -22,7 +22,7 @@ def one(tag, data, path):
     p.lz4_decompress(d_src, d_dst, blk); torch.cuda.synchronize()
     res = int(blk.download()["result"][0])
     out = d_dst.cpu().numpy()
-    meta = np.zeros(32, np.uint32)
+    meta = np.zeros(48, np.uint32)
     p.binding.check(p.lib().fourmc_gpu_debug_read_workspace(meta.ctypes.data, 0, meta.nbytes), "ws")
     got = out[64: 64 + len(data)]
     bad = np.nonzero(got != data)[0]

@@ -15,7 +15,7 @@ B = p.BLOCKSIZE
 names = ["text", "binary", "pcm6", "sdf", "binary", "db", "text", "code", "pcm11", "dict", "xml", "random"]
 def slot_bytes():
     # lz4tile.h: (kMetaWords + kBmWords + 3) & ~3, kBmWords = (kMaxSrc + 31) / 32 + 96, kMaxSrc = 4210768 + 32
-    return ((32 + (4210768 + 32 + 31) // 32 + 96 + 3) & ~3) * 4
+    return ((48 + (4210768 + 32 + 31) // 32 + 96 + 3) & ~3) * 4
 def run(comps, caps, which, tag):
     nb = len(comps)
     offs, pos = [], 0
@@ -30,12 +30,12 @@ def run(comps, caps, which, tag):
     s.record(); p.lz4_decompress(d_src, d_dst, blk2); e.record(); torch.cuda.synchronize()
     print(f"== {tag}: {nb} blocks, {s.elapsed_time(e):.2f} ms")
     for b, name in which:
-        meta = np.zeros(32, np.uint32)
+        meta = np.zeros(48, np.uint32)
         p.binding.check(p.lib().fourmc_gpu_debug_read_workspace(meta.ctypes.data, b * slot_bytes(), meta.nbytes), "ws")
-        w = meta[4:12].view(np.uint64).astype(np.float64); x = meta[12:26].view(np.uint64).astype(np.float64)
+        w = meta[4:12].view(np.uint64).astype(np.float64); x = meta[12:38].view(np.uint64).astype(np.float64)
         print(f"  {name:7s} walk Mclk chains {w[0]/1e6:7.2f} thread {w[1]/1e6:6.2f} check {w[2]/1e6:6.2f} (redone {int(w[3])})"
               f" | exec chunk {x[0]/1e6:6.2f} seqs {x[1]/1e6:6.2f} marks+scan {x[2]/1e6:6.2f} pass1 {x[3]/1e6:6.2f} pass2 {x[4]/1e6:6.2f} flush {x[5]/1e6:6.2f}"
-              f" sum {x[:6].sum()/1e6:7.2f} | tiles {int(x[6])} clk/tile {x[:6].sum()/max(x[6],1):.0f}", flush=True)
+              f" sum {x[:6].sum()/1e6:7.2f} | tiles {int(x[6])} clk/tile {x[:6].sum()/max(x[6],1):.0f} | fused walk: own chain {x[8]/1e6:5.2f} wait {x[9]/1e6:5.2f} threading {x[10]/1e6:5.2f} chain {x[11]/1e6:5.2f} end {x[12]/1e6:5.2f}", flush=True)
 data = helpers.corpus(12 * B)
 comps = []
 for b in range(12):
