@@ -490,12 +490,12 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
     };
     auto arrived = [&]() { asm volatile("" : "+v"(nst.x), "+v"(nst.y), "+v"(nst.z), "+v"(nst.w), "+v"(nbw)); };
     if (tail_ip > 0) prefetch(0);
+    arrived();                                                           // (waited for once, here: inside the loop the wait sits in front of a tile's flush)
     WG_BARRIER();
 
     while (ip < tail_ip && !cut) {
         // ---- the chunk's stream bytes into the stage, its bitmap words through wave 0: token positions, compacted
         const uint32_t sbase = ip & ~15u;
-        arrived();
         if (tid < kStage / 16u) *reinterpret_cast<u32x4*>(stage + 16u * tid) = nst;
         if (wv == 0) {
             const uint32_t w0 = ip >> 5;
@@ -568,7 +568,9 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
         uint32_t incl = 0, outl = 0, mst = 0;
         if (seqwave) {
             uint32_t wbase = 0;
-            for (uint32_t k = 0; k < wv; k++) wbase += sc[S_SUM + k];   // (wave-uniform loop: scalar loads would do; the compiler keeps it on the vector side)
+            const uint32_t w8 = sc[S_SUM + (lane & 7u)];                 // (one load, then lane reads: a load per term would be a wait per term)
+#pragma unroll
+            for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) wbase += k < wv ? rdl(w8, k) : 0u;
             incl = wbase + winc; outl = incl - sz; mst = outl + ll;      // output start of the literals / of the match, chunk-relative
         }
         // how many sequences the chunk takes: those whose output ends below the output-side margin and - but for the first - inside
@@ -590,10 +592,14 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
         }
         WG_BARRIER();
         uint32_t nfo = 0, nft = 0, nbad = 0xFFFFu, total = 0; bool has_beyond = false;
-        for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) {
-            const uint32_t x = rfl(sc[S_NF + k]);
-            nfo += x & 255u; nft += (x >> 8) & 255u; has_beyond |= (x >> 16) != 0u;
-            nbad = min(nbad, rfl(sc[S_FB + k])); total = umax(total, rfl(sc[S_TOT + k]));
+        {
+            const uint32_t l8 = lane & 7u, x8 = sc[S_NF + l8], f8 = sc[S_FB + l8], t8 = sc[S_TOT + l8];
+#pragma unroll
+            for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) {
+                const uint32_t x = rdl(x8, k);
+                nfo += x & 255u; nft += (x >> 8) & 255u; has_beyond |= (x >> 16) != 0u;
+                nbad = min(nbad, rdl(f8, k)); total = umax(total, rdl(t8, k));
+            }
         }
         const uint32_t nfit = nfo < nft ? nfo : nft;
         if (nbad < nfit) { failed = true; break; }
@@ -645,7 +651,9 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
                 uint32_t ex = dpp0<0x138, 0xf>(wi);                      // wave_shr:1 - the lanes in front (0 for lane 0)
                 WG_BARRIER();
                 uint32_t pre = 0;
-                for (uint32_t k = 0; k < wv; k++) pre = umax(pre, rfl(sc[S_SUM + k]));
+                const uint32_t m8 = sc[S_SUM + (lane & 7u)];
+#pragma unroll
+                for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) pre = umax(pre, k < wv ? rdl(m8, k) : 0u);
                 ex = umax(ex, pre);
 #pragma unroll
                 for (int k = 0; k < 8; k++) c[k] = umax(c[k], ex);

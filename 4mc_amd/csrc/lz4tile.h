@@ -27,7 +27,7 @@ constexpr int      kThreads = 512;           // executor workgroup: one thread p
 constexpr uint32_t kTile    = 4096;          // tile coordinates (8 per thread); a tile produces at most kTile - 8 bytes
 constexpr uint32_t kSeqs    = 384;           // sequences per chunk (one per thread of the first six waves)
 constexpr uint32_t kChunk   = 1536;          // stream bytes whose tokens one chunk takes: 48 bitmap words, one per lane of a wave
-constexpr uint32_t kStage   = kChunk + 32 + 272;     // staged stream bytes per chunk (a multiple of 16)
+constexpr uint32_t kStage   = kChunk + 32 + 208;     // staged stream bytes per chunk (a multiple of 16)
 constexpr uint32_t kEntries = 2 * kSeqs + 3; // source entries of a tile: 1 = bytes in front of the tile, 2 + 2 i / 3 + 2 i = literals / match of sequence i, last = bytes behind it
 constexpr uint32_t kRing    = 65536;         // output window in LDS: everything an LZ4 offset can reach
 constexpr uint32_t kFinal   = 0x8000u;       // state of a tile byte: kFinal | value, or (below kFinal) twice the tile coordinate of the byte it copies

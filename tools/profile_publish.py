@@ -11,9 +11,9 @@ def rows(f, per=5):
     if not os.path.exists(f): return d
     for l in open(f):
         m = re.match(r"\| ([\w<>]+)[^|]* \| (\w+) \| (\d+) \| (\d+) \| (\d+) \|", l)
-        if m: d.setdefault(m.group(1), {})[m.group(2)] = int(m.group(per))
+        if m: d.setdefault(m.group(1).split('<')[0], {})[m.group(2)] = int(m.group(per))
     return d
-DEC = ("lz4_seg_walk_kernel", "lz4_seg_exec_kernel", "lz4_decode_resume_kernel", "lz4_decode_wx_kernel", "lz4_decode_retry_kernel")
+DEC = ("lz4_seg_walk_kernel", "lz4_seg_exec_kernel", "lz4_tile_walk_kernel", "lz4_tile_exec_kernel", "lz4_decode_resume_kernel", "lz4_decode_wx_kernel", "lz4_decode_retry_kernel")
 fe, wr = rows(o + "summary_fetch.md"), rows(o + "summary_write.md")
 xk = [k for k in fe if k.startswith("xxh32")][0]
 dks = [k for k in DEC if k in fe and (fe[k].get("FETCH_SIZE", 0) + wr.get(k, {}).get("WRITE_SIZE", 0)) > 64]
@@ -45,13 +45,13 @@ for k in ["lz4_encode_fast_kernel"] + [k for k in DEC if k in a] + [k for k in a
 out += "\n" + open(o + "summary_sq.md").read() + "\n" + open(o + "summary_sq2.md").read()
 open(f"profiles/{name}_sq_counters.md", "w").write(out)
 # the LZ4 decode paths alone (tools/k1_timing.py under FOURMC_DECODE=seg / wx)
-txt = "# FOURMC_DECODE=seg | wx  FOURMC_BENCH_BLOCKS=N  rocprofv3 ... -- python tools/k1_timing.py   (decode only, S-mix; per configuration: kernel trace, two SQ groups; seg at 8192 blocks also FETCH / WRITE_SIZE and TCP / TCC groups)\n"
+txt = "# FOURMC_DECODE=seg | tile  FOURMC_BENCH_BLOCKS=N  rocprofv3 ... -- python tools/k1_timing.py   (decode only, S-mix; per configuration: kernel trace, two SQ groups; seg at 8192 blocks also FETCH / WRITE_SIZE and TCP / TCC groups)\n"
 txt += "# (tools/k1_timing.py compresses with the bound as capacity, so the incompressible blocks of the corpus are LZ4 streams here, not stored blocks as in the container: its times are not the bench's)\n\n" + HDR
-for cfg, nb in (("seg2048", 2048), ("seg8192", 8192), ("wx2048", 2048), ("wx256", 256)):
+for cfg, nb in (("seg2048", 2048), ("seg8192", 8192), ("tile2048", 2048), ("tile512", 512)):
     pa, pb = rows(o + f"summary_{cfg}_sq.md"), rows(o + f"summary_{cfg}_sq2.md")
     for k in DEC:
         if k in pa and pa[k]["SQ_INSTS_VALU"] > 1000: txt += sqrow(f"{cfg}: {k}", pa[k], pb.get(k, {}), nb * 4194304.0)
-for cfg in ("seg2048", "seg8192", "wx2048", "wx256"):
+for cfg in ("seg2048", "seg8192", "tile2048", "tile512"):
     for sfx in ("_stats", "_sq", "_sq2", "_fetch", "_write", "_tcp", "_tcc"):
         f = o + f"summary_{cfg}{sfx}.md"
         if os.path.exists(f):
