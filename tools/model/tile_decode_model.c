@@ -14,6 +14,9 @@
  *         the tile's first write), match bytes whose source lies inside the tile keep a 16-bit POINTER to it and are resolved by
  *         chasing pointers until a byte that is final - no order between the threads is needed for that, and a byte that has been
  *         resolved is final for everyone behind it.  Sequences of any length are simply clipped to the tile (no escapes).
+ * (The kernels kept the steps and changed their shape on the way: the walk runs inside the executor's workgroup with one segment per
+ *  thread, a chunk is 1536 stream bytes and at most 384 sequences, a tile at most 4088 bytes, a thread owns eight consecutive bytes,
+ *  a final byte points to itself and the chase writes shortened pointers back - DESIGN.md section 3, "K1t".)
  * Checked against the oracle on the corpus, on edge inputs and on damaged streams.  A "workgroup" is a loop over 512 threads per
  * phase (a phase ends where the kernel has a barrier); the pointer chase runs its threads in a shuffled order.
  * Design aid / test infrastructure only (links the oracle); not product.
