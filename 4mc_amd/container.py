@@ -122,3 +122,24 @@ def gather_block_index(local_csizes, nblocks, group=None):
     dist.all_gather_into_tensor(out, pad, group=group)
     cs = out.cpu().numpy()[:nblocks].astype(np.int64)
     return cs, block_offsets(cs)
+
+
+def gather_rank_reports(mine, group=None):
+    """Every rank's report (a dict with at least `rank`, `first_block_offset`, `shard_bytes`) gathered to every rank, in rank
+    order, and the footer index they imply CHECKED: rank r's first block has to sit at 12 (the frame header) + the bytes of the
+    shards before it - recomputed here from the gathered shard sizes, independently of the prefix sum the ranks used for their
+    own offsets.  Used by bench.py for N > 1 (`per_rank`); world 1: [mine]."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        reports = [mine]
+    else:
+        reports = [None] * world
+        dist.all_gather_object(reports, mine, group=group)
+        reports = sorted(reports, key=lambda x: x["rank"])
+    run = 12
+    for g in reports:
+        if g["first_block_offset"] != run:
+            raise AssertionError("footer index: rank %d begins at %d, the prefix sum of the gathered shard sizes says %d" % (g["rank"], g["first_block_offset"], run))
+        run += g["shard_bytes"]
+    return reports

@@ -91,6 +91,30 @@ struct Prof {
 #endif
 
 // ================================================================================================ token at a position
+// Length extension bytes from q on - 255, 255, ..., b (b < 255) - eight per load: adds them to `len`, leaves q behind the last.
+// false: they reach `limit`, or len passes cap on a 255 (an incompressible block is one long run per token: a byte per trip to
+// memory made its walk 2 x slower than a text block's).
+__device__ __forceinline__ bool ext_run(cgbyte* s, uint32_t limit, uint32_t& q, uint32_t& len, uint32_t cap)
+{
+    for (;;) {
+        if (q + 8u <= limit) {
+            const u32x2 v = ld8u(s + q);
+            const uint32_t nlo = ~v.x, nhi = ~v.y;
+            if ((nlo | nhi) == 0u) { len += 8u * 255u; q += 8u; if (len > cap) return false; continue; }
+            const uint32_t k = nlo ? uint32_t(__builtin_ctz(nlo)) >> 3 : 4u + (uint32_t(__builtin_ctz(nhi)) >> 3);
+            const uint32_t b = k < 4u ? (v.x >> (8u * k)) & 255u : (v.y >> (8u * (k - 4u))) & 255u;
+            len += 255u * k;
+            if (k && len > cap) return false;
+            len += b; q += k + 1u;
+            return true;
+        }
+        if (q >= limit) return false;
+        const uint32_t b = s[q++]; len += b;
+        if (b != 255u) return true;
+        if (len > cap) return false;
+    }
+}
+
 struct Hop { uint32_t ll, next, offml; bool stop, esc; };      // offml: match offset | match length << 16 (exact unless esc)
 // One token at p (per lane).  stop: the token or its bytes reach beyond limit = csize - kMargin; the chain halts AT p and the exact
 // walker takes over there.  Every byte read lies below csize.
@@ -104,7 +128,7 @@ __device__ __forceinline__ Hop decode_tok(cgbyte* s, uint32_t limit, uint32_t p)
     if (ll == 15) {
         uint32_t b = (L0.x >> 8) & 255u; ll += b; q++;
         if (b == 255u) {
-            for (;;) { if (q >= limit) return h; b = s[q++]; ll += b; if (b != 255u) break; if (ll > (1u << 23)) return h; }
+            if (ll > (1u << 23) || !ext_run(s, limit, q, ll, 1u << 23)) return h;
         }
     }
     const uint32_t mo = q + ll;
@@ -115,7 +139,7 @@ __device__ __forceinline__ Hop decode_tok(cgbyte* s, uint32_t limit, uint32_t p)
         const uint32_t e0 = (L1 >> 16) & 255u; q2++; ml += e0;
         if (e0 == 255u) {
             const uint32_t e1 = L1 >> 24; q2++; ml += e1;
-            if (e1 == 255u) { esc = true; for (;;) { if (q2 >= limit) return h; const uint32_t b = s[q2++]; if (b != 255u) break; } }
+            if (e1 == 255u) { esc = true; uint32_t mx = 0; if (!ext_run(s, limit, q2, mx, 0xFFFFFFFFu)) return h; }
         }
     }
     if (q2 > limit) return h;
@@ -187,7 +211,7 @@ __device__ __forceinline__ void walk_from(LaneSeg& g, cgbyte* s, uint32_t csize,
         uint32_t ll = tok >> 4, q = p + 1; bool stop = false;
         if (ll == 15) {
             uint32_t bq = (L0 >> 8) & 255u; ll += bq; q++;
-            if (bq == 255u) for (;;) { if (q >= limit) { stop = true; break; } bq = s[q++]; ll += bq; if (bq != 255u) break; if (ll > (1u << 23)) { stop = true; break; } }
+            if (bq == 255u) stop = ll > (1u << 23) || !ext_run(s, limit, q, ll, 1u << 23);
         }
         const uint32_t mo = q + ll;
         if (stop || mo + 2 > limit) { tail = true; break; }
@@ -197,7 +221,7 @@ __device__ __forceinline__ void walk_from(LaneSeg& g, cgbyte* s, uint32_t csize,
             const uint32_t e0 = (L1 >> 16) & 255u; q2++; ml += e0;
             if (e0 == 255u) {
                 const uint32_t e1 = L1 >> 24; q2++; ml += e1;
-                if (e1 == 255u) { esc = true; for (;;) { if (q2 >= limit) { stop = true; break; } const uint32_t bq = s[q2++]; if (bq != 255u) break; } }
+                if (e1 == 255u) { esc = true; uint32_t mx = 0; stop = !ext_run(s, limit, q2, mx, 0xFFFFFFFFu); }
             }
         }
         if (stop || q2 > limit) { tail = true; break; }

@@ -497,13 +497,7 @@ def main():
                 "compress_GBps": round(nb * B / (float(np.mean(phase["compress"])) * 1e-3) / 1e9, 3),
                 "decompress_GBps": round(nb * B / (float(np.mean(phase["decompress"])) * 1e-3) / 1e9, 3),
                 "first_block_offset": int(state["img_off"][0].item()), "shard_bytes": int((state["csz"] + 12).sum().item())}
-        gathered = [None] * world
-        dist.all_gather_object(gathered, mine)
-        run = 12
-        for g in sorted(gathered, key=lambda x: x["rank"]):
-            assert g["first_block_offset"] == run, "footer index: rank %d begins at %d, the prefix sum says %d" % (g["rank"], g["first_block_offset"], run)
-            run += g["shard_bytes"]
-        per_rank = sorted(gathered, key=lambda x: x["rank"])
+        per_rank = p.container.gather_rank_reports(mine)        # (asserts the gathered footer index against a prefix sum recomputed from the shard sizes)
         try:
             v = torch.cuda.nccl.version(); ver = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
         except Exception:

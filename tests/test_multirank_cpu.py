@@ -126,3 +126,38 @@ def test_two_ranks_write_one_4mc_file(tmp_path):
     blob = open(path, "rb").read()
     assert len(blob) == man["levels"]["4mc-1"]["file_bytes"]
     assert hashlib.sha256(blob).hexdigest() == man["levels"]["4mc-1"]["sha256"]
+
+
+def _report_worker(rank, world, port, nblocks, break_rank, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, helpers.ROOT)
+    p = helpers.pkg()
+    rng = np.random.default_rng(7)
+    all_c = rng.integers(1, 4 << 20, nblocks)
+    lo, hi = p.shard_range(nblocks, rank, world)
+    cs, offs = p.gather_block_index(torch.from_numpy(all_c[lo:hi].astype(np.int32)), nblocks)
+    mine = {"rank": rank, "first_block_offset": int(offs[lo]) + (4 if rank == break_rank else 0), "shard_bytes": int((cs[lo:hi] + 12).sum()), "blocks": hi - lo}
+    try:
+        rep = p.container.gather_rank_reports(mine)
+        q.put((rank, "ok", [r["rank"] for r in rep], [r["first_block_offset"] for r in rep]))
+    except AssertionError as e:
+        q.put((rank, "bad", str(e), None))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_rank_reports_world2():
+    """what bench.py puts into `per_rank` for N > 1: gathered in rank order on every rank, and an offset that does not follow from the
+    shard sizes is refused on every rank"""
+    for break_rank in (-1, 1):
+        ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+        ps = [ctx.Process(target=_report_worker, args=(r, 2, port, 9, break_rank, q)) for r in range(2)]
+        [p.start() for p in ps]
+        got = sorted(q.get(timeout=120) for _ in range(2))
+        [p.join(60) for p in ps]
+        assert all(p.exitcode == 0 for p in ps)
+        for rank, verdict, a, b in got:
+            if break_rank < 0:
+                assert verdict == "ok" and a == [0, 1] and b[0] == 12 and b[1] > 12, (rank, verdict, a, b)
+            else:
+                assert verdict == "bad" and "rank 1" in a, (rank, verdict, a)
