@@ -72,6 +72,11 @@ __device__ __forceinline__ uint32_t scan_max(uint32_t v)
     v = umax(v, dpp0<0x142, 0xa>(v)); v = umax(v, dpp0<0x143, 0xc>(v));
     return v;
 }
+// inclusive prefix sum / maximum / minimum over the lanes of a row of 16 (three DPP steps): lane 7 holds the first eight lanes' result
+template <int CTRL> __device__ __forceinline__ uint32_t dppk(uint32_t old, uint32_t v) { return uint32_t(__builtin_amdgcn_update_dpp(int(old), int(v), CTRL, 0xf, 0xf, false)); }
+__device__ __forceinline__ uint32_t row_add8(uint32_t v) { v += dppk<0x111>(0u, v); v += dppk<0x112>(0u, v); v += dppk<0x114>(0u, v); return v; }
+__device__ __forceinline__ uint32_t row_max8(uint32_t v) { v = umax(v, dppk<0x111>(0u, v)); v = umax(v, dppk<0x112>(0u, v)); v = umax(v, dppk<0x114>(0u, v)); return v; }
+__device__ __forceinline__ uint32_t row_min8(uint32_t v) { v = min(v, dppk<0x111>(0xFFFFFFFFu, v)); v = min(v, dppk<0x112>(0xFFFFFFFFu, v)); v = min(v, dppk<0x114>(0xFFFFFFFFu, v)); return v; }
 __device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l) { return uint32_t(__builtin_amdgcn_readlane(int(v), int(l))); }
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
 
@@ -528,30 +533,45 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
             // by a global load and merged here would put a wait for every outstanding global operation (the flush before) on everyone
             const uint32_t p = toks[tid];
             const uint32_t t = stage[p], t1 = stage[p + 1], mn = t & 15u;
-            uint32_t q = p + 1; ll = t >> 4;
-            bool slow = false;
-            if (ll == 15u) { uint32_t bq = t1; ll += bq; q++; while (bq == 255u) { if (q >= kStage) { slow = true; break; } bq = stage[q++]; ll += bq; } }
+            // straight line for what nearly every token is: at most one extension byte per length, fields inside the stage; one
+            // branch for everything else (runs of 255, fields beyond the stage)
+            const bool x1 = (t >> 4) == 15u, x2 = mn == 15u;
+            uint32_t q = p + 1u + (x1 ? 1u : 0u);
+            ll = (t >> 4) + (x1 ? t1 : 0u);
             uint32_t mo = q + ll;
-            slow = slow || mo + 3u >= kStage;
-            const uint32_t moc = slow ? 0u : mo;
+            const uint32_t moc = mo + 3u < kStage ? mo : 0u;
             const uint32_t o0 = stage[moc], o1 = stage[moc + 1], e0 = stage[moc + 2], e1 = stage[moc + 3];
             off = o0 | (o1 << 8);
-            uint32_t q2 = mo + 2; ml = mn + 4u;
-            if (mn == 15u) {
-                ml += e0; q2++;
-                if (e0 == 255u) { uint32_t bq = e1; ml += bq; q2++; while (bq == 255u) { if (q2 >= kStage) { slow = true; break; } bq = stage[q2++]; ml += bq; } }
+            ml = mn + 4u + (x2 ? e0 : 0u);
+            uint32_t q2 = mo + 2u + (x2 ? 1u : 0u);
+            if ((x1 && t1 == 255u) || (x2 && e0 == 255u) || mo + 3u >= kStage) {
+                bool slow = mo + 3u >= kStage;
+                if (x1 && t1 == 255u) {                                  // (the first extension byte was not the last: ll, mo and what was read at mo are void)
+                    uint32_t bq = 255u;
+                    while (bq == 255u) { if (q >= kStage) { slow = true; break; } bq = stage[q++]; ll += bq; }
+                    mo = q + ll; slow = slow || mo + 3u >= kStage;
+                    if (!slow) {
+                        off = uint32_t(stage[mo]) | (uint32_t(stage[mo + 1]) << 8);
+                        const uint32_t f0 = stage[mo + 2], f1 = stage[mo + 3];
+                        ml = mn + 4u + (x2 ? f0 : 0u); q2 = mo + 2u + (x2 ? 1u : 0u);
+                        if (x2 && f0 == 255u) { uint32_t b2 = f1; ml += b2; q2++; while (b2 == 255u) { if (q2 >= kStage) { slow = true; break; } b2 = stage[q2++]; ml += b2; } }
+                    }
+                } else if (!slow) {                                      // x2 && e0 == 255
+                    uint32_t b2 = e1; ml += b2; q2++;
+                    while (b2 == 255u) { if (q2 >= kStage) { slow = true; break; } b2 = stage[q2++]; ml += b2; }
+                }
+                if (slow) {
+                    cgbyte* g = s + sbase;
+                    uint32_t L = t >> 4, Q = p + 1;
+                    if (L == 15u) { uint32_t qa = sbase + Q; (void)ext_run(s, csize - kMargin, qa, L, 0xFFFFFFFFu); Q = qa - sbase; }
+                    const uint32_t MO = Q + L;
+                    const uint32_t OF = uint32_t(g[MO]) | (uint32_t(g[MO + 1]) << 8);
+                    uint32_t Q2 = MO + 2, M = mn + 4u;
+                    if (mn == 15u) { uint32_t qa = sbase + Q2; (void)ext_run(s, csize - kMargin, qa, M, 0xFFFFFFFFu); Q2 = qa - sbase; }
+                    sc[S_SLOW] = L; sc[S_SLOW + 1] = M; sc[S_SLOW + 2] = OF; sc[S_SLOW + 3] = Q; sc[S_SLOW + 4] = Q2;
+                }
+                if (slow) { ll = sc[S_SLOW]; ml = sc[S_SLOW + 1]; off = sc[S_SLOW + 2]; q = sc[S_SLOW + 3]; q2 = sc[S_SLOW + 4]; mo = q + ll; }
             }
-            if (slow) {
-                cgbyte* g = s + sbase;
-                uint32_t L = t >> 4, Q = p + 1;
-                if (L == 15u) { uint32_t qa = sbase + Q; (void)ext_run(s, csize - kMargin, qa, L, 0xFFFFFFFFu); Q = qa - sbase; }
-                const uint32_t MO = Q + L;
-                const uint32_t OF = uint32_t(g[MO]) | (uint32_t(g[MO + 1]) << 8);
-                uint32_t Q2 = MO + 2, M = mn + 4u;
-                if (mn == 15u) { uint32_t qa = sbase + Q2; (void)ext_run(s, csize - kMargin, qa, M, 0xFFFFFFFFu); Q2 = qa - sbase; }
-                sc[S_SLOW] = L; sc[S_SLOW + 1] = M; sc[S_SLOW + 2] = OF; sc[S_SLOW + 3] = Q; sc[S_SLOW + 4] = Q2;
-            }
-            if (slow) { ll = sc[S_SLOW]; ml = sc[S_SLOW + 1]; off = sc[S_SLOW + 2]; q = sc[S_SLOW + 3]; q2 = sc[S_SLOW + 4]; mo = q + ll; }
             lsrc = q;                                                    // (relative to the stage)
             beyond = ll != 0u && mo > kStage;
             tpos = sbase + p;
@@ -567,10 +587,10 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
         if (tid < (kSeqs + kGroup - 1) / kGroup) *reinterpret_cast<u32x4*>(code + u0) = u32x4{0, 0, 0, 0};      // (the token positions were here)
         uint32_t incl = 0, outl = 0, mst = 0;
         if (seqwave) {
-            uint32_t wbase = 0;
-            const uint32_t w8 = sc[S_SUM + (lane & 7u)];                 // (one load, then lane reads: a load per term would be a wait per term)
-#pragma unroll
-            for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) wbase += k < wv ? rdl(w8, k) : 0u;
+            // (the eight waves' sums: one load, a prefix sum on the DPP network, one lane read - a load per term is a wait per term,
+            // a lane read and a scalar add per term is the scalar unit's time)
+            const uint32_t w8 = row_add8(sc[S_SUM + (lane & 7u)]);
+            const uint32_t wbase = wv ? rdl(w8, wv - 1u) : 0u;
             incl = wbase + winc; outl = incl - sz; mst = outl + ll;      // output start of the literals / of the match, chunk-relative
         }
         // how many sequences the chunk takes: those whose output ends below the output-side margin and - but for the first - inside
@@ -591,15 +611,12 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
             if (beyond) { sc[S_BYDL] = lsrc - outl; sc[S_BYE] = 2u + 2u * tid; }      // its literals' stage index at chunk output 0, its entry
         }
         WG_BARRIER();
-        uint32_t nfo = 0, nft = 0, nbad = 0xFFFFu, total = 0; bool has_beyond = false;
+        uint32_t nfo, nft, nbad, total; bool has_beyond;
         {
-            const uint32_t l8 = lane & 7u, x8 = sc[S_NF + l8], f8 = sc[S_FB + l8], t8 = sc[S_TOT + l8];
-#pragma unroll
-            for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) {
-                const uint32_t x = rdl(x8, k);
-                nfo += x & 255u; nft += (x >> 8) & 255u; has_beyond |= (x >> 16) != 0u;
-                nbad = min(nbad, rdl(f8, k)); total = umax(total, rdl(t8, k));
-            }
+            const uint32_t l8 = lane & 7u, x8 = sc[S_NF + l8];
+            const uint32_t xs = rdl(row_add8(((x8 & 255u) | ((x8 & 0xFF00u) << 8)) + ((x8 >> 16) << 28)), 7);      // counts side by side (each <= 512), "beyond" flags on top
+            nfo = xs & 0xFFFFu; nft = (xs >> 16) & 0xFFFu; has_beyond = (xs >> 28) != 0u;
+            nbad = rdl(row_min8(sc[S_FB + l8]), 7); total = rdl(row_max8(sc[S_TOT + l8]), 7);
         }
         const uint32_t nfit = nfo < nft ? nfo : nft;
         if (nbad < nfit) { failed = true; break; }
@@ -626,7 +643,16 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
                 first_tile = false;
             }
             // marks: where the sequence's literal part and its match part begin inside the tile
-            if (tid < ntaken) {
+            if (R0 == 0u && T == total) {                                // (the chunk is one tile - nearly always: nothing is clipped)
+                if (tid < ntaken) {
+                    if (ll != 0u) {
+                        code[outl + mis] = uint16_t(2u + 2u * tid);
+                        ent[2 * (2u + 2u * tid)] = 0x20000u | ((lsrc - mis - outl - gb) & 0xFFFFu);      // the literal at tile coordinate u is stage byte lsrc + (u - mis) - outl
+                        ent[2 * (2u + 2u * tid) + 1] = 0x10000u;
+                    }
+                    code[mst + mis] = uint16_t(3u + 2u * tid);
+                }
+            } else if (tid < ntaken) {
                 const uint32_t me = outl + sz;
                 if (ll != 0u && outl < R0 + T && mst > R0) {
                     code[(outl > R0 ? outl : R0) - R0 + mis] = uint16_t(2u + 2u * tid);
@@ -650,11 +676,8 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
                 if (lane == 63) sc[S_SUM + wv] = wi;
                 uint32_t ex = dpp0<0x138, 0xf>(wi);                      // wave_shr:1 - the lanes in front (0 for lane 0)
                 WG_BARRIER();
-                uint32_t pre = 0;
-                const uint32_t m8 = sc[S_SUM + (lane & 7u)];
-#pragma unroll
-                for (uint32_t k = 0; k < uint32_t(kThreads / 64); k++) pre = umax(pre, k < wv ? rdl(m8, k) : 0u);
-                ex = umax(ex, pre);
+                const uint32_t m8 = row_max8(sc[S_SUM + (lane & 7u)]);
+                ex = umax(ex, wv ? rdl(m8, wv - 1u) : 0u);
 #pragma unroll
                 for (int k = 0; k < 8; k++) c[k] = umax(c[k], ex);
             }
@@ -746,9 +769,11 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
             pf.add(5, tp); pf.count(6);
         }
         if (first_tile && ntaken < n) { WG_BARRIER(); next_ip = rfl(sc[S_CUTPOS]); }      // (no output at all: the cut was at the chunk's first sequence)
-        // the next chunk decodes about as many sequences as fill one tile at this chunk's bytes per sequence
-        if (ntaken) { const uint32_t est = uint32_t(float(ntaken) * float(kTile - 8u) / float(total ? total : 1u)); nmax = est + (est >> 4) + 2u; nmax = nmax < 8u ? 8u : (nmax > kSeqs ? kSeqs : nmax); }
-        nmax = rfl(nmax);
+        // the next chunk decodes about as many sequences as fill one tile: more when this one was taken whole and left room, fewer when
+        // the tile was full before the chunk's sequences were
+        if (ntaken == n && total < kTile - 8u - (kTile >> 3)) nmax = nmax + (nmax >> 2) + 8u;
+        else if (ntaken < n) nmax = ntaken + (ntaken >> 4) + 2u;
+        nmax = nmax < 8u ? 8u : (nmax > kSeqs ? kSeqs : nmax);
         ip = next_ip;
         WG_BARRIER();                                                 // (sc, code, ent, stage are rewritten by the next chunk)
     }
