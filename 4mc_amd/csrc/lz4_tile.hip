@@ -374,7 +374,7 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
     uint32_t* const sc   = reinterpret_cast<uint32_t*>(smem + kOffSc);
     uint8_t*  const ring = smem + kOffRing;                                  // [0, 64 KiB): the output window; [64 KiB, + kStage): the chunk's stream bytes
     uint8_t*  const stage = smem + kOffStage;
-    uint16_t* const toks = code;
+    uint16_t* const toks = code + 128;                                       // (behind the chunk's bitmap words)
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
     const fourmc_block blk = uniform_block(blocks[b]);
@@ -499,24 +499,29 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
     WG_BARRIER();
 
     while (ip < tail_ip && !cut) {
-        // ---- the chunk's stream bytes into the stage, its bitmap words through wave 0: token positions, compacted
+        // ---- the chunk's stream bytes into the stage; token positions, compacted: thread t looks at the bits of stream bytes
+        // [3 t, 3 t + 3) of the chunk - a token takes at least three bytes, so at most one begins there - and its rank among the
+        // chunk's tokens is a ballot, a count of the lanes below and the counts of the waves in front
         const uint32_t sbase = ip & ~15u;
-        if (tid < kStage / 16u) *reinterpret_cast<u32x4*>(stage + 16u * tid) = nst;
-        if (wv == 0) {
-            const uint32_t w0 = ip >> 5;
-            uint32_t cend = (w0 << 5) + kChunk; cend = cend < tail_ip ? cend : tail_ip;
-            uint32_t w = nbw;
-            const uint32_t lo = (w0 + lane) << 5;
-            if (lo < ip) w &= ~((1u << (ip - lo)) - 1u);
-            if (lo >= cend) w = 0; else if (cend - lo < 32u) w &= (1u << (cend - lo)) - 1u;
-            const uint32_t c = uint32_t(__builtin_popcount(w)), inc = scan_add(c);
-            uint32_t idx = inc - c;
-            while (w && idx < nmax) {
-                const uint32_t bit = uint32_t(__builtin_ctz(w)); w &= w - 1u;
-                toks[idx] = uint16_t(lo + bit - sbase);
-                idx++;
-            }
-            if (lane == 63) sc[S_NTOK] = inc;
+        {
+            const uint32_t cb = (ip >> 5) << 5;
+            uint32_t cend = cb + kChunk; cend = cend < tail_ip ? cend : tail_ip;
+            if (tid < kStage / 16u) *reinterpret_cast<u32x4*>(stage + 16u * tid) = nst;
+            uint32_t* const bw = reinterpret_cast<uint32_t*>(code);      // (49 words of what is zero between tiles; zeroed again below)
+            if (tid <= kChunk / 32u) bw[tid] = tid < kChunk / 32u ? nbw : 0u;
+            WG_BARRIER();
+            const uint32_t bo = 3u * tid;
+            const uint32_t bits3 = __builtin_amdgcn_alignbit(bw[(bo >> 5) + 1u], bw[bo >> 5], bo & 31u) & 7u;
+            const uint32_t ppos = cb + bo + uint32_t(__builtin_ctz(bits3 | 8u));
+            const bool has = bits3 != 0u && ppos >= ip && ppos < cend;
+            const unsigned long long hm = __ballot(has);
+            const uint32_t rk_w = __builtin_amdgcn_mbcnt_hi(uint32_t(hm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(hm), 0u));
+            if (lane == 0) sc[S_SUM + wv] = uint32_t(__builtin_popcountll(hm));
+            WG_BARRIER();
+            const uint32_t c8 = row_add8(sc[S_SUM + (lane & 7u)]);
+            const uint32_t rank = (wv ? rdl(c8, wv - 1u) : 0u) + rk_w;
+            if (has && rank < nmax) toks[rank] = uint16_t(ppos - sbase);
+            if (tid == 0) sc[S_NTOK] = rdl(c8, 7);
         }
         WG_BARRIER();
         const uint32_t ntok = rfl(sc[S_NTOK]);
@@ -584,7 +589,7 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
         if (seqwave) { winc = scan_add(sz); if (lane == 63) sc[S_SUM + wv] = winc; }
         else if (lane == 63) sc[S_SUM + wv] = 0;
         WG_BARRIER();
-        if (tid < (kSeqs + kGroup - 1) / kGroup) *reinterpret_cast<u32x4*>(code + u0) = u32x4{0, 0, 0, 0};      // (the token positions were here)
+        if (tid < (128u + kSeqs + kGroup - 1) / kGroup) *reinterpret_cast<u32x4*>(code + u0) = u32x4{0, 0, 0, 0};      // (the bitmap words and the token positions were here)
         uint32_t incl = 0, outl = 0, mst = 0;
         if (seqwave) {
             // (the eight waves' sums: one load, a prefix sum on the DPP network, one lane read - a load per term is a wait per term,
