@@ -168,7 +168,8 @@ def test_64gib_launch(gpu, path):
     nd = nb * reps
     torch.cuda.empty_cache()
     free = torch.cuda.mem_get_info()[0]
-    need = (230 if path == 6 else 150) * (1 << 30)                 # 64 GiB out, 8 images of 8 GiB, 8 GiB of input; + the workspace: 92 GB of records / 8.6 GB of bitmaps
+    need = (215 if path == 6 else 150) * (1 << 30)                 # 64 GiB out, 8 images of 8 GiB, 8 GiB of input; + the workspace: 92 GB of records / 8.6 GB of bitmaps
+                                                                   # (less if the engine's stream already holds a workspace from an earlier test)
     if free < need:
         pytest.skip("needs %d GiB of free HBM" % (need >> 30))
     base = helpers.corpus(base_n * B)
