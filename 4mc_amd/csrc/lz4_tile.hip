@@ -368,7 +368,11 @@ __global__ __launch_bounds__(kThreads)
 void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks, uint32_t nblocks,
                           int container_mode, uint32_t* ws)
 {
+#ifdef FOURMC_TILE_PAD      // (occupancy experiment: more LDS than needed = one workgroup per CU)
+    __shared__ __attribute__((aligned(16))) uint8_t smem[kLdsBytes + FOURMC_TILE_PAD];
+#else
     __shared__ __attribute__((aligned(16))) uint8_t smem[kLdsBytes];
+#endif
     uint16_t* const code = reinterpret_cast<uint16_t*>(smem + kOffCode);     // marks, then pointers (while a chunk's tokens are decoded: their positions)
     uint32_t* const ent  = reinterpret_cast<uint32_t*>(smem + kOffEnt);
     uint32_t* const sc   = reinterpret_cast<uint32_t*>(smem + kOffSc);
