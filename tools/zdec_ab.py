@@ -21,7 +21,7 @@ d_stage = torch.empty(nb * B, dtype=torch.uint8, device="cuda")
 p.encode_blocks(d_src, d_stage, enc, codec=p.CODEC_ZSTD, level=level)
 e = enc.download()
 lib = p.lib()
-for split in (0, 1, 0, 1):
+for split in ((1, 1) if os.environ.get("ZDEC_SPLIT_ONLY") else (0, 1, 0, 1)):
     lib.fourmc_gpu_set_zstd_decode_split(split)
     d_out = torch.zeros(nb * B + 64, dtype=torch.uint8, device="cuda")
     ts = []
