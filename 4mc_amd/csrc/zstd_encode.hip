@@ -2115,7 +2115,22 @@ struct LazyState {
     uint32_t* tab; uint32_t* chain; uint8_t* tags; uint32_t ntu, low_limit, dict_limit;
     // row of the NEXT position, read ahead while this position's candidates are compared (row_search)
     uint32_t pf_ip, pf_hash, pf_head, pf_tg, pf_e;
+    // searches computed ahead (row_batch): the results for positions q_pos, q_pos + 1 as the rows will stand when the walk gets there,
+    // and what each needs to enter its row then {row, tag, slot}
+    uint32_t q_pos, q_n, q_ml[2], q_ofb[2], q_rel[2], q_tag[2], q_slot[2];
+#ifdef ZL_PROF
+    unsigned long long pc[20];        // 0 searches from the read-ahead, 1 usual without it, 2 general; 3-5 their cycles; 6 extensions in best_candidate; 7 catch-up insertions; 8 sequences; 9 repcode-after loops
+#endif
 };
+#ifdef ZL_PROF
+#define ZLC(i, n) (Z.pc[i] += (n))
+#define ZLT0() const unsigned long long zl_t0 = __builtin_readcyclecounter()
+#define ZLT(i) (Z.pc[i] += __builtin_readcyclecounter() - zl_t0)
+#else
+#define ZLC(i, n) do {} while (0)
+#define ZLT0() do {} while (0)
+#define ZLT(i) do {} while (0)
+#endif
 
 __device__ __forceinline__ uint32_t lz_low(const LazyState& Z, const Params& P, uint32_t curr)
 { const uint32_t md = 1u << P.wlog; return curr - Z.low_limit > md ? curr - md : Z.low_limit; }
@@ -2180,12 +2195,132 @@ __device__ __forceinline__ void row_insert_range(ZLds& L, LazyState& Z, const Pa
     }
 }
 
+// K consecutive searches in ONE pair of trips to memory (the lazy walk searches ip, ip + 1, ip + 2 one after the other whatever it
+// finds, :1547-1620; each was a row read and a candidate read of its own).  Nothing may be pending (curr == ntu).  The rows of
+// p .. p + K - 1 are read together as they stand; what position j < k will have done to the row of position k by the time the walk
+// searches k - its insertion, when both hash to the same row - is applied in registers; the candidates of all K are compared in one
+// trip.  Only p enters its row here: p + 1, p + 2 are queued with their results and enter when (if) the walk asks for them, in order
+// (row_search), so the table never holds a position the reference has not inserted.
+template <int K>
+__device__ __forceinline__ uint32_t row_batch(LazyState& Z, const Params& P, const uint8_t* s, uint32_t p, uint32_t end, uint32_t& ofb0, int lane)
+{
+    const uint32_t rowlog = min(max(P.slog, 4u), 6u), entries = 1u << rowlog, mask = entries - 1, mls = min(max(P.mml, 4u), 6u);
+    const uint32_t attempts = 1u << min(P.slog, rowlog), hbits = P.hlog - rowlog + 8;
+    const bool in_row = uint32_t(lane) < entries;
+    const unsigned long long emask = entries == 64 ? ~0ull : ((1ull << entries) - 1);
+    uint32_t rel[K], tag[K], headb[K], tg[K], e[K], slot[K];
+#ifdef ZL_PROF
+    unsigned long long bt = __builtin_readcyclecounter(), bn;
+#define ZBT(i) do { bn = __builtin_readcyclecounter(); Z.pc[i] += bn - bt; bt = bn; } while (0)
+#else
+#define ZBT(i) do {} while (0)
+#endif
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const uint32_t h = zhash(ld8(s + p + k), hbits, mls);
+        rel[k] = (h >> 8) << rowlog; tag[k] = h & 255u;
+        const uint8_t* const row = Z.tags + 2 * size_t(rel[k]);
+        headb[k] = row[0];
+        tg[k] = in_row ? uint32_t(row[16 + lane]) : 0u;
+        e[k] = in_row ? Z.tab[rel[k] + lane] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+#pragma unroll
+        for (int j = 0; j < k; j++)
+            if (rel[j] == rel[k]) { headb[k] = slot[j]; if (uint32_t(lane) == slot[j]) { tg[k] = tag[j]; e[k] = p + j + 2; } }
+        slot[k] = (headb[k] - 1u) & mask;
+    }
+    ZBT(10);
+    bool has[K]; uint32_t rank[K];
+    U16B x0[K], x1[K], y0[K], y1[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const uint32_t curr = p + k + 2, low = lz_low(Z, P, curr);
+        const uint32_t head = headb[k] & mask, ord = (uint32_t(lane) - head) & mask;
+        const bool valid = in_row && tg[k] == tag[k];
+        auto rot = [&](unsigned long long m) -> unsigned long long {
+            m &= emask;
+            return head ? ((m >> head) | (m << (entries - head))) & emask : m;
+        };
+        unsigned long long vm = rot(__ballot(valid));
+        const unsigned long long stop = rot(__ballot(valid && e[k] < low));
+        if (stop) vm &= (1ull << __builtin_ctzll(stop)) - 1;
+        rank[k] = uint32_t(__builtin_popcountll(vm & ((1ull << ord) - 1)));
+        has[k] = in_row && ((vm >> ord) & 1) && rank[k] < attempts;
+        const uint32_t a = p + k, b = has[k] ? e[k] - 2 : a;
+        x0[k] = *reinterpret_cast<const U16B*>(s + a); x1[k] = *reinterpret_cast<const U16B*>(s + a + 16);
+        y0[k] = *reinterpret_cast<const U16B*>(s + b); y1[k] = *reinterpret_cast<const U16B*>(s + b + 16);
+    }
+    ZBT(11);
+    uint32_t ml[K], of[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const uint32_t a = p + k, curr = a + 2;
+        const uint64_t d0 = x0[k].a ^ y0[k].a, d1 = x0[k].b ^ y0[k].b, d2 = x1[k].a ^ y1[k].a, d3 = x1[k].b ^ y1[k].b;
+        const uint32_t eq = d0 ? uint32_t(__builtin_ctzll(d0) >> 3) : d1 ? 8u + uint32_t(__builtin_ctzll(d1) >> 3)
+                          : d2 ? 16u + uint32_t(__builtin_ctzll(d2) >> 3) : d3 ? 24u + uint32_t(__builtin_ctzll(d3) >> 3) : 32u;
+        uint32_t cnt = has[k] ? min(eq, end - a) : 0u;
+        ZBT(12);
+        for (unsigned long long todo = __ballot(has[k] && cnt == 32 && a + 32 < end); todo; todo &= todo - 1) {
+            const int l = __builtin_ctzll(todo);
+            const uint32_t extra = count_fwd(s, a + 32, rl(e[k], l) - 2 + 32, end, lane);
+            if (lane == l) cnt += extra;
+            ZLC(14, 1);
+        }
+        ZBT(13);
+        const uint32_t mine = (has[k] && cnt > 3) ? ((cnt << 6) | (63u - rank[k])) : 0u;
+        const uint32_t key = wave_max(mine);
+        ml[k] = 3; of[k] = 999999999u;
+        if (key) {
+            const unsigned long long who = __ballot(mine == key);
+            of[k] = curr - rl(e[k], uint32_t(__builtin_ctzll(who))) + 3; ml[k] = key >> 6;
+        }
+    }
+    ZBT(15);
+    if (lane == 0) {                                                    // p itself goes in (:1229-1234)
+        uint8_t* const row = Z.tags + 2 * size_t(rel[0]);
+        row[0] = uint8_t(slot[0]); row[16 + slot[0]] = uint8_t(tag[0]); Z.tab[rel[0] + slot[0]] = p + 2;
+    }
+    Z.ntu = p + 3;
+    Z.q_pos = p + 1; Z.q_n = K - 1;
+#pragma unroll
+    for (int k = 1; k < K; k++) { Z.q_ml[k - 1] = ml[k]; Z.q_ofb[k - 1] = of[k]; Z.q_rel[k - 1] = rel[k]; Z.q_tag[k - 1] = tag[k]; Z.q_slot[k - 1] = slot[k]; }
+    if (ml[0] > 3) ofb0 = of[0];
+    return ml[0];
+}
+
 __device__ __forceinline__ uint32_t row_search(ZLds& L, LazyState& Z, const Params& P, const uint8_t* s, uint32_t ip, uint32_t end,
                                                uint32_t n_total, uint32_t& ofb, int lane)
 {
     const uint32_t curr = ip + 2, low = lz_low(Z, P, curr);
     const uint32_t rowlog = min(max(P.slog, 4u), 6u), entries = 1u << rowlog, mask = entries - 1, mls = min(max(P.mml, 4u), 6u);
     const uint32_t attempts = 1u << min(P.slog, rowlog);
+    ZLT0();
+#ifndef FOURMC_ZLAZY_NOBATCH
+    if (Z.q_n && Z.q_pos == ip && curr == Z.ntu) {                     // computed ahead by row_batch: the position enters its row now
+        if (lane == 0) {
+            uint8_t* const row = Z.tags + 2 * size_t(Z.q_rel[0]);
+            row[0] = uint8_t(Z.q_slot[0]); row[16 + Z.q_slot[0]] = uint8_t(Z.q_tag[0]); Z.tab[Z.q_rel[0] + Z.q_slot[0]] = curr;
+        }
+        const uint32_t ml = Z.q_ml[0];
+        if (ml > 3) ofb = Z.q_ofb[0];
+        Z.q_ml[0] = Z.q_ml[1]; Z.q_ofb[0] = Z.q_ofb[1]; Z.q_rel[0] = Z.q_rel[1]; Z.q_tag[0] = Z.q_tag[1]; Z.q_slot[0] = Z.q_slot[1];
+        Z.q_pos++; Z.q_n--; Z.ntu = curr + 1;
+        ZLC(0, 1); ZLT(3);
+        return ml;
+    }
+    Z.q_n = 0;
+    const bool batch_ok = ip + 48 <= n_total;
+    if (curr == Z.ntu && batch_ok) {
+        Z.pf_ip = 0xFFFFFFFFu;
+        const uint32_t r_ = P.strat >= 5 ? row_batch<3>(Z, P, s, ip, end, ofb, lane) : row_batch<2>(Z, P, s, ip, end, ofb, lane);
+        ZLC(1, 1); ZLT(4);
+        return r_;
+    }
+#else
+    const bool batch_ok = false;
+#endif
     if (curr - Z.ntu <= 1) {
         // The usual step of the lazy walk: nothing, or exactly one position (the previous one), is still to be inserted.
         // Its row and the row of this search are read in ONE round trip - cursor words first, then both heads, the tags and the
@@ -2243,8 +2378,11 @@ __device__ __forceinline__ uint32_t row_search(ZLds& L, LazyState& Z, const Para
             Z.pf_ip = ip + 1; Z.pf_hash = hN; Z.pf_head = n_head; Z.pf_tg = n_tg; Z.pf_e = n_e;
         }
         Z.ntu = curr + 1;
-        return best_candidate(s, ip, end, n_total, e, has, rank, curr, ofb, lane);
+        const uint32_t r_ = best_candidate(s, ip, end, n_total, e, has, rank, curr, ofb, lane);
+        ZLC(from_pf ? 0 : 1, 1); ZLT(from_pf ? 3 : 4);
+        return r_;
     }
+    ZLC(2, 1); ZLC(7, curr - Z.ntu);
     Z.pf_ip = 0xFFFFFFFFu;                                             // the general path writes rows: nothing read ahead survives it
     {   // ZSTD_row_update_internal: catch up to curr (skipping the middle of long gaps)
         uint32_t idx = Z.ntu;
@@ -2252,6 +2390,13 @@ __device__ __forceinline__ uint32_t row_search(ZLds& L, LazyState& Z, const Para
         row_insert_range(L, Z, P, s, idx, curr, lane);
         Z.ntu = curr;
     }
+#ifndef FOURMC_ZLAZY_NOBATCH
+    if (batch_ok) {
+        const uint32_t r_ = P.strat >= 5 ? row_batch<3>(Z, P, s, ip, end, ofb, lane) : row_batch<2>(Z, P, s, ip, end, ofb, lane);
+        ZLT(5);
+        return r_;
+    }
+#endif
     const uint32_t hash = zhash(ld8(s + ip), P.hlog - rowlog + 8, mls), rel = (hash >> 8) << rowlog, tag = hash & 255;
     uint8_t* const tag_row = Z.tags + 2 * size_t(rel);
     const uint32_t head_byte = tag_row[0], head = head_byte & mask;
@@ -2270,7 +2415,9 @@ __device__ __forceinline__ uint32_t row_search(ZLds& L, LazyState& Z, const Para
         tag_row[0] = uint8_t(p0); tag_row[16 + p0] = uint8_t(tag); Z.tab[rel + p0] = curr;
     }
     Z.ntu = curr + 1;
-    return best_candidate(s, ip, end, n_total, e, has, rank, curr, ofb, lane);
+    const uint32_t r_ = best_candidate(s, ip, end, n_total, e, has, rank, curr, ofb, lane);
+    ZLT(5);
+    return r_;
 }
 
 __device__ __forceinline__ uint32_t hc_search(LazyState& Z, const Params& P, const uint8_t* s, uint32_t ip, uint32_t end,
@@ -2400,6 +2547,7 @@ __device__ __forceinline__ uint32_t lazy_block(ZLds& L, SeqStore& S, LazyState& 
 {
     const bool use_row = !kTree && P.wlog > 14;
     const uint32_t depth = P.strat >= 5 ? 2u : 1u;
+    Z.q_n = 0;                                                     // (searches computed ahead were measured against the previous block's end)
     const int64_t ilimit = int64_t(end) - 8 - (use_row ? 8 : 0);
     const uint32_t prefix_idx = Z.dict_limit, prefix = prefix_idx - 2;
     uint32_t ip = start, anchor = start;
@@ -2468,8 +2616,10 @@ __device__ __forceinline__ uint32_t lazy_block(ZLds& L, SeqStore& S, LazyState& 
             rep2 = rep1; rep1 = off;
         }
         store_seq(S, s, anchor, at - anchor, ofb, ml, lane);
+        ZLC(8, 1);
         anchor = ip = at + ml;
         while ((int64_t(ip) <= ilimit) & (rep2 > 0) && ld4(s + ip) == ld4(s + ip - rep2)) {
+            ZLC(9, 1);
             const uint32_t t = rep2;
             ml = count_fwd(s, ip + 4, ip + 4 - rep2, end, lane) + 4;
             rep2 = rep1; rep1 = t;
@@ -2859,6 +3009,11 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
     LazyState Z;
     Z.tab = tab; Z.ntu = 2; Z.low_limit = 2; Z.dict_limit = 2;
     Z.pf_ip = 0xFFFFFFFFu; Z.pf_hash = Z.pf_head = Z.pf_tg = Z.pf_e = 0;
+    Z.q_pos = 0; Z.q_n = 0;
+    for (int i = 0; i < 2; i++) Z.q_ml[i] = Z.q_ofb[i] = Z.q_rel[i] = Z.q_tag[i] = Z.q_slot[i] = 0;
+#ifdef ZL_PROF
+    for (int i = 0; i < 20; i++) Z.pc[i] = 0;
+#endif
     Z.tags = reinterpret_cast<uint8_t*>(tab) + (size_t(4) << P.hlog);                                   // rows: tag table behind the entries
     Z.chain = tab + (size_t(1) << P.hlog);                                                              // hash chains: chain table there
     uint32_t o = 0;
@@ -2973,6 +3128,10 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
         pos += len; first = false;
     }
     ZPH(t_out);
+#ifdef ZL_PROF
+    if (lane == 0) printf("ZLPROF block %u n %u out %u: mf %llu lit %llu seq %llu out %llu Mclk | searches pf %llu nopf %llu general %llu | Mclk pf %llu nopf %llu general %llu | catch-up ins %llu seqs %llu rep-after %llu | batch Mclk: rows-issued %llu has+cand-issue %llu eq-wait %llu ext %llu (n %llu) keys %llu\n",
+                          blockIdx.x, n, o, t_mf >> 20, t_lit >> 20, t_seq >> 20, t_out >> 20, Z.pc[0], Z.pc[1], Z.pc[2], Z.pc[3] >> 20, Z.pc[4] >> 20, Z.pc[5] >> 20, Z.pc[7], Z.pc[8], Z.pc[9], Z.pc[10] >> 20, Z.pc[11] >> 20, Z.pc[12] >> 20, Z.pc[13] >> 20, Z.pc[14], Z.pc[15] >> 20);
+#endif
     if (lane == 0) { uint64_t* c = reinterpret_cast<uint64_t*>(S.lit + kSub + 64); c[0] = t_mf; c[1] = t_lit; c[2] = t_seq; c[3] = t_out;
 #ifdef Z1_PROF
         for (int i = 0; i < 17; i++) c[4 + i] = S.prof[i];
