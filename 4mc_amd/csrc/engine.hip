@@ -304,12 +304,13 @@ int fourmc_gpu_zstd_decompress(const void* d_src, void* d_dst, fourmc_block* d_b
         HIP_TRY(fourmc_launch_zstd_decode(d_src, d_dst, d_blocks + b0, m, scratch, 0, s)); return FOURMC_OK; });
 }
 
-// zstd levels on the device: 1 (fast), 3 (dfast), 6 (lazy / lazy2), 12 (lazy2, btlazy2, btopt by input size) - the levels 4mz uses;
-// any other level is refused rather than answered with bytes the reference would not emit
+// zstd levels on the device: 1..12 (fast, dfast, greedy, lazy, lazy2 and - for the short last block of a file - btlazy2 / btopt: every
+// strategy clevels.h names for them); 4mz itself uses 1, 3, 6, 12.  Levels 13 and above (btlazy2 on full blocks, btultra) and levels
+// below 1 are refused rather than answered with bytes the reference would not emit
 static int zstd_level_ok(const fourmc_block*, uint32_t, int level, hipStream_t)
 {
-    if (level == 1 || level == 3 || level == 6 || level == 12) return FOURMC_OK;
-    snprintf(g_err, sizeof g_err, "ZSTD level %d not on the device (levels 1, 3, 6 and 12 are)", level);
+    if (fourmc_zstd_enc_level_ok(level)) return FOURMC_OK;
+    snprintf(g_err, sizeof g_err, "ZSTD level %d not on the device (levels 1..12 are)", level);
     return FOURMC_EUNSUP;
 }
 

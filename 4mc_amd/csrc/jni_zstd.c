@@ -8,7 +8,7 @@
  * names and error contract as the LZ4 pair; codec results follow zstd's size_t convention
  * (error <=> value > (size_t)-ZSTD_error_maxCode, native/zstd/common/error_private.h).
  * decompressBytesDirect (any level) and compressBytesDirect (zstd level 1) run on the device;
- * compressBytesDirectMC (zstd level 3) and HC(1|3|6) run on the device; other HC levels fail LOUDLY with
+ * compressBytesDirectMC (zstd level 3) and HC(1 .. 12) run on the device; HC levels beyond 12 fail LOUDLY with
  * java/lang/InternalError("ZSTD_compress returned: <error code>") — there is no CPU fallback.
  *
  * Streaming classes (native/jniZstd.c, native/jniZStreamCompressor.c, native/jniZStreamDecompressor.c)
@@ -51,7 +51,7 @@ static jint zstd_compress_common(JNIEnv* env, jobject self, int level)
     unsigned ulen = (unsigned)(*env)->GetIntField(env, self, zc_ulen);
     size_t r;
     if (!src || !dst) return 0;
-    /* level 1 runs on the device; other levels come back as an error code (no CPU fallback) and throw below */
+    /* levels 1 .. 12 run on the device; other levels come back as an error code (no CPU fallback) and throw below */
     r = fourmc_ZSTD_compress(dst, 1024u * 1024u * 1024u /* enforced in Java, jniZstdCompressor.c:93 */, src, ulen, level);
     if (!z_is_error(r)) (*env)->SetIntField(env, self, zc_ulen, 0);
     else {

@@ -73,6 +73,7 @@ size_t     fourmc_zstd_dec_counter_offset(void);
 hipError_t fourmc_launch_zstd_decode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                      void* d_scratch, int container_mode, hipStream_t stream);
 size_t     fourmc_zstd_enc_work_bytes(uint32_t n, int level);
+int        fourmc_zstd_enc_level_ok(int level);                 /* 1: the device has every strategy the level's rows name (levels 1..12) */
 hipError_t fourmc_launch_zstd_encode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                      void* d_work, int container_mode, int level, int serial, hipStream_t stream);
 hipError_t fourmc_launch_xxh32(const void* d_base, fourmc_block* d_blocks, uint32_t n,

@@ -51,10 +51,35 @@ constexpr size_t   kOffPrev   = kOffLit + kLitBytes;                 // 3 x FseC
 constexpr size_t   kOffTmp    = kOffPrev + 4736;                     // 512 B: FSE_writeNCount trial output (ZSTD_NCountCost)
 constexpr size_t   kStoreBytes = kOffTmp + 512 + 192;
 static_assert(kStoreBytes % 64 == 0, "tables start 64-byte aligned");
-// tables by level: 1 -> hash table (<= 2^15 x u32); 3 -> long 2^17 + short 2^16; 6 -> rows 2^19 x u32 + tags 2^19 x u16;
-// 12 -> rows 2^23 x u32 + tags 2^23 x u16 (inputs > 256 KiB), hash 2^19 x u32 + binary tree 2^19 x u32 (btlazy2, smaller inputs)
+// clevels.h:25-130, levels 1..12: {windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy} for inputs > 256 KB, <= 256 KB,
+// <= 128 KB, <= 16 KB.  Strategies as the reference numbers them: 1 fast, 2 dfast, 3 greedy, 4 lazy, 5 lazy2, 6 btlazy2, 7 btopt (levels 13+ need
+// btultra / btlazy2 on full blocks: not on the device).  4mz uses 1, 3, 6, 12; the JNI name compressBytesDirectHC(level) may pass any.
+struct LevelRow { uint8_t wlog, clog, hlog, slog, mml, tlen, strat; };
+constexpr int kMaxLevel = 12;
+__device__ __constant__ const LevelRow kLevelRowsDev[kMaxLevel][4] = {
+    {{19, 13, 14, 1, 7, 0, 1}, {18, 13, 14, 1, 6, 0, 1}, {17, 12, 13, 1, 6, 0, 1}, {14, 14, 15, 1, 5, 0, 1}},
+    {{20, 15, 16, 1, 6, 0, 1}, {18, 14, 14, 1, 5, 0, 2}, {17, 13, 15, 1, 5, 0, 1}, {14, 14, 15, 1, 4, 0, 1}},
+    {{21, 16, 17, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {17, 15, 16, 2, 5, 0, 2}, {14, 14, 15, 2, 4, 0, 2}},
+    {{21, 18, 18, 1, 5, 0, 2}, {18, 16, 17, 3, 5, 2, 3}, {17, 17, 17, 2, 4, 0, 2}, {14, 14, 14, 4, 4, 2, 3}},
+    {{21, 18, 19, 3, 5, 2, 3}, {18, 17, 18, 5, 5, 2, 3}, {17, 16, 17, 3, 4, 2, 3}, {14, 14, 14, 3, 4, 4, 4}},
+    {{21, 18, 19, 3, 5, 4, 4}, {18, 18, 19, 3, 5, 4, 4}, {17, 16, 17, 3, 4, 4, 4}, {14, 14, 14, 4, 4, 8, 5}},
+    {{21, 19, 20, 4, 5, 8, 4}, {18, 18, 19, 4, 4, 4, 4}, {17, 16, 17, 3, 4, 8, 5}, {14, 14, 14, 6, 4, 8, 5}},
+    {{21, 19, 20, 4, 5, 16, 5}, {18, 18, 19, 4, 4, 8, 5}, {17, 16, 17, 4, 4, 8, 5}, {14, 14, 14, 8, 4, 8, 5}},
+    {{22, 20, 21, 4, 5, 16, 5}, {18, 18, 19, 5, 4, 8, 5}, {17, 16, 17, 5, 4, 8, 5}, {14, 15, 14, 5, 4, 8, 6}},
+    {{22, 21, 22, 5, 5, 16, 5}, {18, 18, 19, 6, 4, 8, 5}, {17, 16, 17, 6, 4, 8, 5}, {14, 15, 14, 9, 4, 8, 6}},
+    {{22, 21, 22, 6, 5, 16, 5}, {18, 18, 19, 5, 4, 12, 6}, {17, 17, 17, 5, 4, 8, 6}, {14, 15, 14, 3, 4, 12, 7}},
+    {{22, 22, 23, 6, 5, 32, 5}, {18, 19, 19, 7, 4, 12, 6}, {17, 18, 17, 7, 4, 12, 6}, {14, 15, 14, 4, 3, 24, 7}}};
+// per-block table area by level.  The levels 4mz uses keep the sizes they always had: 1 -> hash table (<= 2^15 x u32); 3 -> long 2^17 +
+// short 2^16; 6 -> rows 2^19 x u32 + tags 2^19 x u16; 12 -> rows 2^23 x u32 + tags 2^23 x u16 (inputs > 256 KiB), hash 2^19 x u32 + binary
+// tree 2^19 x u32 (btlazy2, smaller inputs).  Any other level: room for the largest hash table of its four rows (entries + tags, or the long
+// table of dfast at its fixed place), the largest chain / short / tree table behind it, and the optimal parser's arrays.
 __host__ __device__ constexpr size_t table_bytes(int level)
-{ return level == 12 ? (size_t(4) << 23) + (size_t(2) << 23) : level == 6 ? (size_t(4) << 19) + (size_t(2) << 19) : level == 3 ? (size_t(4) << 17) + (size_t(4) << 16) : (size_t(4) << 15); }
+{
+    constexpr uint8_t hmax[kMaxLevel] = {15, 16, 17, 18, 19, 19, 20, 20, 21, 22, 22, 23}, cmax[kMaxLevel] = {14, 15, 16, 18, 18, 18, 19, 19, 20, 21, 21, 22};
+    return level == 12 ? (size_t(4) << 23) + (size_t(2) << 23) : level == 6 ? (size_t(4) << 19) + (size_t(2) << 19) : level == 3 ? (size_t(4) << 17) + (size_t(4) << 16)
+         : level == 1 ? (size_t(4) << 15)
+         : level >= 1 && level <= kMaxLevel ? (size_t(6) << (hmax[level - 1] < 17 ? 17 : hmax[level - 1])) + (size_t(8) << cmax[level - 1]) + (size_t(1) << 20) : 0;
+}
 
 struct __attribute__((packed, aligned(1))) S4B { uint32_t v; };
 __device__ __forceinline__ void st4(uint8_t* p, uint32_t v) { reinterpret_cast<S4B*>(p)->v = v; }
@@ -2431,15 +2456,23 @@ __device__ __forceinline__ uint32_t hc_search(LazyState& Z, const Params& P, con
         if (lane == 0) { Z.chain[idx & cmask] = old; Z.tab[h] = idx; }
     }
     Z.ntu = curr;
-    uint32_t mi = Z.tab[zhash(ld8(s + ip), P.hlog, mls)], cand = 0, n = 0;
-    const uint32_t attempts = 1u << P.slog;                        // <= 16 here: candidates gathered one per lane
-    while (mi >= low && n < attempts) {
-        if (uint32_t(lane) == n) cand = mi;
-        n++;
-        if (mi <= min_chain) break;
-        mi = Z.chain[mi & cmask];
+    uint32_t mi = Z.tab[zhash(ld8(s + ip), P.hlog, mls)];
+    const uint32_t attempts = 1u << P.slog;                        // 8 .. 256: candidates gathered one per lane, 64 at a time
+    uint32_t best_ml = 3, best_ofb = 0, total = 0; bool done = false;
+    while (!done && mi >= low && total < attempts) {
+        uint32_t cand = 0, n = 0;
+        while (mi >= low && total < attempts && n < 64) {
+            if (uint32_t(lane) == n) cand = mi;
+            n++; total++;
+            if (mi <= min_chain) { done = true; break; }
+            mi = Z.chain[mi & cmask];
+        }
+        uint32_t o2 = 0;
+        const uint32_t ml2 = best_candidate(s, ip, end, n_total, cand, uint32_t(lane) < n, uint32_t(lane), curr, o2, lane);
+        if (ml2 > best_ml) { best_ml = ml2; best_ofb = o2; }       // a later candidate wins only when strictly longer (:708-716)
     }
-    return best_candidate(s, ip, end, n_total, cand, uint32_t(lane) < n, uint32_t(lane), curr, ofb, lane);
+    if (best_ml > 3) ofb = best_ofb;
+    return best_ml;
 }
 
 // Binary-tree match finder of ZSTD_btlazy2 (compress/zstd_lazy.c:20-58 ZSTD_updateDUBT, :64-150 ZSTD_insertDUBT1, :231-379
@@ -2546,7 +2579,7 @@ __device__ __forceinline__ uint32_t lazy_block(ZLds& L, SeqStore& S, LazyState& 
                                                const uint8_t* s, uint32_t start, uint32_t end, uint32_t n_total, int lane)
 {
     const bool use_row = !kTree && P.wlog > 14;
-    const uint32_t depth = P.strat >= 5 ? 2u : 1u;
+    const uint32_t depth = P.strat >= 5 ? 2u : P.strat == 3 ? 0u : 1u;      // greedy / lazy / lazy2 (btlazy2: 2)
     Z.q_n = 0;                                                     // (searches computed ahead were measured against the previous block's end)
     const int64_t ilimit = int64_t(end) - 8 - (use_row ? 8 : 0);
     const uint32_t prefix_idx = Z.dict_limit, prefix = prefix_idx - 2;
@@ -2568,13 +2601,13 @@ __device__ __forceinline__ uint32_t lazy_block(ZLds& L, SeqStore& S, LazyState& 
         uint32_t ml = 0, at = ip + 1, ofb = 1;
         if ((rep1 > 0) & (ld4(s + ip + 1 - rep1) == ld4(s + ip + 1)))
             ml = count_fwd(s, ip + 1 + 4, ip + 1 + 4 - rep1, end, lane) + 4;
-        {
+        if (!(depth == 0 && ml)) {                                 // greedy takes the repeat match without a search (:1549)
             uint32_t found = 999999999;
             const uint32_t ml2 = search(ip, found);
             if (ml2 > ml) { ml = ml2; at = ip; ofb = found; }
         }
         if (ml < 4) { ip += ((ip - anchor) >> 8) + 1; continue; }
-        while (int64_t(ip) < ilimit) {                              // depth >= 1
+        while (depth && int64_t(ip) < ilimit) {                     // depth >= 1
             ip++;
             if ((rep1 > 0) & (ld4(s + ip) == ld4(s + ip - rep1))) {
                 const uint32_t mr = count_fwd(s, ip + 4, ip + 4 - rep1, end, lane) + 4;
@@ -2729,7 +2762,8 @@ __device__ __forceinline__ uint32_t opt_matches(LazyState& Z, const Params& P, O
     const uint32_t curr = ip + 2, sufficient = min(P.tlen, kOptNum - 1);
     uint32_t* const bt = Z.chain;
     uint32_t* const out = o.match;
-    uint32_t n = 0, best = 2;                                                    // lengthToBeat - 1, minMatch 3
+    const uint32_t minmatch = P.mml == 3 ? 3u : 4u;
+    uint32_t n = 0, best = minmatch - 1;                                         // lengthToBeat - 1
     if (curr < Z.ntu) return 0;                                                  // skipped area
     for (uint32_t idx = Z.ntu; idx < curr; ) idx += opt_tree_insert(Z, P, s, idx, end, curr, lane);
     Z.ntu = curr;
@@ -2742,8 +2776,9 @@ __device__ __forceinline__ uint32_t opt_matches(LazyState& Z, const Params& P, O
         const uint32_t off = code == 3 ? r0 - 1 : code == 0 ? r0 : code == 1 ? r1 : r2;
         uint32_t len = 0;
         if (off - 1 < curr - Z.dict_limit) {                                     // 1 <= off <= distance to the prefix start
-            if (curr - off >= window_low && (word << 8) == (ld4(s + ip - off) << 8))
-                len = count_fwd(s, ip + 3, ip + 3 - off, end, lane) + 3;
+            const uint32_t other = ld4(s + ip - off);
+            if (curr - off >= window_low && (minmatch == 3 ? (word << 8) == (other << 8) : word == other))      // ZSTD_readMINMATCH :369-380
+                len = count_fwd(s, ip + minmatch, ip + minmatch - off, end, lane) + minmatch;
         }
         if (len > best) {
             best = len;
@@ -2751,7 +2786,7 @@ __device__ __forceinline__ uint32_t opt_matches(LazyState& Z, const Params& P, O
             if (len > sufficient || ip + len == end) return n;
         }
     }
-    if (best < 3) {                                                              // 3-byte matches through their own hash table (:385-404, :659-688)
+    if (minmatch == 3 && best < 3) {                                             // 3-byte matches through their own hash table (:385-404, :659-688)
         for (uint32_t idx = o.next3; idx < curr; idx++) o.hash3[opt_hash3(ld4(s + idx - 2), o.hlog3)] = idx;   // in index order
         o.next3 = curr;
         const uint32_t i3 = o.hash3[opt_hash3(word, o.hlog3)];
@@ -2820,7 +2855,7 @@ __device__ __forceinline__ uint32_t opt_block(ZLds& L, SeqStore& S, LazyState& Z
         opt_base_prices(o);
     }
     const int64_t ilimit = int64_t(end) - 8;
-    const uint32_t sufficient = min(P.tlen, kOptNum - 1), minmatch = 3;
+    const uint32_t sufficient = min(P.tlen, kOptNum - 1), minmatch = P.mml == 3 ? 3u : 4u;
     uint32_t ip = start, anchor = start;
     o.next3 = Z.ntu;
     ip += (ip + 2 == Z.dict_limit) ? 1u : 0u;
@@ -2941,36 +2976,17 @@ __device__ __forceinline__ Params level_params(uint32_t n, int level)
 {
     Params p;
     uint32_t wlog, hlog, clog;
-    p.slog = 1;
-    if (level == 12) {                                  // clevels.h level 12: ZSTD_lazy2 above 256 KB, ZSTD_btlazy2 (strat 6) below, ZSTD_btopt (strat 7) at 16 KB and less
-        if (n <= 16 * 1024) { wlog = 14; clog = 15; hlog = 14; p.slog = 4; p.mml = 3; p.strat = 7; }
-        else if (n <= 128 * 1024) { wlog = 17; clog = 18; hlog = 17; p.slog = 7; p.mml = 4; p.strat = 6; }
-        else if (n <= 256 * 1024) { wlog = 18; clog = 19; hlog = 19; p.slog = 7; p.mml = 4; p.strat = 6; }
-        else { wlog = 22; clog = 22; hlog = 23; p.slog = 6; p.mml = 5; p.strat = 5; }
-    } else if (level == 6) {                                   // clevels.h rows of level 6 (ZSTD_lazy; lazy2 for <= 16 KB)
-        if (n <= 16 * 1024) { wlog = 14; clog = 14; hlog = 14; p.slog = 4; p.mml = 4; p.strat = 5; }
-        else if (n <= 128 * 1024) { wlog = 17; clog = 16; hlog = 17; p.slog = 3; p.mml = 4; p.strat = 4; }
-        else if (n <= 256 * 1024) { wlog = 18; clog = 18; hlog = 19; p.slog = 3; p.mml = 5; p.strat = 4; }
-        else { wlog = 21; clog = 18; hlog = 19; p.slog = 3; p.mml = 5; p.strat = 4; }
-    } else if (level == 3) {                                   // clevels.h rows of level 3 (ZSTD_dfast)
-        if (n <= 16 * 1024) { wlog = 14; clog = 14; hlog = 15; p.mml = 4; }
-        else if (n <= 128 * 1024) { wlog = 17; clog = 15; hlog = 16; p.mml = 5; }
-        else if (n <= 256 * 1024) { wlog = 18; clog = 16; hlog = 16; p.mml = 4; }
-        else { wlog = 21; clog = 16; hlog = 17; p.mml = 5; }
-        p.strat = 2;
-    } else {                                            // level 1 (ZSTD_fast)
-        if (n <= 16 * 1024) { wlog = 14; clog = 14; hlog = 15; p.mml = 5; }
-        else if (n <= 128 * 1024) { wlog = 17; clog = 12; hlog = 13; p.mml = 6; }
-        else if (n <= 256 * 1024) { wlog = 18; clog = 13; hlog = 14; p.mml = 6; }
-        else { wlog = 19; clog = 13; hlog = 14; p.mml = 7; }
-        p.strat = 1;
+    {
+        const int lv = level < 1 ? 1 : level > kMaxLevel ? kMaxLevel : level;     // (the launchers refuse every other level)
+        const LevelRow r = kLevelRowsDev[lv - 1][(n <= 256 * 1024) + (n <= 128 * 1024) + (n <= 16 * 1024)];
+        wlog = r.wlog; clog = r.clog; hlog = r.hlog; p.slog = r.slog; p.mml = r.mml; p.tlen = r.tlen; p.strat = r.strat;
     }
     const uint32_t src_log = n < 64 ? 6u : uint32_t(hibit(n - 1)) + 1;
     if (wlog > src_log) wlog = src_log;
     if (hlog > wlog + 1) hlog = wlog + 1;
     if (clog - (p.strat >= 6 ? 1u : 0u) > wlog) clog = wlog + (p.strat >= 6 ? 1u : 0u);   // ZSTD_cycleLog: a binary tree has half as many nodes
     if (wlog < 10) wlog = 10;
-    p.wlog = wlog; p.hlog = hlog; p.clog = clog; p.tlen = p.strat == 7 ? 24u : 0u;
+    p.wlog = wlog; p.hlog = hlog; p.clog = clog;
     return p;
 }
 
@@ -2992,10 +3008,10 @@ __device__ __forceinline__ bool is_rle(const uint8_t* s, uint32_t n, int lane)
 template <bool kTree, int kFast>
 __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* work, int level, bool serial, int lane)
 {
-    Params P = level_params(n, kFast == 1 ? 1 : kFast == 2 ? 3 : level);
-    if (kFast) P.strat = uint32_t(kFast);
+    Params P = level_params(n, level);
+    if (kFast) P.strat = uint32_t(kFast);                         // (zstd_encode_one sent this block here because that is its strategy)
     uint32_t* const tab = reinterpret_cast<uint32_t*>(work + kStoreBytes);
-    uint32_t* const tab_s = reinterpret_cast<uint32_t*>(work + kStoreBytes + (size_t(4) << 17));      // level 3: short-hash table
+    uint32_t* const tab_s = reinterpret_cast<uint32_t*>(work + kStoreBytes + (size_t(4) << max(P.hlog, 17u)));      // dfast: short-hash table
     SeqStore S;
     S.ll = reinterpret_cast<uint32_t*>(work); S.ml = S.ll + kSeqCap; S.off = S.ml + kSeqCap;
     S.llc = work + kOffCodes; S.ofc = S.llc + kCodeBytes; S.mlc = S.ofc + kCodeBytes;
@@ -3045,7 +3061,7 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
             const uint32_t m16 = (4u << P.clog) / 16;
             for (uint32_t i = lane; i < m16; i += 64) s4[i] = make_uint4(0, 0, 0, 0);
         }
-        if (P.strat >= 4) {                                    // tag table (2 bytes per entry) or chain table (4 bytes per entry)
+        if (P.strat >= 3) {                                    // tag table (2 bytes per entry) or chain table (4 bytes per entry)
             uint4* s4 = reinterpret_cast<uint4*>(Z.tags);
             const uint32_t m16 = (P.strat < 6 && P.wlog > 14) ? (2u << P.hlog) / 16 : (4u << P.clog) / 16;
             for (uint32_t i = lane; i < m16; i += 64) s4[i] = make_uint4(0, 0, 0, 0);
@@ -3086,8 +3102,8 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
             else if constexpr (kFast == 2) tail = dfast_block(L, S, tab, tab_s, P, ne.rep, src, pos, pos + len, serial, lane);
             else if constexpr (kTree) tail = P.strat == 7 ? opt_block(L, S, Z, P, ne.rep, Z.chain + (size_t(1) << P.clog), src, pos, pos + len, lane)
                                                      : lazy_block<true>(L, S, Z, P, ne.rep, src, pos, pos + len, n, lane);
-            else if (P.strat >= 4) tail = lazy_block<false>(L, S, Z, P, ne.rep, src, pos, pos + len, n, lane);
-            else return kErrGeneric;                               // levels 1 and 3 are the other kernels' (zstd_encode_fast_kernel, zstd_encode_dfast_kernel)
+            else if (P.strat >= 3) tail = lazy_block<false>(L, S, Z, P, ne.rep, src, pos, pos + len, n, lane);
+            else return kErrGeneric;                               // fast and dfast are the other kernels' (zstd_encode_fast_kernel, zstd_encode_dfast_kernel)
             gather_literals(S, src, pos, lane);
             copy_bytes(S.lit + S.nlit, src + pos + len - tail, tail, lane);
             S.nlit += tail;
@@ -3142,7 +3158,6 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
 
 // container_mode 0: ZSTD_compress(dst + dst_off, dst_cap, src + src_off, src_len, 1) -> size or -(error number)
 // container_mode 1: native/4mc.c:467-489 (capacity n-1; an error stores the block raw)
-__device__ __forceinline__ bool tree_sized(int level, uint32_t n) { return level == 12 && n <= 256 * 1024; }   // clevels.h:66,92,118: btlazy2, btopt
 
 template <bool kTree, int kFast>
 __device__ __forceinline__ void zstd_encode_one(ZLds& L, const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks, uint32_t nblocks,
@@ -3155,7 +3170,11 @@ __device__ __forceinline__ void zstd_encode_one(ZLds& L, const uint8_t* __restri
     // (the descriptor arrives through a vector load: pin what is derived from it to scalar registers, or every length, limit and
     // loop counter of the block is computed on the vector unit)
     const uint32_t n = U(blk.src_len);
-    if (tree_sized(level, n) != kTree) return;                  // the other kernel's block
+    {   // which kernel takes the block: its strategy decides (fast / dfast have kernels of their own, the binary-tree strategies too)
+        const uint32_t st = level_params(n, level).strat;
+        const int family = st == 1 ? 1 : st == 2 ? 2 : st >= 6 ? 3 : 0, mine = kFast ? kFast : kTree ? 3 : 0;
+        if (family != mine) return;                             // another kernel's block
+    }
     const uint8_t* src = src_base + U64(blk.src_off);
     uint8_t* dst = dst_base + U64(blk.dst_off);
     const uint32_t cap = container_mode ? (n ? n - 1 : 0) : U(blk.dst_cap);
@@ -3201,18 +3220,24 @@ void zstd_encode_tree_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
 
 } // namespace
 
+// strategy column of kLevelRowsDev (host side: which kernels a level needs)
+static const uint8_t kLevelRowsHost[kMaxLevel][4] = {{1, 1, 1, 1}, {1, 2, 1, 1}, {2, 2, 2, 2}, {2, 3, 2, 3}, {3, 3, 3, 4}, {4, 4, 4, 5}, {4, 4, 5, 5}, {5, 5, 5, 5},
+                                                     {5, 5, 5, 6}, {5, 5, 5, 6}, {5, 6, 6, 7}, {5, 6, 6, 7}};
+extern "C" int fourmc_zstd_enc_level_ok(int level) { return level >= 1 && level <= kMaxLevel; }
 extern "C" size_t fourmc_zstd_enc_work_bytes(uint32_t n, int level) { return size_t(n) * (kStoreBytes + table_bytes(level)); }
 
 extern "C" hipError_t fourmc_launch_zstd_encode(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                                 void* d_work, int container_mode, int level, int serial, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(level == 1 ? zstd_encode_fast_kernel : level == 3 ? zstd_encode_dfast_kernel : zstd_encode_kernel, dim3(n), dim3(64), 0, stream,
-                       static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n,
-                       static_cast<uint8_t*>(d_work), container_mode, level, serial);
-    if (level == 12)
-        hipLaunchKernelGGL(zstd_encode_tree_kernel, dim3(n), dim3(64), 0, stream,
-                           static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), d_blocks, n,
-                           static_cast<uint8_t*>(d_work), container_mode, level, serial);
+    if (level < 1 || level > kMaxLevel) return hipErrorInvalidValue;
+    // every block is taken by the kernel of its strategy (zstd_encode_one); a level's four rows name at most these kernels
+    bool fam[4] = {false, false, false, false};
+    for (int c = 0; c < 4; c++) { const uint32_t st = kLevelRowsHost[level - 1][c]; fam[st == 1 ? 1 : st == 2 ? 2 : st >= 6 ? 3 : 0] = true; }
+    const uint8_t* s8 = static_cast<const uint8_t*>(d_src); uint8_t* d8 = static_cast<uint8_t*>(d_dst); uint8_t* w8 = static_cast<uint8_t*>(d_work);
+    if (fam[1]) hipLaunchKernelGGL(zstd_encode_fast_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, w8, container_mode, level, serial);
+    if (fam[2]) hipLaunchKernelGGL(zstd_encode_dfast_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, w8, container_mode, level, serial);
+    if (fam[0]) hipLaunchKernelGGL(zstd_encode_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, w8, container_mode, level, serial);
+    if (fam[3]) hipLaunchKernelGGL(zstd_encode_tree_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, w8, container_mode, level, serial);
     return hipGetLastError();
 }

@@ -40,7 +40,7 @@ enum {
     FOURMC_CODEC_LZ4_FAST = 0,   /* LZ4_compress_default            4mc -1  (Lz4Compressor)    */
     FOURMC_CODEC_LZ4_MC   = 1,   /* LZ4_compressMC                  4mc -2                     */
     FOURMC_CODEC_LZ4_HC   = 2,   /* LZ4_compress_HC(level 4 / 8)    4mc -3 / -4                */
-    FOURMC_CODEC_ZSTD     = 3    /* ZSTD_compress(level 1/3/6/12)   4mz -1..-4                 */
+    FOURMC_CODEC_ZSTD     = 3    /* ZSTD_compress(level 1..12)      4mz -1..-4 = 1/3/6/12      */
 };
 
 /* One independent block.  Offsets are relative to the base pointers given to the batch call, so
@@ -98,8 +98,9 @@ int  fourmc_gpu_get_zstd_decode_split(void);
 void fourmc_gpu_one_block_stats(unsigned long long* calls, unsigned long long* launches);
 /* result = ZSTD_compress(dst + dst_off, dst_cap, src + src_off, src_len, level) as int: frame bytes, or
  * -(ZSTD error number), e.g. -70 = dstSize_tooSmall        native/zstd/compress/zstd_compress.c:4806
- * Levels 1, 3, 6 and 12 (what 4mz -1 .. -4 use: strategies fast, dfast, lazy2 + row hash / btlazy2 / btopt) are on the device,
- * byte-identical for every input size; any other level returns FOURMC_EUNSUP - never different bytes. */
+ * Levels 1 .. 12 are on the device, byte-identical for every input size: every strategy their rows of the level table name (clevels.h:25-130:
+ * fast, dfast, greedy, lazy, lazy2 with the row-hash or hash-chain finder, and - for inputs of 256 KiB and less - btlazy2 / btopt).  4mz -1 .. -4
+ * use 1, 3, 6, 12.  Levels 13 and above (btlazy2 on full blocks, btultra) and levels below 1 return FOURMC_EUNSUP - never different bytes. */
 int fourmc_gpu_zstd_compress(const void* d_src, void* d_dst, fourmc_block* d_blocks,
                              uint32_t n, int level, void* stream);
 

@@ -6,8 +6,9 @@
  * Covered: ZSTD_fast (4mz "fast" = zstd level 1), ZSTD_dfast ("medium" = level 3), ZSTD_lazy / lazy2 with the row-hash
  * and hash-chain match finders ("high" = level 6: every size class; "ultra" = level 12: lazy2 for inputs > 256 KiB) and
  * ZSTD_btlazy2 (the binary-tree finder of level 12 between 16 KiB + 1 and 256 KiB) and ZSTD_btopt (the optimal parser of
- * level 12 at 16 KiB and below: compress/zstd_opt.c, optLevel 0, first-block statistics).  Any other level returns
- * ORC_ZSTD_UNSUPPORTED.
+ * level 12 at 16 KiB and below: compress/zstd_opt.c, optLevel 0, first-block statistics), and with them every other level
+ * from 1 to 12 (their rows of clevels.h add ZSTD_greedy and other table sizes, nothing else; the JNI name
+ * compressBytesDirectHC(level) passes any level through).  Levels 13 and above return ORC_ZSTD_UNSUPPORTED.
  *
  *   parameters   ZSTD_getCParams_internal        compress/zstd_compress.c:6465-6488, clevels.h:25-130,
  *                ZSTD_adjustCParams_internal     compress/zstd_compress.c:1335-1399
@@ -27,7 +28,7 @@
  *
  * Positions are offsets into the input; a hash-table index is position + 2 as in the reference
  * (ZSTD_WINDOW_START_INDEX), so 0 means "empty".
- * Parity: pinned — byte-identical to oracle/_ref (ZSTD_compress, level 1) on the corpus blocks, edge
+ * Parity: pinned — byte-identical to oracle/_ref (ZSTD_compress, levels 1 .. 12) on the corpus blocks, edge
  * inputs and tails, with capacity n-1 and ZSTD_compressBound(n) (tests/test_oracle_golden.py), and
  * to the per-block manifest of the reference CLI at `4mc -z -1` (tests/golden/corpus_manifest.json).
  */
@@ -1580,15 +1581,24 @@ shortest_path:
 }
 
 /* ------------------------------------------------------------------------------------------------ frame */
-/* clevels.h rows of the levels 4mz uses; strat: 1 fast, 2 dfast, 4 lazy, 5 lazy2, 6 btlazy2, 7 btopt */
+/* clevels.h:25-130, levels 1..12 (4mz uses 1, 3, 6, 12; the JNI entry point passes any); strat: 1 fast, 2 dfast, 3 greedy, 4 lazy, 5 lazy2,
+ * 6 btlazy2, 7 btopt */
 static zparams level_params(int level, size_t n)
 {
-    static const zparams rows[4][4] = {            /* tables for > 256 KB, <= 256 KB, <= 128 KB, <= 16 KB */
-        {{19, 13, 14, 1, 7, 0, 1}, {18, 13, 14, 1, 6, 0, 1}, {17, 12, 13, 1, 6, 0, 1}, {14, 14, 15, 1, 5, 0, 1}},     /* level 1  */
-        {{21, 16, 17, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {17, 15, 16, 2, 5, 0, 2}, {14, 14, 15, 2, 4, 0, 2}},     /* level 3  */
-        {{21, 18, 19, 3, 5, 4, 4}, {18, 18, 19, 3, 5, 4, 4}, {17, 16, 17, 3, 4, 4, 4}, {14, 14, 14, 4, 4, 8, 5}},     /* level 6  */
-        {{22, 22, 23, 6, 5, 32, 5}, {18, 19, 19, 7, 4, 12, 6}, {17, 18, 17, 7, 4, 12, 6}, {14, 15, 14, 4, 3, 24, 7}}};/* level 12: btlazy2 below 256 KB, btopt at 16 KB and less */
-    zparams p = rows[level == 3 ? 1 : level == 6 ? 2 : level == 12 ? 3 : 0][(n <= 256 * 1024) + (n <= 128 * 1024) + (n <= 16 * 1024)];
+    static const zparams rows[12][4] = {           /* tables for > 256 KB, <= 256 KB, <= 128 KB, <= 16 KB */
+        {{19, 13, 14, 1, 7, 0, 1}, {18, 13, 14, 1, 6, 0, 1}, {17, 12, 13, 1, 6, 0, 1}, {14, 14, 15, 1, 5, 0, 1}},
+        {{20, 15, 16, 1, 6, 0, 1}, {18, 14, 14, 1, 5, 0, 2}, {17, 13, 15, 1, 5, 0, 1}, {14, 14, 15, 1, 4, 0, 1}},
+        {{21, 16, 17, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {17, 15, 16, 2, 5, 0, 2}, {14, 14, 15, 2, 4, 0, 2}},
+        {{21, 18, 18, 1, 5, 0, 2}, {18, 16, 17, 3, 5, 2, 3}, {17, 17, 17, 2, 4, 0, 2}, {14, 14, 14, 4, 4, 2, 3}},
+        {{21, 18, 19, 3, 5, 2, 3}, {18, 17, 18, 5, 5, 2, 3}, {17, 16, 17, 3, 4, 2, 3}, {14, 14, 14, 3, 4, 4, 4}},
+        {{21, 18, 19, 3, 5, 4, 4}, {18, 18, 19, 3, 5, 4, 4}, {17, 16, 17, 3, 4, 4, 4}, {14, 14, 14, 4, 4, 8, 5}},
+        {{21, 19, 20, 4, 5, 8, 4}, {18, 18, 19, 4, 4, 4, 4}, {17, 16, 17, 3, 4, 8, 5}, {14, 14, 14, 6, 4, 8, 5}},
+        {{21, 19, 20, 4, 5, 16, 5}, {18, 18, 19, 4, 4, 8, 5}, {17, 16, 17, 4, 4, 8, 5}, {14, 14, 14, 8, 4, 8, 5}},
+        {{22, 20, 21, 4, 5, 16, 5}, {18, 18, 19, 5, 4, 8, 5}, {17, 16, 17, 5, 4, 8, 5}, {14, 15, 14, 5, 4, 8, 6}},
+        {{22, 21, 22, 5, 5, 16, 5}, {18, 18, 19, 6, 4, 8, 5}, {17, 16, 17, 6, 4, 8, 5}, {14, 15, 14, 9, 4, 8, 6}},
+        {{22, 21, 22, 6, 5, 16, 5}, {18, 18, 19, 5, 4, 12, 6}, {17, 17, 17, 5, 4, 8, 6}, {14, 15, 14, 3, 4, 12, 7}},
+        {{22, 22, 23, 6, 5, 32, 5}, {18, 19, 19, 7, 4, 12, 6}, {17, 18, 17, 7, 4, 12, 6}, {14, 15, 14, 4, 3, 24, 7}}};
+    zparams p = rows[level - 1][(n <= 256 * 1024) + (n <= 128 * 1024) + (n <= 16 * 1024)];
     const uint32_t src_log = n < 64 ? 6 : (uint32_t)hibit((uint32_t)(n - 1)) + 1;
     if (p.wlog > src_log) p.wlog = src_log;
     if (p.hlog > p.wlog + 1) p.hlog = p.wlog + 1;
@@ -1610,7 +1620,7 @@ int64_t orc_zstd_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap
     size_t o = 0, pos = 0, block;
     int64_t result;
     uint8_t *llc, *ofc, *mlc;
-    if (level != 1 && level != 3 && level != 6 && level != 12) return ORC_ZSTD_UNSUPPORTED;
+    if (level < 1 || level > 12) return ORC_ZSTD_UNSUPPORTED;
     p = level_params(level, n);
     if (!p.strat) return ORC_ZSTD_UNSUPPORTED;
     if (cap < 18) return ERR_TOOSMALL;
@@ -1679,7 +1689,7 @@ int64_t orc_zstd_compress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap
                 if (curr > m.next_to_update + 384) { const uint32_t gap = curr - m.next_to_update - 384; m.next_to_update = curr - (gap < 192 ? gap : 192); }
             }
             if (p.strat == 7) tail = opt_block(&m, &opt, next->rep, src, pos, pos + len);
-            else if (p.strat >= 4) tail = lazy_block(&m, next->rep, src, pos, pos + len, p.strat >= 5 ? 2 : 1, p.strat == 6 ? 2 : p.wlog > 14);
+            else if (p.strat >= 3) tail = lazy_block(&m, next->rep, src, pos, pos + len, p.strat >= 5 ? 2 : p.strat == 3 ? 0 : 1, p.strat == 6 ? 2 : p.wlog > 14);
             else tail = p.strat == 2 ? dfast_block(&m, next->rep, src, pos, pos + len) : fast_block(&m, next->rep, src, pos, pos + len);
             memcpy(m.lit + m.nlit, src + pos + len - tail, tail); m.nlit += tail;
             lsz = compress_literals(prev, next, out, bcap, m.lit, m.nlit, m.nseq == 0 || m.nlit / m.nseq >= 20, p.strat);

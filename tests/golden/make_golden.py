@@ -75,13 +75,14 @@ for ln in (0, 1, 3, 4, 15, 16, 17, 31, 32, 33, 100, 1000, 4099):
     for seed in (0, 1, 0x9E3779B1):
         xx.append({"hex": d.tobytes().hex(), "seed": seed, "xxh32": int(ref.XXH32(d.ctypes.data, ln, seed))})
 
-# zstd frames written by the reference's ZSTD_compress (what a 4mz block payload is), levels 1/3/6/12
+# zstd frames written by the reference's ZSTD_compress (what a 4mz block payload is): levels 1/3/6/12 are 4mz's, the others are what
+# the JNI name compressBytesDirectHC(level) may ask for (levels 1..12 run on the device)
 zin = helpers.golden_zstd_inputs()
 zf = {}
 for name, d in zin.items():
     d = np.ascontiguousarray(d)
     zf[name] = {"input_sha256": hashlib.sha256(d.tobytes()).hexdigest(), "input_bytes": len(d), "frames": {}}
-    for lvl in (1, 3, 6, 12):
+    for lvl in range(1, 13):
         out = np.zeros(len(d) + 1024, np.uint8)
         r = ref.ZSTD_compress(out.ctypes.data, len(out), d.ctypes.data, len(d), lvl)
         assert not ref.ZSTD_isError(r)

@@ -236,7 +236,7 @@ def orc_zstd_compress(src, level=1, cap=None):
 
 
 def golden_zstd_inputs():
-    """The inputs of tests/golden/zstd_frames.json (frames written by the reference's ZSTD_compress at levels 1/3/6/12);
+    """The inputs of tests/golden/zstd_frames.json (frames written by the reference's ZSTD_compress at levels 1..12);
     tests/golden/make_golden.py generates the fixture from exactly these."""
     ed = edge_inputs()
     return {"text_30k": ed["text_60k"][:30000], "period37_20k": ed["period37"][:20000], "lit_then_run_30k": ed["lit_then_run"][:30000],

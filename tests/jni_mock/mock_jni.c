@@ -236,12 +236,16 @@ int main(int argc, char** argv)
                 printf("%s_roundtrip %d %s | same=%d clen_after=%d\n", tag, d, g_thrown[0] ? g_thrown : "-", d == n && !memcmp(back, raw, (size_t)n), dob.f[2].ival);
             }
         }
-        if (c == 1) {   /* a zstd level the device does not implement: error code + InternalError, length field untouched */
-            obj_t co = {{{"finish", 0, 0, 0}, {"finished", 0, 0, 0}, {"uncompressedDirectBuf", 1, 0, raw}, {"uncompressedDirectBufLen", 0, n, 0},
-                         {"compressedDirectBuf", 1, 0, comp}, {"directBufferSize", 0, cap, 0}}, 6};
-            g_thrown[0] = 0;
-            jint r = ((call1_fn)sym(lib, ccls, "compressBytesDirectHC"))(&env, &co, 9);
-            printf("Zstd_compressBytesDirectHC_level9 %d %s | ulen_after=%d\n", r, g_thrown[0] ? g_thrown : "-", co.f[3].ival);
+        if (c == 1) {   /* levels the shipped Java classes never pass: 9 (every library serves it) and 15 (the reference serves it; the device
+                         * library has levels 1..12 and answers with an error code + InternalError, length field untouched) */
+            const int lv[2] = {9, 15};
+            for (int k = 0; k < 2; k++) {
+                obj_t co = {{{"finish", 0, 0, 0}, {"finished", 0, 0, 0}, {"uncompressedDirectBuf", 1, 0, raw}, {"uncompressedDirectBufLen", 0, n, 0},
+                             {"compressedDirectBuf", 1, 0, comp}, {"directBufferSize", 0, cap, 0}}, 6};
+                g_thrown[0] = 0;
+                jint r = ((call1_fn)sym(lib, ccls, "compressBytesDirectHC"))(&env, &co, lv[k]);
+                printf("Zstd_compressBytesDirectHC_level%d %d %s | ulen_after=%d\n", lv[k], r, g_thrown[0] ? g_thrown : "-", co.f[3].ival);
+            }
         }
         {   /* corrupt input: the decompressor throws InternalError and returns the codec's error */
             obj_t dob = {{{"finished", 0, 0, 0}, {"compressedDirectBuf", 1, 0, raw}, {"compressedDirectBufLen", 0, n > 1000 ? 1000 : n, 0},

@@ -22,7 +22,7 @@ def test_jni_entry_points_through_mock_env(gpu, tmp_path):
     src = tmp_path / "in.bin"; src.write_bytes(data.tobytes())
     r = subprocess.run([str(exe), gpu.lib_path(), str(src), str(n), str(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    check_jni_protocol(r.stdout, data, tmp_path, level9_on_device=False)
+    check_jni_protocol(r.stdout, data, tmp_path, level15_on_device=False)
 
 
 def test_jni_lz4_compressor_under_the_tolerance_switch(gpu, tmp_path):
@@ -57,7 +57,7 @@ def test_jni_lz4_compressor_under_the_tolerance_switch(gpu, tmp_path):
     assert np.array_equal(np.fromfile(os.path.join(str(tmp_path), "Lz4_compressBytesDirectHC.bin"), dtype=np.uint8), wbytes)
 
 
-def check_jni_protocol(stdout, data, out_dir, level9_on_device):
+def check_jni_protocol(stdout, data, out_dir, level15_on_device):
     """What the mock driver's output has to show, whichever library it drove: this repository's (on the GPU) or the reference's
     shipped artefact (tests/test_jni_reference_artifact.py, on the CPU) - the same expectations for both."""
     n = len(data)
@@ -82,10 +82,13 @@ def check_jni_protocol(stdout, data, out_dir, level9_on_device):
         assert np.array_equal(np.fromfile(os.path.join(str(out_dir), name + ".bin"), dtype=np.uint8), wbytes), name
         d, rest = out[name + "_roundtrip"]
         assert d == n and "same=1" in rest and "clen_after=0" in rest, (name, d, rest)
+    # level 9: a level the shipped Java classes never pass - the reference serves every level, the device levels 1..12: a frame, no
+    # exception, the buffer length reset
     r9, rest = out["Zstd_compressBytesDirectHC_level9"]
-    if level9_on_device:
-        # the reference serves every zstd level: a frame, no exception, the buffer length reset
-        assert r9 > 0 and "InternalError" not in rest and "ulen_after=0" in rest, (r9, rest)
+    assert r9 > 0 and "InternalError" not in rest and "ulen_after=0" in rest, (r9, rest)
+    r15, rest = out["Zstd_compressBytesDirectHC_level15"]
+    if level15_on_device:
+        assert r15 > 0 and "InternalError" not in rest and "ulen_after=0" in rest, (r15, rest)
     else:
         # a zstd level that is not on the device: error code returned AND InternalError thrown, buffer length untouched
         assert "java/lang/InternalError: ZSTD_compress returned: " in rest and ("ulen_after=%d" % n) in rest

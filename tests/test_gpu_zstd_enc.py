@@ -47,16 +47,36 @@ def _check(gpu, names, srcs, caps, tag, level=1):
 
 
 def test_zstd_golden_frames(gpu):
-    """The device writes the committed frames of the reference's ZSTD_compress (tests/golden/zstd_frames.json) at all four levels."""
+    """The device writes the committed frames of the reference's ZSTD_compress (tests/golden/zstd_frames.json) at every level the device has (1..12)."""
     z = json.load(open(os.path.join(G, "zstd_frames.json")))
     inputs = helpers.golden_zstd_inputs()
     names = list(z)
-    for lvl in (1, 3, 6, 12):
+    for lvl in range(1, 13):
         srcs = [np.ascontiguousarray(inputs[k]) for k in names]
         res, outs = _encode(gpu, srcs, [len(s) + 1024 for s in srcs], lvl)
         for k, r, o in zip(names, res, outs):
             hx = z[k]["frames"][str(lvl)]
             assert int(r) == len(hx) // 2 and o.tobytes().hex() == hx, (k, lvl)
+
+
+@pytest.mark.parametrize("level", [2, 4, 5, 7, 8, 9, 10, 11])
+def test_zstd_levels_4mz_does_not_use(gpu, level):
+    """compressBytesDirectHC(level) passes any level through (native/jniZstdCompressor.c:143-173): levels 1..12 run on the device - their
+    rows of the level table name fast, dfast, greedy, lazy, lazy2, btlazy2 and btopt by input size (clevels.h:25-130).  Every size class,
+    the capacities 4mz and the bound give, edge inputs and two full 4 MiB blocks against the oracle port (pinned to the reference's
+    ZSTD_compress at these levels by tests/test_oracle_golden.py and by the frames of tests/golden/zstd_frames.json)."""
+    data = helpers.corpus(8 * B)
+    srcs, names = [], []
+    for b in (0, 3, 5):
+        for n in (700, 5000, 16384, 16385, 60000, 131072, 131073, 200000, 262144, 262145, 600000):
+            srcs.append(np.ascontiguousarray(data[b * B + 1000: b * B + 1000 + n])); names.append("c%d_%d" % (b, n))
+    for b in (1, 7):
+        srcs.append(np.ascontiguousarray(data[b * B:(b + 1) * B])); names.append("block%d" % b)
+    for k, v in helpers.edge_inputs().items():
+        srcs.append(np.ascontiguousarray(v)); names.append(k)
+    _check(gpu, names, srcs, [helpers.zstd_bound(len(s)) for s in srcs], "bound", level)
+    _check(gpu, names, srcs, [max(len(s) - 1, 0) for s in srcs], "n-1", level)
+    _check(gpu, names, srcs, [len(s) // 3 for s in srcs], "n/3", level)
 
 
 @pytest.mark.parametrize("level", [1, 3, 6])
@@ -177,8 +197,8 @@ def test_host_zstd_compress_entry_point(gpu):
     out = np.zeros(64, np.uint8)
     r = L.fourmc_ZSTD_compress(out.ctypes.data, 30, d.ctypes.data, 1000, 1)
     assert r == (1 << 64) - 70                                     # (size_t)-ZSTD_error_dstSize_tooSmall
-    r = L.fourmc_ZSTD_compress(out.ctypes.data, 64, d.ctypes.data, 10, 9)
-    assert r > (1 << 64) - 120                                     # level 9: ZSTD_isError(), no CPU fallback
+    r = L.fourmc_ZSTD_compress(out.ctypes.data, 64, d.ctypes.data, 10, 13)
+    assert r > (1 << 64) - 120                                     # level 13: ZSTD_isError(), no CPU fallback
     out = np.zeros(helpers.zstd_bound(300000) + 64, np.uint8)
     for lvl in (3, 6):
         r = L.fourmc_ZSTD_compress(out.ctypes.data, 1 << 30, d.ctypes.data, 300000, lvl)
@@ -224,10 +244,11 @@ def test_zstd12_golden_manifest_and_every_size_class(gpu, tmp_path):
     _check(gpu, list(edge), [v.copy() for v in edge.values()], [max(len(v) - 1, 0) for v in edge.values()], "btopt edge n-1", 12)
     edge = {k: v[:900] for k, v in helpers.edge_inputs().items()}
     _check(gpu, list(edge), [v.copy() for v in edge.values()], [helpers.zstd_bound(len(v)) for v in edge.values()], "btopt edge 900", 12)
-    # a level 4mz never uses: refused (never a silently different payload)
+    # a level the device does not have (13 and above need btlazy2 on full blocks / btultra): refused, never a silently different payload
     small = gpu.DeviceBatch(gpu.make_blocks([0], [0], [16384], [16384]))
-    with pytest.raises(gpu.EngineError, match="not on the device"):
-        gpu.zstd_compress(d_src, d_dst, small, 9)
+    for lvl in (13, 19, 0, -1):
+        with pytest.raises(gpu.EngineError, match="not on the device"):
+            gpu.zstd_compress(d_src, d_dst, small, lvl)
     # CLI: the full corpus file (12 blocks + a 123457-byte tail) equals the reference CLI's; a file with a tiny (btopt) tail round-trips
     full = tmp_path / "full.bin"; full.write_bytes(helpers.corpus(m["corpus"]["bytes"]).tobytes())
     fo = tmp_path / "full.4mz"

@@ -25,7 +25,7 @@ def test_mock_jni_driver_against_the_reference_artifact(tmp_path):
     src = tmp_path / "in.bin"; src.write_bytes(data.tobytes())
     r = subprocess.run([str(exe), REF_SO, str(src), str(n), str(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    check_jni_protocol(r.stdout, data, tmp_path, level9_on_device=True)
+    check_jni_protocol(r.stdout, data, tmp_path, level15_on_device=True)
 
 
 @pytest.mark.skipif(not os.path.exists(REF_SO), reason="the reference's shipped library is not on this machine")

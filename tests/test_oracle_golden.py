@@ -230,7 +230,7 @@ def test_lz4mc_port_equals_reference_sources():
             assert r == rr and np.array_equal(comp, out[:max(rr, 0)]), (name, cap, r, rr)
 
 
-# ------------------------------------------------------------------------------------------ zstd encoder port (levels 1, 3, 6, 12)
+# ------------------------------------------------------------------------------------------ zstd encoder port (levels 1 .. 12; 4mz uses 1, 3, 6, 12)
 def test_zstd_enc_port_golden_frames():
     """The committed frames the reference's ZSTD_compress wrote (tests/golden/zstd_frames.json) - every strategy 4mz reaches:
     fast, dfast, lazy / lazy2 (rows and chains), btlazy2 (level 12, 16 KiB + 1 .. 256 KiB), btopt (level 12, <= 16 KiB)."""
@@ -270,7 +270,7 @@ def test_zstd_enc_port_level12_size_classes():
     ref = helpers.ref()
     ref.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]; ref.ZSTD_compress.restype = C.c_size_t
     assert helpers.orc_zstd_compress(helpers.corpus(16384), 12)[0] > 0 and helpers.orc_zstd_compress(helpers.corpus(300000), 12)[0] > 0
-    assert helpers.orc_zstd_compress(helpers.corpus(1000), 9)[0] == -1000          # a level 4mz never uses: refused, not guessed
+    assert helpers.orc_zstd_compress(helpers.corpus(1000), 13)[0] == -1000         # a level beyond the port (btlazy2 on full blocks, btultra): refused, not guessed
 
     def check(d, cap, tag):
         d = np.array(d, dtype=np.uint8, copy=True)
@@ -305,6 +305,28 @@ def test_zstd_enc_port_level12_size_classes():
     c = check(d, helpers.zstd_bound(len(d)), "bound")
     for cap in range(max(0, c - 16), c + 6):
         check(d, cap, "tight")
+
+
+@pytest.mark.skipif(helpers.ref() is None, reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("level", [2, 4, 5, 7, 8, 9, 10, 11])
+def test_zstd_enc_port_other_levels_equal_reference_sources(level):
+    """The levels 4mz does not use but the JNI entry point may pass (1..12 run on the device): the port against the reference's own
+    ZSTD_compress over the size classes of the level table, edge inputs, and the capacities 4mz / the bound give."""
+    import ctypes as C
+    ref = helpers.ref()
+    ref.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]; ref.ZSTD_compress.restype = C.c_size_t
+    src = helpers.corpus(2 * B, first_block=5)
+    cases = [(k, v) for k, v in helpers.edge_inputs().items()]
+    for n in (700, 5000, 16384, 16385, 60000, 131072, 131073, 262144, 262145, 600000):
+        cases.append(("n%d" % n, src[12345:12345 + n]))
+    for name, d in cases:
+        d = np.ascontiguousarray(d)
+        for cap in (helpers.zstd_bound(len(d)), max(len(d) - 1, 0)):
+            out = np.zeros(max(cap, 1) + 64, np.uint8)
+            rr = ref.ZSTD_compress(out.ctypes.data, cap, d.ctypes.data, len(d), level)
+            rr = rr if rr < (1 << 62) else rr - (1 << 64)
+            r, comp = helpers.orc_zstd_compress(d, level, cap)
+            assert r == rr and np.array_equal(comp, out[:max(rr, 0)]), (name, len(d), cap, r, rr)
 
 
 @pytest.mark.skipif(helpers.ref() is None, reason="oracle/_ref not built (needs /root/reference)")
