@@ -56,30 +56,45 @@ static_assert(kStoreBytes % 64 == 0, "tables start 64-byte aligned");
 // btultra / btlazy2 on full blocks: not on the device).  4mz uses 1, 3, 6, 12; the JNI name compressBytesDirectHC(level) may pass any.
 struct LevelRow { uint8_t wlog, clog, hlog, slog, mml, tlen, strat; };
 constexpr int kMaxLevel = 12;
-__device__ __constant__ const LevelRow kLevelRowsDev[kMaxLevel][4] = {
-    {{19, 13, 14, 1, 7, 0, 1}, {18, 13, 14, 1, 6, 0, 1}, {17, 12, 13, 1, 6, 0, 1}, {14, 14, 15, 1, 5, 0, 1}},
-    {{20, 15, 16, 1, 6, 0, 1}, {18, 14, 14, 1, 5, 0, 2}, {17, 13, 15, 1, 5, 0, 1}, {14, 14, 15, 1, 4, 0, 1}},
-    {{21, 16, 17, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {17, 15, 16, 2, 5, 0, 2}, {14, 14, 15, 2, 4, 0, 2}},
-    {{21, 18, 18, 1, 5, 0, 2}, {18, 16, 17, 3, 5, 2, 3}, {17, 17, 17, 2, 4, 0, 2}, {14, 14, 14, 4, 4, 2, 3}},
-    {{21, 18, 19, 3, 5, 2, 3}, {18, 17, 18, 5, 5, 2, 3}, {17, 16, 17, 3, 4, 2, 3}, {14, 14, 14, 3, 4, 4, 4}},
-    {{21, 18, 19, 3, 5, 4, 4}, {18, 18, 19, 3, 5, 4, 4}, {17, 16, 17, 3, 4, 4, 4}, {14, 14, 14, 4, 4, 8, 5}},
-    {{21, 19, 20, 4, 5, 8, 4}, {18, 18, 19, 4, 4, 4, 4}, {17, 16, 17, 3, 4, 8, 5}, {14, 14, 14, 6, 4, 8, 5}},
-    {{21, 19, 20, 4, 5, 16, 5}, {18, 18, 19, 4, 4, 8, 5}, {17, 16, 17, 4, 4, 8, 5}, {14, 14, 14, 8, 4, 8, 5}},
-    {{22, 20, 21, 4, 5, 16, 5}, {18, 18, 19, 5, 4, 8, 5}, {17, 16, 17, 5, 4, 8, 5}, {14, 15, 14, 5, 4, 8, 6}},
-    {{22, 21, 22, 5, 5, 16, 5}, {18, 18, 19, 6, 4, 8, 5}, {17, 16, 17, 6, 4, 8, 5}, {14, 15, 14, 9, 4, 8, 6}},
-    {{22, 21, 22, 6, 5, 16, 5}, {18, 18, 19, 5, 4, 12, 6}, {17, 17, 17, 5, 4, 8, 6}, {14, 15, 14, 3, 4, 12, 7}},
-    {{22, 22, 23, 6, 5, 32, 5}, {18, 19, 19, 7, 4, 12, 6}, {17, 18, 17, 7, 4, 12, 6}, {14, 15, 14, 4, 3, 24, 7}}};
+#define FOURMC_ZSTD_LEVEL_ROWS { \
+    {{19, 13, 14, 1, 7, 0, 1}, {18, 13, 14, 1, 6, 0, 1}, {17, 12, 13, 1, 6, 0, 1}, {14, 14, 15, 1, 5, 0, 1}}, \
+    {{20, 15, 16, 1, 6, 0, 1}, {18, 14, 14, 1, 5, 0, 2}, {17, 13, 15, 1, 5, 0, 1}, {14, 14, 15, 1, 4, 0, 1}}, \
+    {{21, 16, 17, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {17, 15, 16, 2, 5, 0, 2}, {14, 14, 15, 2, 4, 0, 2}}, \
+    {{21, 18, 18, 1, 5, 0, 2}, {18, 16, 17, 3, 5, 2, 3}, {17, 17, 17, 2, 4, 0, 2}, {14, 14, 14, 4, 4, 2, 3}}, \
+    {{21, 18, 19, 3, 5, 2, 3}, {18, 17, 18, 5, 5, 2, 3}, {17, 16, 17, 3, 4, 2, 3}, {14, 14, 14, 3, 4, 4, 4}}, \
+    {{21, 18, 19, 3, 5, 4, 4}, {18, 18, 19, 3, 5, 4, 4}, {17, 16, 17, 3, 4, 4, 4}, {14, 14, 14, 4, 4, 8, 5}}, \
+    {{21, 19, 20, 4, 5, 8, 4}, {18, 18, 19, 4, 4, 4, 4}, {17, 16, 17, 3, 4, 8, 5}, {14, 14, 14, 6, 4, 8, 5}}, \
+    {{21, 19, 20, 4, 5, 16, 5}, {18, 18, 19, 4, 4, 8, 5}, {17, 16, 17, 4, 4, 8, 5}, {14, 14, 14, 8, 4, 8, 5}}, \
+    {{22, 20, 21, 4, 5, 16, 5}, {18, 18, 19, 5, 4, 8, 5}, {17, 16, 17, 5, 4, 8, 5}, {14, 15, 14, 5, 4, 8, 6}}, \
+    {{22, 21, 22, 5, 5, 16, 5}, {18, 18, 19, 6, 4, 8, 5}, {17, 16, 17, 6, 4, 8, 5}, {14, 15, 14, 9, 4, 8, 6}}, \
+    {{22, 21, 22, 6, 5, 16, 5}, {18, 18, 19, 5, 4, 12, 6}, {17, 17, 17, 5, 4, 8, 6}, {14, 15, 14, 3, 4, 12, 7}}, \
+    {{22, 22, 23, 6, 5, 32, 5}, {18, 19, 19, 7, 4, 12, 6}, {17, 18, 17, 7, 4, 12, 6}, {14, 15, 14, 4, 3, 24, 7}}}
+__device__ __constant__ const LevelRow kLevelRowsDev[kMaxLevel][4] = FOURMC_ZSTD_LEVEL_ROWS;     // what the kernels read
+constexpr LevelRow kLevelRows[kMaxLevel][4] = FOURMC_ZSTD_LEVEL_ROWS;                             // the same rows for the host (launcher, table sizes)
 // per-block table area by level.  The levels 4mz uses keep the sizes they always had: 1 -> hash table (<= 2^15 x u32); 3 -> long 2^17 +
 // short 2^16; 6 -> rows 2^19 x u32 + tags 2^19 x u16; 12 -> rows 2^23 x u32 + tags 2^23 x u16 (inputs > 256 KiB), hash 2^19 x u32 + binary
 // tree 2^19 x u32 (btlazy2, smaller inputs).  Any other level: room for the largest hash table of its four rows (entries + tags, or the long
 // table of dfast at its fixed place), the largest chain / short / tree table behind it, and the optimal parser's arrays.
 __host__ __device__ constexpr size_t table_bytes(int level)
 {
+    // largest hashLog / chainLog of a level's four rows (checked against the rows below)
     constexpr uint8_t hmax[kMaxLevel] = {15, 16, 17, 18, 19, 19, 20, 20, 21, 22, 22, 23}, cmax[kMaxLevel] = {14, 15, 16, 18, 18, 18, 19, 19, 20, 21, 21, 22};
     return level == 12 ? (size_t(4) << 23) + (size_t(2) << 23) : level == 6 ? (size_t(4) << 19) + (size_t(2) << 19) : level == 3 ? (size_t(4) << 17) + (size_t(4) << 16)
          : level == 1 ? (size_t(4) << 15)
          : level >= 1 && level <= kMaxLevel ? (size_t(6) << (hmax[level - 1] < 17 ? 17 : hmax[level - 1])) + (size_t(8) << cmax[level - 1]) + (size_t(1) << 20) : 0;
 }
+
+constexpr bool level_maxima_ok()
+{
+    constexpr uint8_t hmax[kMaxLevel] = {15, 16, 17, 18, 19, 19, 20, 20, 21, 22, 22, 23}, cmax[kMaxLevel] = {14, 15, 16, 18, 18, 18, 19, 19, 20, 21, 21, 22};
+    for (int l = 0; l < kMaxLevel; l++) {
+        uint8_t h = 0, c = 0;
+        for (int k = 0; k < 4; k++) { if (kLevelRows[l][k].hlog > h) h = kLevelRows[l][k].hlog; if (kLevelRows[l][k].clog > c) c = kLevelRows[l][k].clog; }
+        if (h != hmax[l] || c != cmax[l]) return false;
+    }
+    return true;
+}
+static_assert(level_maxima_ok(), "table_bytes: the maxima do not match the level rows");
 
 struct __attribute__((packed, aligned(1))) S4B { uint32_t v; };
 __device__ __forceinline__ void st4(uint8_t* p, uint32_t v) { reinterpret_cast<S4B*>(p)->v = v; }
@@ -3220,9 +3235,6 @@ void zstd_encode_tree_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
 
 } // namespace
 
-// strategy column of kLevelRowsDev (host side: which kernels a level needs)
-static const uint8_t kLevelRowsHost[kMaxLevel][4] = {{1, 1, 1, 1}, {1, 2, 1, 1}, {2, 2, 2, 2}, {2, 3, 2, 3}, {3, 3, 3, 4}, {4, 4, 4, 5}, {4, 4, 5, 5}, {5, 5, 5, 5},
-                                                     {5, 5, 5, 6}, {5, 5, 5, 6}, {5, 6, 6, 7}, {5, 6, 6, 7}};
 extern "C" int fourmc_zstd_enc_level_ok(int level) { return level >= 1 && level <= kMaxLevel; }
 extern "C" size_t fourmc_zstd_enc_work_bytes(uint32_t n, int level) { return size_t(n) * (kStoreBytes + table_bytes(level)); }
 
@@ -3233,7 +3245,7 @@ extern "C" hipError_t fourmc_launch_zstd_encode(const void* d_src, void* d_dst, 
     if (level < 1 || level > kMaxLevel) return hipErrorInvalidValue;
     // every block is taken by the kernel of its strategy (zstd_encode_one); a level's four rows name at most these kernels
     bool fam[4] = {false, false, false, false};
-    for (int c = 0; c < 4; c++) { const uint32_t st = kLevelRowsHost[level - 1][c]; fam[st == 1 ? 1 : st == 2 ? 2 : st >= 6 ? 3 : 0] = true; }
+    for (int c = 0; c < 4; c++) { const uint32_t st = kLevelRows[level - 1][c].strat; fam[st == 1 ? 1 : st == 2 ? 2 : st >= 6 ? 3 : 0] = true; }
     const uint8_t* s8 = static_cast<const uint8_t*>(d_src); uint8_t* d8 = static_cast<uint8_t*>(d_dst); uint8_t* w8 = static_cast<uint8_t*>(d_work);
     if (fam[1]) hipLaunchKernelGGL(zstd_encode_fast_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, w8, container_mode, level, serial);
     if (fam[2]) hipLaunchKernelGGL(zstd_encode_dfast_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, w8, container_mode, level, serial);

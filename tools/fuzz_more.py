@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Extra seeds of tests/test_gpu_fuzz.py for the LZ4 encoders (fast, MC, HC 4/8) and the zstd encoder (levels 1, 3, 6, 12;
-half of the level-12 inputs cut to the btopt / btlazy2 size classes) - run by hand after kernel changes:
+"""Extra seeds of tests/test_gpu_fuzz.py for the LZ4 encoders (fast, MC, HC 4/8) and the zstd encoder (levels 1 .. 12; FUZZ_ZLEVELS="2 4 5" picks; half of the
+inputs of the levels with tree strategies - 9 .. 12 - cut to the btopt / btlazy2 size classes) - run by hand after kernel changes:
     python tools/fuzz_more.py [first_seed] [count]"""
 import importlib, sys, os
 import numpy as np, torch
@@ -17,7 +17,7 @@ for seed in range(first, first + count):
     pick = rng.integers(0, 3, len(srcs))
     bound = [helpers.oracle().orc_lz4_compress_bound(len(s)) for s in srcs]
     caps = [b if p == 0 else max(len(s) - 1, 0) if p == 1 else len(s) // 2 for s, b, p in zip(srcs, bound, pick)]
-    for name, launch, orc in (("fast", lambda a, b, c: gpu.lz4_compress_fast(a, b, c), lambda s, cap: helpers.orc_compress(s, cap)),
+    for name, launch, orc in () if os.environ.get("FUZZ_ZSTD_ONLY") else (("fast", lambda a, b, c: gpu.lz4_compress_fast(a, b, c), lambda s, cap: helpers.orc_compress(s, cap)),
                               ("mc", lambda a, b, c: gpu.lz4_compress_mc(a, b, c), lambda s, cap: helpers.orc_compress_mc(s, cap)),
                               ("hc4", lambda a, b, c: gpu.lz4_compress_hc(a, b, c, 4), lambda s, cap: helpers.orc_compress_hc(s, 4, cap)),
                               ("hc8", lambda a, b, c: gpu.lz4_compress_hc(a, b, c, 8), lambda s, cap: helpers.orc_compress_hc(s, 8, cap))):
@@ -36,9 +36,9 @@ for seed in range(first, first + count):
             o = int(blocks["dst_off"][k])
             if int(got["result"][k]) != len(srcs[i]) or not np.array_equal(back[o:o + len(srcs[i])], srcs[i]):
                 bad += 1; print("DECODE MISMATCH", name, seed, i)
-    for level in (1, 3, 6, 12):
+    for level in [int(x) for x in os.environ.get("FUZZ_ZLEVELS", "1 3 6 12").split()]:
         zs = srcs
-        if level == 12:                                   # small last blocks: optimal parser (<= 16 KiB), binary tree (<= 256 KiB)
+        if level >= 9:                                   # small last blocks: optimal parser (<= 16 KiB), binary tree (<= 256 KiB)
             zs = [s[: int(rng.integers(0, 16385))] if k % 2 else s for k, s in enumerate(srcs)]
         zcaps = [helpers.zstd_bound(len(s)) if p == 0 else max(len(s) - 1, 0) if p == 1 else len(s) // 2 for s, p in zip(zs, pick)]
         res, outs, d_out, dsts = tf._run(gpu, zs, zcaps, lambda a, b, c: gpu.zstd_compress(a, b, c, level))
