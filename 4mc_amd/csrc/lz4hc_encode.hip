@@ -94,14 +94,19 @@ struct HC {
     uint32_t  pl_byte, pl_dst, pl_n;   // literal run of the last sequence: read, not yet written (see hc_emit)
 #ifdef K2_PROF   // side build (make prof): cycles in window build / searches / emission, call counts
     uint64_t  pt_build, pt_search, pt_emit, pt0; uint32_t n_build, n_search, n_emit, n_mem;
+    uint64_t  px_emit, px_skip, px_first; uint32_t nx_emit, nx_skip;
 #endif
 };
 #ifdef K2_PROF
 #define K3PH(c, acc) do { const uint64_t t_ = __builtin_readcyclecounter(); (c).acc += t_ - (c).pt0; (c).pt0 = t_; } while (0)
 #define K3CNT(c, f) do { (c).f++; } while (0)
+#define K3X0() const uint64_t x0_ = __builtin_readcyclecounter()
+#define K3X(c, acc) do { (c).acc += __builtin_readcyclecounter() - x0_; } while (0)
 #else
 #define K3PH(c, acc) do { } while (0)
 #define K3CNT(c, f) do { } while (0)
+#define K3X0() do { } while (0)
+#define K3X(c, acc) do { } while (0)
 #endif
 
 // LZ4HC_Insert (lz4hc.c:120-141): positions [ntu, upto) enter the tables in order, 64 per step.  Inside one step the
@@ -386,6 +391,7 @@ __device__ __forceinline__ int hc_wider(HC& c, uint32_t ip, uint32_t low, uint32
 __device__ __forceinline__ bool hc_emit(HC& c, const uint8_t* src, uint8_t* dst, uint32_t& ip, uint32_t& op, uint32_t& anchor,
                                         int ml, uint32_t match, bool limited, uint32_t cap, int lane)
 {
+    K3X0();
     const uint32_t lit = ip - anchor;
     const uint32_t token_pos = op++;
     if (limited && op + lit / 255 + lit + (2 + 1 + kLastLit) > cap) return true;
@@ -413,6 +419,7 @@ __device__ __forceinline__ bool hc_emit(HC& c, const uint8_t* src, uint8_t* dst,
     if (lane == 0) dst[token_pos] = uint8_t(tok);
     ip += uint32_t(ml);
     anchor = ip;
+    K3X(c, px_emit); K3CNT(c, nx_emit);
     return false;
 }
 
@@ -457,6 +464,7 @@ __device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int c
     c.pl_byte = 0; c.pl_dst = 0; c.pl_n = 0;
 #ifdef K2_PROF
     c.pt_build = c.pt_search = c.pt_emit = 0; c.n_build = c.n_search = c.n_emit = c.n_mem = 0; c.pt0 = __builtin_readcyclecounter();
+    c.px_emit = c.px_skip = c.px_first = 0; c.nx_emit = c.nx_skip = 0;
 #endif
     c.n = uint32_t(n); c.matchlimit = n > kLastLit ? uint32_t(n) - kLastLit : 0u; c.mflimit = n > kMfLimit ? uint32_t(n) - kMfLimit : 0u;
     c.heads = reinterpret_cast<uint32_t*>(work);
@@ -473,6 +481,7 @@ __device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int c
             // the search that opens a sequence looks back at nothing: its answer was prepared with the window
             if (c.wbase == 0xFFFFFFFFu || ip - c.wbase >= 64u) { K3PH(c, pt_emit); hc_acquire(c, ip, attempts); K3CNT(c, n_build); K3PH(c, pt_build); }
             if (c.failed) return 0;
+            K3X0();
             {
                 const uint32_t f = c.win->fm[ip - c.wbase];
                 if (f != 0xFF) { ml = f ? int(f) : kMinMatch - 1; ref = c.win->fr[ip - c.wbase] - kIdx0; }
@@ -488,8 +497,10 @@ __device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int c
                     nip += m ? uint32_t(__builtin_ctzll(m)) : 64u - rel;
                 }
                 ip = nip;
+                K3X(c, px_skip); K3CNT(c, nx_skip);
                 continue;
             }
+            K3X(c, px_first);
             start0 = ip; ref0 = ref; ml0 = ml;
         search2:
             if (ip + ml <= mflimit) ml2 = hc_wider(c, ip + ml - 2, ip, matchlimit, ml, ref2, start2, attempts);
@@ -559,6 +570,7 @@ __device__ int lz4hc_encode_block(const uint8_t* src, uint8_t* dst, int n, int c
     if (lane == 0 && n == (4 << 20) && op + 256 < uint32_t(n)) {
         uint64_t* o = reinterpret_cast<uint64_t*>(dst + n - 128);
         o[0] = c.pt_build; o[1] = c.pt_search; o[2] = c.pt_emit; o[3] = c.n_build; o[4] = c.n_search; o[5] = c.n_mem;
+        o[6] = c.px_emit; o[7] = c.px_skip; o[8] = c.px_first; o[9] = c.nx_emit; o[10] = c.nx_skip;
     }
 #endif
     return int(op);

@@ -18,7 +18,8 @@ for b in (0, 1, 3, 5, 7, 10):
     p.encode_blocks(src, stage, enc, codec=p.CODEC_LZ4_HC, level=level); torch.cuda.synchronize()
     s.record(); p.encode_blocks(src, stage, enc, codec=p.CODEC_LZ4_HC, level=level); e.record(); torch.cuda.synchronize()
     r = int(enc.download()["result"][0])
-    c = stage[B - 128: B - 80].cpu().numpy().view(np.uint64)
+    c = stage[B - 128: B - 40].cpu().numpy().view(np.uint64)
     tot = float(c[:3].sum()) or 1.0
     print(f"{names[b]:7s} csize {r:8d} hc{level} {s.elapsed_time(e):8.2f} ms  window build {100*c[0]/tot:4.1f}%  searches {100*c[1]/tot:4.1f}%  parser+emit {100*c[2]/tot:4.1f}%"
-          f"  windows {int(c[3])} searches {int(c[4])} memory extensions {int(c[5])}  clk/search {c[1]/max(1,int(c[4])):.0f} clk/window {c[0]/max(1,int(c[3])):.0f}")
+          f"  windows {int(c[3])} searches {int(c[4])} memory extensions {int(c[5])}  clk/search {c[1]/max(1,int(c[4])):.0f} clk/window {c[0]/max(1,int(c[3])):.0f}"
+          f"  | emits {int(c[9])} x {c[6]/max(1,int(c[9])):.0f} clk, no-match steps {int(c[10])} x {c[7]/max(1,int(c[10])):.0f} clk, first-search hits {c[8]/max(1,int(c[9])):.0f} clk/seq; Mclk total {tot/1e6:.0f} emit {c[6]/1e6:.0f} skip {c[7]/1e6:.0f} first {c[8]/1e6:.0f}")
