@@ -18,7 +18,7 @@ from .binding import (  # noqa: F401
     make_blocks, gpu_init,
 )
 from .engine import (  # noqa: F401
-    lz4_decompress, zstd_decompress, zstd_compress, lz4_compress_fast, lz4_compress_hc, lz4_compress_mc, xxh32, encode_blocks, decode_blocks, pack_image, DeviceBatch,
+    lz4_decompress, zstd_decompress, zstd_compress, lz4_compress_fast, lz4_compress_hc, lz4_compress_mc, xxh32, encode_blocks, decode_blocks, pack_image, DeviceBatch, release_workspaces,
 )
 from .container import (  # noqa: F401
     frame_header, frame_footer, parse_footer, assemble_container, split_container, shard_range,

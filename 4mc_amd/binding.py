@@ -64,6 +64,7 @@ _GPU_API = {
     "fourmc_gpu_debug_lz4_parse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "fourmc_debug_one_block_counters": (None, [C.c_void_p, C.c_void_p]),
     "fourmc_gpu_one_block_stats": (None, [C.c_void_p, C.c_void_p]),
+    "fourmc_gpu_release_workspaces": (C.c_int, []),
     "fourmc_gpu_xxh32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "fourmc_gpu_4mc_encode_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
     "fourmc_gpu_4mc_decode_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),

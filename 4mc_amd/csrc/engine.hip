@@ -104,6 +104,25 @@ public:
     }
 };
 
+} // namespace (the export below is part of the boundary)
+// Gives the device back every workspace the engine keeps per stream (a 64 GiB decode leaves 92 GB behind on its stream; they are kept
+// because the next call of the same size reuses them).  Each stream is synchronized before its buffer goes; a lease in flight on
+// another thread is waited for.  Returns FOURMC_OK or a device error.
+extern "C" int fourmc_gpu_release_workspaces(void)
+{
+    std::vector<std::pair<hipStream_t, StreamWs*>> all;
+    { std::lock_guard<std::mutex> lk(g_wsmu); for (auto& kv : g_ws) all.push_back(kv); }
+    for (auto& kv : all) {
+        std::lock_guard<std::mutex> lk(kv.second->mu);
+        if (kv.second->p) {
+            HIP_TRY(hipStreamSynchronize(kv.first)); HIP_TRY(hipFree(kv.second->p));
+            kv.second->p = nullptr; kv.second->cap = 0;
+        }
+    }
+    return FOURMC_OK;
+}
+namespace {
+
 // The LZ4 decode workspace.  Path, piece size and bytes are resolved once (fourmc_lz4_decode_plan) and handed to the launcher; when
 // the device cannot give the workspace the pieces halve FOR THIS CALL (the launch is then cut into more of them), and an automatic
 // choice ends at the walk + window copier, which needs none.

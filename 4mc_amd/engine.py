@@ -94,3 +94,8 @@ def pack_image(d_staging, d_image, batch, d_image_off, stream=None):
     """Block headers + payloads -> contiguous file image (native/4mc.c:309-315); d_image_off: int64/uint64 tensor."""
     check(lib().fourmc_gpu_4mc_pack_image(_ptr(d_staging), _ptr(d_image), batch.ptr, _ptr(d_image_off), batch.n,
                                           _stream_ptr(stream)), "fourmc_gpu_4mc_pack_image")
+
+
+def release_workspaces():
+    """Frees the device workspaces the engine keeps per stream (fourmc_gpu_release_workspaces); the next call allocates again."""
+    check(lib().fourmc_gpu_release_workspaces(), "fourmc_gpu_release_workspaces")

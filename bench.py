@@ -344,7 +344,7 @@ def main():
         its own copy: nothing is read twice).  Runs as 8 launches' worth of blocks in one call (the engine's decode entry point)."""
         nd = args.decode_blocks
         reps = -(-nd // nb)
-        torch.cuda.empty_cache()
+        p.release_workspaces(); torch.cuda.empty_cache()
         img_bytes = int((state["loc_off"][-1] + 12 + state["csz"][-1]).item())
         img_pad = (img_bytes + 4095) & ~4095
         free, _ = torch.cuda.mem_get_info()
@@ -390,7 +390,7 @@ def main():
         if nd % nb: return {"skipped": "decode blocks not a multiple of the launch"}
         reps = nd // nb
         slot = (B + B // 255 + 16 + 4095) & ~4095
-        torch.cuda.empty_cache()
+        p.release_workspaces(); torch.cuda.empty_cache()
         free, _ = torch.cuda.mem_get_info()
         if free < nd * B + (reps + 1) * nb * slot + (4 << 30):
             return {"skipped": "not enough free HBM (%d GiB free)" % (free >> 30)}

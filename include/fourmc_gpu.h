@@ -96,6 +96,9 @@ int  fourmc_gpu_get_zstd_decode_split(void);
  * JNI entry points: one call = one block) and the launches that served them - calls that arrive while a launch is in flight
  * share the next one (engine.hip: host_one), so launches < calls under concurrency. */
 void fourmc_gpu_one_block_stats(unsigned long long* calls, unsigned long long* launches);
+/* The engine keeps one device workspace per stream and reuses it (the segment-parallel LZ4 decode of 8192 blocks needs 92 GB, the zstd
+ * level-12 encoder 48 MiB per block).  This frees them all, synchronizing each stream first; the next call allocates again. */
+int fourmc_gpu_release_workspaces(void);
 /* result = ZSTD_compress(dst + dst_off, dst_cap, src + src_off, src_len, level) as int: frame bytes, or
  * -(ZSTD error number), e.g. -70 = dstSize_tooSmall        native/zstd/compress/zstd_compress.c:4806
  * Levels 1 .. 12 are on the device, byte-identical for every input size: every strategy their rows of the level table name (clevels.h:25-130:
