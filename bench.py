@@ -143,9 +143,14 @@ def main():
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # FOURMC_BENCH_BACKEND=gloo: test aid - several ranks on ONE GPU (RCCL refuses two ranks on a device); the collectives then go through
+    # host copies.  The driver's runs use the default, nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("FOURMC_BENCH_BACKEND", "nccl")
+    if backend != "nccl": local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl": dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else: dist.init_process_group(backend)
     arch = p.gpu_init(local)
     dev = torch.device("cuda", local)
     B = p.BLOCKSIZE
@@ -192,7 +197,10 @@ def main():
         csz = desc[:, 6].to(torch.int64)                         # result = stored payload size
         if world > 1:                                            # footer index spans ranks: gather sizes
             allc = torch.empty(world * nb, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(allc, csz)
+            if backend == "nccl": dist.all_gather_into_tensor(allc, csz)
+            else:
+                parts = [torch.empty(nb, dtype=torch.int64) for _ in range(world)]
+                dist.all_gather(parts, csz.cpu()); allc.copy_(torch.cat(parts))
             before = int((allc[: rank * nb] + 12).sum().item())
         else:
             before = 0
@@ -489,7 +497,7 @@ def main():
     own_wall = wall
     per_rank = None; rccl_ranks = None
     if world > 1:
-        w = torch.tensor([wall], dtype=torch.float64, device=dev)
+        w = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
         # every rank's own numbers into rank 0's line, and the gathered footer index checked against a prefix sum recomputed locally

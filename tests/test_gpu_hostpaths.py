@@ -258,3 +258,30 @@ def test_workspace_that_does_not_fit_is_taken_in_pieces(gpu, tmp_path, flags, li
     r = subprocess.run([gpu.cli_path(), "-d"] + (["-z"] if "-z" in flags else []) + ["-f", str(tmp_path / "o1"), str(back)], capture_output=True, env=env)
     assert r.returncode == 0, r.stderr
     assert back.read_bytes() == data.tobytes()
+
+
+@pytest.mark.parametrize("config", ["fast", "ultra_logs"])
+def test_bench_line_of_two_ranks(gpu, config):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), with two ranks: block ranges per
+    rank, the footer index gathered, every rank's numbers in rank 0's line (`per_rank`), the gathered index checked against a
+    recomputed prefix sum.  RCCL refuses two ranks on one device, so on a one-GPU box the collectives go through gloo
+    (FOURMC_BENCH_BACKEND, a test aid: same calls, host copies); a reduced launch (256 / 64 blocks per rank)."""
+    import json, socket, sys
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    nb = 256 if config == "fast" else 64
+    env = dict(os.environ, FOURMC_BENCH_BACKEND="gloo", FOURMC_BENCH_NO_PMC="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(helpers.ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--blocks", str(nb), "--no-cpu", "--no-extras", "--config", config], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints, the others do not
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 2
+    pr = j["per_rank"]
+    assert [g["rank"] for g in pr] == [0, 1] and all(g["blocks"] == pr[0]["blocks"] for g in pr)
+    assert pr[0]["first_block_offset"] == 12 and pr[1]["first_block_offset"] == 12 + pr[0]["shard_bytes"]
+    assert j["rccl_ranks"]["world_size"] == 2
+    total = sum(g["blocks"] for g in pr) * helpers.B
+    assert abs(j["value"] - total / (j["ms_per_step"] * 1e-3) / 1e9) < 0.02 * j["value"]      # whole-job aggregate over both ranks
