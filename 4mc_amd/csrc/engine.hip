@@ -96,7 +96,13 @@ public:
         if (need > w_->cap) {
             if (w_->p) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(w_->p)); w_->p = nullptr; w_->cap = 0; }
             const size_t want = need + need / 16 + 4096;
-            HIP_TRY(hipMalloc(&w_->p, want));
+            const hipError_t me = hipMalloc(&w_->p, want);
+            if (me == hipErrorOutOfMemory) {          // the one failure a caller may answer with smaller pieces
+                (void)hipGetLastError(); w_->p = nullptr;
+                snprintf(g_err, sizeof g_err, "hipMalloc(%zu bytes of workspace): out of memory", want);
+                return FOURMC_ENOMEM;
+            }
+            HIP_TRY(me);
             w_->cap = want;
         }
         *out = w_->p;
@@ -128,13 +134,18 @@ namespace {
 // choice ends at the walk + window copier, which needs none.
 int lease_lz4_decode(WsLease& ws, hipStream_t s, uint32_t n, void** work, fourmc_lz4_plan* plan)
 {
+    fourmc_lz4_plan prev; prev.path = -1; prev.batch = 0; prev.work_bytes = 0; prev.ok = 0;
     for (uint32_t shrink = 0;; shrink++) {
         *plan = fourmc_lz4_decode_plan(n, shrink);
         if (!plan->ok) { snprintf(g_err, sizeof g_err, "LZ4 decode workspace cannot be allocated"); return FOURMC_ENOMEM; }
         if (plan->work_bytes == 0) { *work = nullptr; return FOURMC_OK; }
         const int r = ws.get(s, plan->work_bytes, work);
         if (r == FOURMC_OK) return r;
-        (void)hipGetLastError();
+        // only "out of memory" is answered with smaller pieces: any other device error is the caller's to see; and a plan that did
+        // not change (a path without a shrinkable batch) cannot succeed on the next turn either (this loop spun forever)
+        if (r != FOURMC_ENOMEM) return r;
+        if (shrink && plan->path == prev.path && plan->batch == prev.batch && plan->work_bytes == prev.work_bytes) return r;
+        prev = *plan;
     }
 }
 
@@ -154,8 +165,7 @@ int in_pieces(hipStream_t s, uint32_t n, uint32_t cap, Bytes bytes, Launch launc
         if (fail_above && need > fail_above) { snprintf(g_err, sizeof g_err, "workspace of %zu bytes refused (FOURMC_WS_FAIL_ABOVE)", need); r = FOURMC_ENOMEM; }
         else r = ws.get(s, need, &work);
         if (r == FOURMC_OK) break;
-        (void)hipGetLastError();
-        if (piece <= 1) return r;
+        if (r != FOURMC_ENOMEM || piece <= 1) return r;
         piece = (piece + 1) / 2;
     }
     for (uint32_t b0 = 0; b0 < n; b0 += piece)

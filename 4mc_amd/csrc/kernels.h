@@ -46,6 +46,10 @@ hipError_t fourmc_launch_lz4_tile(const void* d_src, void* d_dst, fourmc_block* 
                                   int container_mode, void* d_work, hipStream_t stream);
 hipError_t fourmc_launch_lz4_seg(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                  int container_mode, void* d_work, hipStream_t stream);
+hipError_t fourmc_launch_lz4_seg_walk(const void* d_src, fourmc_block* d_blocks, uint32_t n, int container_mode,
+                                      void* d_work, hipStream_t stream);
+hipError_t fourmc_launch_lz4_ring(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,
+                                  int container_mode, void* d_work, hipStream_t stream);
 hipError_t fourmc_launch_lz4_parse(const void* d_src, const void* d_dst, fourmc_block* d_blocks, uint32_t n,
                                    int container_mode, void* d_work, hipStream_t stream);
 hipError_t fourmc_launch_lz4_exec(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,

@@ -629,9 +629,10 @@ extern "C" fourmc_lz4_plan fourmc_lz4_decode_plan(uint32_t n, uint32_t shrink)
     fourmc_lz4_plan pl; pl.path = fourmc_gpu_get_lz4_decode_path(); pl.batch = n ? n : 1; pl.work_bytes = 0; pl.ok = 1;
     const bool automatic = pl.path == 6;
     if (pl.path == 6) pl.path = n <= auto_tile_max() ? 13 : 11;
-    if (pl.path == 11 || pl.path == 12 || pl.path == 13 || pl.path == 14) {
-        const bool tile = pl.path >= 13;
+    if (pl.path >= 11 && pl.path <= 16) {
+        const bool tile = pl.path == 13 || pl.path == 14;
         uint32_t b = tile ? fourmc_lz4_tile_batch() : fourmc_lz4_seg_batch();
+        if (b < 64) b = 64;                                       // (FOURMC_TILE_BATCH / FOURMC_SEG_BATCH below 64: an explicit choice would fail before any allocation)
         for (uint32_t k = 0; k < shrink && b >= 64; k++) b /= 2;
         if (b < 64) {
             if (automatic) { pl.path = 9; return pl; }
@@ -665,9 +666,9 @@ static int g_decode_path = -1;
 static bool path_known(int path)
 {
 #ifdef FOURMC_RESEARCH
-    return path >= 0 && path <= 14;
+    return path >= 0 && path <= 16;
 #else
-    return path == 2 || path == 6 || path == 9 || path == 10 || path == 11 || path == 12 || path == 13 || path == 14;
+    return path == 2 || path == 6 || (path >= 9 && path <= 16);
 #endif
 }
 extern "C" void fourmc_gpu_set_lz4_decode_path(int path) { g_decode_path = path_known(path) ? path : 6; }
@@ -688,6 +689,8 @@ extern "C" int fourmc_gpu_get_lz4_decode_path(void)
         if (mode && !strcmp(mode, "segonly")) p = 12;
         if (mode && !strcmp(mode, "tile")) p = 13;
         if (mode && !strcmp(mode, "tileonly")) p = 14;
+        if (mode && !strcmp(mode, "ring")) p = 15;
+        if (mode && !strcmp(mode, "ringonly")) p = 16;
         if (mode && !strcmp(mode, "par")) p = 1;
         if (mode && !strcmp(mode, "paronly")) p = 3;
         g_decode_path = path_known(p) ? p : 6;
@@ -704,19 +707,20 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
     const int path = plan->path;
     // (6 "auto" was resolved by fourmc_lz4_decode_plan: the tile path - lz4_tile.hip, one workgroup per block with the LZ4 window in
     // LDS - up to 1536 blocks, the segment-parallel path above; the walk + window copier, K1wx, when neither can have its workspace)
-    if (path == 13 || path == 14 || path == 11 || path == 12) {
+    if (path >= 11 && path <= 16) {
         // walk + executor (tile: lz4_tile.hip, segment-parallel: lz4_seg.hip), then the exact walker for the last bytes of every
         // block and for whatever was handed back; 12 / 14: test aid, blocks handed back stay kRetry
-        const bool tile = path >= 13;
+        const bool tile = path == 13 || path == 14, ring = path >= 15;
         const uint32_t step = plan->batch ? plan->batch : n;
         if (plan->work_bytes == 0 || d_work == nullptr) return hipErrorInvalidValue;
         for (uint32_t b0 = 0; b0 < n; b0 += step) {
             const uint32_t m = n - b0 < step ? n - b0 : step;
             hipError_t e = tile ? fourmc_launch_lz4_tile(d_src, d_dst, d_blocks + b0, m, container_mode, d_work, stream)
+                         : ring ? fourmc_launch_lz4_ring(d_src, d_dst, d_blocks + b0, m, container_mode, d_work, stream)
                                 : fourmc_launch_lz4_seg(d_src, d_dst, d_blocks + b0, m, container_mode, d_work, stream);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(lz4_decode_resume_kernel, dim3(m), dim3(64), 0, stream, s8, d8, d_blocks + b0, m, container_mode,
-                               static_cast<const uint32_t*>(d_work), (path == 11 || path == 13) ? 1 : 0,
+                               static_cast<const uint32_t*>(d_work), (path == 11 || path == 13 || path == 15) ? 1 : 0,
                                tile ? uint32_t(lz4tile::kWsWords) : uint32_t(lz4seg::kWsWords), tile ? lz4tile::kMetaResIp : lz4seg::kMetaResIp);
         }
         return hipGetLastError();

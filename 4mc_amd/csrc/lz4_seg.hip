@@ -509,18 +509,31 @@ void lz4_seg_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base
             pf.add(1, tp);
             // ---- matches.  M1: sources that end in front of the batch, from memory
             const int x = int(mrel) - int(off);                         // source, relative to the batch's first byte
+#ifdef K1S_NODEPS
+            // CEILING build (tools/ubench/seq_copy.py; never the product): the same sequences and the same copies - every match's
+            // bytes fetched and placed - but NO dependency is honoured: a match's source is read from memory whatever state it is in
+            // (no wait for the flush before, no order between the matches of a step).  The output is wrong wherever a source was not
+            // there yet; the time is what this engine would take if dependencies were free.
+            const bool m1 = act;
+            if (__ballot(m1)) {
+                copy_strings((cgbyte*)dst, x < 0 && uint32_t(-x) > opos ? 0u : opos + uint32_t(x), mrel, ml < 528u ? ml : 528u, m1 && int(opos) + x >= 0);
+            }
+            LDS_FENCE();
+            const bool pend = false;
+#else
             const bool m1 = act && x + int(ml) <= 0;
             if (__ballot(m1)) {
                 VM_DRAIN();                                              // the flush of the batch before has to have arrived
                 copy_strings((cgbyte*)dst, opos + uint32_t(x), mrel, ml, m1);
             }
             LDS_FENCE();
+            const bool pend = act && !m1;
+#endif
             pf.add(2, tp);
             // ---- M2: sources in the batch or its prologue, and overlapping matches: one sequence at a time in lane order, a byte
             // per lane, inside the staging buffer.  Up to 64 bytes with the source in the buffer: the short loop (an overlapping
             // match reads its period: byte i from i mod offset).  Everything else: the general one (bytes in front of the
             // prologue come from memory, long matches go in rounds).
-            const bool pend = act && !m1;
             const bool tight = pend && ml <= 64u && x >= -kPro;
             unsigned long long m2 = __ballot(pend);
             const unsigned long long tmask = __ballot(tight), omask = __ballot(tight && off < ml);
@@ -655,6 +668,16 @@ extern "C" uint32_t fourmc_lz4_seg_batch(void)
         v = b;
     }
     return v;
+}
+
+// the walk alone: the group executor (lz4_ring.hip) runs on its records too
+extern "C" hipError_t fourmc_launch_lz4_seg_walk(const void* d_src, fourmc_block* d_blocks, uint32_t n, int container_mode,
+                                                 void* d_work, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(lz4_seg_walk_kernel, dim3(n), dim3(64), 0, stream, static_cast<const uint8_t*>(d_src), d_blocks, n,
+                       container_mode, static_cast<uint32_t*>(d_work));
+    return hipGetLastError();
 }
 
 extern "C" hipError_t fourmc_launch_lz4_seg(const void* d_src, void* d_dst, fourmc_block* d_blocks, uint32_t n,

@@ -345,6 +345,10 @@ constexpr uint32_t S_NTOK = 0, S_NEXT = 1, S_CUTPOS = 2, S_BYDL = 3, S_SUM = 4, 
 // the wave's outstanding GLOBAL loads and stores - the next chunk's bytes, loaded a chunk ahead, and the tile's flush would be waited
 // for at the next of the ~8 barriers per tile.)
 #define WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// ... and for what the waves of the workgroup hand each other through GLOBAL memory (the fused walk's bitmap words: written by the
+// segment's thread, read by its neighbour's and by the one thread of phase 3): the stores have left for the CU's write-through L1 /
+// the L2 before the barrier lets anyone read (the plain barrier relied on same-CU ordering it did not enforce)
+#define WG_BARRIER_G() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
 __device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | c; }
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return uint32_t(uintptr_t((const __attribute__((address_space(3))) void*)p)); }
 // p[k] = the 16-bit word at LDS address p[k] (eight independent reads, one wait)
@@ -425,18 +429,18 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
         pf.add(8, tp);
         X[tid] = g.exitp; X[XT + tid] = g.tail ? 1u : 0u; X[XD + tid] = 0u;
         if (tid == 0) sc[S_ANY] = 0u;
-        WG_BARRIER();
+        WG_BARRIER_G();
         pf.add(9, tp);
         // phase 2: the chain of the segment in front left at `pe`: assume it is the true one, thread it into this segment
         {
             const uint32_t pj = tid ? tid - 1u : 0u;
             const uint32_t pe = X[pj], pt = X[XT + pj];
-            WG_BARRIER();                                                // (everyone has read what phase 1 left)
+            WG_BARRIER_G();                                                // (everyone has read what phase 1 left)
             uint32_t sj = pe / seglen; sj = sj > nseg - 1 ? nseg - 1 : sj;
             if (mine && tid >= 1 && !pt && sj == tid && pe != g.sj) walk_from_entry(g, s, limit, pe);
             X[tid] = g.exitp; X[XT + tid] = g.tail ? 1u : 0u; X[XE + tid] = g.entry;
         }
-        WG_BARRIER();
+        WG_BARRIER_G();
         // ... and again where the chain in front did not fall back onto its own before its segment ended (it then leaves somewhere
         // else than assumed): all such segments at once, a few rounds; what is still open after them is the one thread's below
         for (uint32_t round = 1; round <= 6u; round++) {
@@ -445,10 +449,10 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
             uint32_t sj = pe / seglen; sj = sj > nseg - 1 ? nseg - 1 : sj;
             const bool need = mine && tid >= 1 && !pt && sj == tid && pe != g.entry;
             if (__ballot(need) && lane == 0) sc[S_ANY] = round;
-            WG_BARRIER();                                                // (and everyone has read what the round before left)
+            WG_BARRIER_G();                                                // (and everyone has read what the round before left)
             if (rfl(sc[S_ANY]) != round) break;
             if (need) { walk_from_entry(g, s, limit, pe); X[tid] = g.exitp; X[XT + tid] = g.tail ? 1u : 0u; X[XE + tid] = g.entry; }
-            WG_BARRIER();
+            WG_BARRIER_G();
         }
         pf.add(10, tp);
         // phase 3: one thread follows the true chain through the segments and redoes what was assumed wrong (rare)
@@ -468,7 +472,7 @@ void lz4_tile_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_bas
             }
             sc[S_TAIL] = tip;
         }
-        WG_BARRIER();
+        WG_BARRIER_G();
         pf.add(11, tp);
         if (mine && X[XD + tid]) for (uint32_t x = g.sj >> 5; x < g.wend; x++) g.bm[x] = 0;       // segments the chain jumps over have no tokens
         tail_ip = rfl(sc[S_TAIL]);

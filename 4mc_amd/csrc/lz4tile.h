@@ -36,7 +36,11 @@ constexpr uint32_t kSzClamp = (4u << 20) + 1u;
 constexpr uint32_t kMetaStatus = 0, kMetaTailIp = 1, kMetaResIp = 2, kMetaResOp = 3;
 constexpr uint32_t kMetaProf   = 4;                                      // 44 words: cycle counters of profiling builds
 constexpr uint32_t kMetaWords  = 48;
-constexpr uint32_t kBmWords    = (kMaxSrc + 31) / 32 + 96;      // (+ the words segment ends rounded up to 32 bytes may reach beyond the stream)
+// (+ the words segments rounded up to 32 bytes may start and end beyond the stream: segment j starts at j * seglen <= limit + 32 j, so
+// with one segment per thread of the fused walk the last word written lies below nwords + kThreads; ADVICE r5: 96 words covered the
+// 64 segments of the one-wave walk only, and an incompressible 4 MiB block - csize 4210754 - wrote 154 words into its neighbour's slot)
+constexpr uint32_t kBmWords    = (kMaxSrc + 31) / 32 + kThreads + 32;
+static_assert(kThreads >= kSegs, "bitmap slack is sized for the walk with the most segments");
 constexpr uint32_t kWsWords    = (kMetaWords + kBmWords + 3) & ~3u;      // 131.6 K words = 526 KB per block
 constexpr int kResumeCode = -1000000004;     // blocks[b].result while a block waits for the exact walker to finish it (= lz4seg's)
 

@@ -86,7 +86,14 @@ int fourmc_shard_write(int fd, uint32_t magic, int rank, uint64_t first, uint64_
 }
 
 /* Every rank calls this with the same arguments and its own rank, after selecting its device (fourmc_gpu_init).
- * level / magic as fourM{C,Z}compressFilename.  Returns 0; -1 input, -2 output, -3 engine, -4 collective, -5 memory. */
+ * level / magic as fourM{C,Z}compressFilename.  Returns 0; -1 input, -2 output, -3 engine, -4 collective, -5 memory,
+ * -6 another rank failed (this one had nothing to report).
+ * ONE RANK'S FAILURE ENDS THE CALL ON EVERY RANK: the row a rank contributes to the all-gather is {status, sizes...}, a rank that
+ * failed before the exchange still takes part in it (with its status and zeros), and after it every rank that sees a status other
+ * than 0 leaves without writing - with its own code, or -6 when the failure was a peer's.  (Round 5 skipped the collective on the
+ * failing rank: the others then waited in ncclAllGather forever.)  What cannot be reported this way: a rank that cannot stat the
+ * input or cannot allocate its two gather rows returns at once, like a rank that was never started.
+ * FOURMC_SHARD_FAIL_RANK=r (test aid): rank r reports an engine failure without encoding anything. */
 int fourmc_file_compress_sharded(const char* in_name, const char* out_name, int level, uint32_t magic, int rank, int world,
                                  fourmc_allgather_fn allgather, void* ctx)
 {
@@ -123,37 +130,40 @@ int fourmc_file_compress_sharded(const char* in_name, const char* out_name, int 
         if (nbatch > count) nbatch = count ? count : 1;
         in_buf = (uint8_t*)malloc(nbatch * FOURMC_BLOCKSIZE); out_buf = (uint8_t*)malloc(nbatch * FOURMC_BLOCKSIZE);
         blk = (fourmc_block*)calloc(nbatch + 1, sizeof *blk);
-        cs_pad = (uint32_t*)calloc(per + 1, 4); cs_all = (uint32_t*)calloc(per * (uint64_t)(world > 0 ? world : 1) + 1, 4);
+        /* the gather rows first: a rank that has them can always take part in the exchange */
+        cs_pad = (uint32_t*)calloc(per + 2, 4); cs_all = (uint32_t*)calloc((per + 1) * (uint64_t)(world > 0 ? world : 1) + 1, 4);
+        if (!cs_pad || !cs_all) { rc = -5; goto done; }
         usz = (uint32_t*)calloc(count + 1, 4); xs = (uint32_t*)calloc(count + 1, 4);
         off_all = (uint64_t*)calloc(nblocks + 1, 8); poff = (uint64_t*)calloc(count + 1, 8);
-        cs_mine = cs_pad;
-        if (!in_buf || !out_buf || !blk || !cs_pad || !cs_all || !usz || !xs || !off_all || !poff) { rc = -5; goto done; }
+        cs_mine = cs_pad + 1;                                      /* word 0 of the row: this rank's status */
+        if (!in_buf || !out_buf || !blk || !usz || !xs || !off_all || !poff) { rc = -5; goto gather; }
+        { const char* fr = getenv("FOURMC_SHARD_FAIL_RANK"); if (fr && atoi(fr) == rank) { rc = -3; goto gather; } }
         fdin = open(in_name, O_RDONLY);
-        if (fdin < 0) { rc = -1; goto done; }
+        if (fdin < 0) { rc = -1; goto gather; }
         for (b0 = 0; b0 < count; b0 += nbatch) {
             const uint64_t nb = count - b0 < nbatch ? count - b0 : nbatch;
             const uint64_t at = (first + b0) * FOURMC_BLOCKSIZE;
             const uint64_t bytes = ((uint64_t)st.st_size - at < nb * FOURMC_BLOCKSIZE) ? (uint64_t)st.st_size - at : nb * FOURMC_BLOCKSIZE;
             uint64_t got = 0, need = 0;
             while (got < bytes) { ssize_t r = pread(fdin, in_buf + got, (size_t)(bytes - got), (off_t)(at + got)); if (r <= 0) break; got += (uint64_t)r; }
-            if (got != bytes) { close(fdin); rc = -1; goto done; }
+            if (got != bytes) { close(fdin); rc = -1; goto gather; }
             for (b = 0; b < nb; b++) {
                 const uint64_t left = bytes - b * FOURMC_BLOCKSIZE;
                 blk[b].src_off = b * FOURMC_BLOCKSIZE; blk[b].dst_off = b * FOURMC_BLOCKSIZE;
                 blk[b].src_len = (uint32_t)(left < FOURMC_BLOCKSIZE ? left : FOURMC_BLOCKSIZE);
                 blk[b].dst_cap = blk[b].src_len; blk[b].result = 0; blk[b].xxh32 = 0;
             }
-            if (fourmc_host_4mc_encode(in_buf, (size_t)bytes, out_buf, (size_t)(nb * FOURMC_BLOCKSIZE), blk, (uint32_t)nb, codec, codec_level) != FOURMC_OK) { close(fdin); rc = -3; goto done; }
+            if (fourmc_host_4mc_encode(in_buf, (size_t)bytes, out_buf, (size_t)(nb * FOURMC_BLOCKSIZE), blk, (uint32_t)nb, codec, codec_level) != FOURMC_OK) { close(fdin); rc = -3; goto gather; }
             for (b = 0; b < nb; b++) {
                 /* a per-block failure code must not become a 4 GiB size that every rank then builds its offsets on */
-                if (blk[b].result <= 0 || (uint32_t)blk[b].result > blk[b].src_len) { close(fdin); rc = -3; goto done; }
+                if (blk[b].result <= 0 || (uint32_t)blk[b].result > blk[b].src_len) { close(fdin); rc = -3; goto gather; }
                 need += (uint32_t)blk[b].result;
             }
             if (store_len + need > store_cap) {
                 uint8_t* ns;
                 store_cap = (store_len + need) + (store_len + need) / 4 + (1u << 20);
                 ns = (uint8_t*)realloc(store, (size_t)store_cap);
-                if (!ns) { close(fdin); rc = -5; goto done; }
+                if (!ns) { close(fdin); rc = -5; goto gather; }
                 store = ns;
             }
             for (b = 0; b < nb; b++) {
@@ -166,11 +176,22 @@ int fourmc_file_compress_sharded(const char* in_name, const char* out_name, int 
         close(fdin);
     }
 
-    /* the one exchange of the path: per-block compressed sizes, padded to equal counts per rank */
-    if (allgather) { if (allgather(ctx, cs_pad, per * 4, cs_all) != 0) { rc = -4; goto done; } }   /* also with one rank: the launcher's collective is the real one */
-    else if (world <= 1) memcpy(cs_all, cs_pad, per * 4);
-    else { rc = -4; goto done; }
-    {   /* ranks' padded rows -> one array in block order (row r holds blocks [r * per, ..)) : already contiguous */
+gather:
+    /* the one exchange of the path: {status, per-block compressed sizes padded to equal counts per rank} */
+    cs_pad[0] = (uint32_t)rc;
+    if (rc) memset(cs_pad + 1, 0, per * 4);
+    if (allgather) { if (allgather(ctx, cs_pad, (per + 1) * 4, cs_all) != 0) { if (!rc) rc = -4; goto done; } }   /* also with one rank: the launcher's collective is the real one */
+    else if (world <= 1) memcpy(cs_all, cs_pad, (per + 1) * 4);
+    else { if (!rc) rc = -4; goto done; }
+    {   /* every rank sees every status: all leave together (before anything is written) when any of them failed */
+        const uint64_t w = (uint64_t)(world > 0 ? world : 1);
+        uint64_t r;
+        int peer_failed = 0;
+        for (r = 0; r < w; r++) if (cs_all[r * (per + 1)] != 0) peer_failed = 1;
+        if (rc) goto done;
+        if (peer_failed) { rc = -6; goto done; }
+        /* ranks' rows without their status words -> one array in block order (row r holds blocks [r * per, ..)) */
+        for (r = 0; r < w; r++) memmove(cs_all + r * per, cs_all + r * (per + 1) + 1, (size_t)per * 4);
         fourmc_shard_offsets(cs_all, nblocks, off_all);
     }
     fd = open(out_name, O_WRONLY | O_CREAT, 0644);

@@ -78,7 +78,9 @@ void fourmc_shard_range(uint64_t nblocks, int rank, int world, uint64_t* first, 
 void fourmc_shard_offsets(const uint32_t* csize_all, uint64_t nblocks, uint64_t* off_all);
 int  fourmc_shard_write(int fd, uint32_t magic, int rank, uint64_t first, uint64_t count, uint64_t nblocks, const uint64_t* off_all,
                         const uint32_t* csize_all, const uint32_t* usize, const uint32_t* xxh32, const uint8_t* payloads, const uint64_t* payload_off);
-/* 0 ok; -1 input, -2 output, -3 engine (fourmc_gpu_last_error()), -4 collective, -5 memory */
+/* 0 ok; -1 input, -2 output, -3 engine (fourmc_gpu_last_error()), -4 collective, -5 memory, -6 another rank failed.
+ * The row a rank sends through `allgather` is {status, its blocks' compressed sizes}: a rank that failed still takes part in the
+ * exchange, and every rank leaves with an error - before anything is written - when any status is not 0. */
 int  fourmc_file_compress_sharded(const char* in_name, const char* out_name, int level, uint32_t magic, int rank, int world,
                                   fourmc_allgather_fn allgather, void* ctx);
 

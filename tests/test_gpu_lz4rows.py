@@ -15,8 +15,8 @@ pytestmark = pytest.mark.gpu
 RETRY = -1000000003
 
 
-@pytest.fixture(scope="module", params=[4, 5, 7, 8, 9, 10, 11, 12, 13, 14],
-                ids=["rows", "rows-alone", "lanes", "lanes-alone", "wx", "wx-alone", "seg", "seg-alone", "tile", "tile-alone"])
+@pytest.fixture(scope="module", params=[4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16],
+                ids=["rows", "rows-alone", "lanes", "lanes-alone", "wx", "wx-alone", "seg", "seg-alone", "tile", "tile-alone", "ring", "ring-alone"])
 def gpu(request):
     p = pkg(); p.gpu_init()
     research = request.param in (4, 5, 7, 8)          # the row pipeline and the lane-per-sequence path live in the research side build
@@ -24,10 +24,10 @@ def gpu(request):
     before = p.lib().fourmc_gpu_get_lz4_decode_path()
     p.lib().fourmc_gpu_set_lz4_decode_path(request.param)
     assert p.lib().fourmc_gpu_get_lz4_decode_path() == request.param
-    p.rows_alone = request.param in (5, 8, 10, 12, 14)
+    p.rows_alone = request.param in (5, 8, 10, 12, 14, 16)
     # below these sizes a path leaves the block to the exact walker (seg: lz4seg.h kMinSrc / kMinCap; "alone" = blocks handed
     # back entirely stay RETRY - the exact walker still finishes the last bytes of the blocks the segment path executed)
-    p.min_cap, p.min_src = (256, 256) if request.param in (12, 14) else (64, 8)
+    p.min_cap, p.min_src = (256, 256) if request.param in (12, 14, 16) else (64, 8)
     yield p
     p.lib().fourmc_gpu_set_lz4_decode_path(before)
     if research: p.use_research(False)
@@ -102,3 +102,29 @@ def test_decode_mutated_streams_match_oracle(gpu):
             assert np.array_equal(out[doffs[i]: doffs[i] + want_r], want), i
         assert doffs[i] == 0 or out[doffs[i] - 1] == 0xA5, i
         assert np.all(out[doffs[i] + caps[i]: doffs[i] + caps[i] + 7] == 0xA5), i
+
+
+def test_incompressible_full_blocks_raw_mode(gpu):
+    """Several consecutive incompressible 4 MiB blocks in RAW mode (the JNI / fourmc_gpu_lz4_decompress route: the container would
+    store them).  Their streams are the longest a block can have (one token, 4 MiB of literals), which is where the fused walk of
+    the tile path wrote bitmap words beyond its block's workspace slot; a compressible block decoded in the same launch
+    right behind each of them shows a neighbour's slot is left alone."""
+    rng = np.random.default_rng(0x4D43)
+    text = corpus(B)
+    ins, comps = [], []
+    for i in range(3):
+        noise = rng.integers(0, 256, B, dtype=np.uint8)
+        r, comp = orc_compress(noise)
+        assert r >= B                                                    # an LZ4 stream longer than the block
+        ins.append(noise); comps.append(comp)
+        r, comp = orc_compress(text)
+        ins.append(text); comps.append(comp)
+    caps = [B] * len(ins)
+    res, out, doffs = par._decode(gpu, comps, caps)
+    for i in range(len(ins)):
+        if gpu.rows_alone and res[i] == RETRY:
+            continue
+        assert res[i] == B, (i, int(res[i]))
+        bad = np.nonzero(out[doffs[i]: doffs[i] + B] != ins[i])[0]
+        assert len(bad) == 0, (i, int(bad[0]), len(bad))
+        assert np.all(out[doffs[i] + B: doffs[i] + B + 7] == 0xA5), i

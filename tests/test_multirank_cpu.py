@@ -161,3 +161,44 @@ def test_rank_reports_world2():
                 assert verdict == "ok" and a == [0, 1] and b[0] == 12 and b[1] > 12, (rank, verdict, a, b)
             else:
                 assert verdict == "bad" and "rank 1" in a, (rank, verdict, a)
+
+
+# ---- a rank that fails must not leave the others waiting in the collective (4mc_amd/csrc/shard.c) ----------
+def _failing_worker(rank, world, port, src, out, q):
+    import ctypes as C
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), FOURMC_SHARD_FAIL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, helpers.ROOT)
+    p = helpers.pkg(); L = p.lib()
+    AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+    seen = []
+    def allgather(ctx, send, nbytes, recv):
+        a = torch.from_numpy(np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), (nbytes,)).copy())
+        o = torch.empty(nbytes * world, dtype=torch.uint8)
+        dist.all_gather_into_tensor(o, a)
+        C.memmove(recv, o.numpy().ctypes.data, nbytes * world)
+        seen.append(nbytes)
+        return 0
+    cb = AG(allgather)
+    L.fourmc_file_compress_sharded.restype = C.c_int
+    L.fourmc_file_compress_sharded.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    rc = L.fourmc_file_compress_sharded(src.encode(), out.encode(), 1, p.MAGIC_4MC, rank, world, C.cast(cb, C.c_void_p), None)
+    q.put((rank, rc, seen))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_a_failing_rank_ends_the_call_on_every_rank(tmp_path):
+    """One block, two ranks: rank 0 owns it and reports an engine failure (FOURMC_SHARD_FAIL_RANK, no device needed); rank 1 owns
+    nothing and has nothing to fail on.  Both take part in the ONE all-gather (its rows carry a status word), both come back - rank 0
+    with its own code (-3), rank 1 with -6 "another rank failed" - and nothing is written."""
+    src = tmp_path / "one_block.bin"; src.write_bytes(helpers.corpus(100000).tobytes())
+    out = tmp_path / "never.4mc"
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+    ps = [ctx.Process(target=_failing_worker, args=(r, 2, port, str(src), str(out), q)) for r in range(2)]
+    [p.start() for p in ps]
+    got = sorted(q.get(timeout=120) for _ in range(2))           # a hang (round 5: the peers waited in the collective) ends here
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    assert [(g[0], g[1]) for g in got] == [(0, -3), (1, -6)], got
+    assert all(g[2] == [(1 + 1) * 4] for g in got), got           # one exchange each: {status, one size}
+    assert not out.exists()
