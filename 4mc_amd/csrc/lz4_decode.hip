@@ -247,7 +247,6 @@ void lz4_decode_exact_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
 // Long literal runs / long matches (length nibble 15) and the block tail take the one-sequence
 // path, which is already 64 bytes wide per step.
 constexpr int kRetry = -1000000003;      // internal: "let the exact kernel decide"
-constexpr int kOwnBytes = 4096;          // cap on the bytes one batch may produce (owner map size)
 
 // Wave64 inclusive scans on the VALU cross-lane network (DPP row shifts + row broadcasts, no LDS):
 // 4 row_shr steps scan each row of 16 lanes, row_bcast15 / row_bcast31 carry the row totals.
@@ -270,294 +269,9 @@ __device__ __forceinline__ uint32_t scan_max(uint32_t v, int)      // values are
     return v;
 }
 
-// The fast path runs on 1 + kCopiers wavefronts per block: what the tokens say (lengths, offsets, where each sequence's
-// output starts) depends on the compressed stream alone, so a PARSER wave walks the stream and hands finished records
-// (a batch of sequences, or one general sequence) to COPIER waves through a ring in LDS; record k belongs to copier
-// k % kCopiers.  The output ranges of records are disjoint, so copiers only meet where a match reads what a record still
-// in flight on another copier produces: the parser works out, per record, the youngest earlier record its sources touch
-// (`need`), and a copier starts record k once every record <= need is complete (done[] counters, release / acquire at
-// workgroup scope; the waves of a workgroup share the CU's L1, so completed stores are visible to plain loads).
-constexpr int kCopiers = 2;
-constexpr int kRec = 8;
-enum : uint32_t { kRecBatch = 1, kRecGeneral = 2, kRecEnd = 3, kRecRetry = 4 };
-struct Rec {
-    uint32_t type;
-    uint32_t T;              // batch: output bytes; general: match length (0: the block's last, literal-only sequence)
-    uint32_t op;             // output position where the record starts (end: the decoded size)
-    uint32_t lit, lit_ip, off;      // general sequence
-    int      need;           // every record with an index <= need has to be complete before this one reads the output
-    unsigned long long tokmask;     // batch: lanes (window slots) that are tokens
-    uint32_t pack[64];       // batch, per token lane: output start in the batch | literals << 13 | (token header - 1) << 19
-    uint32_t offb[64];       // batch: match offset | this slot's stream byte << 16
-};
-struct DSync {
-    uint32_t produced;               // records published
-    uint32_t total;                  // number of records of the block, once the parser has stopped (else 0xFFFFFFFF)
-    uint32_t consumed[kCopiers];     // copier w has taken every record of its own below this index into registers
-    int      done[kCopiers];         // copier w has completed every record of its own below this index
-    uint32_t failed;                 // someone gave up: the retry kernel decides
-    int      end_value;              // the End record's decoded size
-};
-__device__ __forceinline__ uint32_t ld_acq(uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ int ld_acq(int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void st_rel(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void st_rel(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-constexpr uint32_t kSpinLimit = 1u << 24;    // a wait that long means the other wave is gone: give up (-> retry kernel) instead of hanging
-
-// PARSER wave: same acceptance rules as before, no output access at all
-__device__ void lz4_fast_parse(const uint8_t* src, int csize, int cap, uint8_t* lds, Rec* recs, DSync* sy, int lane)
-{
-    uint32_t k = 0;                                                     // records published
-    uint32_t op_km1 = 0, op_km2 = 0;                                    // where the two previous records start
-    auto stop = [&](bool failed) { if (lane == 0) { if (failed) sy->failed = 1; st_rel(&sy->total, k); } };
-    auto slot = [&]() -> Rec* {                                         // next record, once its copier has freed it
-        if (k >= uint32_t(kRec)) {
-            uint32_t* c = &sy->consumed[(k - kRec) % kCopiers];
-            for (uint32_t spins = 0; ld_acq(c) <= k - kRec; ) { __builtin_amdgcn_s_sleep(1); if (++spins > kSpinLimit) { stop(true); return nullptr; } }
-        }
-        return recs + (k % kRec);
-    };
-    auto publish = [&](uint32_t at) { if (lane == 0) st_rel(&sy->produced, k + 1); k++; op_km2 = op_km1; op_km1 = at; };
-    // the youngest earlier record whose output [its start, this record's start) a source range ending at `reach` touches
-    auto need_of = [&](uint32_t reach) -> int {
-        if (reach > op_km1) return int(k) - 1;
-        if (kCopiers >= 3 && reach > op_km2) return int(k) - 2;
-        return int(k) - kCopiers;
-    };
-    auto finish = [&](uint32_t type, int value) {
-        Rec* r = slot(); if (!r) return;
-        if (lane == 0) { r->type = type; r->op = uint32_t(value); r->need = int(k) - kCopiers; }
-        publish(uint32_t(value)); stop(false);
-    };
-    if (cap < 64 || csize < 1) { finish(kRecRetry, 0); return; }
-    Stream s; s.init(src, csize, lds, lane);
-    const int iend = csize, oend = cap;
-    int ip = 0, op = 0;
-    for (;;) {
-        ip = __builtin_amdgcn_readfirstlane(ip); op = __builtin_amdgcn_readfirstlane(op); k = uint32_t(__builtin_amdgcn_readfirstlane(int(k)));
-        op_km1 = uint32_t(__builtin_amdgcn_readfirstlane(int(op_km1))); op_km2 = uint32_t(__builtin_amdgcn_readfirstlane(int(op_km2)));
-        s.fill_hi = __builtin_amdgcn_readfirstlane(s.fill_hi); s.la_pos = __builtin_amdgcn_readfirstlane(s.la_pos);
-        // ---------------------------------------------------------------- batch of sequences inside one window
-        if (ip + 64 + 16 <= iend && op + kOwnBytes + 64 + 16 <= oend) {
-            // w: 4 consecutive stream bytes per lane (lane j = bytes ip+j .. ip+j+3)
-            s.reload(ip);
-            const int q0 = ip + s.delta + lane;
-            const uint32_t w = s.la | (uint32_t(s.ring[(q0 + 1) & (kRing - 1)]) << 8) |
-                               (uint32_t(s.ring[(q0 + 2) & (kRing - 1)]) << 16) | (uint32_t(s.ring[(q0 + 3) & (kRing - 1)]) << 24);
-            const uint32_t b = w & 0xff, b1 = (w >> 8) & 0xff;
-            const uint32_t L0 = b >> 4, M0 = b & 15;
-            // literal count: nibble, or 15 + ONE continuation byte (longer runs take the general path)
-            const uint32_t L = (L0 == 15) ? 15 + b1 : L0;
-            const uint32_t lhdr = (L0 == 15) ? 2 : 1;                   // token (+ continuation byte)
-            const uint32_t offpos = uint32_t(lane) + lhdr + L;         // window slot of the offset's low byte
-            const uint32_t wo = __shfl(w, offpos & 63);                 // offset lo, hi, first match continuation byte
-            const uint32_t e1 = (wo >> 16) & 0xff;
-            const uint32_t ml = (M0 == 15) ? 19 + e1 : M0 + 4;
-            const uint32_t nxt = offpos + 2 + (M0 == 15 ? 1 : 0);
-            const bool ok = (L0 != 15 || b1 != 255) && (M0 != 15 || e1 != 255) && nxt <= 64;
-            // Token chain over a per-lane jump table, without a branch per token: a token never starts in slots 62 / 63 (it needs
-            // three bytes), so slot 63 is an absorbing end state and the walk is a straight run of v_readlane + s_bitset1
-            // pairs, checked for the end every 7 tokens (a window holds at most 21).
-            const uint32_t jump = ok ? nxt : 128u + uint32_t(lane);     // 64: the window ends behind this token; >= 128: no batch token
-            const uint32_t hop = lane == 63 ? 63u : min(jump, 63u);
-            unsigned long long tokmask = 0;
-            uint32_t pos = 0;
-            for (int round = 0; round < 3 && pos != 63; round++) {
-#pragma unroll
-                for (int i = 0; i < 7; i++) {
-                    asm volatile("s_bitset1_b64 %0, %1" : "+s"(tokmask) : "s"(pos));
-                    pos = uint32_t(__builtin_amdgcn_readlane(int(hop), int(pos)));
-                }
-            }
-            tokmask &= ~(1ull << 63);
-            {   // where the chain left the window: behind its last token (64), or at a slot that is no batch token (the batch ends before it)
-                const uint32_t last = 63u - uint32_t(__builtin_clzll(tokmask));
-                const uint32_t j = uint32_t(__builtin_amdgcn_readlane(int(jump), int(last)));
-                if (j >= 128) { tokmask &= ~(1ull << last); pos = last; } else pos = j;
-            }
-            if (tokmask) {
-                bool is_tok = (tokmask >> lane) & 1;
-                uint32_t sz = is_tok ? L + ml : 0;
-                uint32_t incl = scan_add(sz, lane);
-                uint32_t T = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
-                if (T > uint32_t(kOwnBytes)) {                           // cap the batch (first sequence always fits)
-                    tokmask = __ballot(is_tok && incl <= uint32_t(kOwnBytes));
-                    const int last = 63 - __builtin_clzll(tokmask);
-                    pos = uint32_t(__builtin_amdgcn_readlane(int(nxt), last));
-                    T = uint32_t(__builtin_amdgcn_readlane(int(incl), last));
-                    is_tok = (tokmask >> lane) & 1;
-                    sz = is_tok ? sz : 0;
-                }
-                const uint32_t ostart = incl - sz;
-                const uint32_t off = wo & 0xffff;
-                const uint32_t mstart = uint32_t(op) + ostart + L;       // where this sequence's match starts
-                const bool bad = is_tok && (off == 0 || off > mstart);
-                if (__ballot(bad)) { finish(kRecRetry, 0); return; }
-                // how far the sources that lie before this record reach
-                const uint32_t reach1 = (is_tok && mstart - off < uint32_t(op)) ? min(mstart - off + ml, uint32_t(op)) : 0u;
-                const uint32_t reach = uint32_t(__builtin_amdgcn_readlane(int(scan_max(reach1, lane)), 63));
-                Rec* r = slot();
-                if (!r) return;
-                r->pack[lane] = ostart | (L << 13) | ((lhdr - 1) << 19);
-                r->offb[lane] = off | (b << 16);
-                if (lane == 0) { r->type = kRecBatch; r->T = T; r->op = uint32_t(op); r->tokmask = tokmask; r->need = need_of(reach); }
-                publish(uint32_t(op));
-                op += int(T);
-                ip += int(pos);
-                continue;
-            }
-        }
-        // ---------------------------------------------------------------- one general sequence (strict rules)
-        if (ip >= iend) { finish(kRecRetry, 0); return; }
-        if (ip < s.la_pos || ip + 24 > s.la_pos + 64) s.reload(ip);
-        const uint32_t token = s.get(ip); ip++;
-        int lit = int(token >> 4), mlen = int(token & 15);
-        if (lit == 15) { if (!more_len(s, ip, iend - 15, true, lit)) { finish(kRecRetry, 0); return; } }
-        if (op + lit > oend - 12 || ip + lit > iend - 8) {
-            if (ip + lit != iend || op + lit > oend) { finish(kRecRetry, 0); return; }
-            Rec* r = slot();
-            if (!r) return;
-            if (lane == 0) { r->type = kRecGeneral; r->T = 0; r->op = uint32_t(op); r->lit = uint32_t(lit); r->lit_ip = uint32_t(ip); r->off = 0; r->need = int(k) - kCopiers; }
-            publish(uint32_t(op));
-            finish(kRecEnd, op + lit);
-            return;
-        }
-        const int lit_ip = ip;
-        ip += lit;
-        const int op2 = op + lit;
-        const int off = int(s.get(ip)) | (int(s.get(ip + 1)) << 8);
-        ip += 2;
-        if (mlen == 15) { if (!more_len(s, ip, iend - 4, false, mlen)) { finish(kRecRetry, 0); return; } }
-        mlen += 4;
-        if (off == 0 || off > op2 || op2 + mlen > oend - 5) { finish(kRecRetry, 0); return; }
-        Rec* r = slot();
-        if (!r) return;
-        const uint32_t reach = (op2 - off < op) ? uint32_t(min(op2 - off + mlen, op)) : 0u;
-        if (lane == 0) { r->type = kRecGeneral; r->T = uint32_t(mlen); r->op = uint32_t(op); r->lit = uint32_t(lit); r->lit_ip = uint32_t(lit_ip); r->off = uint32_t(off); r->need = need_of(reach); }
-        publish(uint32_t(op));
-        op = op2 + mlen;
-    }
-}
-
-// COPIER wave w: executes records w, w + kCopiers, ... in order
-__device__ void lz4_fast_copy(const uint8_t* src, uint8_t* dst, Rec* recs, DSync* sy, uint8_t* own, int w, int lane)
-{
-    auto leave = [&](bool failed) {                                      // nobody may wait for this wave any more
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) { if (failed) sy->failed = 1; st_rel(&sy->done[w], 0x7FFFFFFF); st_rel(&sy->consumed[w], 0xFFFFFFFFu); }
-    };
-    for (uint32_t k = uint32_t(w);; k += kCopiers) {
-        for (uint32_t spins = 0; ld_acq(&sy->produced) <= k; ) {
-            if (ld_acq(&sy->total) <= k) { leave(false); return; }
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > kSpinLimit) { leave(true); return; }
-        }
-        Rec* r = recs + (k % kRec);
-        const uint32_t type = r->type, T = r->T;
-        const int op = int(r->op), need = r->need;
-        const unsigned long long tokmask = r->tokmask;
-        const uint32_t pack = r->pack[lane], ob = r->offb[lane];
-        const uint32_t lit = r->lit, lit_ip = r->lit_ip, goff = r->off;
-        if (lane == 0) st_rel(&sy->consumed[w], k + 1);                 // everything of the record is in registers now
-        if (type == kRecEnd) { if (lane == 0) sy->end_value = op; leave(false); return; }
-        if (type != kRecBatch && type != kRecGeneral) { leave(true); return; }
-        // the records this one reads from have to be complete
-        for (int o = 0; o < kCopiers; o++) {
-            if (o == w) continue;
-            for (uint32_t spins = 0; ld_acq(&sy->done[o]) <= need; ) { __builtin_amdgcn_s_sleep(1); if (++spins > kSpinLimit) { leave(true); return; } }
-        }
-        if (type == kRecBatch) {
-            const uint32_t off = ob & 0xffff, b = ob >> 16;
-            const bool is_tok = (tokmask >> lane) & 1;
-            // owner map: own[o] = token lane + 1 at the first output byte of each sequence
-            for (uint32_t i = 4u * lane; i < T; i += 256) *reinterpret_cast<uint32_t*>(own + i) = 0;
-            if (is_tok) own[pack & 0x1FFF] = uint8_t(lane + 1);
-            // One 64-byte step of output is kept PENDING in registers: it is stored only after the next step's loads
-            // have been issued, so a step waits for its own loads (vmcnt leaves the younger store outstanding) and never
-            // for a store acknowledgement.  Sources that fall into the pending step are forwarded from its registers.
-            uint32_t carry = 0, pv = 0;
-            auto step = [&](uint32_t c0, auto first) {
-                const uint32_t o = c0 + lane;
-                const bool live = o < T;
-                uint32_t m = live ? uint32_t(own[o]) : 0u;
-                m = max(scan_max(m, lane), carry);
-                carry = uint32_t(__builtin_amdgcn_readlane(int(m), 63));
-                const int tl = int(m) - 1;                                  // owning token lane
-                const uint32_t P = __shfl(pack, tl & 63);
-                const uint32_t offt = __shfl(off, tl & 63);
-                const uint32_t rel = o - (P & 0x1FFF);
-                const uint32_t Lt = (P >> 13) & 63, hdr = 1 + ((P >> 19) & 1);
-                const bool is_lit = rel < Lt;
-                uint32_t v = __shfl(b, (tl + int(hdr) + int(rel)) & 63);    // literal byte from the window
-                const int sp = op + int(o) - int(offt);                     // absolute source of a match byte
-                const int cs = op + int(c0);
-                const int pn = decltype(first)::value ? 0 : 64;             // bytes pending (the previous step was a full one)
-                const bool is_match = live && !is_lit;
-                const bool from_mem = is_match && sp < cs - pn;
-                const bool in_pend = is_match && sp >= cs - pn && sp < cs;
-                const uint32_t ld = dst[from_mem ? sp : 0];                 // issue this step's loads (branch-free) ...
-                if constexpr (!decltype(first)::value) {
-                    dst[cs - 64 + lane] = uint8_t(pv);                      // ... then store the previous step
-                    const uint32_t fw = __shfl(pv, (sp - (cs - 64)) & 63);
-                    if (in_pend) v = fw;
-                }
-                if (from_mem) v = ld;
-                bool done = !is_match || from_mem || in_pend;
-                int dep = sp - cs;                                          // lane that produces my byte
-                while (__ballot(!done)) {                                   // pointer jumping, <= 6 rounds
-                    const int d = dep & 63;
-                    const uint32_t v2 = __shfl(v, d);
-                    const int dn = __shfl(int(done), d);
-                    const int dd = __shfl(dep, d);
-                    if (!done) { if (dn) { v = v2; done = true; } else dep = dd; }
-                }
-                pv = v;
-            };
-            step(0u, std::true_type{});
-            uint32_t c0 = 64;
-            for (; c0 < T; c0 += 64) step(c0, std::false_type{});
-            if (uint32_t(lane) < T - (c0 - 64)) dst[op + int(c0 - 64) + lane] = uint8_t(pv);
-        } else {
-            wave_copy(dst + op, src + lit_ip, int(lit), lane);
-            if (T) copy_match(dst, op + int(lit), int(goff), int(T), lane);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) st_rel(&sy->done[w], int(k) + kCopiers);
-    }
-}
-
-// retry_only = 0: fast path for every block (container rules as in the exact kernel);
-__global__ __launch_bounds__(64 * (kCopiers + 1))
-void lz4_decode_fast_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base,
-                            fourmc_block* blocks, uint32_t nblocks, int container_mode, const uint32_t* pick, uint32_t want)
-{
-    if (pick && *pick != want) return;                                  // (see lz4_pick_kernel)
-    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
-    __shared__ __attribute__((aligned(16))) uint8_t own[kCopiers][kOwnBytes];
-    __shared__ Rec recs[kRec];
-    __shared__ DSync sy;
-    const uint32_t b = blockIdx.x;
-    if (b >= nblocks) return;
-    const fourmc_block blk = uniform_block(blocks[b]);
-    if (container_mode && blk.result == FOURMC_BLK_BADSUM) return;
-    if (threadIdx.x == 0) {
-        sy.produced = 0; sy.total = 0xFFFFFFFFu; sy.failed = 0; sy.end_value = kRetry;
-        for (int w = 0; w < kCopiers; w++) { sy.consumed[w] = 0; sy.done[w] = w; }
-    }
-    __syncthreads();
-    const uint8_t* src = src_base + blk.src_off;
-    uint8_t* dst = dst_base + blk.dst_off;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
-    const bool stored = container_mode && blk.src_len == blk.dst_cap;
-    if (stored) {
-        if (wave == 0) { wave_copy(dst, src, int(blk.src_len), lane); if (lane == 0) blocks[b].result = int(blk.src_len); }
-        return;
-    }
-    if (wave == kCopiers) lz4_fast_parse(src, int(blk.src_len), int(blk.dst_cap), ring, recs, &sy, lane);
-    else lz4_fast_copy(src, dst, recs, &sy, own[wave], wave, lane);
-    __syncthreads();
-    if (threadIdx.x == 0) blocks[b].result = sy.failed ? kRetry : sy.end_value;
-}
+#ifdef FOURMC_RESEARCH
+#include "../../tools/research/lz4_trio.inc"
+#endif
 
 // second pass: blocks the fast path handed back (result == kRetry) are decoded by the exact walker
 __global__ __launch_bounds__(64)
@@ -613,8 +327,8 @@ extern "C" size_t fourmc_lz4_parse_work_bytes(uint32_t n)
 extern "C" int fourmc_gpu_get_lz4_decode_path(void);
 // Which kernels a launch of n blocks runs, in pieces of how many blocks, with how much workspace: resolved ONCE per call (the
 // lease and the launch see the same answer even if another thread changes the selection in between).  shrink: how often the
-// workspace could not be had - the pieces halve; below 64 blocks an automatic choice falls back to the walk + window copier,
-// which needs no workspace.
+// workspace could not be had - the pieces halve; below 64 blocks an automatic choice falls back to the exact walker, which needs
+// no workspace (until round 5 the fallback was the walk + window copier, which left the product in round 6).
 // "auto" by launch size (measured on the container corpus, tools/decode_sizes.sh: 128 .. 512 blocks 13.5 - 15 ms through the tile
 // path against 30 ms through either other path, 1024: 24 / 31 ms, 1536: 34 / 34 ms, 2048: 43 / 35 ms, 16 384: 299 / 172 ms): the tile
 // path - one workgroup per block, two per CU, the shortest chain per block - up to kAutoTileMax blocks, the segment-parallel path
@@ -635,7 +349,7 @@ extern "C" fourmc_lz4_plan fourmc_lz4_decode_plan(uint32_t n, uint32_t shrink)
         if (b < 64) b = 64;                                       // (FOURMC_TILE_BATCH / FOURMC_SEG_BATCH below 64: an explicit choice would fail before any allocation)
         for (uint32_t k = 0; k < shrink && b >= 64; k++) b /= 2;
         if (b < 64) {
-            if (automatic) { pl.path = 9; return pl; }
+            if (automatic) { pl.path = 2; return pl; }
             pl.ok = 0; return pl;
         }
         pl.batch = n < b ? (n ? n : 1) : b;
@@ -648,27 +362,22 @@ extern "C" fourmc_lz4_plan fourmc_lz4_decode_plan(uint32_t n, uint32_t shrink)
     return pl;
 }
 
-// Which fast path serves LZ4 decode launches.  Both produce identical results (anything irregular goes to the exact
-// walker either way); they differ in how a block is parallelised:
-//   6  "auto"            9: the default since the end of round 3
-//   9  "wx"              walk wave + sequence / literal wave + window copier (plan and execute waves), lz4_rows.hip (K1wx)
-//   4  "rows"            row-parallel pipeline of four waves per block (lz4_rows.hip)
-//   7  "lanes"           one lane per sequence, wide pieces (lz4_rows.hip, K1w): 84 ms on the S-mix, opt-in
-//   0  "wave trio"       one parser wave walks the token chain, two copier waves execute (lz4_decode_fast_kernel)
-//   1  "block parallel"  parse kernel (token chain found by the whole workgroup, records in HBM) + executor kernel
-//                        (16 KiB LDS ring, literal / chain / flush waves)            lz4_parse.hip, lz4_exec.hip
-// Measured on 2048 x 4 MiB of S-mix (profiles/r02_*): 0 = 57 ms, 1 = 38 + 52 ms, so 0 stays the default; the
-// environment variable FOURMC_DECODE (auto | wx | rows | lanes | exact | trio | par | paronly | rowsonly | lanesonly | wxonly) or fourmc_gpu_set_lz4_decode_path() select.
+// Which path serves LZ4 decode launches.  All produce identical results (anything irregular goes to the exact walker either way):
+//   6  "auto"            the tile path up to FOURMC_TILE_MAX blocks per launch, the segment-parallel path above
+//   13 "tile"            one workgroup per block, the LZ4 window in LDS (lz4_tile.hip)            14: without the exact walker behind it (test aid)
+//   11 "seg"             walk kernel (one lane per stream segment) + batch executor (lz4_seg.hip) 12: test aid
+//   2  "exact"           the exact walker alone (one wave per block; also what an automatic choice ends at without any workspace)
+// The research side build (make research: libhadoop-4mc-research.so, -DFOURMC_RESEARCH; sources under tools/research/) adds the
+// measured alternatives that no launch of the product selects: 0 wave trio, 1 / 3 block-parallel parse + executor, 4 / 5 row
+// pipeline, 7 / 8 lane per sequence, 9 / 10 walk + window copier (K1wx: the default of rounds 3 - 4), 15 / 16 group executor (round 6).
+// FOURMC_DECODE (auto | tile | seg | exact, and the research names) or fourmc_gpu_set_lz4_decode_path() select.
 static int g_decode_path = -1;
-// The product library carries three decoders: the exact walker (2), the walk + window copier (9, 10) and the segment-parallel path
-// (11, 12); 6 = auto.  The wave trio, the row pipeline, the lane-per-sequence path and the block-parallel pair are measured
-// alternatives kept in the research side build (make research: libhadoop-4mc-research.so, -DFOURMC_RESEARCH).
 static bool path_known(int path)
 {
 #ifdef FOURMC_RESEARCH
     return path >= 0 && path <= 16;
 #else
-    return path == 2 || path == 6 || (path >= 9 && path <= 16);
+    return path == 2 || path == 6 || (path >= 11 && path <= 14);
 #endif
 }
 extern "C" void fourmc_gpu_set_lz4_decode_path(int path) { g_decode_path = path_known(path) ? path : 6; }
@@ -706,8 +415,12 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
     uint8_t* d8 = static_cast<uint8_t*>(d_dst);
     const int path = plan->path;
     // (6 "auto" was resolved by fourmc_lz4_decode_plan: the tile path - lz4_tile.hip, one workgroup per block with the LZ4 window in
-    // LDS - up to 1536 blocks, the segment-parallel path above; the walk + window copier, K1wx, when neither can have its workspace)
+    // LDS - up to 1536 blocks, the segment-parallel path above; the exact walker when neither can have its workspace)
+#ifdef FOURMC_RESEARCH
     if (path >= 11 && path <= 16) {
+#else
+    if (path >= 11 && path <= 14) {
+#endif
         // walk + executor (tile: lz4_tile.hip, segment-parallel: lz4_seg.hip), then the exact walker for the last bytes of every
         // block and for whatever was handed back; 12 / 14: test aid, blocks handed back stay kRetry
         const bool tile = path == 13 || path == 14, ring = path >= 15;
@@ -715,9 +428,15 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
         if (plan->work_bytes == 0 || d_work == nullptr) return hipErrorInvalidValue;
         for (uint32_t b0 = 0; b0 < n; b0 += step) {
             const uint32_t m = n - b0 < step ? n - b0 : step;
+#ifdef FOURMC_RESEARCH
             hipError_t e = tile ? fourmc_launch_lz4_tile(d_src, d_dst, d_blocks + b0, m, container_mode, d_work, stream)
                          : ring ? fourmc_launch_lz4_ring(d_src, d_dst, d_blocks + b0, m, container_mode, d_work, stream)
                                 : fourmc_launch_lz4_seg(d_src, d_dst, d_blocks + b0, m, container_mode, d_work, stream);
+#else
+            (void)ring;
+            hipError_t e = tile ? fourmc_launch_lz4_tile(d_src, d_dst, d_blocks + b0, m, container_mode, d_work, stream)
+                                : fourmc_launch_lz4_seg(d_src, d_dst, d_blocks + b0, m, container_mode, d_work, stream);
+#endif
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(lz4_decode_resume_kernel, dim3(m), dim3(64), 0, stream, s8, d8, d_blocks + b0, m, container_mode,
                                static_cast<const uint32_t*>(d_work), (path == 11 || path == 13 || path == 15) ? 1 : 0,
@@ -729,13 +448,13 @@ extern "C" hipError_t fourmc_launch_lz4_decode(const void* d_src, void* d_dst, f
         hipLaunchKernelGGL(lz4_decode_exact_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
         return hipGetLastError();
     }
+#ifdef FOURMC_RESEARCH
     if (path == 9 || path == 10) {
         hipError_t e = fourmc_launch_lz4_wx(d_src, d_dst, d_blocks, n, container_mode, stream, nullptr, 0);
         if (e != hipSuccess || path == 10) return e;      // 10: test aid, shows what the path alone did
         hipLaunchKernelGGL(lz4_decode_retry_kernel, dim3(n), dim3(64), 0, stream, s8, d8, d_blocks, n, container_mode);
         return hipGetLastError();
     }
-#ifdef FOURMC_RESEARCH
     if (path == 4 || path == 5) {
         hipError_t e = fourmc_launch_lz4_rows(d_src, d_dst, d_blocks, n, container_mode, stream);
         if (e != hipSuccess || path == 5) return e;       // 5: test aid, shows what the row pipeline alone did

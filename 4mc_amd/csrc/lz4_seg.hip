@@ -645,6 +645,11 @@ void lz4_seg_exec_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_base
     }
 }
 
+
+#ifdef FOURMC_RESEARCH
+#include "../../tools/research/lz4_seg_exec2.inc"
+#endif
+
 } // namespace
 
 extern "C" size_t fourmc_lz4_seg_work_bytes(uint32_t n) { return size_t(n) * lz4seg::kWsWords * 4u; }
@@ -686,6 +691,15 @@ extern "C" hipError_t fourmc_launch_lz4_seg(const void* d_src, void* d_dst, four
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(lz4_seg_walk_kernel, dim3(n), dim3(64), 0, stream, static_cast<const uint8_t*>(d_src), d_blocks, n,
                        container_mode, static_cast<uint32_t*>(d_work));
+#ifdef FOURMC_RESEARCH
+    // FOURMC_SEG_EXEC=2 (research build): the pipelined executor of tools/research/lz4_seg_exec2.inc
+    static const int which = [] { const char* e = getenv("FOURMC_SEG_EXEC"); return e ? atoi(e) : 1; }();
+    if (which == 2) {
+        hipLaunchKernelGGL(lz4_seg_exec2_kernel, dim3(n), dim3(64), 0, stream, static_cast<const uint8_t*>(d_src),
+                           static_cast<uint8_t*>(d_dst), d_blocks, n, container_mode, static_cast<uint32_t*>(d_work));
+        return hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL(lz4_seg_exec_kernel, dim3(n), dim3(64), 0, stream, static_cast<const uint8_t*>(d_src),
                        static_cast<uint8_t*>(d_dst), d_blocks, n, container_mode, static_cast<uint32_t*>(d_work));
     return hipGetLastError();

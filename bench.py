@@ -439,15 +439,16 @@ def main():
         return names.get(path, "path %d" % path)
 
     def decode_path_comparison():
-        """The three LZ4 decode fast paths of the product on the same launch (identical results): the walk + window copier (K1wx), the
-        segment-parallel path and the tile path; HIP events around the decode_blocks call minus the hash launch.  "auto" (the default)
-        takes the tile path up to 1536 blocks per launch, the segment-parallel path above.  (The older designs live in the research
-        side build: tools/k1_timing.py.)"""
+        """The LZ4 decode fast paths of the product on the same launch (identical results): the segment-parallel path and the tile path
+        (and the exact walker, the path without a workspace); HIP events around the decode_blocks call minus the hash launch.  "auto"
+        (the default) takes the tile path up to 1536 blocks per launch, the segment-parallel path above.  (Every other design -
+        walk + window copier, wave trio, row pipeline, group executor, pipelined executor - lives under tools/research/ and in the
+        research side build only.)"""
         out = {}
         before = L.fourmc_gpu_get_lz4_decode_path()
         vb = state["dec"].clone()
         x_ver = timed(lambda: p.binding.check(L.fourmc_gpu_xxh32(d_image.data_ptr(), vb.data_ptr(), nb, 0, sp), "xxh32"))
-        for path, name in ((9, "walk_window_copier"), (11, "segment_parallel"), (13, "tile")):
+        for path, name in ((2, "exact_walker"), (11, "segment_parallel"), (13, "tile")):
             L.fourmc_gpu_set_lz4_decode_path(path)
             dd = state["dec"].clone(); dd[:, 6] = 0
             t = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_image.data_ptr(), d_out.data_ptr(), dd.data_ptr(), nb, 0, sp), name))
@@ -456,7 +457,7 @@ def main():
         for m in (256, 1024):                          # launches that do not fill the chip: what the file API sends
             if m >= nb: continue
             xv = timed(lambda: p.binding.check(L.fourmc_gpu_xxh32(d_image.data_ptr(), state["dec"][:m].clone().data_ptr(), m, 0, sp), "xxh32"))
-            for path, name in ((9, "walk_window_copier"), (11, "segment_parallel"), (13, "tile")):
+            for path, name in ((2, "exact_walker"), (11, "segment_parallel"), (13, "tile")):
                 L.fourmc_gpu_set_lz4_decode_path(path)
                 dd = state["dec"][:m].clone(); dd[:, 6] = 0
                 t = timed(lambda: p.binding.check(L.fourmc_gpu_4mc_decode_blocks(d_image.data_ptr(), d_out.data_ptr(), dd.data_ptr(), m, 0, sp), name))

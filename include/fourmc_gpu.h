@@ -84,8 +84,9 @@ int fourmc_gpu_lz4_compress_mc(const void* d_src, void* d_dst, fourmc_block* d_b
 void fourmc_gpu_set_lz4_encode_mode(int mode);
 int  fourmc_gpu_get_lz4_encode_mode(void);
 /* Tuning knob (not part of the reference boundary): which LZ4 decode path serves the launches - 6 auto (default: the tile path
- * up to 1536 blocks per launch, the segment-parallel path above), 2 the exact walker alone, 9 the walk + window copier, 11 the
- * segment-parallel path, 13 the tile path; results are identical (env FOURMC_DECODE = auto | exact | wx | seg | tile). */
+ * up to 1536 blocks per launch, the segment-parallel path above), 2 the exact walker alone (what an automatic choice ends at when
+ * no workspace can be had), 11 the segment-parallel path, 13 the tile path; results are identical (env FOURMC_DECODE = auto | exact |
+ * seg | tile).  Any other value selects auto: the designs measured and not kept are sources under tools/research/. */
 void fourmc_gpu_set_lz4_decode_path(int path);
 int  fourmc_gpu_get_lz4_decode_path(void);
 /* Tuning knob: 4mz decode as entropy kernel + execute kernel (1, default; FOURMC_ZDECODE=split) or all in the one-wave kernel

@@ -19,7 +19,7 @@ RETRY = -1000000003
                 ids=["rows", "rows-alone", "lanes", "lanes-alone", "wx", "wx-alone", "seg", "seg-alone", "tile", "tile-alone", "ring", "ring-alone"])
 def gpu(request):
     p = pkg(); p.gpu_init()
-    research = request.param in (4, 5, 7, 8)          # the row pipeline and the lane-per-sequence path live in the research side build
+    research = request.param in (4, 5, 7, 8, 9, 10, 15, 16)   # designs no launch of the product selects: tools/research/, research side build
     if research: p.use_research(True); p.gpu_init()
     before = p.lib().fourmc_gpu_get_lz4_decode_path()
     p.lib().fourmc_gpu_set_lz4_decode_path(request.param)

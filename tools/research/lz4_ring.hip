@@ -1,4 +1,4 @@
-// 4mc_amd/csrc/lz4_ring.hip - K1g: group executor of the LZ4 block decode on gfx950 (wave64), round 6.
+// tools/research/lz4_ring.hip - K1g: group executor of the LZ4 block decode on gfx950 (wave64), round 6.
 //
 // Replaces LZ4_decompress_safe(in, out, csize, usize) per block (native/4mc.c:661, native/jniDecompressor.c:88 ->
 // native/lz4/lz4.c:2345-2350 -> :1936-2339) for every block the exact walker (lz4_decode.hip) does not have to see.  Where the

@@ -1,4 +1,4 @@
-// 4mc_amd/csrc/lz4ring.h - constants of the group executor of the LZ4 decode (lz4_ring.hip).  The walk that finds the tokens and
+// tools/research/lz4ring.h - constants of the group executor of the LZ4 decode (lz4_ring.hip).  The walk that finds the tokens and
 // the workspace layout are lz4_seg.hip's (lz4seg.h); the exact walker finishes its blocks the same way (kResumeCode).
 #ifndef FOURMC_LZ4RING_H
 #define FOURMC_LZ4RING_H
