@@ -3021,11 +3021,14 @@ __device__ __forceinline__ bool is_rle(const uint8_t* s, uint32_t n, int lane)
 // other match finders are not compiled into an instance, so its
 // registers are allocated for the dense window alone)
 template <bool kTree, int kFast>
-__device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* work, int level, bool serial, int lane)
+__device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* work, int level, bool serial, int lane,
+                                                 uint32_t* lds_tab = nullptr)
 {
     Params P = level_params(n, level);
     if (kFast) P.strat = uint32_t(kFast);                         // (zstd_encode_one sent this block here because that is its strategy)
-    uint32_t* const tab = reinterpret_cast<uint32_t*>(work + kStoreBytes);
+    // (lds_tab: the measurement build -DZ1_LDS_TABLE hands the level-1 kernel 64 KiB of LDS for the hash table of blocks whose
+    // hashLog is 14 - one block per CU instead of eight; profiles/r06_encoders.md has what that costs)
+    uint32_t* const tab = (lds_tab && P.hlog <= 14) ? lds_tab : reinterpret_cast<uint32_t*>(work + kStoreBytes);
     uint32_t* const tab_s = reinterpret_cast<uint32_t*>(work + kStoreBytes + (size_t(4) << max(P.hlog, 17u)));      // dfast: short-hash table
     SeqStore S;
     S.ll = reinterpret_cast<uint32_t*>(work); S.ml = S.ll + kSeqCap; S.off = S.ml + kSeqCap;
@@ -3176,7 +3179,7 @@ __device__ __forceinline__ int zstd_encode_frame(ZLds& L, const uint8_t* src, ui
 
 template <bool kTree, int kFast>
 __device__ __forceinline__ void zstd_encode_one(ZLds& L, const uint8_t* __restrict__ src_base, uint8_t* dst_base, fourmc_block* blocks, uint32_t nblocks,
-                                                uint8_t* work_base, int container_mode, int level, int serial)
+                                                uint8_t* work_base, int container_mode, int level, int serial, uint32_t* lds_tab = nullptr)
 {
     const uint32_t b = blockIdx.x;
     if (b >= nblocks) return;
@@ -3193,7 +3196,7 @@ __device__ __forceinline__ void zstd_encode_one(ZLds& L, const uint8_t* __restri
     const uint8_t* src = src_base + U64(blk.src_off);
     uint8_t* dst = dst_base + U64(blk.dst_off);
     const uint32_t cap = container_mode ? (n ? n - 1 : 0) : U(blk.dst_cap);
-    int r = zstd_encode_frame<kTree, kFast>(L, src, n, dst, cap, work_base + size_t(b) * (kStoreBytes + table_bytes(level)), level, serial != 0, lane);
+    int r = zstd_encode_frame<kTree, kFast>(L, src, n, dst, cap, work_base + size_t(b) * (kStoreBytes + table_bytes(level)), level, serial != 0, lane, lds_tab);
     if (container_mode && r <= 0) { copy_bytes(dst, src, n, lane); r = int(n); }
     if (lane == 0) blocks[b].result = r;
 }
@@ -3212,7 +3215,12 @@ void zstd_encode_fast_kernel(const uint8_t* __restrict__ src_base, uint8_t* dst_
                              uint8_t* work_base, int container_mode, int level, int serial)
 {
     __shared__ ZLds L;
+#ifdef Z1_LDS_TABLE
+    __shared__ __attribute__((aligned(16))) uint32_t ldstab[1u << 14];
+    zstd_encode_one<false, 1>(L, src_base, dst_base, blocks, nblocks, work_base, container_mode, level, serial, ldstab);
+#else
     zstd_encode_one<false, 1>(L, src_base, dst_base, blocks, nblocks, work_base, container_mode, level, serial);
+#endif
 }
 
 // level 3 (4mz "medium")

@@ -301,7 +301,7 @@ def main():
         """roofline object of the tolerant encoder's two kernels together; traffic: the PMC passes kept under profiles/ (same launch size)"""
         traffic = None
         try:
-            t = json.load(open(os.path.join(ROOT, "profiles", "r04_k2p_traffic.json")))
+            t = json.load(open(os.path.join(ROOT, "profiles", "r06_k2p_traffic.json")))
             if t.get("blocks") == nb:
                 traffic = int(sum(1024 * (v.get("fetch_KiB") or 0) + 1024 * (v.get("write_KiB") or 0) for k, v in t.items() if isinstance(v, dict)))
         except Exception:
@@ -309,7 +309,7 @@ def main():
         a = algb / (ms * 1e-3) / 1e9
         return {"kernel": "lz4_par_segment_kernel + lz4_par_stitch_kernel", "bound": "hbm", "achieved": round(a, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(a / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "traffic_source": "profiles/r04_k2p_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 2048 blocks): the candidates' lines miss the L2" if traffic else None,
+                "traffic_source": "profiles/r06_k2p_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 2048 blocks, re-measured in round 6: unchanged): the candidates' lines miss the L2" if traffic else None,
                 "algorithmic_bytes_per_launch": int(algb), "avg_launch_ms": round(ms, 3)}
 
     def tolerant_leg():
@@ -345,6 +345,24 @@ def main():
                 "ratio_vs_reference": round(float((exact + 12).sum()) / float((cs + 12).sum()), 6),
                 "tolerance": "sizes within 3 %% of the reference parse over the S-mix (tests/test_gpu_lz4par_encode.py); this run: %+.2f %%" % (100.0 * (float((cs + 12).sum()) / float((exact + 12).sum()) - 1)),
                 "round_trip": "decoded by the device decoder and compared with the input in this run"}
+
+    def seq_copy_ceiling(alg, t_ms):
+        """What the copy engine of the decode path would take for this leg if DEPENDENCIES WERE FREE: the same
+        executor fetching and placing every literal run and match of the real sequence list without ever waiting for a source
+        (tools/ubench/seq_copy.sh, `make nodeps`; measured on the GPU box this round, profiles/r06_seq_copy.md).  Not re-measured inside
+        this run (it needs the side build and a wrong-output decode of 64 GiB); the leg of THIS run is put beside it."""
+        try:
+            c = json.load(open(os.path.join(ROOT, "profiles", "r06_seq_copy.json")))
+            ms = float(c["dependency_free"]["leg_ms"])
+        except Exception:
+            return None
+        a = alg / (ms * 1e-3) / 1e9
+        return {"dependency_free_leg_ms": ms, "GBps_algorithmic": round(a, 1), "frac_of_hbm_peak": round(a / HBM_PEAK_GBS, 4),
+                "this_leg_over_ceiling": round(ms / t_ms, 3),
+                "below_40_percent_target": a < 0.4 * HBM_PEAK_GBS,
+                "what": "lz4_seg_exec_kernel with no wait for a flush and no order between near matches (every copy still made, output wrong by design) + the real walk and tail kernels + the checksum pass; one sequence per lane, 9 - 21 byte strings",
+                "other_engines_leg_ms": c.get("other_engines_ms"),
+                "source": "profiles/r06_seq_copy.md / .json (tools/ubench/seq_copy.sh)"}
 
     def decode_64gib():
         """Decode-only at the size the north-star target is quoted on: 16384 blocks = 64 GiB written, read from a 35 GB image of
@@ -387,7 +405,8 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": round(alg / (t * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                              "over": "the whole decode call: checksum verify pass + decode kernels (payload bytes counted once)",
-                             "frac_decode_kernels_only": round(alg / ((t - hash_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                             "frac_decode_kernels_only": round(alg / ((t - hash_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                             "ceiling_seq_copy": seq_copy_ceiling(alg, t)},
                 "note": "%d distinct copies of the 8 GiB image in HBM (%.1f GB of payloads, each read once); 64 GiB of distinct output" % (reps, reps * img_bytes / 1e9)}
 
     def decode_64gib_lz4_only():
